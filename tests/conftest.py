@@ -1,0 +1,31 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "pytorch-bayesiancnn_amd")
+for p in (PKG, os.path.join(ROOT, "oracle"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+sys.dont_write_bytecode = True
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+REFERENCE = "/root/reference"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "reference: needs the read-only upstream checkout at /root/reference")
+
+
+def pytest_collection_modifyitems(config, items):
+    have_ref = os.path.isdir(REFERENCE)
+    for item in items:
+        if "reference" in item.keywords and not have_ref:
+            item.add_marker(pytest.mark.skip(reason="/root/reference not present (GPU box)"))
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import numpy as np
+    return {n: np.load(os.path.join(GOLDEN, n + ".npz")) for n in ("layers_small", "functions", "models")}

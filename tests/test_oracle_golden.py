@@ -1,0 +1,184 @@
+"""The oracle (oracle/bbb_numpy.py, oracle/ref_port_torch.py) against fixtures produced by the
+unmodified reference (tests/golden/make_golden.py).  CPU only."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import bbb_numpy as O
+import ref_port_torch as P
+
+
+def _bias(L, tag, key):
+    k = f"{tag}.{key}"
+    return L[k] if k in L.files else None
+
+
+@pytest.mark.parametrize("tag", ["bbb_conv", "bbb_conv_nb"])
+def test_numpy_bbb_conv(golden, tag):
+    L = golden["layers_small"]
+    cin, cout, kh, kw, s, p, d, hb = L[f"{tag}.meta"]
+    y, Ws, bs = O.bbb_conv2d_forward(L[f"{tag}.x"], L[f"{tag}.W_mu"], L[f"{tag}.W_rho"], _bias(L, tag, "bias_mu"),
+                                     _bias(L, tag, "bias_rho"), L[f"{tag}.eps0"], _bias(L, tag, "eps1"), int(s), int(p), int(d))
+    np.testing.assert_allclose(Ws, L[f"{tag}.W_sigma"], rtol=2e-7, atol=0)
+    np.testing.assert_allclose(y, L[f"{tag}.y"], rtol=1e-5, atol=1e-6)
+    kl = O.kl_loss(L[f"{tag}.W_mu"], Ws, 0, 0.1) + (O.kl_loss(L[f"{tag}.bias_mu"], bs, 0, 0.1) if hb else 0.0)
+    assert abs(kl - float(L[f"{tag}.kl"])) <= 2e-6 * abs(kl)
+    y0 = O.conv2d(L[f"{tag}.x"], L[f"{tag}.W_mu"], _bias(L, tag, "bias_mu"), int(s), int(p), int(d))
+    np.testing.assert_allclose(y0, L[f"{tag}.y_nosample"], rtol=1e-5, atol=1e-6)
+
+
+def test_numpy_bbb_linear(golden):
+    L, tag = golden["layers_small"], "bbb_lin"
+    y, Ws, bs = O.bbb_linear_forward(L[f"{tag}.x"], L[f"{tag}.W_mu"], L[f"{tag}.W_rho"], L[f"{tag}.bias_mu"],
+                                     L[f"{tag}.bias_rho"], L[f"{tag}.eps0"], L[f"{tag}.eps1"])
+    np.testing.assert_allclose(y, L[f"{tag}.y"], rtol=1e-5, atol=1e-6)
+    kl = O.kl_loss(L[f"{tag}.W_mu"], Ws, 0, 0.1) + O.kl_loss(L[f"{tag}.bias_mu"], bs, 0, 0.1)
+    assert abs(kl - float(L[f"{tag}.kl"])) <= 2e-6 * abs(kl)
+
+
+def test_numpy_lrt(golden):
+    L = golden["layers_small"]
+    tag = "lrt_conv"
+    am, av = O.lrt_moments_conv2d(L[f"{tag}.x"], L[f"{tag}.W_mu"], L[f"{tag}.W_rho"], L[f"{tag}.bias_mu"], L[f"{tag}.bias_rho"], 1, 1, 1)
+    np.testing.assert_allclose(O.lrt_output(am, av, L[f"{tag}.eps0"]), L[f"{tag}.y"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(am, L[f"{tag}.y_nosample"], rtol=1e-5, atol=1e-6)
+    for tag in ("lrt_lin", "lrt_lin_nb"):
+        am, av = O.lrt_moments_linear(L[f"{tag}.x"], L[f"{tag}.W_mu"], L[f"{tag}.W_rho"], _bias(L, tag, "bias_mu"), _bias(L, tag, "bias_rho"))
+        np.testing.assert_allclose(O.lrt_output(am, av, L[f"{tag}.eps0"]), L[f"{tag}.y"], rtol=1e-5, atol=1e-6)
+
+
+def test_numpy_kl_is_the_swapped_form(golden):
+    Fn = golden["functions"]
+    mu, sig = Fn["kl.mu"], Fn["kl.sigma"]
+    np.testing.assert_allclose(O.sigma_from_rho(Fn["kl.rho"]), sig, rtol=2e-7)
+    kl = O.kl_loss(mu, sig, 0, 0.1)
+    assert abs(kl - float(Fn["kl.value_cfg"])) <= 2e-6 * kl
+    assert abs(kl - float(Fn["kl.value_textbook"])) > 0.5 * kl      # NOT KL(q||p)
+    kl3 = O.kl_loss(mu, O.sigma_from_rho(Fn["kl.rho3"]), 0, 0.1)
+    assert abs(kl3 - float(Fn["kl.value_default"])) <= 2e-6 * kl3
+
+
+def test_numpy_kl_grads_match_autograd(golden):
+    L, tag = golden["layers_small"], "bbb_lin"
+    # d/dmu, d/drho of 0.37*kl only: subtract the data term using the stored g / eps
+    gmu, grho = O.kl_grads(L[f"{tag}.bias_mu"], L[f"{tag}.bias_rho"], 0, 0.1)
+    g = L[f"{tag}.g"]
+    gb = g.sum(0)                                     # d(sum y*g)/d bias
+    sig = 1.0 / (1.0 + np.exp(-L[f"{tag}.bias_rho"].astype(np.float64)))
+    np.testing.assert_allclose(gb + 0.37 * gmu, L[f"{tag}.grad_bias_mu"], rtol=2e-5, atol=1e-5)
+    np.testing.assert_allclose(gb * L[f"{tag}.eps1"] * sig + 0.37 * grho, L[f"{tag}.grad_bias_rho"], rtol=2e-5, atol=1e-4)
+
+
+def test_numpy_tail_functions(golden):
+    Fn = golden["functions"]
+    np.testing.assert_allclose(O.logmeanexp(Fn["lme.x"], 2), Fn["lme.dim2"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(O.logmeanexp(Fn["lme.x"], 0)[None], Fn["lme.dim0_keep"], rtol=1e-6, atol=1e-6)
+    v = O.elbo(Fn["elbo.log_outputs"], Fn["elbo.target"], 1234.5, 0.1, 50000)
+    assert abs(v - float(Fn["elbo.value"])) <= 1e-6 * abs(v)
+    for row, bt in zip(Fn["beta.table"], ["Blundell", "Soenderby", "Standard", "nonsense", 0.25]):
+        assert [float(O.get_beta(b, 10, bt, 3, 40)) for b in range(4)] == list(row)
+
+
+def _lenet_params(M, tag):
+    names = ["conv1", "conv2", "fc1", "fc2", "fc3"]
+    return {n: {k: M[f"{tag}.sd.{n}.{k}"] for k in ("W_mu", "W_rho", "bias_mu", "bias_rho")} for n in names}
+
+
+def test_numpy_lenet_with_cpu_replayed_eps(golden):
+    """Whole-model numpy forward with eps replayed from torch's CPU generator == reference logits."""
+    M = golden["models"]
+    for tag, lt, act, pri in (("lenet_bbb", "bbb", "softplus", P.CONFIG_PRIORS), ("lenet_lrt", "lrt", "relu", P.DEFAULT_PRIORS)):
+        params = _lenet_params(M, tag)
+        params["_prior_mu"], params["_prior_sigma"] = pri["prior_mu"], pri["prior_sigma"]
+        torch.manual_seed(int(M[f"{tag}.meta"][4]) + 1)
+        eps_fn = lambda name, kind, shape: torch.empty(tuple(shape)).normal_(0, 1).numpy()
+        logits, kl = O.model_forward("lenet", params, M[f"{tag}.x"], lt, act, eps_fn)
+        np.testing.assert_allclose(logits, M[f"{tag}.logits"], rtol=2e-4, atol=2e-5)
+        assert abs(kl - float(M[f"{tag}.kl"])) <= 3e-6 * kl
+
+
+CASES = [("lenet_bbb", "lenet", "bbb", "softplus", "cfg"), ("lenet_lrt", "lenet", "lrt", "relu", None),
+         ("alexnet_bbb", "alexnet", "bbb", "softplus", "cfg"), ("alexnet_lrt", "alexnet", "lrt", "softplus", "cfg"),
+         ("3conv3fc_bbb", "3conv3fc", "bbb", "softplus", "cfg"), ("3conv3fc_lrt", "3conv3fc", "lrt", "relu", "cfg"),
+         ("alexnet224_bbb", "alexnet", "bbb", "softplus", "cfg")]
+
+
+@pytest.mark.parametrize("tag,net,lt,act,pri", CASES)
+def test_port_reproduces_reference_by_seed(golden, tag, net, lt, act, pri):
+    """ref_port_torch draws parameters, input and eps in the reference's order: same seed -> same numbers."""
+    M = golden["models"]
+    ncls, cin, B, hw, seed = [int(v) for v in M[f"{tag}.meta"]]
+    torch.manual_seed(seed)
+    params = P.init_params(net, cin, ncls, P.CONFIG_PRIORS if pri else None)
+    x = torch.rand(B, cin, hw, hw)
+    cs = []
+    for n in [op[1] for op in O.TOPOLOGY[net] if op[0] in ("conv", "fc")]:
+        for k in ("W_mu", "W_rho", "bias_mu", "bias_rho"):
+            d = params[n][k].double()
+            cs.append([d.sum().item(), (d * d).sum().item()])
+    np.testing.assert_allclose(np.array(cs), M[f"{tag}.checksums"], rtol=1e-12)
+    torch.manual_seed(seed + 1)
+    logits, kl = P.forward(net, params, x, lt, act)
+    # fixtures were made single-threaded; mkldnn's accumulation order changes with the thread count
+    np.testing.assert_allclose(logits.numpy(), M[f"{tag}.logits"], rtol=5e-4, atol=5e-5)
+    assert abs(float(kl) - float(M[f"{tag}.kl"])) <= 1e-6 * abs(float(kl))
+
+
+def test_port_mc_step(golden):
+    M = golden["models"]
+    torch.manual_seed(21)
+    params = P.init_params("lenet", 1, 10, P.CONFIG_PRIORS)
+    x = torch.rand(4, 1, 32, 32)
+    labels = torch.randint(0, 10, (4,))
+    torch.manual_seed(22)
+    lo, kl = P.mc_step("lenet", params, x, 10, 3, "bbb", "softplus")
+    np.testing.assert_allclose(lo.numpy(), M["mc_lenet.log_outputs"], rtol=1e-5, atol=1e-6)
+    assert abs(float(kl) - float(M["mc_lenet.kl_sum"])) <= 1e-6 * float(kl)
+    np.testing.assert_allclose(O.mc_log_outputs(M["mc_lenet.logits"]), M["mc_lenet.log_outputs"], rtol=1e-5, atol=2e-6)
+    v = O.elbo(M["mc_lenet.log_outputs"], M["mc_lenet.labels"], float(M["mc_lenet.kl_sum"]) / 3, 0.1, 1000)
+    assert abs(v - float(M["mc_lenet.elbo_train"])) <= 1e-6 * abs(v)
+
+
+def test_philox_known_answers():
+    """Random123 kat_vectors for philox4x32-10."""
+    def run(c, k):
+        r = O.philox4x32_10(*[np.array([v], dtype=np.uint32) for v in c], k[0], k[1])
+        return [int(v[0]) for v in r]
+    assert run([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert run([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert run([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_eps_stream_moments_and_windows():
+    e = O.normal_eps(1234, 5, 3, 400000)
+    assert abs(e.mean()) < 0.006 and abs(e.std() - 1) < 0.005
+    assert abs(np.mean(e ** 3)) < 0.02 and abs(np.mean(e ** 4) - 3) < 0.05
+    np.testing.assert_array_equal(O.normal_eps(1234, 5, 3, 11, start=6), e[6:17])
+    assert not np.array_equal(O.normal_eps(1234, 6, 3, 16), e[:16])
+    assert not np.array_equal(O.normal_eps(1234, 5, 4, 16), e[:16])
+
+
+@pytest.mark.reference
+def test_port_matches_live_reference():
+    """Build-container only: the port against the live, unmodified upstream modules."""
+    import subprocess
+    code = r'''
+import sys; sys.dont_write_bytecode=True
+sys.path.insert(0, "/root/reference"); sys.path.insert(0, "%s")
+import torch, numpy as np
+import ref_port_torch as P
+from models.BayesianModels.BayesianAlexNet import BBBAlexNet
+import config_bayesian as cfg
+torch.manual_seed(5); net = BBBAlexNet(10, 3, cfg.priors, "bbb", "softplus"); x = torch.rand(4,3,32,32)
+torch.manual_seed(6); a, ka = net(x)
+torch.manual_seed(5); params = P.init_params("alexnet", 3, 10, P.CONFIG_PRIORS); x2 = torch.rand(4,3,32,32)
+torch.manual_seed(6); b, kb = P.forward("alexnet", params, x2, "bbb", "softplus")
+assert torch.equal(a, b) and torch.equal(ka, kb), (float((a-b).abs().max()), float(ka), float(kb))
+print("OK")
+''' % os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:]
