@@ -1,0 +1,148 @@
+/*
+ * bbb_hip.h -- C ABI of libbbb_hip.so, the MI355X (gfx950) Bayes-by-Backprop hot path.
+ *
+ * The upstream project (kumar-shridhar/PyTorch-BayesianCNN) is pure Python and has no FFI; this
+ * header is the native boundary its `layers` package would bind.  Each entry point names the
+ * upstream lines it replaces.  Conventions:
+ *   - every pointer is a DEVICE pointer to fp32 data unless it says "host";
+ *   - nothing is allocated, freed or retained; outputs are caller-owned buffers;
+ *   - `stream` is a hipStream_t (0 = the null stream); every call only enqueues work on it;
+ *   - return value: 0 on success, a negative BBB_E* code for argument errors, or the positive
+ *     hipError_t of a failed launch.  No call aborts or throws.
+ *   - tensors are contiguous: activations NCHW, conv weights [Cout, Cin, kh, kw], linear weights
+ *     [out, in], all row-major (the reference's own layouts).
+ *
+ * Noise contract (replaces torch.empty(shape).normal_(0,1) on the CPU generator,
+ * layers/BBB/BBBConv.py:63,68; layers/BBB_LRT/BBBConv.py:78): element i of noise stream
+ * (seed, call, stream_id) is output (i & 3) of
+ *     Philox4x32-10(counter = {lo32(i >> 2), i >> 34, stream_id, call}, key = {lo32(seed), hi32(seed)})
+ * pushed through Box-Muller pairs (x0,x1)->(z0,z1), (x2,x3)->(z2,z3) with
+ *     u1 = ((xa >> 8) + 1) * 2^-24,  u2 = (xb >> 8) * 2^-24,  z = sqrt(-2 ln u1) * {cos,sin}(2 pi u2).
+ * Monte-Carlo draw j of an ensemble uses call = call0 + j, so a batched E-draw launch and E
+ * single-draw launches produce the same numbers, and any GPU can materialise any draw.
+ */
+#ifndef BBB_HIP_H
+#define BBB_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BBB_ABI_VERSION 1
+#define BBB_MAX_SEGMENTS 16
+
+#define BBB_EINVAL (-1)   /* bad argument (null pointer, non-positive size, too many segments) */
+#define BBB_EALIGN (-2)   /* pointer not 4-byte aligned */
+#define BBB_ESHAPE (-3)   /* inconsistent convolution geometry */
+
+/* One parameter tensor pair (mu, rho) of a Bayesian layer: W or bias. */
+typedef struct bbb_segment {
+    const float* mu;      /* [n]  W_mu / bias_mu */
+    const float* rho;     /* [n]  W_rho / bias_rho */
+    float* w;             /* out [draws][n] at w + e*draw_stride: mu + softplus(rho)*eps; NULL = no sampling */
+    float* sigma;         /* out [n]: softplus(rho), or its square when BBB_SIGMA_SQUARED; NULL = skip */
+    const float* eps;     /* test entry: external noise [draws][n] (same stride as w); NULL = on-chip Philox */
+    int64_t n;            /* elements */
+    int64_t draw_stride;  /* elements between consecutive draws of w / eps (>= n) */
+    uint32_t stream_id;   /* noise stream of this tensor */
+    uint32_t reserved;
+} bbb_segment_t;
+
+#define BBB_SIGMA_SQUARED 1u   /* flags: write sigma^2 (the LRT variance operand) instead of sigma */
+#define BBB_KL_TEXTBOOK   2u   /* flags: KL(q||p) instead of the reference's swapped-argument form */
+
+/*
+ * Fused reparameterisation + KL over up to BBB_MAX_SEGMENTS tensors and `draws` Monte-Carlo draws in
+ * ONE pass over (mu, rho).  Replaces, per layer and per draw: the CPU normal_ + H2D copy, log1p(exp(rho)),
+ * mu + eps*sigma (layers/BBB/BBBConv.py:63-70, BBBLinear.py:56-63), the sigma / sigma**2 of the LRT
+ * layers (layers/BBB_LRT/BBBConv.py:64-69, BBBLinear.py:58-63) and metrics.calculate_kl as called by
+ * kl_loss() (metrics.py:27-29 via layers/BBB/BBBConv.py:79-83), plus the Python sum over layers
+ * (layers/misc.py:20-23).
+ *   segs        host array of nseg descriptors (copied into the kernel arguments)
+ *   kl_partials device scratch, at least bbb_reparam_partials(segs, nseg) doubles
+ *   kl_out      device float: sum over all segments of the KL term (NULL = no KL)
+ *   kl_out64    optional device double with the same sum (NULL = skip)
+ * KL does not depend on eps; the sum is reduced in a fixed order in fp64 (bitwise reproducible).
+ */
+int bbb_reparam_kl_fwd(const bbb_segment_t* segs, int nseg, int draws,
+                       float prior_mu, float prior_sigma,
+                       uint64_t seed, uint32_t call0, uint32_t flags,
+                       double* kl_partials, float* kl_out, double* kl_out64, void* stream);
+
+/* Number of doubles of scratch bbb_reparam_kl_fwd needs for these segments (host-only helper). */
+int64_t bbb_reparam_partials(const bbb_segment_t* segs, int nseg);
+
+/*
+ * Backward of bbb_reparam_kl_fwd (what autograd derives for the reference):
+ *   grad_mu  = sum_e gw[e] + gkl * (mu - mu0) / sigma^2
+ *   grad_rho = (sum_e gw[e]*eps[e] + gkl * (1/sigma - sigma0^2/sigma^3 - (mu-mu0)^2/sigma^3)) * sigmoid(rho)
+ * eps is regenerated from (seed, call0 + e, stream_id), never stored.  In each segment `w` holds the
+ * incoming gradient gw [draws][n] (may be NULL = 0), `sigma` is unused, `eps` optional external noise.
+ * grad_mu / grad_rho are arrays of nseg device pointers given on the host.  gkl: device float
+ * (d loss / d kl), NULL = 0.
+ */
+int bbb_reparam_kl_bwd(const bbb_segment_t* segs, int nseg, int draws,
+                       float prior_mu, float prior_sigma,
+                       uint64_t seed, uint32_t call0, uint32_t flags,
+                       const float* gkl, float* const* grad_mu, float* const* grad_rho, void* stream);
+
+/* Test entry: materialise n elements of a noise stream starting at element `start`. */
+int bbb_eps_dump(float* out, int64_t n, int64_t start, uint64_t seed, uint32_t call, uint32_t stream_id, void* stream);
+
+/* Geometry of one conv2d / linear contraction, batched over Monte-Carlo draws. */
+typedef struct bbb_conv_desc {
+    int32_t batch;        /* B images per draw */
+    int32_t cin, h, w;    /* input  [draws|1][B][cin][h][w]  (linear: h = w = 1) */
+    int32_t cout, kh, kw; /* weight [draws|1][cout][cin][kh][kw] */
+    int32_t stride_h, stride_w, pad_h, pad_w, dil_h, dil_w;
+    int32_t draws;        /* E: independent weight sets / output slabs */
+    int64_t x_draw_stride; /* elements between draws of x (0 = every draw reads the same x) */
+    int64_t w_draw_stride; /* elements between draws of w (0 = shared weights) */
+    int64_t b_draw_stride; /* elements between draws of bias (0 = shared) */
+    int32_t act;          /* fused epilogue: 0 none, 1 ReLU, 2 Softplus(beta=1, threshold=20) */
+    int32_t reserved;
+} bbb_conv_desc_t;
+
+/*
+ * y[e] = conv2d(x[e], w[e], bias[e]) on the fp32 matrix cores (implicit im2col GEMM, groups = 1).
+ * Replaces F.conv2d / F.linear in layers/BBB/BBBConv.py:77 and layers/BBB/BBBLinear.py:70.
+ * y: [draws][B][cout][ho][wo], contiguous.  bias may be NULL.
+ */
+int bbb_conv2d_fwd(const bbb_conv_desc_t* d, const float* x, const float* w, const float* bias,
+                   float* y, void* stream);
+
+/*
+ * Local-reparameterisation layer in one launch (layers/BBB_LRT/BBBConv.py:71-81, BBBLinear.py:65-73):
+ *   act_mu  = conv(x, w_mu, b_mu);  act_var = 1e-16 + conv(x*x, w_var, b_var)
+ *   y       = act_mu + sqrt(act_var) * eps          (sample != 0)   |   act_mu   (sample == 0)
+ * Both contractions share one staged x tile (squared in registers); eps is generated in the epilogue,
+ * element index ((b*cout + c)*ho + oh)*wo + ow of stream (seed, call0 + e, stream_id).  Here d->draws
+ * slabs of x are independent samples sharing w_mu / w_var (w_draw_stride must be 0).
+ *   eps_ext   test entry: external noise with y's layout (NULL = Philox)
+ *   act_mu_out / act_var_out: optional copies of the two moments (NULL = skip)
+ */
+int bbb_lrt_conv2d_fwd(const bbb_conv_desc_t* d, const float* x, const float* w_mu, const float* w_var,
+                       const float* b_mu, const float* b_var, float* y,
+                       float* act_mu_out, float* act_var_out, const float* eps_ext,
+                       uint64_t seed, uint32_t call0, uint32_t stream_id, int sample, void* stream);
+
+/*
+ * Monte-Carlo tail (main_bayesian.py:49,53 / :78,80 + utils.py:14-22): per draw log_softmax over
+ * classes, then log-sum-exp over the local draws.
+ *   logits [draws][B][C]  ->  lse [B][C] = log sum_e exp(log_softmax(logits[e])[b][c])
+ * log_outputs = lse - log(E_total) (applied when mean_over > 0: lse - log(mean_over)).
+ * Ranks of an ensemble-sharded job combine their lse blocks with one more log-sum-exp.
+ */
+int bbb_mc_tail(const float* logits, int draws, int batch, int classes, int mean_over,
+                float* lse_out, void* stream);
+
+/* Library / device introspection (host-only). */
+int bbb_abi_version(void);
+const char* bbb_build_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BBB_HIP_H */

@@ -1,0 +1,13 @@
+"""MI355X-native Bayes-by-Backprop hot path: host side (Python) over libbbb_hip.so.
+
+  _lib      ctypes binding of the C ABI (include/bbb_hip.h); no fallback if the .so is missing
+  rng       seed / call-counter contract of the on-chip Philox noise
+  ops       tensor-level entry points + autograd wiring
+  ensemble  the num_ens Monte-Carlo loop of main_bayesian.py:43-53 / 73-80, batched over draws and
+            sharded over GPUs
+  zoo       BBBLeNet / BBBAlexNet / BBB3Conv3FC built from a topology table (same constructor surface as
+            the reference's models/BayesianModels/*.py, for hosts where /root/reference is absent)
+The drop-in boundary itself is the sibling package ``layers``.
+"""
+from . import _lib, rng, ops  # noqa: F401
+from ._lib import BBBHipError, LIB_PATH  # noqa: F401

@@ -1,0 +1,103 @@
+"""ctypes binding of libbbb_hip.so (C ABI in include/bbb_hip.h).
+
+The shared object is built in-tree by ``build.sh`` / ``__graft_entry__.build()``.  There is NO fallback:
+if the library is missing or a symbol does not resolve, importing the compute ops raises.  torch is
+imported first on purpose: libbbb_hip.so needs libamdhip64.so.7 and must bind to the HIP runtime torch
+already loaded, so that device pointers and streams are shared.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must precede CDLL: shares torch's HIP runtime)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbbb_hip.so")
+
+MAX_SEGMENTS = 16
+SIGMA_SQUARED = 1
+KL_TEXTBOOK = 2
+
+c_void_p, c_int, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+c_u64, c_u32, c_i64, c_i32 = ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int64, ctypes.c_int32
+
+
+class Segment(ctypes.Structure):
+    _fields_ = [("mu", c_void_p), ("rho", c_void_p), ("w", c_void_p), ("sigma", c_void_p), ("eps", c_void_p),
+                ("n", c_i64), ("draw_stride", c_i64), ("stream_id", c_u32), ("reserved", c_u32)]
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [("batch", c_i32), ("cin", c_i32), ("h", c_i32), ("w", c_i32), ("cout", c_i32), ("kh", c_i32),
+                ("kw", c_i32), ("stride_h", c_i32), ("stride_w", c_i32), ("pad_h", c_i32), ("pad_w", c_i32),
+                ("dil_h", c_i32), ("dil_w", c_i32), ("draws", c_i32), ("x_draw_stride", c_i64),
+                ("w_draw_stride", c_i64), ("b_draw_stride", c_i64), ("act", c_i32), ("reserved", c_i32)]
+
+
+_SIGNATURES = {
+    "bbb_reparam_kl_fwd": (c_int, [ctypes.POINTER(Segment), c_int, c_int, c_float, c_float, c_u64, c_u32, c_u32,
+                                   c_void_p, c_void_p, c_void_p, c_void_p]),
+    "bbb_reparam_partials": (c_i64, [ctypes.POINTER(Segment), c_int]),
+    "bbb_reparam_kl_bwd": (c_int, [ctypes.POINTER(Segment), c_int, c_int, c_float, c_float, c_u64, c_u32, c_u32,
+                                   c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), c_void_p]),
+    "bbb_eps_dump": (c_int, [c_void_p, c_i64, c_i64, c_u64, c_u32, c_u32, c_void_p]),
+    "bbb_conv2d_fwd": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "bbb_lrt_conv2d_fwd": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_void_p, c_u64, c_u32, c_u32, c_int, c_void_p]),
+    "bbb_mc_tail": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "bbb_abi_version": (c_int, []),
+    "bbb_build_info": (ctypes.c_char_p, []),
+}
+EXPORTS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+class BBBHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises if the in-tree .so is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise BBBHipError(
+                f"{LIB_PATH} not found: the HIP kernels are not built. Run ./build.sh "
+                "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+        h = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(h, name)          # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        if h.bbb_abi_version() != 1:
+            raise BBBHipError(f"ABI mismatch: library reports {h.bbb_abi_version()}, binding expects 1")
+        _lib = h
+    return _lib
+
+
+_ERR = {-1: "BBB_EINVAL (bad argument)", -2: "BBB_EALIGN (pointer not 4-byte aligned)", -3: "BBB_ESHAPE (bad geometry)"}
+
+
+def check(rc, what):
+    if rc != 0:
+        raise BBBHipError(f"{what} failed: {_ERR.get(rc, 'hipError_t %d' % rc)}")
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def require_device(*tensors):
+    """Every compute entry point works on MI355X memory only; fail loudly otherwise."""
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise BBBHipError("bbb_hip computes on an MI355X only (tensor is on %s); there is no CPU path. "
+                              "Move the module / input to 'cuda'." % t.device)
+        if t.dtype != torch.float32:
+            raise BBBHipError(f"bbb_hip expects float32 tensors, got {t.dtype}")
+
+
+def cur_stream(device):
+    return torch.cuda.current_stream(device).cuda_stream

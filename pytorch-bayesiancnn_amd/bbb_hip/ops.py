@@ -1,0 +1,358 @@
+"""Tensor-level entry points over the C ABI + their autograd wiring.
+
+Forward math is entirely in the HIP kernels.  Backward: the parameter pass has its own fused HIP kernel
+(eps regenerated from the counter, never stored); the conv/linear data and weight gradients currently go
+through ATen's convolution_backward (MIOpen/rocBLAS) -- a declared stop-gap for the training extension
+(SURVEY.md section 8f N1), not part of the forward metric path.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import Segment, ConvDesc, check, ptr, require_device, cur_stream
+
+_scratch = {}
+
+
+def _partials(device, n):
+    key = (device.index, "kl")
+    buf = _scratch.get(key)
+    if buf is None or buf.numel() < n:
+        buf = torch.empty(max(n, 4096), dtype=torch.float64, device=device)
+        _scratch[key] = buf
+    return buf
+
+
+def _segments(mus, rhos, ws, sigmas, epss, stream_ids, draws):
+    arr = (Segment * len(mus))()
+    for i, (mu, rho) in enumerate(zip(mus, rhos)):
+        n = mu.numel()
+        s = arr[i]
+        s.mu, s.rho = mu.data_ptr(), rho.data_ptr()
+        s.w = ptr(ws[i]) if ws is not None else 0
+        s.sigma = ptr(sigmas[i]) if sigmas is not None else 0
+        s.eps = ptr(epss[i]) if epss is not None else 0
+        s.n = n
+        s.draw_stride = n
+        s.stream_id = stream_ids[i]
+    return arr
+
+
+def reparam_kl_forward(mus, rhos, prior_mu, prior_sigma, stream_ids, seed, call0, draws=1, sample=True,
+                       want_sigma=False, sigma_squared=False, want_kl=True, eps=None, textbook_kl=False):
+    """Raw (no autograd) fused pass.  mus/rhos: lists of contiguous fp32 device tensors.
+    Returns (ws | None, sigmas | None, kl | None); ws[i] has shape [draws, *mus[i].shape]."""
+    if len(mus) == 0 or len(mus) > _lib.MAX_SEGMENTS:
+        raise _lib.BBBHipError(f"1..{_lib.MAX_SEGMENTS} tensors per launch, got {len(mus)}")
+    require_device(*mus, *rhos)
+    dev = mus[0].device
+    mus = [m.contiguous() for m in mus]
+    rhos = [r.contiguous() for r in rhos]
+    ws = [torch.empty((draws,) + tuple(m.shape), dtype=torch.float32, device=dev) for m in mus] if sample else None
+    sigmas = [torch.empty_like(m) for m in mus] if want_sigma else None
+    if eps is not None:
+        eps = [e.contiguous() for e in eps]
+        require_device(*eps)
+        for e, m in zip(eps, mus):
+            if e.numel() != draws * m.numel():
+                raise _lib.BBBHipError("external eps must have shape [draws, *param.shape]")
+    segs = _segments(mus, rhos, ws, sigmas, eps, stream_ids, draws)
+    kl = torch.empty((), dtype=torch.float32, device=dev) if want_kl else None
+    L = _lib.lib()
+    nparts = L.bbb_reparam_partials(segs, len(mus))
+    parts = _partials(dev, nparts) if want_kl else None
+    flags = (_lib.SIGMA_SQUARED if sigma_squared else 0) | (_lib.KL_TEXTBOOK if textbook_kl else 0)
+    with torch.cuda.device(dev):
+        rc = L.bbb_reparam_kl_fwd(segs, len(mus), draws, float(prior_mu), float(prior_sigma), seed, call0 & 0xFFFFFFFF,
+                                  flags, ptr(parts), ptr(kl), 0, cur_stream(dev))
+    check(rc, "bbb_reparam_kl_fwd")
+    return ws, sigmas, kl
+
+
+def reparam_kl_backward(mus, rhos, gws, gkl, prior_mu, prior_sigma, stream_ids, seed, call0, draws, eps=None,
+                        textbook_kl=False):
+    """grad_mu[i], grad_rho[i] for every tensor (see bbb_reparam_kl_bwd)."""
+    require_device(*mus, *rhos)
+    dev = mus[0].device
+    mus = [m.contiguous() for m in mus]
+    rhos = [r.contiguous() for r in rhos]
+    gws = [None if g is None else g.contiguous() for g in gws]
+    if eps is not None:
+        eps = [e.contiguous() for e in eps]
+    segs = _segments(mus, rhos, gws, None, eps, stream_ids, draws)
+    gmu = [torch.empty_like(m) for m in mus]
+    grho = [torch.empty_like(m) for m in mus]
+    pm = (ctypes.c_void_p * len(mus))(*[g.data_ptr() for g in gmu])
+    pr = (ctypes.c_void_p * len(mus))(*[g.data_ptr() for g in grho])
+    if gkl is not None:
+        gkl = gkl.to(device=dev, dtype=torch.float32).contiguous()
+    flags = _lib.KL_TEXTBOOK if textbook_kl else 0
+    with torch.cuda.device(dev):
+        rc = _lib.lib().bbb_reparam_kl_bwd(segs, len(mus), draws, float(prior_mu), float(prior_sigma), seed,
+                                           call0 & 0xFFFFFFFF, flags, ptr(gkl), pm, pr, cur_stream(dev))
+    check(rc, "bbb_reparam_kl_bwd")
+    return gmu, grho
+
+
+def eps_dump(n, seed, call, stream_id, device, start=0):
+    out = torch.empty(n, dtype=torch.float32, device=device)
+    with torch.cuda.device(out.device):
+        check(_lib.lib().bbb_eps_dump(out.data_ptr(), n, start, seed, call & 0xFFFFFFFF, stream_id, cur_stream(out.device)),
+              "bbb_eps_dump")
+    return out
+
+
+def _pair(v):
+    return (int(v), int(v)) if isinstance(v, int) else (int(v[0]), int(v[1]))
+
+
+ACT_CODE = {None: 0, "none": 0, "relu": 1, "softplus": 2}
+
+
+def _desc(x, w, stride, padding, dilation, draws, x_shared, w_shared, act):
+    """x: [E|1... folded][B, Cin, H, W] given as 5-d [Ex, B, Cin, H, W]; w: [Ew, Cout, Cin, kh, kw]."""
+    d = ConvDesc()
+    Ex, B, Cin, H, W = x.shape
+    Ew, Cout, Cin2, kh, kw = w.shape
+    if Cin != Cin2:
+        raise _lib.BBBHipError(f"channel mismatch: input has {Cin}, weight expects {Cin2}")
+    sh, sw = _pair(stride)
+    ph, pw = _pair(padding)
+    dh, dw = _pair(dilation)
+    d.batch, d.cin, d.h, d.w, d.cout, d.kh, d.kw = B, Cin, H, W, Cout, kh, kw
+    d.stride_h, d.stride_w, d.pad_h, d.pad_w, d.dil_h, d.dil_w = sh, sw, ph, pw, dh, dw
+    d.draws = draws
+    d.x_draw_stride = 0 if x_shared else B * Cin * H * W
+    d.w_draw_stride = 0 if w_shared else Cout * Cin * kh * kw
+    d.b_draw_stride = 0 if w_shared else Cout
+    d.act = ACT_CODE[act]
+    ho = (H + 2 * ph - dh * (kh - 1) - 1) // sh + 1
+    wo = (W + 2 * pw - dw * (kw - 1) - 1) // sw + 1
+    return d, ho, wo
+
+
+def conv2d_forward(x, w, bias, stride=1, padding=0, dilation=1, act=None):
+    """Batched-over-draws conv on the fp32 matrix cores (no autograd).
+    x: [E, B, Cin, H, W] or [1, B, Cin, H, W] (shared by all draws); w: [E, Cout, Cin, kh, kw] (or [1, ...]
+    shared); bias: [E|1, Cout] or None.  Returns y [E, B, Cout, Ho, Wo] with E = max of the leading dims."""
+    require_device(x, w, bias)
+    x, w = x.contiguous(), w.contiguous()
+    bias = None if bias is None else bias.contiguous()
+    E = max(x.shape[0], w.shape[0])
+    if x.shape[0] not in (1, E) or w.shape[0] not in (1, E):
+        raise _lib.BBBHipError("leading (draw) dims of x and w must be 1 or equal")
+    d, ho, wo = _desc(x, w, stride, padding, dilation, E, x.shape[0] == 1 and E > 1, w.shape[0] == 1 and E > 1, act)
+    y = torch.empty((E, x.shape[1], w.shape[1], ho, wo), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.lib().bbb_conv2d_fwd(ctypes.byref(d), x.data_ptr(), w.data_ptr(), ptr(bias), y.data_ptr(),
+                                        cur_stream(x.device)), "bbb_conv2d_fwd")
+    return y
+
+
+def lrt_conv2d_forward(x, w_mu, w_var, b_mu, b_var, seed, call0, stream_id, stride=1, padding=0, dilation=1,
+                       sample=True, eps=None, want_moments=False, act=None):
+    """LRT layer in one launch.  x: [E, B, Cin, H, W] (E independent sample slabs); weights shared.
+    Returns (y, act_mu | None, act_var | None), each [E, B, Cout, Ho, Wo]."""
+    require_device(x, w_mu, w_var, b_mu, b_var, eps)
+    x = x.contiguous()
+    w_mu, w_var = w_mu.contiguous(), w_var.contiguous()
+    b_mu = None if b_mu is None else b_mu.contiguous()
+    b_var = None if b_var is None else b_var.contiguous()
+    E = x.shape[0]
+    d, ho, wo = _desc(x, w_mu.unsqueeze(0), stride, padding, dilation, E, False, True, act)
+    d.w_draw_stride = 0
+    d.b_draw_stride = 0
+    shape = (E, x.shape[1], w_mu.shape[0], ho, wo)
+    y = torch.empty(shape, dtype=torch.float32, device=x.device)
+    am = torch.empty(shape, dtype=torch.float32, device=x.device) if want_moments else None
+    av = torch.empty(shape, dtype=torch.float32, device=x.device) if want_moments else None
+    if eps is not None:
+        eps = eps.contiguous()
+        if eps.numel() != y.numel():
+            raise _lib.BBBHipError("external eps must have the output's shape")
+    with torch.cuda.device(x.device):
+        check(_lib.lib().bbb_lrt_conv2d_fwd(ctypes.byref(d), x.data_ptr(), w_mu.data_ptr(), w_var.data_ptr(), ptr(b_mu),
+                                            ptr(b_var), y.data_ptr(), ptr(am), ptr(av), ptr(eps), seed,
+                                            call0 & 0xFFFFFFFF, stream_id, 1 if sample else 0, cur_stream(x.device)),
+              "bbb_lrt_conv2d_fwd")
+    return y, am, av
+
+
+def mc_tail(logits, mean_over=0):
+    """logits [E, B, C] -> [B, C]: log-sum-exp over draws of the per-draw log_softmax, minus log(mean_over)
+    when mean_over > 0 (== utils.logmeanexp of the stacked log_softmax when mean_over == E)."""
+    require_device(logits)
+    logits = logits.contiguous()
+    E, B, C = logits.shape
+    out = torch.empty((B, C), dtype=torch.float32, device=logits.device)
+    with torch.cuda.device(logits.device):
+        check(_lib.lib().bbb_mc_tail(logits.data_ptr(), E, B, C, int(mean_over), out.data_ptr(), cur_stream(logits.device)),
+              "bbb_mc_tail")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# autograd wiring
+# ------------------------------------------------------------------------------------------------
+class _SampleWeights(torch.autograd.Function):
+    """(mu_0, rho_0, mu_1, rho_1, ...) -> (kl, w_0, w_1, ...), one fused launch; w_i: [draws, *shape]."""
+
+    @staticmethod
+    def forward(ctx, cfg, *params):
+        mus, rhos = list(params[0::2]), list(params[1::2])
+        ws, _, kl = reparam_kl_forward(mus, rhos, cfg["prior_mu"], cfg["prior_sigma"], cfg["stream_ids"], cfg["seed"],
+                                       cfg["call0"], cfg["draws"], sample=True, eps=cfg.get("eps"),
+                                       textbook_kl=cfg.get("textbook_kl", False))
+        ctx.cfg = cfg
+        ctx.save_for_backward(*params)
+        return (kl, *ws)
+
+    @staticmethod
+    def backward(ctx, gkl, *gws):
+        params = ctx.saved_tensors
+        cfg = ctx.cfg
+        mus, rhos = list(params[0::2]), list(params[1::2])
+        gmu, grho = reparam_kl_backward(mus, rhos, list(gws), gkl, cfg["prior_mu"], cfg["prior_sigma"], cfg["stream_ids"],
+                                        cfg["seed"], cfg["call0"], cfg["draws"], eps=cfg.get("eps"),
+                                        textbook_kl=cfg.get("textbook_kl", False))
+        out = [None]
+        for a, b in zip(gmu, grho):
+            out += [a, b]
+        return tuple(out)
+
+
+class _KLOnly(torch.autograd.Function):
+    """KL (and optionally sigma / sigma^2 as a differentiable output) without sampling."""
+
+    @staticmethod
+    def forward(ctx, cfg, *params):
+        mus, rhos = list(params[0::2]), list(params[1::2])
+        _, sig, kl = reparam_kl_forward(mus, rhos, cfg["prior_mu"], cfg["prior_sigma"], cfg["stream_ids"], 0, 0, 1,
+                                        sample=False, want_sigma=cfg.get("want_sigma", False),
+                                        sigma_squared=cfg.get("sigma_squared", False),
+                                        textbook_kl=cfg.get("textbook_kl", False))
+        ctx.cfg = cfg
+        ctx.save_for_backward(*params)
+        if sig is None:
+            return (kl,)
+        return (kl, *sig)
+
+    @staticmethod
+    def backward(ctx, gkl, *gsig):
+        params = ctx.saved_tensors
+        cfg = ctx.cfg
+        mus, rhos = list(params[0::2]), list(params[1::2])
+        gmu, grho = reparam_kl_backward(mus, rhos, [None] * len(mus), gkl, cfg["prior_mu"], cfg["prior_sigma"],
+                                        cfg["stream_ids"], 0, 0, 1, textbook_kl=cfg.get("textbook_kl", False))
+        out = [None]
+        for i, (a, b) in enumerate(zip(gmu, grho)):
+            if gsig and gsig[i] is not None:
+                # d sigma/d rho = sigmoid(rho); d sigma^2/d rho = 2 sigma sigmoid(rho)   (training extension, torch ops)
+                sg = torch.sigmoid(rhos[i])
+                if cfg.get("sigma_squared", False):
+                    sg = sg * 2.0 * torch.nn.functional.softplus(rhos[i])
+                b = b + gsig[i] * sg
+            out += [a, b]
+        return tuple(out)
+
+
+class _Conv2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, padding, dilation):
+        y = conv2d_forward(x, w, bias, stride, padding, dilation)
+        ctx.save_for_backward(x, w)
+        ctx.geom = (_pair(stride), _pair(padding), _pair(dilation), bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        stride, padding, dilation, has_bias = ctx.geom
+        E = gy.shape[0]
+        gx = torch.zeros_like(x) if ctx.needs_input_grad[0] else None
+        gw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
+        gb = gy.sum(dim=(1, 3, 4)) if has_bias and ctx.needs_input_grad[2] else None
+        if gb is not None and w.shape[0] == 1 and E > 1:
+            gb = gb.sum(0, keepdim=True)
+        for e in range(E):   # stop-gap: ATen (MIOpen) dgrad / wgrad per draw
+            xe = x[e if x.shape[0] > 1 else 0]
+            we = w[e if w.shape[0] > 1 else 0]
+            gxe, gwe, _ = torch.ops.aten.convolution_backward(
+                gy[e], xe, we, None, list(stride), list(padding), list(dilation), False, [0, 0], 1,
+                [gx is not None, gw is not None, False])
+            if gx is not None:
+                if x.shape[0] > 1:
+                    gx[e] = gxe
+                else:
+                    gx[0] += gxe
+            if gw is not None:
+                if w.shape[0] > 1:
+                    gw[e] = gwe
+                elif e == 0:
+                    gw[0] = gwe
+                else:
+                    gw[0] += gwe
+        return gx, gw, gb, None, None, None
+
+
+class _LrtConv2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w_mu, w_var, b_mu, b_var, cfg):
+        y, am, av = lrt_conv2d_forward(x, w_mu, w_var, b_mu, b_var, cfg["seed"], cfg["call0"], cfg["stream_id"],
+                                       cfg["stride"], cfg["padding"], cfg["dilation"], sample=cfg["sample"],
+                                       eps=cfg.get("eps"), want_moments=True)
+        ctx.cfg = cfg
+        ctx.save_for_backward(x, w_mu, w_var, y, am, av)
+        ctx.has_bias = b_mu is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w_mu, w_var, y, am, av = ctx.saved_tensors
+        cfg = ctx.cfg
+        st, pd, dl = list(_pair(cfg["stride"])), list(_pair(cfg["padding"])), list(_pair(cfg["dilation"]))
+        E, B = x.shape[0], x.shape[1]
+        x4 = x.reshape((E * B,) + tuple(x.shape[2:]))
+        g4 = gy.reshape((E * B,) + tuple(gy.shape[2:]))
+        # out = am + sqrt(av) * eps  ->  d/d am = g ;  d/d av = g * eps / (2 sqrt(av)) = g * (y - am) / (2 av)
+        if cfg["sample"]:
+            gv4 = (g4 * (y - am).reshape_as(g4) / (2.0 * av.reshape_as(g4)))
+        else:
+            gv4 = torch.zeros_like(g4)
+        gx1, gwm, _ = torch.ops.aten.convolution_backward(g4, x4, w_mu, None, st, pd, dl, False, [0, 0], 1, [True, True, False])
+        gx2, gwv, _ = torch.ops.aten.convolution_backward(gv4, x4 * x4, w_var, None, st, pd, dl, False, [0, 0], 1, [True, True, False])
+        gx = (gx1 + gx2 * 2.0 * x4).reshape_as(x)
+        gbm = g4.sum(dim=(0, 2, 3)) if ctx.has_bias else None
+        gbv = gv4.sum(dim=(0, 2, 3)) if ctx.has_bias else None
+        return gx, gwm, gwv, gbm, gbv, None
+
+
+def sample_weights(mus, rhos, prior_mu, prior_sigma, stream_ids, seed, call0, draws=1, eps=None, textbook_kl=False):
+    cfg = dict(prior_mu=prior_mu, prior_sigma=prior_sigma, stream_ids=list(stream_ids), seed=seed, call0=call0,
+               draws=draws, eps=eps, textbook_kl=textbook_kl)
+    flat = []
+    for m, r in zip(mus, rhos):
+        flat += [m, r]
+    out = _SampleWeights.apply(cfg, *flat)
+    return out[0], list(out[1:])
+
+
+def kl_only(mus, rhos, prior_mu, prior_sigma, want_sigma=False, sigma_squared=False, textbook_kl=False):
+    cfg = dict(prior_mu=prior_mu, prior_sigma=prior_sigma, stream_ids=[0] * len(mus), want_sigma=want_sigma,
+               sigma_squared=sigma_squared, textbook_kl=textbook_kl)
+    flat = []
+    for m, r in zip(mus, rhos):
+        flat += [m, r]
+    out = _KLOnly.apply(cfg, *flat)
+    return out[0], list(out[1:])
+
+
+def conv2d(x, w, bias, stride=1, padding=0, dilation=1):
+    return _Conv2d.apply(x, w, bias, stride, padding, dilation)
+
+
+def lrt_conv2d(x, w_mu, w_var, b_mu, b_var, seed, call0, stream_id, stride=1, padding=0, dilation=1, sample=True, eps=None):
+    cfg = dict(seed=seed, call0=call0, stream_id=stream_id, stride=stride, padding=padding, dilation=dilation,
+               sample=sample, eps=eps)
+    return _LrtConv2d.apply(x, w_mu, w_var, b_mu, b_var, cfg)

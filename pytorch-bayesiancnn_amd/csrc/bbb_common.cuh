@@ -1,0 +1,74 @@
+// Device-side helpers shared by the gfx950 kernels: Philox4x32-10, Box-Muller on the hardware
+// transcendental units, wave64 reductions.  CDNA4 only (wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bbb {
+
+constexpr int kWave = 64;
+
+// Philox4x32-10 (Random123).  One call yields four 32-bit words = noise for four consecutive
+// elements.  The 32x32->64 products lower to v_mad_u64_u32 / v_mul_hi_u32.
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1;
+        c3 = (uint32_t)p0;
+        c0 = n0;
+        c2 = n2;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// Two uniform words -> two N(0,1).  v_log_f32 (log2), v_sqrt_f32, v_sin_f32 / v_cos_f32 (which take
+// their argument in revolutions, so 2*pi*u2 is never formed).
+__device__ __forceinline__ void box_muller(uint32_t xa, uint32_t xb, float& z0, float& z1) {
+    const float u1 = (float)((xa >> 8) + 1u) * 0x1.0p-24f;   // (0, 1], exact
+    const float u2 = (float)(xb >> 8) * 0x1.0p-24f;          // [0, 1), exact
+    const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));  // -2 ln2 log2(u1)
+    z0 = r * __builtin_amdgcn_cosf(u2);
+    z1 = r * __builtin_amdgcn_sinf(u2);
+}
+
+// eps for the four elements of group g of stream (seed, call, stream_id).
+__device__ __forceinline__ void normal4(uint64_t g, uint32_t stream_id, uint32_t call,
+                                        uint32_t k0, uint32_t k1, float (&z)[4]) {
+    uint32_t x[4];
+    philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), stream_id, call, k0, k1, x);
+    box_muller(x[0], x[1], z[0], z[1]);
+    box_muller(x[2], x[3], z[2], z[3]);
+}
+
+// softplus as the reference writes it, log1p(exp(rho)) (layers/BBB/BBBConv.py:64); rho > 20 returns rho,
+// which is the same fp32 value and does not overflow where the reference's exp does (rho > ~88).
+__device__ __forceinline__ float softplus_ref(float rho) {
+    return rho > 20.0f ? rho : log1pf(expf(rho));
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+    return v;
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, kWave));
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum_all(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+    return v;
+}
+
+}  // namespace bbb

@@ -1,0 +1,348 @@
+// Fused reparameterisation + KL for Bayes-by-Backprop layers on gfx950 (MI355X).
+//
+// One pass over (mu, rho) of up to 16 parameter tensors and E Monte-Carlo draws:
+//   sigma = log1p(exp(rho));  w[e] = mu + sigma * eps[e]  (eps from on-chip Philox4x32-10);
+//   KL term of the reference's call order (prior as "q", posterior as "p"), reduced per thread in
+//   fp64 -> wave shuffles -> LDS -> one partial per block; a second tiny kernel sums the partials in
+//   a fixed order.  HBM traffic per element: 8 B read + 4 B written per draw; eps and KL cost none.
+// Replaces layers/BBB/BBBConv.py:63-70,79-83, layers/BBB/BBBLinear.py:56-63,72-76,
+// layers/BBB_LRT/BBBConv.py:64-69,83-87, layers/BBB_LRT/BBBLinear.py:58-63,75-79, metrics.py:27-29,
+// layers/misc.py:20-23 of the reference.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/bbb_hip.h"
+#include "bbb_common.cuh"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kGroupsPerThread = 1;                          // groups of 4 elements
+constexpr int kChunk = kThreads * 4 * kGroupsPerThread;      // elements per block
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+
+struct ReparamArgs {
+    bbb_segment_t seg[BBB_MAX_SEGMENTS];
+    float* grad_mu[BBB_MAX_SEGMENTS];    // backward only
+    float* grad_rho[BBB_MAX_SEGMENTS];   // backward only
+    int32_t chunk_begin[BBB_MAX_SEGMENTS + 1];
+    int32_t nseg;
+    int32_t draws;
+    float prior_mu, prior_sigma;
+    uint32_t k0, k1, call0, flags;
+    double* partials;
+    const float* gkl;
+};
+
+// KL term exactly in the reference's operator order (metrics.py:28 with the call-site argument
+// order): 0.5 * (2*log(sig_p/sig_q) - 1 + (sig_q/sig_p)^2 + ((mu_p - mu_q)/sig_p)^2),
+// q = prior scalars, p = posterior tensors.  Correctly rounded fp32 divisions and logf.
+__device__ __forceinline__ float kl_term(float mu, float sigma, float mu0, float sig0, bool textbook) {
+    float t;
+    if (!textbook) {
+        const float a = sig0 / sigma;
+        const float b = (mu - mu0) / sigma;
+        t = 2.0f * logf(sigma / sig0) - 1.0f + a * a + b * b;
+    } else {  // KL(q||p): q = posterior, p = prior (opt-in)
+        const float a = sigma / sig0;
+        const float b = (mu0 - mu) / sig0;
+        t = 2.0f * logf(sig0 / sigma) - 1.0f + a * a + b * b;
+    }
+    return 0.5f * t;
+}
+
+__device__ __forceinline__ int find_segment(const ReparamArgs& a, int chunk) {
+    int s = 0;
+    while (s + 1 < a.nseg && chunk >= a.chunk_begin[s + 1]) ++s;
+    return s;
+}
+
+__global__ __launch_bounds__(kThreads) void reparam_kl_fwd_kernel(const ReparamArgs a) {
+    __shared__ double wave_part[kThreads / bbb::kWave];
+    const int chunk = blockIdx.x;
+    const int s = find_segment(a, chunk);
+    const bbb_segment_t sg = a.seg[s];
+    const int64_t base = (int64_t)(chunk - a.chunk_begin[s]) * kChunk;
+    const float mu0 = a.prior_mu, sig0 = a.prior_sigma;
+    const bool textbook = (a.flags & BBB_KL_TEXTBOOK) != 0;
+    const bool sq = (a.flags & BBB_SIGMA_SQUARED) != 0;
+    const bool want_kl = a.partials != nullptr;
+    // vector path needs 16-byte aligned rows for every draw
+    const bool aligned = ((((uintptr_t)sg.mu | (uintptr_t)sg.rho | (uintptr_t)sg.w | (uintptr_t)sg.sigma |
+                            (uintptr_t)sg.eps) & 15u) == 0) && ((sg.draw_stride & 3) == 0);
+
+    double kl_acc = 0.0;
+#pragma unroll
+    for (int it = 0; it < kGroupsPerThread; ++it) {
+        const int64_t i0 = base + ((int64_t)it * kThreads + threadIdx.x) * 4;
+        if (i0 >= sg.n) break;
+        const uint64_t g = (uint64_t)i0 >> 2;
+        const int cnt = (sg.n - i0) >= 4 ? 4 : (int)(sg.n - i0);
+        float mu[4], rho[4], sigma[4];
+        if (aligned && cnt == 4) {
+            const f32x4 m4 = *reinterpret_cast<const f32x4*>(sg.mu + i0);
+            const f32x4 r4 = *reinterpret_cast<const f32x4*>(sg.rho + i0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { mu[j] = m4[j]; rho[j] = r4[j]; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                mu[j] = j < cnt ? sg.mu[i0 + j] : 0.0f;
+                rho[j] = j < cnt ? sg.rho[i0 + j] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            sigma[j] = bbb::softplus_ref(rho[j]);
+            if (want_kl && j < cnt) kl_acc += (double)kl_term(mu[j], sigma[j], mu0, sig0, textbook);
+        }
+        if (sg.sigma != nullptr) {
+            if (aligned && cnt == 4) {
+                f32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = sq ? sigma[j] * sigma[j] : sigma[j];
+                *reinterpret_cast<f32x4*>(sg.sigma + i0) = o;
+            } else {
+                for (int j = 0; j < cnt; ++j) sg.sigma[i0 + j] = sq ? sigma[j] * sigma[j] : sigma[j];
+            }
+        }
+        if (sg.w != nullptr) {
+            for (int e = 0; e < a.draws; ++e) {
+                float z[4];
+                const int64_t o = (int64_t)e * sg.draw_stride + i0;
+                if (sg.eps != nullptr) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) z[j] = j < cnt ? sg.eps[o + j] : 0.0f;
+                } else {
+                    bbb::normal4(g, sg.stream_id, a.call0 + (uint32_t)e, a.k0, a.k1, z);
+                }
+                if (aligned && cnt == 4) {
+                    f32x4 w4;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) w4[j] = mu[j] + z[j] * sigma[j];   // mul then add, like the reference
+                    *reinterpret_cast<f32x4*>(sg.w + o) = w4;   // plain store: the GEMM re-reads w from L2 / Infinity Cache
+                } else {
+                    for (int j = 0; j < cnt; ++j) sg.w[o + j] = mu[j] + z[j] * sigma[j];
+                }
+            }
+        }
+    }
+
+    if (want_kl) {
+        kl_acc = bbb::wave_sum(kl_acc);
+        const int lane = threadIdx.x & (bbb::kWave - 1), wv = threadIdx.x / bbb::kWave;
+        if (lane == 0) wave_part[wv] = kl_acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+#pragma unroll
+            for (int i = 0; i < kThreads / bbb::kWave; ++i) t += wave_part[i];
+            a.partials[blockIdx.x] = t;
+        }
+    }
+}
+
+// Deterministic second stage: fixed strided order, fp64.
+__global__ __launch_bounds__(kThreads) void kl_finish_kernel(const double* partials, int n, float* out32, double* out64) {
+    __shared__ double sm[kThreads];
+    double t = 0.0;
+    for (int i = threadIdx.x; i < n; i += kThreads) t += partials[i];
+    sm[threadIdx.x] = t;
+    __syncthreads();
+    for (int s = kThreads / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (out32) *out32 = (float)sm[0];
+        if (out64) *out64 = sm[0];
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void reparam_kl_bwd_kernel(const ReparamArgs a) {
+    const int chunk = blockIdx.x;
+    const int s = find_segment(a, chunk);
+    const bbb_segment_t sg = a.seg[s];
+    float* gmu_out = a.grad_mu[s];
+    float* grho_out = a.grad_rho[s];
+    const int64_t base = (int64_t)(chunk - a.chunk_begin[s]) * kChunk;
+    const float mu0 = a.prior_mu, sig0 = a.prior_sigma;
+    const bool textbook = (a.flags & BBB_KL_TEXTBOOK) != 0;
+    const float gkl = a.gkl ? *a.gkl : 0.0f;
+    const bool aligned = ((((uintptr_t)sg.mu | (uintptr_t)sg.rho | (uintptr_t)sg.w | (uintptr_t)sg.eps |
+                            (uintptr_t)gmu_out | (uintptr_t)grho_out) & 15u) == 0) && ((sg.draw_stride & 3) == 0);
+#pragma unroll
+    for (int it = 0; it < kGroupsPerThread; ++it) {
+        const int64_t i0 = base + ((int64_t)it * kThreads + threadIdx.x) * 4;
+        if (i0 >= sg.n) break;
+        const uint64_t g = (uint64_t)i0 >> 2;
+        const int cnt = (sg.n - i0) >= 4 ? 4 : (int)(sg.n - i0);
+        float mu[4], rho[4];
+        if (aligned && cnt == 4) {
+            const f32x4 m4 = *reinterpret_cast<const f32x4*>(sg.mu + i0);
+            const f32x4 r4 = *reinterpret_cast<const f32x4*>(sg.rho + i0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { mu[j] = m4[j]; rho[j] = r4[j]; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                mu[j] = j < cnt ? sg.mu[i0 + j] : 0.0f;
+                rho[j] = j < cnt ? sg.rho[i0 + j] : 0.0f;
+            }
+        }
+        float acc_mu[4] = {0, 0, 0, 0}, acc_sig[4] = {0, 0, 0, 0};
+        if (sg.w != nullptr) {
+            for (int e = 0; e < a.draws; ++e) {
+                float z[4], gw[4];
+                const int64_t o = (int64_t)e * sg.draw_stride + i0;
+                if (sg.eps != nullptr) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) z[j] = j < cnt ? sg.eps[o + j] : 0.0f;
+                } else {
+                    bbb::normal4(g, sg.stream_id, a.call0 + (uint32_t)e, a.k0, a.k1, z);
+                }
+                if (aligned && cnt == 4) {
+                    const f32x4 g4 = *reinterpret_cast<const f32x4*>(sg.w + o);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) gw[j] = g4[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) gw[j] = j < cnt ? sg.w[o + j] : 0.0f;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { acc_mu[j] += gw[j]; acc_sig[j] += gw[j] * z[j]; }
+            }
+        }
+        float gm[4], gr[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float sigma = bbb::softplus_ref(rho[j]);
+            const float sgm = 1.0f / (1.0f + expf(-rho[j]));     // d sigma / d rho
+            const float d = mu[j] - mu0;
+            const float is = 1.0f / sigma;
+            float kmu, ksig;
+            if (!textbook) {
+                kmu = d * is * is;
+                ksig = is - (sig0 * sig0 + d * d) * is * is * is;
+            } else {
+                kmu = d / (sig0 * sig0);
+                ksig = sigma / (sig0 * sig0) - is;
+            }
+            gm[j] = acc_mu[j] + gkl * kmu;
+            gr[j] = (acc_sig[j] + gkl * ksig) * sgm;
+        }
+        if (aligned && cnt == 4) {
+            f32x4 a4, b4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { a4[j] = gm[j]; b4[j] = gr[j]; }
+            *reinterpret_cast<f32x4*>(gmu_out + i0) = a4;
+            *reinterpret_cast<f32x4*>(grho_out + i0) = b4;
+        } else {
+            for (int j = 0; j < cnt; ++j) { gmu_out[i0 + j] = gm[j]; grho_out[i0 + j] = gr[j]; }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void eps_dump_kernel(float* out, int64_t n, int64_t start, uint32_t k0, uint32_t k1,
+                                                            uint32_t call, uint32_t stream_id) {
+    const int64_t g0 = start >> 2;
+    const int64_t g = g0 + (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    float z[4];
+    bbb::normal4((uint64_t)g, stream_id, call, k0, k1, z);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t i = g * 4 + j - start;
+        if (i >= 0 && i < n) out[i] = z[j];
+    }
+}
+
+int fill_args(ReparamArgs& a, const bbb_segment_t* segs, int nseg, int draws, bool bwd) {
+    if (segs == nullptr || nseg <= 0 || nseg > BBB_MAX_SEGMENTS || draws <= 0) return BBB_EINVAL;
+    int chunks = 0;
+    for (int s = 0; s < nseg; ++s) {
+        const bbb_segment_t& g = segs[s];
+        if (g.mu == nullptr || g.rho == nullptr || g.n <= 0) return BBB_EINVAL;
+        if (g.draw_stride < g.n && draws > 1 && (g.w || g.eps)) return BBB_EINVAL;
+        if ((((uintptr_t)g.mu | (uintptr_t)g.rho | (uintptr_t)g.w | (uintptr_t)g.sigma | (uintptr_t)g.eps) & 3u) != 0)
+            return BBB_EALIGN;
+        a.seg[s] = g;
+        a.chunk_begin[s] = chunks;
+        chunks += (int)((g.n + kChunk - 1) / kChunk);
+        (void)bwd;
+    }
+    for (int s = nseg; s <= BBB_MAX_SEGMENTS; ++s) a.chunk_begin[s] = chunks;
+    a.nseg = nseg;
+    a.draws = draws;
+    return chunks;
+}
+
+}  // namespace
+
+extern "C" int64_t bbb_reparam_partials(const bbb_segment_t* segs, int nseg) {
+    if (segs == nullptr || nseg <= 0 || nseg > BBB_MAX_SEGMENTS) return BBB_EINVAL;
+    int64_t chunks = 0;
+    for (int s = 0; s < nseg; ++s) chunks += (segs[s].n + kChunk - 1) / kChunk;
+    return chunks;
+}
+
+extern "C" int bbb_reparam_kl_fwd(const bbb_segment_t* segs, int nseg, int draws, float prior_mu, float prior_sigma,
+                                  uint64_t seed, uint32_t call0, uint32_t flags, double* kl_partials, float* kl_out,
+                                  double* kl_out64, void* stream) {
+    ReparamArgs a = {};
+    const int chunks = fill_args(a, segs, nseg, draws, false);
+    if (chunks < 0) return chunks;
+    const bool want_kl = (kl_out != nullptr) || (kl_out64 != nullptr);
+    if (want_kl && kl_partials == nullptr) return BBB_EINVAL;
+    if (!(prior_sigma > 0.0f)) return BBB_EINVAL;
+    a.prior_mu = prior_mu;
+    a.prior_sigma = prior_sigma;
+    a.k0 = (uint32_t)seed;
+    a.k1 = (uint32_t)(seed >> 32);
+    a.call0 = call0;
+    a.flags = flags;
+    a.partials = want_kl ? kl_partials : nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(reparam_kl_fwd_kernel, dim3(chunks), dim3(kThreads), 0, st, a);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return (int)err;
+    if (want_kl) {
+        hipLaunchKernelGGL(kl_finish_kernel, dim3(1), dim3(kThreads), 0, st, (const double*)kl_partials, chunks, kl_out, kl_out64);
+        err = hipGetLastError();
+    }
+    return (int)err;
+}
+
+extern "C" int bbb_reparam_kl_bwd(const bbb_segment_t* segs, int nseg, int draws, float prior_mu, float prior_sigma,
+                                  uint64_t seed, uint32_t call0, uint32_t flags, const float* gkl,
+                                  float* const* grad_mu, float* const* grad_rho, void* stream) {
+    ReparamArgs a = {};
+    const int chunks = fill_args(a, segs, nseg, draws, true);
+    if (chunks < 0) return chunks;
+    if (grad_mu == nullptr || grad_rho == nullptr || !(prior_sigma > 0.0f)) return BBB_EINVAL;
+    for (int s = 0; s < nseg; ++s) {
+        if (grad_mu[s] == nullptr || grad_rho[s] == nullptr) return BBB_EINVAL;
+        if ((((uintptr_t)grad_mu[s] | (uintptr_t)grad_rho[s]) & 3u) != 0) return BBB_EALIGN;
+        a.grad_mu[s] = grad_mu[s];
+        a.grad_rho[s] = grad_rho[s];
+    }
+    a.prior_mu = prior_mu;
+    a.prior_sigma = prior_sigma;
+    a.k0 = (uint32_t)seed;
+    a.k1 = (uint32_t)(seed >> 32);
+    a.call0 = call0;
+    a.flags = flags;
+    a.gkl = gkl;
+    hipLaunchKernelGGL(reparam_kl_bwd_kernel, dim3(chunks), dim3(kThreads), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int bbb_eps_dump(float* out, int64_t n, int64_t start, uint64_t seed, uint32_t call, uint32_t stream_id, void* stream) {
+    if (out == nullptr || n <= 0 || start < 0) return BBB_EINVAL;
+    const int64_t groups = ((start + n + 3) >> 2) - (start >> 2);
+    const int blocks = (int)((groups + kThreads - 1) / kThreads);
+    hipLaunchKernelGGL(eps_dump_kernel, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, out, n, start,
+                       (uint32_t)seed, (uint32_t)(seed >> 32), call, stream_id);
+    return (int)hipGetLastError();
+}

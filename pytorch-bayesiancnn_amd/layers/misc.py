@@ -1,0 +1,38 @@
+"""ModuleWrapper / FlattenLayer with the reference's semantics (layers/misc.py:4-35 upstream).
+
+ModuleWrapper.forward: run the registered children in definition order, then return
+(output, sum of kl_loss() over every sub-module that has one) -- the models define no forward of their
+own, so attribute order is the graph.
+"""
+from torch import nn
+
+
+class ModuleWrapper(nn.Module):
+    """nn.Module with recursive flags and the universal (x) -> (x, kl) forward."""
+
+    def set_flag(self, flag_name, value):
+        setattr(self, flag_name, value)
+        for child in self.children():
+            setter = getattr(child, "set_flag", None)
+            if setter is not None:
+                setter(flag_name, value)
+
+    def forward(self, x):
+        for child in self.children():
+            x = child(x)
+        kl = 0.0
+        for mod in self.modules():          # self included, like the reference
+            if hasattr(mod, "kl_loss"):
+                kl = kl + mod.kl_loss()
+        return x, kl
+
+
+class FlattenLayer(ModuleWrapper):
+    """x.view(-1, num_features): [B,128,1,1] -> [B,128]; a 224x224 AlexNet input gives [B*49, 128]."""
+
+    def __init__(self, num_features):
+        super().__init__()
+        self.num_features = num_features
+
+    def forward(self, x):
+        return x.view(-1, self.num_features)

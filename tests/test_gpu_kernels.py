@@ -1,0 +1,237 @@
+"""HIP kernels (through the C ABI / ctypes) against the numpy oracle and the reference-generated fixtures.
+Needs an MI355X: run with -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+import bbb_numpy as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from bbb_hip import ops as _ops
+    return _ops
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).cuda()
+
+
+# ---------------------------------------------------------------- noise stream
+def test_eps_matches_oracle_stream(ops):
+    seed, call, stream = 0x1234567890ABCDEF, 7, 13
+    got = ops.eps_dump(100003, seed, call, stream, "cuda").cpu().numpy()
+    want = O.normal_eps(seed, call, stream, 100003)
+    # hardware log2 / sin / cos vs float64 libm: stated tolerance 2e-5 absolute on N(0,1) samples
+    assert np.max(np.abs(got - want)) < 2e-5
+    off = ops.eps_dump(1001, seed, call, stream, "cuda", start=4099).cpu().numpy()
+    np.testing.assert_array_equal(off, got[4099:5100])
+
+
+def test_eps_moments(ops):
+    z = ops.eps_dump(1 << 22, 99, 0, 1, "cuda").double()
+    assert abs(z.mean().item()) < 2e-3 and abs(z.std().item() - 1) < 2e-3
+    assert abs((z ** 3).mean().item()) < 1e-2 and abs((z ** 4).mean().item() - 3) < 3e-2
+    assert torch.isfinite(z).all()
+
+
+# ---------------------------------------------------------------- fused reparam + KL
+@pytest.mark.parametrize("n", [1, 3, 4, 5, 1023, 1024, 1025, 40003])
+def test_reparam_kl_ragged_sizes(ops, n):
+    rng = np.random.default_rng(n)
+    mu = (rng.standard_normal(n) * 0.1).astype(np.float32)
+    rho = (rng.standard_normal(n) * 0.1 - 5).astype(np.float32)
+    eps = rng.standard_normal((3, n)).astype(np.float32)
+    ws, sig, kl = ops.reparam_kl_forward([dev(mu)], [dev(rho)], 0.0, 0.1, [5], 1, 0, draws=3, want_sigma=True,
+                                         eps=[dev(eps)])
+    s = O.sigma_from_rho(rho)
+    np.testing.assert_allclose(sig[0].cpu().numpy(), s, rtol=3e-7)
+    np.testing.assert_allclose(ws[0].cpu().numpy(), mu[None] + eps * s[None], rtol=1e-6, atol=1e-7)
+    want = O.kl_loss(mu, s, 0.0, 0.1)
+    assert abs(kl.item() - want) <= 1e-6 * abs(want)
+
+
+def test_reparam_kl_multitensor_philox_and_determinism(ops):
+    rng = np.random.default_rng(0)
+    shapes = [(64, 3, 11, 11), (64,), (192, 64, 5, 5), (192,), (10, 128), (10,), (7,)]
+    mus = [(rng.standard_normal(s) * 0.1).astype(np.float32) for s in shapes]
+    rhos = [(rng.standard_normal(s) * 0.1 - 5).astype(np.float32) for s in shapes]
+    ids = list(range(len(shapes)))
+    seed, call0, E = 42, 3, 4
+    dm, dr = [dev(m) for m in mus], [dev(r) for r in rhos]
+    ws, _, kl = ops.reparam_kl_forward(dm, dr, 0.0, 0.1, ids, seed, call0, draws=E)
+    ws2, _, kl2 = ops.reparam_kl_forward(dm, dr, 0.0, 0.1, ids, seed, call0, draws=E)
+    assert kl.item() == kl2.item()                        # fixed reduction tree: bitwise reproducible
+    want_kl = sum(O.kl_loss(m, O.sigma_from_rho(r), 0.0, 0.1) for m, r in zip(mus, rhos))
+    assert abs(kl.item() - want_kl) <= 1e-6 * want_kl
+    for i, (m, r) in enumerate(zip(mus, rhos)):
+        assert torch.equal(ws[i], ws2[i])
+        s = O.sigma_from_rho(r).reshape(-1)
+        for e in range(E):
+            eps = O.normal_eps(seed, call0 + e, ids[i], m.size)
+            want = m.reshape(-1) + eps * s
+            np.testing.assert_allclose(ws[i][e].cpu().numpy().reshape(-1), want, rtol=1e-6, atol=2e-7)
+    # draw e of a batched launch == a single-draw launch at call0 + e
+    w1, _, _ = ops.reparam_kl_forward(dm, dr, 0.0, 0.1, ids, seed, call0 + 2, draws=1)
+    for i in range(len(shapes)):
+        assert torch.equal(w1[i][0], ws[i][2])
+
+
+def test_reparam_kl_against_reference_fixture(ops, golden):
+    Fn = golden["functions"]
+    _, sig, kl = ops.reparam_kl_forward([dev(Fn["kl.mu"])], [dev(Fn["kl.rho"])], 0, 0.1, [0], 0, 0, sample=False, want_sigma=True)
+    np.testing.assert_allclose(sig[0].cpu().numpy(), Fn["kl.sigma"], rtol=3e-7)
+    assert abs(kl.item() - float(Fn["kl.value_cfg"])) <= 2e-6 * float(Fn["kl.value_cfg"])
+    _, _, klt = ops.reparam_kl_forward([dev(Fn["kl.mu"])], [dev(Fn["kl.rho"])], 0, 0.1, [0], 0, 0, sample=False, textbook_kl=True)
+    assert abs(klt.item() - float(Fn["kl.value_textbook"])) <= 2e-6 * float(Fn["kl.value_textbook"])
+    _, s2, _ = ops.reparam_kl_forward([dev(Fn["kl.mu"])], [dev(Fn["kl.rho"])], 0, 0.1, [0], 0, 0, sample=False, want_sigma=True,
+                                      sigma_squared=True, want_kl=False)
+    np.testing.assert_allclose(s2[0].cpu().numpy(), Fn["kl.sigma"] ** 2, rtol=6e-7)
+
+
+def test_reparam_large_rho_is_finite(ops):
+    mu = torch.zeros(8, device="cuda")
+    rho = torch.tensor([-30., -10., 0., 10., 19.9, 20.1, 60., 100.], device="cuda")
+    _, sig, _ = ops.reparam_kl_forward([mu], [rho], 0, 0.1, [0], 0, 0, sample=False, want_sigma=True)
+    with np.errstate(over="ignore"):
+        want = O.sigma_from_rho(rho.cpu().numpy())
+    got = sig[0].cpu().numpy()
+    np.testing.assert_allclose(got[:7], want[:7], rtol=3e-7)
+    assert got[7] == 100.0 and np.isinf(want[7])       # documented departure: no overflow
+
+
+def test_reparam_backward_matches_oracle_grads(ops):
+    rng = np.random.default_rng(3)
+    n, E = 777, 3
+    mu = (rng.standard_normal(n) * 0.1).astype(np.float32)
+    rho = (rng.standard_normal(n) * 0.3 - 3).astype(np.float32)
+    gw = rng.standard_normal((E, n)).astype(np.float32)
+    seed, call0, sid = 5, 11, 2
+    gkl = torch.tensor(0.37, device="cuda")
+    gm, gr = ops.reparam_kl_backward([dev(mu)], [dev(rho)], [dev(gw)], gkl, 0.0, 0.1, [sid], seed, call0, E)
+    eps = np.stack([O.normal_eps(seed, call0 + e, sid, n) for e in range(E)]).astype(np.float64)
+    kmu, krho = O.kl_grads(mu, rho, 0.0, 0.1)
+    sgm = 1 / (1 + np.exp(-rho.astype(np.float64)))
+    np.testing.assert_allclose(gm[0].cpu().numpy(), gw.sum(0) + 0.37 * kmu, rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(gr[0].cpu().numpy(), (gw * eps).sum(0) * sgm + 0.37 * krho, rtol=2e-4, atol=2e-4)
+
+
+# ---------------------------------------------------------------- conv / linear on the fp32 matrix cores
+CONV_CASES = [
+    # B, Cin, H, W, Cout, kh, kw, stride, pad, dil, E, x_shared
+    (2, 3, 9, 9, 5, 3, 3, 2, 1, 1, 1, False),
+    (3, 2, 8, 7, 4, 2, 3, 1, 2, 2, 1, False),       # ragged kernel, dilation
+    (5, 3, 32, 32, 64, 11, 11, 4, 5, 1, 2, True),   # AlexNet conv1 geometry, K = 363 (not a multiple of 4)
+    (4, 64, 4, 4, 192, 5, 5, 1, 2, 1, 3, False),    # AlexNet conv2
+    (7, 192, 2, 2, 384, 3, 3, 1, 1, 1, 2, False),   # AlexNet conv3 (2x2 images)
+    (6, 1, 32, 32, 6, 5, 5, 1, 0, 1, 1, False),     # LeNet conv1 (Cout = 6 << tile)
+    (3, 32, 15, 15, 64, 5, 5, 1, 2, 1, 1, False),   # 3Conv3FC conv2
+    (130, 16, 6, 6, 70, 3, 3, 1, 1, 1, 1, False),   # M and Cout straddle tiles
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_against_oracle(ops, case):
+    B, Cin, H, W, Cout, kh, kw, s, p, d, E, shared = case
+    rng = np.random.default_rng(sum(case[:11]))
+    x = rng.standard_normal((1 if shared else E, B, Cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((E, Cout, Cin, kh, kw)) * 0.1).astype(np.float32)
+    b = rng.standard_normal((E, Cout)).astype(np.float32)
+    y = ops.conv2d_forward(dev(x), dev(w), dev(b), s, p, d).cpu().numpy()
+    for e in range(E):
+        want = O.conv2d(x[0 if shared else e], w[e], b[e], s, p, d)
+        # fp32 fmaf chain vs fp64 accumulation: ~1e-7 * sum|a*b|; stated as rtol/atol 2e-5 on O(1) outputs
+        np.testing.assert_allclose(y[e], want, rtol=2e-5, atol=2e-5)
+
+
+def test_conv2d_transpose_detecting(ops):
+    """Asymmetric operands: a swapped row/col or (kh,kw) mapping cannot pass."""
+    B, Cin, H, W, Cout = 1, 2, 5, 6, 3
+    x = np.arange(B * Cin * H * W, dtype=np.float32).reshape(1, B, Cin, H, W) / 10
+    w = np.zeros((1, Cout, Cin, 2, 3), np.float32)
+    w[0, 1, 0, 0, 2] = 1.0
+    w[0, 2, 1, 1, 0] = -2.0
+    y = ops.conv2d_forward(dev(x), dev(w), None, 1, 0, 1).cpu().numpy()[0]
+    np.testing.assert_allclose(y, O.conv2d(x[0], w[0], None, 1, 0, 1), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("M,K,N,E", [(5, 7, 4, 1), (64, 400, 120, 2), (256, 512, 1000, 1), (512, 128, 10, 3), (33, 84, 10, 1)])
+def test_linear_against_oracle(ops, M, K, N, E):
+    rng = np.random.default_rng(M * K + N)
+    x = rng.standard_normal((E, M, K)).astype(np.float32)
+    w = (rng.standard_normal((E, N, K)) * 0.1).astype(np.float32)
+    b = rng.standard_normal((E, N)).astype(np.float32)
+    y = ops.conv2d_forward(dev(x).reshape(E, M, K, 1, 1), dev(w).reshape(E, N, K, 1, 1), dev(b)).cpu().numpy().reshape(E, M, N)
+    for e in range(E):
+        np.testing.assert_allclose(y[e], O.linear(x[e], w[e], b[e]), rtol=2e-5, atol=2e-5)
+
+
+def test_conv2d_fused_activation(ops):
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((1, 4, 3, 8, 8)).astype(np.float32) * 5
+    w = rng.standard_normal((1, 6, 3, 3, 3)).astype(np.float32)
+    base = O.conv2d(x[0], w[0], None, 1, 1, 1)
+    np.testing.assert_allclose(ops.conv2d_forward(dev(x), dev(w), None, 1, 1, 1, act="relu").cpu().numpy()[0], O.relu_act(base), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(ops.conv2d_forward(dev(x), dev(w), None, 1, 1, 1, act="softplus").cpu().numpy()[0], O.softplus_act(base), rtol=2e-5, atol=2e-5)
+
+
+# ---------------------------------------------------------------- LRT dual-accumulator kernel
+@pytest.mark.parametrize("case", [(3, 4, 6, 6, 6, 3, 1, 1, 2), (2, 3, 32, 32, 64, 11, 4, 5, 1), (5, 64, 4, 4, 192, 5, 1, 2, 2), (9, 40, 1, 1, 10, 1, 1, 0, 1)])
+def test_lrt_moments_and_output(ops, case):
+    B, Cin, H, W, Cout, k, s, p, E = case
+    rng = np.random.default_rng(sum(case))
+    x = rng.random((E, B, Cin, H, W)).astype(np.float32)
+    wmu = (rng.standard_normal((Cout, Cin, k, k)) * 0.1).astype(np.float32)
+    wrho = (rng.standard_normal((Cout, Cin, k, k)) * 0.1 - 3).astype(np.float32)
+    bmu = (rng.standard_normal(Cout) * 0.1).astype(np.float32)
+    brho = (rng.standard_normal(Cout) * 0.1 - 3).astype(np.float32)
+    wvar = O.sigma_from_rho(wrho) ** 2
+    bvar = O.sigma_from_rho(brho) ** 2
+    seed, call0, sid = 77, 5, 6
+    y, am, av = ops.lrt_conv2d_forward(dev(x), dev(wmu), dev(wvar), dev(bmu), dev(bvar), seed, call0, sid, s, p, 1, want_moments=True)
+    for e in range(E):
+        wam, wav = O.lrt_moments_conv2d(x[e], wmu, wrho, bmu, brho, s, p, 1)
+        np.testing.assert_allclose(am[e].cpu().numpy(), wam, rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(av[e].cpu().numpy(), wav, rtol=3e-5, atol=1e-9)
+        eps = O.normal_eps(seed, call0 + e, sid, wam.size).reshape(wam.shape)
+        np.testing.assert_allclose(y[e].cpu().numpy(), O.lrt_output(wam, wav, eps), rtol=3e-5, atol=3e-5)
+    # external eps (replay entry) and sample=False
+    eps = rng.standard_normal(tuple(y.shape)).astype(np.float32)
+    y2, _, _ = ops.lrt_conv2d_forward(dev(x), dev(wmu), dev(wvar), dev(bmu), dev(bvar), 0, 0, 0, s, p, 1, eps=dev(eps))
+    y3, _, _ = ops.lrt_conv2d_forward(dev(x), dev(wmu), dev(wvar), dev(bmu), dev(bvar), 0, 0, 0, s, p, 1, sample=False)
+    for e in range(E):
+        wam, wav = O.lrt_moments_conv2d(x[e], wmu, wrho, bmu, brho, s, p, 1)
+        np.testing.assert_allclose(y2[e].cpu().numpy(), O.lrt_output(wam, wav, eps[e]), rtol=3e-5, atol=3e-5)
+        np.testing.assert_allclose(y3[e].cpu().numpy(), wam, rtol=2e-5, atol=2e-5)
+
+
+# ---------------------------------------------------------------- Monte-Carlo tail
+@pytest.mark.parametrize("E,B,C", [(1, 4, 10), (10, 512, 10), (3, 7, 100), (25, 16, 257)])
+def test_mc_tail(ops, E, B, C):
+    rng = np.random.default_rng(E * B + C)
+    z = (rng.standard_normal((E, B, C)) * 4).astype(np.float32)
+    got = ops.mc_tail(dev(z), mean_over=E).cpu().numpy()
+    np.testing.assert_allclose(got, O.mc_log_outputs(z), rtol=2e-6, atol=2e-6)
+    lse = ops.mc_tail(dev(z), mean_over=0).cpu().numpy()
+    np.testing.assert_allclose(lse - np.log(E), got, rtol=2e-6, atol=2e-6)
+
+
+def test_mc_tail_against_reference_fixture(ops, golden):
+    M = golden["models"]
+    got = ops.mc_tail(dev(M["mc_lenet.logits"]), mean_over=3).cpu().numpy()
+    np.testing.assert_allclose(got, M["mc_lenet.log_outputs"], rtol=1e-5, atol=2e-6)
+
+
+# ---------------------------------------------------------------- argument errors
+def test_errors_are_loud(ops):
+    from bbb_hip import BBBHipError
+    with pytest.raises(BBBHipError):
+        ops.conv2d_forward(torch.zeros(1, 1, 3, 4, 4), torch.zeros(1, 2, 3, 3, 3), None)          # CPU tensors
+    with pytest.raises(BBBHipError):
+        ops.conv2d_forward(torch.zeros(1, 1, 3, 4, 4).cuda(), torch.zeros(1, 2, 4, 3, 3).cuda(), None)  # channel mismatch
+    with pytest.raises(BBBHipError):
+        ops.conv2d_forward(torch.zeros(1, 1, 3, 2, 2).cuda(), torch.zeros(1, 2, 3, 3, 3).cuda(), None)  # kernel > image
+    with pytest.raises(BBBHipError):
+        ops.reparam_kl_forward([torch.zeros(4).cuda()], [torch.zeros(4).cuda()], 0, -1.0, [0], 0, 0)     # bad prior sigma
