@@ -1,0 +1,269 @@
+"""The num_ens Monte-Carlo loop of the reference, batched over draws and sharded over GPUs.
+
+Reference semantics (main_bayesian.py:43-53 train, :73-80 validate):
+    for j in range(num_ens): net_out, _kl = net(x); kl += _kl; outputs[:, :, j] = log_softmax(net_out, 1)
+    log_outputs = utils.logmeanexp(outputs, dim=2)
+Here the E draws run as ONE pass: one fused reparam+KL launch materialises the E weight sets of every
+layer (draw j uses noise call index call0 + j, so the result equals the Python loop over `net(x)`), each
+conv / linear is one launch batched over draws, and one tail kernel does log_softmax + log-sum-exp over
+draws.  Multi-GPU: contiguous blocks of draws per rank (parameters replicated, no weight traffic), local
+log-sum-exp, ONE all_gather of [B*C + 1] floats (the lse block + the KL sum) over RCCL, then a log-sum-exp
+over ranks in rank order -- every rank ends with the same bits.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops, rng, _lib
+
+try:
+    from layers.bbb import _BBBLayer, BBBConv2d as _BBBConv, BBBLinear as _BBBLin
+    from layers.lrt import _LRTLayer, BBBConv2d as _LRTConv, BBBLinear as _LRTLin
+    from layers.misc import FlattenLayer
+except ImportError as e:  # pragma: no cover
+    raise ImportError("bbb_hip.ensemble needs the sibling `layers` package on sys.path") from e
+
+
+def draw_range(num_ens, rank, world):
+    """Contiguous, balanced block of global draw indices for `rank`: [lo, hi)."""
+    base, rem = divmod(num_ens, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def bayesian_layers(net):
+    return [m for m in net.modules() if isinstance(m, (_BBBLayer, _LRTLayer))]
+
+
+class Timers:
+    """Optional HIP-event brackets around individual kernel launches (bench.py roofline)."""
+
+    def __init__(self):
+        self.records = []   # (tag, info, start_event, end_event)
+
+    def bracket(self, tag, info, fn):
+        s = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        s.record()
+        out = fn()
+        e.record()
+        self.records.append((tag, info, s, e))
+        return out
+
+    def summary(self):
+        agg = {}
+        for tag, info, s, e in self.records:
+            a = agg.setdefault(tag, {"ms": 0.0, "n": 0, "work": 0.0})
+            a["ms"] += s.elapsed_time(e)
+            a["n"] += 1
+            a["work"] += info
+        return agg
+
+
+def _run(timers, tag, info, fn):
+    return timers.bracket(tag, info, fn) if timers is not None else fn()
+
+
+def _sample_all(layers, draws, seed, call0, timers=None, eps=None):
+    """One fused launch (per <=16 tensors) for every BBB layer: -> ({layer: (w, b)}, kl)."""
+    mus, rhos, ids, owners = [], [], [], []
+    for l in layers:
+        m, r, i = l._param_lists()
+        mus += m
+        rhos += r
+        ids += i
+        owners += [l] * len(m)
+    pri = {(l.prior_mu, l.prior_sigma) for l in layers}
+    out, kl_total = {}, None
+    ws_all = []
+    if len(pri) == 1:
+        pm, ps = next(iter(pri))
+        for s in range(0, len(mus), _lib.MAX_SEGMENTS):
+            sl = slice(s, s + _lib.MAX_SEGMENTS)
+            n_el = sum(m.numel() for m in mus[sl])
+            kl, ws = _run(timers, "reparam_kl", n_el,
+                          lambda: ops.sample_weights(mus[sl], rhos[sl], pm, ps, ids[sl], seed, call0, draws,
+                                                     eps=None if eps is None else eps[sl]))
+            kl_total = kl if kl_total is None else kl_total + kl
+            ws_all += ws
+    else:  # layers with different priors: one launch per layer
+        k = 0
+        for l in layers:
+            m, r, i = l._param_lists()
+            kl, ws = ops.sample_weights(m, r, l.prior_mu, l.prior_sigma, i, seed, call0, draws,
+                                        eps=None if eps is None else eps[k:k + len(m)])
+            k += len(m)
+            kl_total = kl if kl_total is None else kl_total + kl
+            ws_all += ws
+    k = 0
+    for l in layers:
+        w = ws_all[k]
+        b = ws_all[k + 1] if l.use_bias else None
+        k += 2 if l.use_bias else 1
+        out[l] = (w, b)
+    return out, kl_total
+
+
+def _variances_all(layers, timers=None):
+    """One fused launch for every LRT layer: sigma^2 tensors + KL."""
+    mus, rhos = [], []
+    for l in layers:
+        m, r, _ = l._param_lists()
+        mus += m
+        rhos += r
+    pri = {(l.prior_mu, l.prior_sigma) for l in layers}
+    if len(pri) != 1 or len(mus) > _lib.MAX_SEGMENTS:
+        out, kl_total = {}, None
+        for l in layers:
+            m, r, _ = l._param_lists()
+            kl, s2 = ops.kl_only(m, r, l.prior_mu, l.prior_sigma, want_sigma=True, sigma_squared=True)
+            out[l] = (s2[0], s2[1] if l.use_bias else None)
+            kl_total = kl if kl_total is None else kl_total + kl
+        return out, kl_total
+    pm, ps = next(iter(pri))
+    kl, s2 = _run(timers, "reparam_kl", sum(m.numel() for m in mus),
+                  lambda: ops.kl_only(mus, rhos, pm, ps, want_sigma=True, sigma_squared=True))
+    out, k = {}, 0
+    for l in layers:
+        out[l] = (s2[k], s2[k + 1] if l.use_bias else None)
+        k += 2 if l.use_bias else 1
+    return out, kl
+
+
+def _act_name(mod):
+    if isinstance(mod, nn.ReLU):
+        return "relu"
+    if isinstance(mod, nn.Softplus) and mod.beta == 1 and mod.threshold == 20:
+        return "softplus"
+    return None
+
+
+def mc_logits(net, x, draws, seed, call0, fuse_act=True, timers=None, eps=None):
+    """E stochastic forwards of `net` on the same batch x -> (logits [E, B', C], kl of ONE forward).
+
+    Equivalent to `[net(x)[0] for _ in range(E)]` under noise calls call0 .. call0+E-1 (B' = B except for
+    the 224x224 AlexNet flatten quirk, where B' = B*49)."""
+    _lib.require_device(x)
+    layers = bayesian_layers(net)
+    bbb = [l for l in layers if isinstance(l, _BBBLayer)]
+    lrt = [l for l in layers if isinstance(l, _LRTLayer)]
+    kl = None
+    sampled, variances = {}, {}
+    if bbb:
+        sampled, k1 = _sample_all(bbb, draws, seed, call0, timers, eps)
+        kl = k1
+    if lrt:
+        variances, k2 = _variances_all(lrt, timers)
+        kl = k2 if kl is None else kl + k2
+    E = draws
+    h = x.unsqueeze(0)                      # [1, B, ...] shared by all draws until a Bayesian layer splits it
+    children = list(net.children())
+    i = 0
+    while i < len(children):
+        mod = children[i]
+        nxt = children[i + 1] if i + 1 < len(children) else None
+        act = _act_name(nxt) if (fuse_act and nxt is not None) else None
+        if isinstance(mod, (_BBBLayer, _LRTLayer)):
+            is_conv = isinstance(mod, (_BBBConv, _LRTConv))
+            if is_conv:
+                h5 = h
+                geom = (mod.stride, mod.padding, mod.dilation)
+            else:
+                h5 = h.reshape(h.shape[0], -1, mod.in_features, 1, 1)
+                geom = (1, 0, 1)
+            if isinstance(mod, _BBBLayer):
+                w, b = sampled[mod]
+                if not is_conv:
+                    w = w.reshape(E, mod.out_features, mod.in_features, 1, 1)
+                flops = 2.0 * E * h5.shape[1] * w[0].numel()
+                if torch.is_grad_enabled() and (h5.requires_grad or w.requires_grad):
+                    y = ops.conv2d(h5, w, b, *geom)
+                    if act is not None:
+                        y = F.relu(y) if act == "relu" else F.softplus(y)
+                else:
+                    y = _run(timers, "conv_gemm", flops, lambda: ops.conv2d_forward(h5, w, b, *geom, act=act))
+            else:
+                w_var, b_var = variances[mod]
+                w_mu = mod.W_mu
+                if not is_conv:
+                    shp = (mod.out_features, mod.in_features, 1, 1)
+                    w_mu, w_var = w_mu.reshape(shp), w_var.reshape(shp)
+                if h5.shape[0] == 1 and E > 1:
+                    h5 = h5.expand(E, *h5.shape[1:])
+                if torch.is_grad_enabled() and (h5.requires_grad or w_mu.requires_grad):
+                    y = ops.lrt_conv2d(h5, w_mu, w_var, mod.bias_mu if mod.use_bias else None, b_var, seed, call0,
+                                       mod._stream_base + 2, *geom, sample=True)
+                    if act is not None:
+                        y = F.relu(y) if act == "relu" else F.softplus(y)
+                else:
+                    flops = 4.0 * E * h5.shape[1] * w_mu.numel()
+                    y = _run(timers, "lrt_gemm", flops,
+                             lambda: ops.lrt_conv2d_forward(h5, w_mu, w_var, mod.bias_mu if mod.use_bias else None, b_var,
+                                                            seed, call0, mod._stream_base + 2, *geom, sample=True, act=act)[0])
+            if not is_conv:
+                y = y.reshape(E, -1, mod.out_features)
+            h = y
+            if act is not None:
+                i += 1                       # the activation module was fused into the epilogue
+        elif isinstance(mod, FlattenLayer):
+            h = h.reshape(h.shape[0], -1, mod.num_features)
+        else:                                # stock torch module (pool, activation, ...): fold draws into batch
+            lead = h.shape[:2]
+            y = mod(h.reshape(-1, *h.shape[2:]))
+            h = y.reshape(*lead, *y.shape[1:])
+        i += 1
+    if h.shape[0] == 1 and E > 1:
+        h = h.expand(E, *h.shape[1:])
+    return h, kl
+
+
+def mc_forward(net, x, num_ens, group=None, fuse_act=True, timers=None, kl_mode="sum"):
+    """One Monte-Carlo step: -> (log_outputs [B, C], kl).
+
+    kl_mode "sum": kl summed over the num_ens calls as validate_model does (main_bayesian.py:76-77);
+            "mean": divided by num_ens as train_model does (main_bayesian.py:51).
+    With a process group, rank r runs draws draw_range(num_ens, r, world) and the ranks combine through one
+    all_gather; every rank returns identical values."""
+    world = 1 if group is None else torch.distributed.get_world_size(group)
+    rank = 0 if group is None else torch.distributed.get_rank(group)
+    seed, call0 = rng.next_calls(num_ens)            # all ranks advance identically
+    lo, hi = draw_range(num_ens, rank, world)
+    if hi > lo:
+        logits, kl1 = mc_logits(net, x, hi - lo, seed, call0 + lo, fuse_act=fuse_act, timers=timers)
+        if torch.is_grad_enabled() and logits.requires_grad:
+            # training extension: differentiable tail through torch ops
+            lse = torch.logsumexp(F.log_softmax(logits, dim=2), dim=0) - (0.0 if world > 1 else math.log(num_ens))
+        else:
+            lse = _run(timers, "mc_tail", 0, lambda: ops.mc_tail(logits, mean_over=0 if world > 1 else num_ens))
+        kl_local = kl1 * float(hi - lo)
+    else:                                            # more ranks than draws
+        lse, kl_local = None, None
+    if world == 1:
+        kl = kl_local if kl_mode == "sum" else kl_local / num_ens
+        return lse, kl
+    return combine_ranks(lse, kl_local, num_ens, group, kl_mode)
+
+
+def combine_ranks(lse_local, kl_local, num_ens, group, kl_mode="sum", shape=None):
+    """All-gather [B*C + 1] floats per rank, then log-sum-exp over ranks in rank order.
+    lse_local: [B, C] log-sum-exp over this rank's draws (None if the rank had no draw)."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    if lse_local is None:
+        if shape is None:
+            raise _lib.BBBHipError("a rank without draws must be given the [B, C] shape")
+        dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        lse_local = torch.full(shape, -float("inf"), device=dev)
+        kl_local = torch.zeros((), device=dev)
+    B, C = lse_local.shape
+    buf = torch.cat([lse_local.reshape(-1), kl_local.detach().reshape(1).to(lse_local.dtype)])
+    gathered = torch.empty((world, buf.numel()), dtype=buf.dtype, device=buf.device)
+    dist.all_gather_into_tensor(gathered, buf, group=group)
+    blocks = gathered[:, :-1].reshape(world, B, C)
+    log_outputs = torch.logsumexp(blocks, dim=0) - math.log(num_ens)
+    kl = gathered[:, -1].sum()
+    if kl_mode != "sum":
+        kl = kl / num_ens
+    return log_outputs, kl

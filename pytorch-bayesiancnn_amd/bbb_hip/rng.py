@@ -40,6 +40,29 @@ def next_calls(n=1):
     return _state["seed"], c
 
 
+_scope = []   # (seed, call) of the whole-model forward in progress (ModuleWrapper.forward), innermost last
+
+
+def push_forward_scope():
+    """Called by a model-level ModuleWrapper.forward: ONE call index for every layer of this forward, so that
+    `net(x)` number j of a Python MC loop == draw j of a batched launch."""
+    sc = next_calls(1)
+    _scope.append(sc)
+    return sc
+
+
+def pop_forward_scope():
+    _scope.pop()
+
+
+def layer_call():
+    """Call index a layer's forward should use: the enclosing model forward's, or a fresh one if the layer is
+    used stand-alone."""
+    if _scope:
+        return _scope[-1]
+    return next_calls(1)
+
+
 _next_stream = [0]
 
 

@@ -46,6 +46,7 @@ class BayesianLayer(ModuleWrapper):
         self._stream_base = rng.new_stream_base()
         self._kl = None
         self._presampled = None      # (w, bias) handed over by a fused whole-model launch
+        self.eps_source = None       # None: on-chip Philox.  callable(shape) -> tensor: external noise (replay tests)
         self.reset_parameters()
 
     def reset_parameters(self):

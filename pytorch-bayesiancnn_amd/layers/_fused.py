@@ -1,0 +1,58 @@
+"""Whole-model fusion behind ModuleWrapper.forward.
+
+The reference runs, per layer and per forward, ~15 small ATen kernels for eps / softplus / mu+sigma*eps / KL.
+When a model-level wrapper starts a forward we instead (a) reserve ONE noise call index for all its layers
+and (b) launch the fused reparam+KL kernel ONCE over every layer's (W, bias) tensors, handing each layer its
+sampled weights (BBB) or sigma^2 tensors (LRT) and returning the total KL as one device scalar.
+Falls back to per-layer launches (same numbers) when a layer replays external eps or priors differ.
+"""
+import torch
+
+from bbb_hip import rng
+
+
+class _Scope:
+    __slots__ = ("kl", "pushed")
+
+    def __init__(self):
+        self.kl = None
+        self.pushed = False
+
+
+def enter(wrapper):
+    from ._base import BayesianLayer
+    if isinstance(wrapper, BayesianLayer):
+        return None
+    layers = [m for m in wrapper.modules() if isinstance(m, BayesianLayer)]
+    if not layers:
+        return None
+    sc = _Scope()
+    seed, call = rng.push_forward_scope()
+    sc.pushed = True
+    dev_ok = all(l.W_mu.is_cuda for l in layers)
+    replay = any(l.eps_source is not None for l in layers)
+    if dev_ok and not replay:
+        from bbb_hip import ensemble
+        from .bbb import _BBBLayer
+        from .lrt import _LRTLayer
+        bbb = [l for l in layers if isinstance(l, _BBBLayer)]
+        lrt = [l for l in layers if isinstance(l, _LRTLayer)]
+        kl = None
+        if bbb:
+            sampled, kl = ensemble._sample_all(bbb, 1, seed, call)
+            for l, wb in sampled.items():
+                l._presampled = wb
+                l._kl = None
+        if lrt:
+            variances, k2 = ensemble._variances_all(lrt)
+            for l, v in variances.items():
+                l._presampled = v
+                l._kl = None
+            kl = k2 if kl is None else kl + k2
+        sc.kl = kl
+    return sc
+
+
+def leave(scope):
+    if scope is not None and scope.pushed:
+        rng.pop_forward_scope()

@@ -17,9 +17,11 @@ class _BBBLayer(BayesianLayer):
             self._presampled = None
             return w, b
         if self.training or sample:
-            seed, call = rng.next_calls(1)
-            kl, ws = ops.sample_weights(mus, rhos, self.prior_mu, self.prior_sigma, ids, seed, call, 1,
-                                        eps=getattr(self, "_eps_override", None))
+            seed, call = rng.layer_call()
+            eps = None
+            if self.eps_source is not None:      # test / replay entry: external noise, W first then bias
+                eps = [self.eps_source(tuple(m.shape)).to(m.device).unsqueeze(0) for m in mus]
+            kl, ws = ops.sample_weights(mus, rhos, self.prior_mu, self.prior_sigma, ids, seed, call, 1, eps=eps)
             self._take_kl(kl)
             return ws[0], (ws[1] if self.use_bias else None)
         kl, _ = ops.kl_only(mus, rhos, self.prior_mu, self.prior_sigma)

@@ -22,10 +22,20 @@ class _LRTLayer(BayesianLayer):
 
     def _lrt(self, x5, w_mu5, w_var5, sample, stride, padding, dilation):
         w_var, b_var = w_var5
-        seed, call = rng.next_calls(1)
+        seed, call = rng.layer_call()
+        do_sample = bool(self.training or sample)
+        eps = None
+        if self.eps_source is not None and do_sample:   # test / replay entry: one activation-shaped draw
+            _, B, _, H, W = x5.shape
+            kh, kw = w_mu5.shape[2:]
+            sh, sw = ops._pair(stride)
+            ph, pw = ops._pair(padding)
+            dh, dw = ops._pair(dilation)
+            ho = (H + 2 * ph - dh * (kh - 1) - 1) // sh + 1
+            wo = (W + 2 * pw - dw * (kw - 1) - 1) // sw + 1
+            eps = self.eps_source((B, w_mu5.shape[0], ho, wo)).to(x5.device).unsqueeze(0)
         return ops.lrt_conv2d(x5, w_mu5, w_var, self.bias_mu if self.use_bias else None, b_var, seed, call,
-                              self._stream_base + 2, stride, padding, dilation,
-                              sample=bool(self.training or sample), eps=getattr(self, "_eps_override", None))
+                              self._stream_base + 2, stride, padding, dilation, sample=do_sample, eps=eps)
 
 
 class BBBConv2d(_LRTLayer):

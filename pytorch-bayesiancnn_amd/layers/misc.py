@@ -18,13 +18,20 @@ class ModuleWrapper(nn.Module):
                 setter(flag_name, value)
 
     def forward(self, x):
-        for child in self.children():
-            x = child(x)
-        kl = 0.0
-        for mod in self.modules():          # self included, like the reference
-            if hasattr(mod, "kl_loss"):
-                kl = kl + mod.kl_loss()
-        return x, kl
+        from . import _fused
+        scope = _fused.enter(self)          # one noise call index (and, when possible, ONE fused reparam+KL
+        try:                                # launch) for every Bayesian layer below this wrapper
+            for child in self.children():
+                x = child(x)
+            if scope is not None and scope.kl is not None:
+                return x, scope.kl          # KL of all layers, already reduced on the device
+            kl = 0.0
+            for mod in self.modules():      # self included, like the reference
+                if hasattr(mod, "kl_loss"):
+                    kl = kl + mod.kl_loss()
+            return x, kl
+        finally:
+            _fused.leave(scope)
 
 
 class FlattenLayer(ModuleWrapper):

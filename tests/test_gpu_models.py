@@ -1,0 +1,256 @@
+"""Whole-layer / whole-model parity on the MI355X: the drop-in `layers` package and the batched MC-ensemble
+path against fixtures generated from the unmodified reference (eps replayed from torch's CPU generator,
+SURVEY.md section 4.2) and against the oracle.  Run with -m gpu."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import bbb_numpy as O
+import ref_port_torch as P
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import layers
+    from bbb_hip import ops, rng, ensemble, zoo
+    return dict(layers=layers, ops=ops, rng=rng, ens=ensemble, zoo=zoo)
+
+
+def cpu_eps(shape):
+    return torch.empty(tuple(shape)).normal_(0, 1)
+
+
+def load_params(net, params):
+    sd = {}
+    for name, p in params.items():
+        if name.startswith("_"):
+            continue
+        for k, v in p.items():
+            sd[f"{name}.{k}"] = v
+    net.load_state_dict(sd, strict=True)
+    return net.cuda()
+
+
+def set_eps_source(net, fn):
+    for m in net.modules():
+        if hasattr(m, "eps_source"):
+            m.eps_source = fn
+
+
+# ---------------------------------------------------------------- single layers vs reference fixtures
+def _mk_layer(env, L, tag, cls, *args, **kw):
+    layer = cls(*args, **kw)
+    sd = {k: torch.from_numpy(L[f"{tag}.{k}"]) for k in ("W_mu", "W_rho", "bias_mu", "bias_rho") if f"{tag}.{k}" in L.files}
+    layer.load_state_dict(sd)
+    return layer.cuda()
+
+
+LAYER_CASES = [
+    ("bbb_conv", "BBB_Conv2d", (3, 5, 3), dict(stride=2, padding=1), None),
+    ("bbb_conv_nb", "BBB_Conv2d", (2, 4, (2, 3)), dict(stride=1, padding=2, dilation=2, bias=False), None),
+    ("bbb_lin", "BBB_Linear", (7, 4), {}, None),
+    ("lrt_conv", "BBB_LRT_Conv2d", (4, 6, 3), dict(stride=1, padding=1), "cfg"),
+    ("lrt_lin_nb", "BBB_LRT_Linear", (9, 5), dict(bias=False), None),
+    ("lrt_lin", "BBB_LRT_Linear", (33, 10), {}, "cfg"),
+]
+
+
+@pytest.mark.parametrize("tag,cls,args,kw,pri", LAYER_CASES)
+def test_layer_forward_kl_and_grads_vs_reference(env, golden, tag, cls, args, kw, pri):
+    L = golden["layers_small"]
+    if pri:
+        kw = dict(kw, priors=P.CONFIG_PRIORS)
+    layer = _mk_layer(env, L, tag, getattr(env["layers"], cls), *args, **kw)
+    eps = [L[f"{tag}.eps0"]] + ([L[f"{tag}.eps1"]] if f"{tag}.eps1" in L.files else [])
+    it = iter(eps)
+    layer.eps_source = lambda shape: torch.from_numpy(next(it)).reshape(shape)
+    x = torch.from_numpy(L[f"{tag}.x"]).cuda().requires_grad_(True)
+    layer.train()
+    y = layer(x)
+    kl = layer.kl_loss()
+    np.testing.assert_allclose(y.detach().cpu().numpy(), L[f"{tag}.y"], rtol=2e-5, atol=2e-6)
+    assert abs(kl.item() - float(L[f"{tag}.kl"])) <= 2e-6 * abs(float(L[f"{tag}.kl"]))
+    np.testing.assert_allclose(layer.W_sigma.detach().cpu().numpy(), L[f"{tag}.W_sigma"], rtol=1e-6)
+    # backward of sum(y*g) + 0.37*kl, same eps (HIP reparam backward + declared ATen stop-gap for dgrad/wgrad)
+    g = torch.from_numpy(L[f"{tag}.g"]).cuda()
+    ((y * g).sum() + 0.37 * kl).backward()
+    np.testing.assert_allclose(x.grad.cpu().numpy(), L[f"{tag}.grad_x"], rtol=2e-4, atol=2e-5)
+    for k in ("W_mu", "W_rho", "bias_mu", "bias_rho"):
+        if f"{tag}.grad_{k}" in L.files:
+            want = L[f"{tag}.grad_{k}"]
+            got = getattr(layer, k).grad.cpu().numpy()
+            np.testing.assert_allclose(got, want, rtol=3e-4, atol=3e-4 * max(1.0, np.abs(want).max() * 1e-2))
+    # deterministic path: eval() + sample=False
+    layer.eval()
+    layer.eps_source = None
+    y0 = layer(x.detach(), sample=False)
+    np.testing.assert_allclose(y0.detach().cpu().numpy(), L[f"{tag}.y_nosample"], rtol=2e-5, atol=2e-6)
+    assert abs(layer.kl_loss().item() - float(L[f"{tag}.kl"])) <= 2e-6 * abs(float(L[f"{tag}.kl"]))
+
+
+def test_eval_does_not_turn_sampling_off(env):
+    """Reference quirk (layers/BBB/BBBConv.py:61-62): forward(x) samples even in eval()."""
+    layer = env["layers"].BBB_Linear(16, 8).cuda().eval()
+    x = torch.randn(4, 16, device="cuda")
+    a, b = layer(x), layer(x)
+    assert not torch.equal(a, b)
+    assert torch.equal(layer(x, sample=False), layer(x, sample=False))
+
+
+# ---------------------------------------------------------------- whole models vs reference fixtures
+MODEL_CASES = [("lenet_bbb", "lenet", "bbb", "softplus", True), ("lenet_lrt", "lenet", "lrt", "relu", False),
+               ("alexnet_bbb", "alexnet", "bbb", "softplus", True), ("alexnet_lrt", "alexnet", "lrt", "softplus", True),
+               ("3conv3fc_bbb", "3conv3fc", "bbb", "softplus", True), ("3conv3fc_lrt", "3conv3fc", "lrt", "relu", True),
+               ("alexnet224_bbb", "alexnet", "bbb", "softplus", True)]
+
+
+@pytest.mark.parametrize("tag,net_type,lt,act,cfgpri", MODEL_CASES)
+def test_model_forward_vs_reference(env, golden, tag, net_type, lt, act, cfgpri):
+    """Same seed -> same parameters and input as the reference (checked through checksums), eps replayed from
+    the CPU generator in the reference's draw order -> logits and KL of the unmodified reference."""
+    M = golden["models"]
+    ncls, cin, B, hw, seed = [int(v) for v in M[f"{tag}.meta"]]
+    pri = P.CONFIG_PRIORS if cfgpri else None
+    torch.manual_seed(seed)
+    params = P.init_params(net_type, cin, ncls, pri)
+    x = torch.rand(B, cin, hw, hw)
+    assert abs(x.double().sum().item() - float(M[f"{tag}.x_checksum"])) < 1e-9
+    net = load_params(env["zoo"].getModel(net_type, cin, ncls, pri, lt, act), params)
+    net.train()
+    torch.manual_seed(seed + 1)
+    set_eps_source(net, cpu_eps)
+    with torch.no_grad():
+        logits, kl = net(x.cuda())
+    assert logits.shape == M[f"{tag}.logits"].shape
+    # fp32 MFMA (sequential fmaf chain over K <= 3456) vs mkldnn's blocked accumulation through up to 8 layers:
+    # stated tolerance 5e-4 relative + 2e-5 of the logit scale absolute
+    want = M[f"{tag}.logits"]
+    scale = max(1.0, float(np.abs(want).max()))
+    np.testing.assert_allclose(logits.cpu().numpy(), want, rtol=5e-4, atol=2e-5 * scale)
+    assert abs(kl.item() - float(M[f"{tag}.kl"])) <= 2e-6 * float(M[f"{tag}.kl"])
+
+
+def test_mc_step_vs_reference(env, golden):
+    """main_bayesian.py:73-83 on LeNet, E=3: log_outputs, summed KL and both ELBO conventions."""
+    M = golden["models"]
+    torch.manual_seed(21)
+    params = P.init_params("lenet", 1, 10, P.CONFIG_PRIORS)
+    x = torch.rand(4, 1, 32, 32)
+    labels = torch.randint(0, 10, (4,))
+    net = load_params(env["zoo"].BBBLeNet(10, 1, P.CONFIG_PRIORS, "bbb", "softplus"), params)
+    torch.manual_seed(22)
+    set_eps_source(net, cpu_eps)
+    E = 3
+    outs, kl = [], 0.0
+    with torch.no_grad():
+        for j in range(E):
+            o, k = net(x.cuda())
+            kl = kl + k
+            outs.append(o)
+    logits = torch.stack(outs)
+    np.testing.assert_allclose(logits.cpu().numpy(), M["mc_lenet.logits"], rtol=5e-4, atol=5e-5)
+    lo = env["ops"].mc_tail(logits, mean_over=E)
+    np.testing.assert_allclose(lo.cpu().numpy(), M["mc_lenet.log_outputs"], rtol=5e-4, atol=5e-5)
+    assert abs(kl.item() - float(M["mc_lenet.kl_sum"])) <= 2e-6 * float(M["mc_lenet.kl_sum"])
+    nll = F.nll_loss(lo, labels.cuda(), reduction="mean")
+    elbo_valid = nll * 1000 + 0.1 * kl
+    elbo_train = nll * 1000 + 0.1 * kl / E
+    assert abs(elbo_valid.item() - float(M["mc_lenet.elbo_valid"])) <= 1e-4 * abs(float(M["mc_lenet.elbo_valid"]))
+    assert abs(elbo_train.item() - float(M["mc_lenet.elbo_train"])) <= 1e-4 * abs(float(M["mc_lenet.elbo_train"]))
+
+
+# ---------------------------------------------------------------- batched ensemble == python loop (Philox path)
+@pytest.mark.parametrize("net_type,lt,B,hw,cin", [("lenet", "bbb", 8, 32, 1), ("alexnet", "bbb", 16, 32, 3),
+                                                   ("3conv3fc", "bbb", 4, 32, 3), ("alexnet", "lrt", 8, 32, 3),
+                                                   ("lenet", "lrt", 4, 32, 1)])
+def test_batched_ensemble_equals_loop(env, net_type, lt, B, hw, cin):
+    torch.manual_seed(3)
+    net = env["zoo"].getModel(net_type, cin, 10, P.CONFIG_PRIORS, lt, "softplus").cuda()
+    env["rng"].assign_stream_ids(net)
+    x = torch.rand(B, cin, hw, hw, device="cuda")
+    E = 5
+    with torch.no_grad():
+        env["rng"].manual_seed(1234, call=10)
+        loop = torch.stack([net(x)[0] for _ in range(E)])
+        kl_loop = net(x)[1]
+        batched, kl = env["ens"].mc_logits(net, x, E, 1234, 10, fuse_act=False)
+        fused, _ = env["ens"].mc_logits(net, x, E, 1234, 10, fuse_act=True)
+    assert torch.equal(loop, batched)                   # same kernels, same k order, same noise calls
+    np.testing.assert_allclose(fused.cpu().numpy(), loop.cpu().numpy(), rtol=1e-4, atol=1e-5)   # epilogue softplus vs torch's
+    assert abs(kl.item() - kl_loop.item()) <= 1e-6 * kl_loop.item()
+    # the whole step
+    env["rng"].manual_seed(1234, call=10)
+    with torch.no_grad():
+        lo, klsum = env["ens"].mc_forward(net, x, E, fuse_act=False)
+    want = O.mc_log_outputs(loop.cpu().numpy())
+    np.testing.assert_allclose(lo.cpu().numpy(), want, rtol=2e-5, atol=2e-6)
+    assert abs(klsum.item() - E * kl_loop.item()) <= 2e-6 * E * kl_loop.item()
+    assert env["rng"].get_state()[1] == 10 + E
+
+
+def test_simulated_rank_sharding_matches_single_device(env):
+    """Draw-sharding without a second GPU: compute each rank's block on this device and combine as
+    combine_ranks does; must equal the unsharded step."""
+    torch.manual_seed(5)
+    net = env["zoo"].BBBAlexNet(10, 3, P.CONFIG_PRIORS, "bbb", "softplus").cuda()
+    env["rng"].assign_stream_ids(net)
+    x = torch.rand(32, 3, 32, 32, device="cuda")
+    E, world = 10, 4
+    with torch.no_grad():
+        full, _ = env["ens"].mc_logits(net, x, E, 77, 0)
+        want = env["ops"].mc_tail(full, mean_over=E)
+        blocks = []
+        for r in range(world):
+            lo, hi = env["ens"].draw_range(E, r, world)
+            lg, _ = env["ens"].mc_logits(net, x, hi - lo, 77, lo)
+            assert torch.equal(lg, full[lo:hi])
+            blocks.append(env["ops"].mc_tail(lg, mean_over=0))
+        got = torch.logsumexp(torch.stack(blocks), 0) - np.log(E)
+    np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=2e-6, atol=2e-6)
+
+
+# ---------------------------------------------------------------- statistics of the Philox path
+def test_bbb_outputs_follow_lrt_moments(env):
+    """For fixed x and parameters the BBB layer's output over draws is N(act_mu, act_var) elementwise, where
+    those are exactly the LRT moments -- a known-answer test for RNG + reparam + GEMM together."""
+    torch.manual_seed(0)
+    pri = dict(P.DEFAULT_PRIORS)
+    layer = env["layers"].BBB_Conv2d(3, 8, 3, padding=1, priors=pri).cuda()
+    x = torch.rand(2, 3, 6, 6, device="cuda")
+    E = 4000
+    env["rng"].manual_seed(9)
+    with torch.no_grad():
+        seed, call0 = env["rng"].next_calls(E)
+        mus, rhos, ids = layer._param_lists()
+        ws, _, _ = env["ops"].reparam_kl_forward(mus, rhos, 0, 0.1, ids, seed, call0, draws=E)
+        y = env["ops"].conv2d_forward(x.unsqueeze(0), ws[0], ws[1], 1, 1, 1)          # [E, 2, 8, 6, 6]
+    am, av = O.lrt_moments_conv2d(x.cpu().numpy(), *[p.detach().cpu().numpy() for p in
+                                                     (layer.W_mu, layer.W_rho, layer.bias_mu, layer.bias_rho)], 1, 1, 1)
+    mean = y.mean(0).cpu().numpy()
+    var = y.var(0).cpu().numpy()
+    z = np.abs(mean - am) / np.sqrt(av / E)
+    assert z.max() < 5.0 and np.mean(z) < 1.2            # |mean - act_mu| within sampling error
+    ratio = var / av
+    assert 0.85 < ratio.min() and ratio.max() < 1.15 and abs(ratio.mean() - 1) < 0.01
+
+
+def test_train_step_runs_and_learns(env):
+    """train_model's inner step (main_bayesian.py:40-58) on the batched path: loss decreases."""
+    torch.manual_seed(1)
+    net = env["zoo"].BBBLeNet(10, 1, P.CONFIG_PRIORS, "bbb", "softplus").cuda()
+    env["rng"].assign_stream_ids(net)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    x = torch.rand(64, 1, 32, 32, device="cuda")
+    y = torch.randint(0, 10, (64,), device="cuda")
+    losses = []
+    for it in range(30):
+        opt.zero_grad()
+        lo, kl = env["ens"].mc_forward(net, x, 2, kl_mode="mean")
+        loss = F.nll_loss(lo, y, reduction="mean") * 64 + 1e-7 * kl
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
