@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""MC-forward samples/sec of BayesianAlexNet (CIFAR-10 shape, bs=512, num_ens=10, BBB layers) on MI355X.
+
+One step = main_bayesian.py:73-80 of the reference: num_ens x net(x) + log_softmax, then utils.logmeanexp --
+forward only, no_grad, inputs resident in HBM.  Synthetic data: torch.manual_seed(0), parameters from the
+layers' own reset_parameters with config_bayesian.priors, x ~ U[0,1).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+N > 1 (weak scaling): every rank runs num_ens=10 draws of the same 512-image batch -- a 10*N-draw ensemble
+sharded over the GPUs (draw j is noise call call0 + j on whichever rank owns it) -- and the ranks combine
+their log-sum-exp blocks and KL sums with ONE all_gather over RCCL per step.  value = B * 10 * N / step time.
+
+Prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
+  roofline      the dominant kernel (fp32-MFMA implicit-GEMM conv): algorithmic FLOP / HIP-event time vs the
+                157.3 TFLOP/s fp32 matrix peak; plus roofline_reparam for the fused reparam+KL pass vs HBM.
+  cpu_baseline  the oracle's torch-CPU port of the reference MC step (oracle/ref_port_torch.py, bit-identical
+                to the upstream nn.Modules under the same seed) timed on this host's cores, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "pytorch-bayesiancnn_amd"))
+sys.dont_write_bytecode = True
+
+import torch  # noqa: E402
+
+PRIORS = {"prior_mu": 0, "prior_sigma": 0.1, "posterior_mu_initial": (0, 0.1), "posterior_rho_initial": (-5, 0.1)}
+BATCH, NUM_ENS, CLASSES = 512, 10, 10
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
+PEAK_HBM_GBS = 8000.0             # HBM3E spec (6.3 TB/s achievable)
+
+
+def usable_cpus():
+    """CPUs this process may actually use: min(affinity, cgroup cpu.max quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(budget_s=16.0):
+    """Reference CPU path (oracle port: same ATen ops / order as the upstream modules), bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ref_port_torch as P
+    avail = usable_cpus()
+    torch.manual_seed(0)
+    params = P.init_params("alexnet", 3, CLASSES, P.CONFIG_PRIORS)
+    x = torch.rand(BATCH, 3, 32, 32)
+
+    def run(nthreads, budget):
+        torch.set_num_threads(nthreads)
+        with torch.no_grad():
+            P.mc_step("alexnet", params, x, CLASSES, 1, "bbb", "softplus")      # warm-up (1 draw)
+            t0 = time.perf_counter()
+            n = 0
+            while True:
+                P.mc_step("alexnet", params, x, CLASSES, NUM_ENS, "bbb", "softplus")
+                n += 1
+                el = time.perf_counter() - t0
+                if (n >= 3 and el > budget) or n >= 100 or el > 4 * budget:
+                    break
+        return BATCH * NUM_ENS * n / el, n, el
+
+    # mkldnn does not always scale to every core of the cgroup: time all cores and half of them, report the best
+    best = None
+    for nt in sorted({avail, max(1, avail // 2)}, reverse=True):
+        v, n, el = run(nt, budget_s / 2)
+        if best is None or v > best[0]:
+            best = (v, n, el, nt)
+    v, n, el, nt = best
+    return {"value": round(v, 1), "unit": "samples/s", "cores": nt, "kind": "port",
+            "sample": f"{n} full MC steps (bs={BATCH}, num_ens={NUM_ENS}, fp32, no_grad) of oracle/ref_port_torch.mc_step "
+                      f"in {el:.1f}s after a warm-up; {avail} CPUs usable (cgroup quota / affinity) of "
+                      f"{os.cpu_count()} logical, best of {{all, half}} thread counts"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--layer-type", default="bbb", choices=["bbb", "lrt"])
+    ap.add_argument("--no-kernel-timers", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    group = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+        group = dist.group.WORLD
+
+    from bbb_hip import ensemble, rng, zoo, _lib
+    _lib.lib()   # fail loudly here if the HIP library is missing
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    torch.manual_seed(0)
+    net = zoo.BBBAlexNet(CLASSES, 3, PRIORS, args.layer_type, "softplus").to(dev)
+    rng.assign_stream_ids(net)
+    x = torch.rand(BATCH, 3, 32, 32).to(dev)
+    total_ens = NUM_ENS * world
+    n_params = sum(p.numel() for n, p in net.named_parameters() if n.endswith("_mu"))
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier(group=group)
+        torch.cuda.synchronize(dev)
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            ensemble.mc_forward(net, x, total_ens, group=group)
+        timers = None if args.no_kernel_timers else ensemble.Timers()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            lo, kl = ensemble.mc_forward(net, x, total_ens, group=group, timers=timers)
+        barrier()
+        elapsed = time.perf_counter() - t0
+
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=group)
+        elapsed = t.item()
+    assert torch.isfinite(lo).all() and torch.isfinite(kl).all()
+
+    if rank == 0:
+        ms = 1e3 * elapsed / args.steps
+        out = {
+            "metric": "MC-forward samples/sec, BayesianAlexNet CIFAR-10 bs=512 num_ens=10",
+            "value": round(BATCH * total_ens / (elapsed / args.steps), 1),
+            "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BayesianAlexNet 3x32x32 -> {CLASSES} classes, layer_type={args.layer_type}, "
+                                   f"softplus, bs={BATCH}, num_ens={NUM_ENS} per GPU ({total_ens} draws total), "
+                                   "forward only (main_bayesian.py:73-80)",
+                       "global_batch": BATCH, "num_ens_total": total_ens,
+                       "parallelism": f"mc-ensemble x{world}" if world > 1 else "single"},
+        }
+        if timers is not None:
+            agg = timers.summary()
+            g = agg.get("conv_gemm") or agg.get("lrt_gemm")
+            if g:
+                tf = g["work"] / (g["ms"] * 1e-3) / 1e12
+                out["roofline"] = {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                                   "unit": "TFLOP/s", "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                                   "kernel": "conv_gemm_kernel (fp32 v_mfma_f32_32x32x2_f32), all conv/linear launches",
+                                   "launches": g["n"], "avg_us": round(1e3 * g["ms"] / g["n"], 2),
+                                   "flop_per_step": g["work"] / args.steps,
+                                   "share_of_step": round(g["ms"] / (1e3 * elapsed), 4)}
+            r = agg.get("reparam_kl")
+            if r:
+                e_loc = NUM_ENS
+                byts = (8 + 4 * e_loc) * n_params if args.layer_type == "bbb" else 12 * n_params
+                gbs = byts * r["n"] / (r["ms"] * 1e-3) / 1e9
+                out["roofline_reparam"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                           "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None,
+                                           "kernel": "reparam_kl_fwd_kernel (+kl_finish), one multi-tensor multi-draw launch",
+                                           "bytes_per_launch": byts, "avg_us": round(1e3 * r["ms"] / r["n"], 2),
+                                           "note": "(8 + 4E) B per weight element, E draws per launch; working set is "
+                                                   "Infinity-Cache resident at this size"}
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+            out["speedup_vs_cpu"] = round(out["value"] / cpu["value"], 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -49,7 +49,7 @@ class Timers:
         s.record()
         out = fn()
         e.record()
-        self.records.append((tag, info, s, e))
+        self.records.append((tag, info(out) if callable(info) else info, s, e))
         return out
 
     def summary(self):
@@ -177,7 +177,8 @@ def mc_logits(net, x, draws, seed, call0, fuse_act=True, timers=None, eps=None):
                 w, b = sampled[mod]
                 if not is_conv:
                     w = w.reshape(E, mod.out_features, mod.in_features, 1, 1)
-                flops = 2.0 * E * h5.shape[1] * w[0].numel()
+                kdim = w[0][0].numel()                          # Cin*kh*kw
+                flops = lambda yy: 2.0 * yy.numel() * kdim      # 2*M*N*K summed over draws
                 if torch.is_grad_enabled() and (h5.requires_grad or w.requires_grad):
                     y = ops.conv2d(h5, w, b, *geom)
                     if act is not None:
@@ -198,7 +199,8 @@ def mc_logits(net, x, draws, seed, call0, fuse_act=True, timers=None, eps=None):
                     if act is not None:
                         y = F.relu(y) if act == "relu" else F.softplus(y)
                 else:
-                    flops = 4.0 * E * h5.shape[1] * w_mu.numel()
+                    kdim = w_mu[0].numel()
+                    flops = lambda yy: 4.0 * yy.numel() * kdim   # two contractions
                     y = _run(timers, "lrt_gemm", flops,
                              lambda: ops.lrt_conv2d_forward(h5, w_mu, w_var, mod.bias_mu if mod.use_bias else None, b_var,
                                                             seed, call0, mod._stream_base + 2, *geom, sample=True, act=act)[0])
