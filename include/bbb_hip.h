@@ -129,6 +129,25 @@ int bbb_lrt_conv2d_fwd(const bbb_conv_desc_t* d, const float* x, const float* w_
                        uint64_t seed, uint32_t call0, uint32_t stream_id, int sample, void* stream);
 
 /*
+ * Batch-innermost ("CHWN") variants used by the batched Monte-Carlo ensemble path.
+ *   x: [draws|1][cin][h][w][B]   y: [draws][cout][ho][wo][B]   (B = d->batch, B % 4 == 0, 16-byte aligned)
+ * Same contraction and same results as bbb_conv2d_fwd / bbb_lrt_conv2d_fwd (weights keep the reference's
+ * [cout][cin][kh][kw] layout); one workgroup per (output pixel, 64 channels, 64|128 images) and kernel taps
+ * that fall into the zero padding are skipped instead of multiplied.  LRT eps is indexed by the canonical
+ * NCHW element index, so both layouts consume the identical noise stream.
+ */
+int bbb_conv2d_chwn_fwd(const bbb_conv_desc_t* d, const float* x, const float* w, const float* bias,
+                        float* y, void* stream);
+int bbb_lrt_conv2d_chwn_fwd(const bbb_conv_desc_t* d, const float* x, const float* w_mu, const float* w_var,
+                            const float* b_mu, const float* b_var, float* y,
+                            float* act_mu_out, float* act_var_out, const float* eps_ext,
+                            uint64_t seed, uint32_t call0, uint32_t stream_id, int sample, void* stream);
+
+/* nn.MaxPool2d(kernel_size=k, stride=s) (no padding, floor mode; models/BayesianModels/BayesianAlexNet.py:37)
+ * on batch-innermost planes: x [planes][h][w][B] -> y [planes][(h-k)/s+1][(w-k)/s+1][B]. */
+int bbb_maxpool_chwn(const float* x, float* y, int64_t planes, int h, int w, int batch, int k, int s, void* stream);
+
+/*
  * Monte-Carlo tail (main_bayesian.py:49,53 / :78,80 + utils.py:14-22): per draw log_softmax over
  * classes, then log-sum-exp over the local draws.
  *   logits [draws][B][C]  ->  lse [B][C] = log sum_e exp(log_softmax(logits[e])[b][c])

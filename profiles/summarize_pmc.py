@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Per-kernel averages of rocprofv3 --pmc counters from a rocpd sqlite database.
+usage: summarize_pmc.py results.db [name-substring]"""
+import re
+import sqlite3
+import sys
+
+
+def short(name):
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"^void ", "", name)
+    return name[:70]
+
+
+def main():
+    c = sqlite3.connect(sys.argv[1])
+    filt = sys.argv[2] if len(sys.argv) > 2 else ""
+    rows = c.execute("select kernel_name, grid_size_x, grid_size_y, grid_size_z, workgroup_size_x, dispatch_id, counter_name, "
+                     "value, duration from counters_collection").fetchall()
+    per = {}
+    for n, gx, gy, gz, wx, did, cn, v, dur in rows:
+        if filt and filt not in n:
+            continue
+        key = (short(n), gx // max(wx, 1), gy, gz)
+        d = per.setdefault(key, {}).setdefault(cn, [0.0, 0])
+        d[0] += v
+        d[1] += 1
+        dd = per[key].setdefault("_dur_ns", [0.0, 0])
+        dd[0] += dur
+        dd[1] += 1
+    for key, cs in per.items():
+        print(key)
+        for cn, (s, n) in sorted(cs.items()):
+            print(f"    {cn:32s} avg {s / n:16.1f}   (n={n})")
+
+
+if __name__ == "__main__":
+    main()

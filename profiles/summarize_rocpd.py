@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Per-kernel summary (calls, total, average, share) from a rocprofv3 rocpd sqlite database.
+usage: summarize_rocpd.py results.db [--skip-first N]   (the same numbers as `rocprofv3 --stats`, as text)"""
+import re
+import sqlite3
+import sys
+
+
+def short(name):
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"^void ", "", name)
+    return name if len(name) < 110 else name[:107] + "..."
+
+
+def main():
+    db = sys.argv[1]
+    c = sqlite3.connect(db)
+    rows = c.execute("select name, start, end, grid_x, grid_y, grid_z, workgroup_x from kernels order by start").fetchall() \
+        if "grid_x" in [r[1] for r in c.execute("pragma table_info(kernels)")] else \
+        [(r[0], r[1], r[2], 0, 0, 0, 0) for r in c.execute("select name, start, end from kernels order by start")]
+    agg = {}
+    for name, s, e, gx, gy, gz, wx in rows:
+        a = agg.setdefault(short(name), [0, 0, 1 << 62, 0])
+        d = e - s
+        a[0] += 1
+        a[1] += d
+        a[2] = min(a[2], d)
+        a[3] = max(a[3], d)
+    tot = sum(a[1] for a in agg.values())
+    span = rows[-1][2] - rows[0][1] if rows else 0
+    print(f"# {db}: {len(rows)} dispatches, kernel time {tot/1e6:.3f} ms, span {span/1e6:.3f} ms")
+    print(f"{'calls':>7} {'total_us':>12} {'avg_us':>10} {'min_us':>9} {'max_us':>9} {'share':>7}  kernel")
+    for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        print(f"{a[0]:7d} {a[1]/1e3:12.1f} {a[1]/a[0]/1e3:10.2f} {a[2]/1e3:9.2f} {a[3]/1e3:9.2f} {100*a[1]/tot:6.2f}%  {k}")
+
+
+if __name__ == "__main__":
+    main()

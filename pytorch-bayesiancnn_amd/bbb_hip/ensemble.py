@@ -53,12 +53,19 @@ class Timers:
         return out
 
     def summary(self):
+        """tag -> {ms, n, work, work_im2col}: `work` = FLOPs actually required (in-bounds taps only) or elements,
+        `work_im2col` = the 2*M*N*K of the zero-padded im2col GEMM (SURVEY.md section 8d figure)."""
         agg = {}
         for tag, info, s, e in self.records:
-            a = agg.setdefault(tag, {"ms": 0.0, "n": 0, "work": 0.0})
+            a = agg.setdefault(tag, {"ms": 0.0, "n": 0, "work": 0.0, "work_im2col": 0.0})
             a["ms"] += s.elapsed_time(e)
             a["n"] += 1
-            a["work"] += info
+            if isinstance(info, tuple):
+                a["work"] += info[0]
+                a["work_im2col"] += info[1]
+            elif info is not None:
+                a["work"] += info
+                a["work_im2col"] += info
         return agg
 
 
@@ -140,12 +147,117 @@ def _act_name(mod):
     return None
 
 
-def mc_logits(net, x, draws, seed, call0, fuse_act=True, timers=None, eps=None):
+def conv_flops(B, Cin, H, W, Cout, kh, kw, stride, padding, dilation, draws, contractions=1):
+    """(useful, im2col) FLOPs of a conv layer: useful counts only kernel taps that land inside the image."""
+    sh, sw = ops._pair(stride)
+    ph, pw = ops._pair(padding)
+    dh, dw = ops._pair(dilation)
+    ho = (H + 2 * ph - dh * (kh - 1) - 1) // sh + 1
+    wo = (W + 2 * pw - dw * (kw - 1) - 1) // sw + 1
+    vr = sum(1 for o in range(ho) for r in range(kh) if 0 <= o * sh - ph + r * dh < H)
+    vq = sum(1 for o in range(wo) for q in range(kw) if 0 <= o * sw - pw + q * dw < W)
+    base = 2.0 * contractions * draws * B * Cout * Cin
+    return base * vr * vq, base * ho * wo * kh * kw
+
+
+def _chwn_ok(net, x):
+    """The batch-innermost fast path handles: 4-d input, B % 4 == 0, no autograd, and only module kinds it
+    knows how to run in that layout (Bayesian layers, ReLU/Softplus, MaxPool2d without padding, FlattenLayer
+    that flattens whole images)."""
+    if torch.is_grad_enabled() and any(p.requires_grad for p in net.parameters()):
+        return False
+    if x.dim() != 4 or x.shape[0] % 4 != 0:
+        return False
+    for m in net.children():
+        if isinstance(m, (_BBBLayer, _LRTLayer, FlattenLayer, nn.ReLU)):
+            continue
+        if isinstance(m, nn.Softplus) and m.beta == 1 and m.threshold == 20:
+            continue
+        if isinstance(m, nn.MaxPool2d):
+            k, s = m.kernel_size, m.stride
+            if isinstance(k, int) and isinstance(s, int) and m.padding == 0 and m.dilation == 1 and not m.ceil_mode:
+                continue
+        return False
+    return True
+
+
+def _mc_logits_chwn(net, x, draws, seed, call0, timers=None):
+    """Inference path of mc_logits in the batch-innermost layout ([E, C, H, W, B]): pixel-major GEMMs that
+    skip padding taps, activation fused into the GEMM epilogue, pooling on contiguous image vectors."""
+    layers = bayesian_layers(net)
+    bbb = [l for l in layers if isinstance(l, _BBBLayer)]
+    lrt = [l for l in layers if isinstance(l, _LRTLayer)]
+    kl, sampled, variances = None, {}, {}
+    if bbb:
+        sampled, kl = _sample_all(bbb, draws, seed, call0, timers)
+    if lrt:
+        variances, k2 = _variances_all(lrt, timers)
+        kl = k2 if kl is None else kl + k2
+    E, B = draws, x.shape[0]
+    h = x.permute(1, 2, 3, 0).contiguous().unsqueeze(0)          # [1, C, H, W, B], shared by all draws
+    children = list(net.children())
+    i = 0
+    while i < len(children):
+        mod = children[i]
+        nxt = children[i + 1] if i + 1 < len(children) else None
+        act = _act_name(nxt) if nxt is not None else None
+        if isinstance(mod, (_BBBLayer, _LRTLayer)):
+            is_conv = isinstance(mod, (_BBBConv, _LRTConv))
+            geom = (mod.stride, mod.padding, mod.dilation) if is_conv else (1, 0, 1)
+            h5 = h if is_conv else h.reshape(h.shape[0], mod.in_features, 1, 1, -1)
+            if h5.dim() != 5 or h5.shape[-1] != B:
+                return None                                      # flatten quirk etc.: caller falls back
+            if isinstance(mod, _BBBLayer):
+                w, b = sampled[mod]
+                if not is_conv:
+                    w = w.reshape(E, mod.out_features, mod.in_features, 1, 1)
+                fl = conv_flops(B, h5.shape[1], h5.shape[2], h5.shape[3], w.shape[1], w.shape[3], w.shape[4], *geom, E) \
+                    if timers is not None else None
+                y = _run(timers, "conv_gemm", fl, lambda: ops.conv2d_chwn_forward(h5, w, b, *geom, act=act))
+            else:
+                w_var, b_var = variances[mod]
+                w_mu = mod.W_mu
+                if not is_conv:
+                    shp = (mod.out_features, mod.in_features, 1, 1)
+                    w_mu, w_var = w_mu.reshape(shp), w_var.reshape(shp)
+                if h5.shape[0] == 1 and E > 1:
+                    h5 = h5.expand(E, *h5.shape[1:])
+                fl = conv_flops(B, h5.shape[1], h5.shape[2], h5.shape[3], w_mu.shape[0], w_mu.shape[2], w_mu.shape[3],
+                                *geom, E, 2) if timers is not None else None
+                y = _run(timers, "lrt_gemm", fl,
+                         lambda: ops.lrt_conv2d_chwn_forward(h5, w_mu, w_var, mod.bias_mu if mod.use_bias else None, b_var,
+                                                             seed, call0, mod._stream_base + 2, *geom, sample=True, act=act)[0])
+            h = y
+            if act is not None:
+                i += 1
+        elif isinstance(mod, FlattenLayer):
+            if h.dim() != 5 or h.shape[1] * h.shape[2] * h.shape[3] != mod.num_features:
+                return None
+            h = h.reshape(h.shape[0], mod.num_features, 1, 1, B)
+        elif isinstance(mod, nn.MaxPool2d):
+            h = _run(timers, "maxpool", None, lambda: ops.maxpool_chwn(h, mod.kernel_size, mod.stride))
+        elif isinstance(mod, nn.ReLU):
+            h = torch.relu(h)
+        else:
+            h = F.softplus(h)
+        i += 1
+    if h.shape[0] == 1 and E > 1:
+        h = h.expand(E, *h.shape[1:])
+    logits = h.reshape(E, -1, B).permute(0, 2, 1).contiguous()   # [E, B, C] for the tail kernel
+    return logits, kl
+
+
+def mc_logits(net, x, draws, seed, call0, fuse_act=True, timers=None, eps=None, layout="auto"):
     """E stochastic forwards of `net` on the same batch x -> (logits [E, B', C], kl of ONE forward).
 
     Equivalent to `[net(x)[0] for _ in range(E)]` under noise calls call0 .. call0+E-1 (B' = B except for
-    the 224x224 AlexNet flatten quirk, where B' = B*49)."""
+    the 224x224 AlexNet flatten quirk, where B' = B*49).  layout "auto" takes the batch-innermost fast path
+    when it applies (inference, B % 4 == 0, known module kinds), "nchw" forces the reference layout."""
     _lib.require_device(x)
+    if layout != "nchw" and eps is None and fuse_act and _chwn_ok(net, x):
+        out = _mc_logits_chwn(net, x, draws, seed, call0, timers)
+        if out is not None:
+            return out
     layers = bayesian_layers(net)
     bbb = [l for l in layers if isinstance(l, _BBBLayer)]
     lrt = [l for l in layers if isinstance(l, _LRTLayer)]

@@ -179,6 +179,73 @@ def lrt_conv2d_forward(x, w_mu, w_var, b_mu, b_var, seed, call0, stream_id, stri
     return y, am, av
 
 
+def _desc_chwn(x, w, stride, padding, dilation, draws, x_shared, w_shared, act):
+    """x: [Ex, Cin, H, W, B]; w: [Ew, Cout, Cin, kh, kw]."""
+    Ex, Cin, H, W, B = x.shape
+    d, ho, wo = _desc(x.new_empty((Ex, B, Cin, H, W), device="meta"), w, stride, padding, dilation, draws, x_shared, w_shared, act)
+    d.x_draw_stride = 0 if x_shared else Cin * H * W * B
+    return d, ho, wo
+
+
+def conv2d_chwn_forward(x, w, bias, stride=1, padding=0, dilation=1, act=None):
+    """Batch-innermost conv for the ensemble path.  x: [E|1, Cin, H, W, B] (B % 4 == 0); w: [E|1, Cout, Cin, kh, kw];
+    bias [E|1, Cout] or None -> y [E, Cout, Ho, Wo, B].  Padding taps are skipped, not multiplied."""
+    require_device(x, w, bias)
+    x, w = x.contiguous(), w.contiguous()
+    bias = None if bias is None else bias.contiguous()
+    E = max(x.shape[0], w.shape[0])
+    if x.shape[0] not in (1, E) or w.shape[0] not in (1, E):
+        raise _lib.BBBHipError("leading (draw) dims of x and w must be 1 or equal")
+    d, ho, wo = _desc_chwn(x, w, stride, padding, dilation, E, x.shape[0] == 1 and E > 1, w.shape[0] == 1 and E > 1, act)
+    y = torch.empty((E, w.shape[1], ho, wo, x.shape[4]), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.lib().bbb_conv2d_chwn_fwd(ctypes.byref(d), x.data_ptr(), w.data_ptr(), ptr(bias), y.data_ptr(),
+                                             cur_stream(x.device)), "bbb_conv2d_chwn_fwd")
+    return y
+
+
+def lrt_conv2d_chwn_forward(x, w_mu, w_var, b_mu, b_var, seed, call0, stream_id, stride=1, padding=0, dilation=1,
+                            sample=True, eps=None, want_moments=False, act=None):
+    """LRT layer, batch-innermost.  x: [E, Cin, H, W, B] -> (y, act_mu|None, act_var|None) [E, Cout, Ho, Wo, B]."""
+    require_device(x, w_mu, w_var, b_mu, b_var, eps)
+    x = x.contiguous()
+    w_mu, w_var = w_mu.contiguous(), w_var.contiguous()
+    b_mu = None if b_mu is None else b_mu.contiguous()
+    b_var = None if b_var is None else b_var.contiguous()
+    E = x.shape[0]
+    d, ho, wo = _desc_chwn(x, w_mu.unsqueeze(0), stride, padding, dilation, E, False, True, act)
+    d.w_draw_stride = 0
+    d.b_draw_stride = 0
+    shape = (E, w_mu.shape[0], ho, wo, x.shape[4])
+    y = torch.empty(shape, dtype=torch.float32, device=x.device)
+    am = torch.empty(shape, dtype=torch.float32, device=x.device) if want_moments else None
+    av = torch.empty(shape, dtype=torch.float32, device=x.device) if want_moments else None
+    if eps is not None:
+        eps = eps.contiguous()
+    with torch.cuda.device(x.device):
+        check(_lib.lib().bbb_lrt_conv2d_chwn_fwd(ctypes.byref(d), x.data_ptr(), w_mu.data_ptr(), w_var.data_ptr(), ptr(b_mu),
+                                                 ptr(b_var), y.data_ptr(), ptr(am), ptr(av), ptr(eps), seed,
+                                                 call0 & 0xFFFFFFFF, stream_id, 1 if sample else 0, cur_stream(x.device)),
+              "bbb_lrt_conv2d_chwn_fwd")
+    return y, am, av
+
+
+def maxpool_chwn(x, k, s):
+    """MaxPool2d(k, s) on [..., H, W, B] (B innermost, B % 4 == 0)."""
+    require_device(x)
+    x = x.contiguous()
+    *lead, H, W, B = x.shape
+    planes = 1
+    for v in lead:
+        planes *= v
+    ho, wo = (H - k) // s + 1, (W - k) // s + 1
+    y = torch.empty((*lead, ho, wo, B), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.lib().bbb_maxpool_chwn(x.data_ptr(), y.data_ptr(), planes, H, W, B, int(k), int(s), cur_stream(x.device)),
+              "bbb_maxpool_chwn")
+    return y
+
+
 def mc_tail(logits, mean_over=0):
     """logits [E, B, C] -> [B, C]: log-sum-exp over draws of the per-draw log_softmax, minus log(mean_over)
     when mean_over > 0 (== utils.logmeanexp of the stacked log_softmax when mean_over == E)."""

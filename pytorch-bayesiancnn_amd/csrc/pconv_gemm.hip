@@ -1,0 +1,358 @@
+// Pixel-major implicit GEMM for the Monte-Carlo ensemble path on gfx950: batch-innermost activations,
+// padding taps never computed.
+//
+// Layout: activations are [draw][C][H][W][B] (B innermost, B % 4 == 0); weights stay in the reference's
+// [draw][Cout][Cin][kh][kw].  One workgroup owns ONE output pixel (oh, ow), 64 output channels and BM images:
+//     D[n][b] = sum over ci and over the kernel taps (r, q) that fall INSIDE the image for this pixel
+//               W[n][ci][r][q] * X[ci][oh*s - p + r*d][ow*s - p + q*d][b]
+// so the contraction length is K_eff = Cin * nr * nq (nr, nq = number of in-bounds taps per axis) instead of
+// Cin*kh*kw.  On AlexNet/CIFAR the 2x2 and 4x4 feature maps make more than half of the im2col matrix padding
+// zeros; skipping them halves the matrix-core work (7.07 instead of 14.11 GFLOP per draw at bs=512).
+// Every X row of a tile is one contiguous run of BM floats (16-byte vector loads straight into LDS rows),
+// every output row is contiguous in b: fully coalesced on both sides, no per-element im2col arithmetic.
+//
+// Matrix core: v_mfma_f32_32x32x2_f32 (exact fp32), weights as the "A" operand, X as "B" -> lanes = images.
+// Workgroup = 256 threads = 4 waves, tile 64 (n) x BM (b) x 32 (k); register-staged double buffering;
+// per-tile (k_eff -> weight offset, x row) tables computed by 32 lanes into LDS.
+// Workgroups that share a weight tile (same draw, same 64 channels) are mapped to the same XCD (block id
+// mod 8) so the tile stays in that XCD's private L2.
+//
+// LRT variant: second accumulator set for sigma^2 * x^2, epilogue act_mu + sqrt(1e-16 + act_var) * eps with eps
+// indexed by the canonical NCHW element index (identical stream to the NCHW kernel and the oracle).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/bbb_hip.h"
+#include "bbb_common.cuh"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kThreads = 256;
+constexpr int BN = 64;
+constexpr int BK = 32;
+constexpr int LDW = BN + 1;
+
+struct PConvArgs {
+    const float* x;
+    const float* w;
+    const float* w2;
+    const float* bias;
+    const float* bias2;
+    float* y;
+    float* y_mu;
+    float* y_var;
+    const float* eps_ext;
+    int64_t x_ds, w_ds, b_ds, y_ds;
+    int32_t B, Cin, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, Ho, Wo;
+    int32_t K, khkw, act, sample;
+    int32_t Mtiles, nbt, Ntiles, G;
+    uint32_t k0, k1, call0, stream_id;
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == 1) return fmaxf(v, 0.0f);
+    if (act == 2) return v > 20.0f ? v : log1pf(expf(v));
+    return v;
+}
+
+template <int BM, bool LRT>
+__global__ __launch_bounds__(kThreads) void pconv_gemm_kernel(const PConvArgs p) {
+    constexpr int LDX = BM + 4;
+    constexpr int NT = (BM == 128) ? 2 : 1;
+    constexpr int WSETS = LRT ? 2 : 1;
+    constexpr int XL = BM / 4;                 // lanes per X row (float4 each)
+    constexpr int XRPP = kThreads / XL;        // X rows per pass
+    constexpr int XPASS = BK / XRPP;
+
+    __shared__ __attribute__((aligned(16))) float Xs[2][BK * LDX];
+    __shared__ float Ws[2][WSETS][BK * LDW];
+    __shared__ int32_t kt_w[2][BK];
+    __shared__ int32_t kt_x[2][BK];
+
+    // ---- block -> (draw, channel tile, pixel, batch tile); weight-tile sharers on one XCD ----
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7;
+    const int slot = bid >> 3;
+    const int tg = slot / p.Mtiles;
+    const int j = slot - tg * p.Mtiles;
+    const int g = xcd + 8 * tg;
+    if (g >= p.G) return;
+    const int e = g / p.Ntiles;
+    const int n0 = (g - e * p.Ntiles) * BN;
+    const int pix = j / p.nbt;
+    const int b0 = (j - pix * p.nbt) * BM;
+    const int oh = pix / p.Wo, ow = pix - oh * p.Wo;
+    // in-bounds tap ranges for this pixel
+    const int ihb = oh * p.sh - p.ph, iwb = ow * p.sw - p.pw;
+    int r_lo = ihb < 0 ? (-ihb + p.dh - 1) / p.dh : 0;
+    int q_lo = iwb < 0 ? (-iwb + p.dw - 1) / p.dw : 0;
+    int r_hi = (p.H - 1 - ihb) >= 0 ? (p.H - 1 - ihb) / p.dh + 1 : 0;
+    int q_hi = (p.W - 1 - iwb) >= 0 ? (p.W - 1 - iwb) / p.dw + 1 : 0;
+    r_hi = r_hi < p.kh ? r_hi : p.kh;
+    q_hi = q_hi < p.kw ? q_hi : p.kw;
+    const int nr = r_hi > r_lo ? r_hi - r_lo : 0;
+    const int nq = q_hi > q_lo ? q_hi - q_lo : 0;
+    const int nrq = nr * nq;
+    const int Keff = p.Cin * nrq;
+    const int ntiles = (Keff + BK - 1) / BK;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = (BM == 128) ? 0 : (wave >> 1) * 32;
+    const int wm = (BM == 128) ? wave * 32 : (wave & 1) * 32;
+
+    const float* __restrict__ xg = p.x + (int64_t)e * p.x_ds + b0;
+    const float* __restrict__ wg = p.w + (int64_t)e * p.w_ds;
+    const float* __restrict__ w2g = LRT ? p.w2 + (int64_t)e * p.w_ds : nullptr;
+
+    // loaders
+    const int wkl = tid & 31, wnl = tid >> 5;            // weights: lane -> k, 8 channel rows per pass
+    const int xb4 = (tid % XL) * 4, xkr = tid / XL;      // x: lane -> 4 images, XRPP k rows per pass
+    const bool xb_ok = (b0 + xb4) < p.B;
+
+    float wreg[WSETS][8];
+    f32x4 xreg[XPASS];
+
+    auto fill_ktab = [&](int tile, int buf) {
+        if (tid < BK) {
+            const int k = tile * BK + tid;
+            int wo = -1, xo = -1;
+            if (k < Keff) {
+                const int ci = k / nrq;
+                const int rq = k - ci * nrq;
+                const int rr = rq / nq;
+                const int r = r_lo + rr;
+                const int q = q_lo + (rq - rr * nq);
+                wo = ci * p.khkw + r * p.kw + q;
+                xo = (ci * p.H + ihb + r * p.dh) * p.W + iwb + q * p.dw;     // row index; * B at use
+            }
+            kt_w[buf][tid] = wo;
+            kt_x[buf][tid] = xo;
+        }
+    };
+
+    auto load_tile = [&](int buf) {
+        const int wo = kt_w[buf][wkl];
+#pragma unroll
+        for (int s = 0; s < WSETS; ++s) {
+            const float* __restrict__ src = (s == 0) ? wg : w2g;
+#pragma unroll
+            for (int ps = 0; ps < 8; ++ps) {
+                const int n = n0 + wnl + ps * 8;
+                wreg[s][ps] = (wo >= 0 && n < p.Cout) ? src[(int64_t)n * p.K + wo] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int ps = 0; ps < XPASS; ++ps) {
+            const int xo = kt_x[buf][xkr + ps * XRPP];
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (xo >= 0 && xb_ok) v = *reinterpret_cast<const f32x4*>(xg + (int64_t)xo * p.B + xb4);
+            xreg[ps] = v;
+        }
+    };
+
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int s = 0; s < WSETS; ++s)
+#pragma unroll
+            for (int ps = 0; ps < 8; ++ps) Ws[buf][s][wkl * LDW + wnl + ps * 8] = wreg[s][ps];
+#pragma unroll
+        for (int ps = 0; ps < XPASS; ++ps)
+            *reinterpret_cast<f32x4*>(&Xs[buf][(xkr + ps * XRPP) * LDX + xb4]) = xreg[ps];
+    };
+
+    f32x16 acc[NT];
+    f32x16 accv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[t][r] = 0.0f; accv[t][r] = 0.0f; }
+
+    const int lrow = lane & 31, lk = lane >> 5;
+    if (ntiles > 0) {
+        fill_ktab(0, 0);
+        fill_ktab(1, 1);
+        __syncthreads();
+        load_tile(0);
+        store_tile(0);
+        __syncthreads();
+        for (int t = 0; t < ntiles; ++t) {
+            const int cur = t & 1;
+            const bool more = (t + 1) < ntiles;
+            if (more) load_tile(cur ^ 1);
+            if (t + 2 < ntiles) fill_ktab(t + 2, cur);   // kt[cur] was last read before the previous barrier
+#pragma unroll
+            for (int kk = 0; kk < BK / 2; ++kk) {
+                const int krow = kk * 2 + lk;
+                const float b = Xs[cur][krow * LDX + wm + lrow];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float a = Ws[cur][0][krow * LDW + wn + nt * 32 + lrow];
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[nt], 0, 0, 0);
+                    if (LRT) {
+                        const float a2 = Ws[cur][WSETS - 1][krow * LDW + wn + nt * 32 + lrow];
+                        accv[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b * b, accv[nt], 0, 0, 0);
+                    }
+                }
+            }
+            if (more) store_tile(cur ^ 1);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: rows = channels, lanes = images ----
+    const int b = b0 + wm + lrow;
+    if (b < p.B) {
+        const int HoWo = p.Ho * p.Wo;
+        const int64_t ybase = (int64_t)e * p.y_ds + (int64_t)pix * p.B + b;
+        const float* __restrict__ bg = p.bias ? p.bias + (int64_t)e * p.b_ds : nullptr;
+        const float* __restrict__ b2g = (LRT && p.bias2) ? p.bias2 + (int64_t)e * p.b_ds : nullptr;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wn + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (n < p.Cout) {
+                    const int64_t o = ybase + (int64_t)n * HoWo * p.B;
+                    float v = acc[nt][r] + (bg ? bg[n] : 0.0f);
+                    if (LRT) {
+                        const float var = 1e-16f + (accv[nt][r] + (b2g ? b2g[n] : 0.0f));
+                        if (p.y_mu) p.y_mu[o] = v;
+                        if (p.y_var) p.y_var[o] = var;
+                        if (p.sample) {
+                            float z;
+                            if (p.eps_ext) {
+                                z = p.eps_ext[o];
+                            } else {   // canonical NCHW element index of this draw's [B][Cout][Ho][Wo] slab
+                                const uint64_t idx = (uint64_t)(((int64_t)b * p.Cout + n) * HoWo + pix);
+                                float z4[4];
+                                bbb::normal4(idx >> 2, p.stream_id, p.call0 + (uint32_t)e, p.k0, p.k1, z4);
+                                const int c = (int)(idx & 3);
+                                z = c == 0 ? z4[0] : c == 1 ? z4[1] : c == 2 ? z4[2] : z4[3];
+                            }
+                            v = v + __builtin_amdgcn_sqrtf(var) * z;
+                        }
+                    }
+                    p.y[o] = apply_act(v, p.act);
+                }
+            }
+        }
+    }
+}
+
+// maxpool over [planes][H][W][B] (planes = draws * channels), B innermost; 4 images per thread.
+__global__ __launch_bounds__(256) void maxpool_chwn_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t total4,
+                                                           int H, int W, int Ho, int Wo, int B4, int k, int s) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total4) return;
+    const int b4 = (int)(i % B4);
+    int64_t t = i / B4;
+    const int ow = (int)(t % Wo);
+    t /= Wo;
+    const int oh = (int)(t % Ho);
+    const int64_t pl = t / Ho;
+    const f32x4* xp = reinterpret_cast<const f32x4*>(x) + ((pl * H + (int64_t)oh * s) * W + (int64_t)ow * s) * B4 + b4;
+    f32x4 m = xp[0];
+    for (int a = 0; a < k; ++a)
+        for (int c = 0; c < k; ++c) {
+            const f32x4 v = xp[((int64_t)a * W + c) * B4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) m[u] = fmaxf(m[u], v[u]);
+        }
+    reinterpret_cast<f32x4*>(y)[i] = m;
+}
+
+int fill(const bbb_conv_desc_t* d, PConvArgs& a) {
+    if (d == nullptr) return BBB_EINVAL;
+    if (d->batch <= 0 || d->cin <= 0 || d->h <= 0 || d->w <= 0 || d->cout <= 0 || d->kh <= 0 || d->kw <= 0 ||
+        d->stride_h <= 0 || d->stride_w <= 0 || d->pad_h < 0 || d->pad_w < 0 || d->dil_h <= 0 || d->dil_w <= 0 ||
+        d->draws <= 0 || d->act < 0 || d->act > 2)
+        return BBB_EINVAL;
+    if (d->batch % 4 != 0) return BBB_ESHAPE;        // batch-innermost rows are moved as 16-byte vectors
+    const int ho = (d->h + 2 * d->pad_h - d->dil_h * (d->kh - 1) - 1) / d->stride_h + 1;
+    const int wo = (d->w + 2 * d->pad_w - d->dil_w * (d->kw - 1) - 1) / d->stride_w + 1;
+    if (ho <= 0 || wo <= 0) return BBB_ESHAPE;
+    if ((int64_t)d->cin * d->h * d->w > 0x7fffffffLL || (int64_t)d->cin * d->kh * d->kw > 0x7fffffffLL) return BBB_ESHAPE;
+    a.B = d->batch; a.Cin = d->cin; a.H = d->h; a.W = d->w; a.Cout = d->cout; a.kh = d->kh; a.kw = d->kw;
+    a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w; a.dh = d->dil_h; a.dw = d->dil_w;
+    a.Ho = ho; a.Wo = wo; a.K = d->cin * d->kh * d->kw; a.khkw = d->kh * d->kw; a.act = d->act;
+    a.x_ds = d->x_draw_stride; a.w_ds = d->w_draw_stride; a.b_ds = d->b_draw_stride;
+    a.y_ds = (int64_t)d->cout * ho * wo * d->batch;
+    return 0;
+}
+
+template <bool LRT>
+int launch(PConvArgs& a, int draws, hipStream_t st) {
+    a.Ntiles = (a.Cout + BN - 1) / BN;
+    a.G = a.Ntiles * draws;
+    const int64_t pixels = (int64_t)a.Ho * a.Wo;
+    // tile choice: fewest "rounds x tile width" over the 256 CUs
+    const int64_t nb128 = pixels * ((a.B + 127) / 128) * a.G, nb64 = pixels * ((a.B + 63) / 64) * a.G;
+    const int64_t c128 = ((nb128 + 255) / 256) * 128, c64 = ((nb64 + 255) / 256) * 64;
+    const int bm = (LRT || c64 < c128) ? 64 : 128;   // LRT stages two weight tiles: 64-wide only (LDS budget)
+    a.nbt = (a.B + bm - 1) / bm;
+    const int64_t mt = pixels * a.nbt;
+    if (mt > 0x7fffffffLL) return BBB_ESHAPE;
+    a.Mtiles = (int)mt;
+    const int64_t blocks = (int64_t)8 * ((a.G + 7) / 8) * mt;
+    if (blocks > 0x7fffffffLL) return BBB_ESHAPE;
+    if constexpr (!LRT) {
+        if (bm == 128) {
+            hipLaunchKernelGGL((pconv_gemm_kernel<128, false>), dim3((unsigned)blocks), dim3(kThreads), 0, st, a);
+            return (int)hipGetLastError();
+        }
+    }
+    hipLaunchKernelGGL((pconv_gemm_kernel<64, LRT>), dim3((unsigned)blocks), dim3(kThreads), 0, st, a);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" int bbb_conv2d_chwn_fwd(const bbb_conv_desc_t* d, const float* x, const float* w, const float* bias, float* y,
+                                   void* stream) {
+    PConvArgs a = {};
+    const int rc = fill(d, a);
+    if (rc != 0) return rc;
+    if (x == nullptr || w == nullptr || y == nullptr) return BBB_EINVAL;
+    if ((((uintptr_t)x | (uintptr_t)y) & 15u) != 0 || (((uintptr_t)w | (uintptr_t)bias) & 3u) != 0) return BBB_EALIGN;
+    a.x = x; a.w = w; a.bias = bias; a.y = y;
+    return launch<false>(a, d->draws, (hipStream_t)stream);
+}
+
+extern "C" int bbb_lrt_conv2d_chwn_fwd(const bbb_conv_desc_t* d, const float* x, const float* w_mu, const float* w_var,
+                                       const float* b_mu, const float* b_var, float* y, float* act_mu_out,
+                                       float* act_var_out, const float* eps_ext, uint64_t seed, uint32_t call0,
+                                       uint32_t stream_id, int sample, void* stream) {
+    PConvArgs a = {};
+    const int rc = fill(d, a);
+    if (rc != 0) return rc;
+    if (x == nullptr || w_mu == nullptr || w_var == nullptr || y == nullptr) return BBB_EINVAL;
+    if ((b_mu == nullptr) != (b_var == nullptr)) return BBB_EINVAL;
+    if (d->w_draw_stride != 0 || d->b_draw_stride != 0) return BBB_EINVAL;
+    if ((((uintptr_t)x | (uintptr_t)y) & 15u) != 0) return BBB_EALIGN;
+    if ((((uintptr_t)w_mu | (uintptr_t)w_var | (uintptr_t)b_mu | (uintptr_t)b_var | (uintptr_t)act_mu_out |
+          (uintptr_t)act_var_out | (uintptr_t)eps_ext) & 3u) != 0)
+        return BBB_EALIGN;
+    a.x = x; a.w = w_mu; a.w2 = w_var; a.bias = b_mu; a.bias2 = b_var; a.y = y;
+    a.y_mu = act_mu_out; a.y_var = act_var_out; a.eps_ext = eps_ext;
+    a.k0 = (uint32_t)seed; a.k1 = (uint32_t)(seed >> 32); a.call0 = call0; a.stream_id = stream_id;
+    a.sample = sample ? 1 : 0;
+    return launch<true>(a, d->draws, (hipStream_t)stream);
+}
+
+extern "C" int bbb_maxpool_chwn(const float* x, float* y, int64_t planes, int h, int w, int batch, int k, int s, void* stream) {
+    if (x == nullptr || y == nullptr || planes <= 0 || h <= 0 || w <= 0 || batch <= 0 || k <= 0 || s <= 0) return BBB_EINVAL;
+    if (batch % 4 != 0 || h < k || w < k) return BBB_ESHAPE;
+    if ((((uintptr_t)x | (uintptr_t)y) & 15u) != 0) return BBB_EALIGN;
+    const int ho = (h - k) / s + 1, wo = (w - k) / s + 1;
+    const int64_t total4 = planes * ho * wo * (batch / 4);
+    const int64_t blocks = (total4 + 255) / 256;
+    if (blocks > 0x7fffffffLL) return BBB_ESHAPE;
+    hipLaunchKernelGGL(maxpool_chwn_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, y, total4, h, w, ho, wo,
+                       batch / 4, k, s);
+    return (int)hipGetLastError();
+}

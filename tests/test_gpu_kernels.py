@@ -235,3 +235,66 @@ def test_errors_are_loud(ops):
         ops.conv2d_forward(torch.zeros(1, 1, 3, 2, 2).cuda(), torch.zeros(1, 2, 3, 3, 3).cuda(), None)  # kernel > image
     with pytest.raises(BBBHipError):
         ops.reparam_kl_forward([torch.zeros(4).cuda()], [torch.zeros(4).cuda()], 0, -1.0, [0], 0, 0)     # bad prior sigma
+
+
+# ---------------------------------------------------------------- batch-innermost (CHWN) kernels of the ensemble path
+CHWN_CASES = [
+    # B, Cin, H, W, Cout, kh, kw, stride, pad, dil, E, x_shared
+    (8, 3, 9, 9, 5, 3, 3, 2, 1, 1, 1, False),
+    (4, 2, 8, 7, 4, 2, 3, 1, 2, 2, 2, False),
+    (132, 3, 32, 32, 64, 11, 11, 4, 5, 1, 2, True),    # AlexNet conv1; B straddles the 128 tile
+    (64, 64, 4, 4, 192, 5, 5, 1, 2, 1, 3, False),      # AlexNet conv2 (half the taps are padding)
+    (260, 192, 2, 2, 384, 3, 3, 1, 1, 1, 2, False),    # AlexNet conv3 (2x2 maps)
+    (12, 1, 32, 32, 6, 5, 5, 1, 0, 1, 1, False),       # LeNet conv1
+    (8, 32, 15, 15, 64, 5, 5, 1, 2, 1, 1, False),      # 3Conv3FC conv2
+    (36, 16, 6, 6, 70, 3, 3, 1, 1, 1, 1, False),
+    (256, 512, 1, 1, 1000, 1, 1, 1, 0, 1, 1, False),   # linear as 1x1
+    (4, 5, 3, 3, 7, 5, 5, 1, 3, 1, 1, False),          # kernel larger than the image: most taps out of bounds
+]
+
+
+@pytest.mark.parametrize("case", CHWN_CASES)
+def test_conv2d_chwn_matches_oracle_and_nchw_kernel(ops, case):
+    B, Cin, H, W, Cout, kh, kw, s, p, d, E, shared = case
+    rng = np.random.default_rng(sum(case[:11]) + 1)
+    x = rng.standard_normal((1 if shared else E, B, Cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((E, Cout, Cin, kh, kw)) * 0.1).astype(np.float32)
+    b = rng.standard_normal((E, Cout)).astype(np.float32)
+    xd = dev(x)
+    y = ops.conv2d_chwn_forward(xd.permute(0, 2, 3, 4, 1).contiguous(), dev(w), dev(b), s, p, d)      # [E, Cout, Ho, Wo, B]
+    y = y.permute(0, 4, 1, 2, 3).contiguous()
+    y_nchw = ops.conv2d_forward(xd, dev(w), dev(b), s, p, d)
+    # skipping padding taps only drops exact zeros from the fmaf chain: same bits as the NCHW kernel
+    assert torch.equal(y, y_nchw)
+    for e in range(E):
+        np.testing.assert_allclose(y[e].cpu().numpy(), O.conv2d(x[0 if shared else e], w[e], b[e], s, p, d), rtol=2e-5, atol=2e-5)
+
+
+def test_lrt_chwn_matches_nchw_kernel_and_oracle(ops):
+    B, Cin, H, W, Cout, k, s, p, E = 8, 16, 6, 6, 70, 3, 1, 1, 2
+    rng = np.random.default_rng(5)
+    x = rng.random((E, B, Cin, H, W)).astype(np.float32)
+    wmu = (rng.standard_normal((Cout, Cin, k, k)) * 0.1).astype(np.float32)
+    wvar = (rng.random((Cout, Cin, k, k)) * 1e-3).astype(np.float32)
+    bmu = (rng.standard_normal(Cout) * 0.1).astype(np.float32)
+    bvar = (rng.random(Cout) * 1e-3).astype(np.float32)
+    xd = dev(x)
+    y1, am1, av1 = ops.lrt_conv2d_forward(xd, dev(wmu), dev(wvar), dev(bmu), dev(bvar), 7, 3, 2, s, p, 1, want_moments=True, act="softplus")
+    y2, am2, av2 = ops.lrt_conv2d_chwn_forward(xd.permute(0, 2, 3, 4, 1).contiguous(), dev(wmu), dev(wvar), dev(bmu), dev(bvar),
+                                               7, 3, 2, s, p, 1, want_moments=True, act="softplus")
+    back = lambda t: t.permute(0, 4, 1, 2, 3).contiguous()
+    assert torch.equal(back(am2), am1) and torch.equal(back(av2), av1)
+    assert torch.equal(back(y2), y1)                           # same eps stream (canonical NCHW element index)
+    for e in range(E):
+        want = O.conv2d(x[e], wmu, bmu, s, p, 1)
+        np.testing.assert_allclose(am1[e].cpu().numpy(), want, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("k,s,H,W", [(2, 2, 8, 8), (3, 2, 15, 15), (3, 2, 7, 9), (2, 2, 5, 5)])
+def test_maxpool_chwn(ops, k, s, H, W):
+    rng = np.random.default_rng(k * H)
+    x = rng.standard_normal((3, 5, H, W, 8)).astype(np.float32)
+    y = ops.maxpool_chwn(dev(x), k, s).cpu().numpy()
+    want = O.maxpool2d(np.ascontiguousarray(x.transpose(0, 4, 1, 2, 3)).reshape(-1, 5, H, W), k, s)
+    want = want.reshape(3, 8, 5, *want.shape[2:]).transpose(0, 2, 3, 4, 1)
+    np.testing.assert_array_equal(y, want)
