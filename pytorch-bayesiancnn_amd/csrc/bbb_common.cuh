@@ -53,6 +53,18 @@ __device__ __forceinline__ float softplus_ref(float rho) {
     return rho > 20.0f ? rho : log1pf(expf(rho));
 }
 
+// Epilogue activations.  Softplus(beta=1, threshold=20) on the hardware exp2 / log2 units:
+// log(1 + e^v) = ln2 * log2(1 + 2^(v*log2 e)); absolute error <= ~1e-7 (v < -16.6 flushes to 0 instead of e^v < 6e-8).
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == 1) return fmaxf(v, 0.0f);
+    if (act == 2) {
+        const float t = __builtin_amdgcn_exp2f(fminf(v, 20.0f) * 1.4426950408889634f);
+        const float sp = 0.6931471805599453f * __builtin_amdgcn_logf(1.0f + t);
+        return v > 20.0f ? v : sp;
+    }
+    return v;
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);

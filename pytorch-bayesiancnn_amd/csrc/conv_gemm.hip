@@ -51,11 +51,6 @@ struct ConvArgs {
     uint32_t k0, k1, call0, stream_id;
 };
 
-__device__ __forceinline__ float apply_act(float v, int act) {
-    if (act == 1) return fmaxf(v, 0.0f);
-    if (act == 2) return v > 20.0f ? v : log1pf(expf(v));
-    return v;
-}
 
 template <int BM, bool LRT, bool LINEAR>
 __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const ConvArgs p) {
@@ -290,7 +285,7 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const ConvArgs p) {
                             v = v + __builtin_amdgcn_sqrtf(var) * z;
                         }
                     }
-                    p.y[o] = apply_act(v, p.act);
+                    p.y[o] = bbb::apply_act(v, p.act);
                 }
             }
         }

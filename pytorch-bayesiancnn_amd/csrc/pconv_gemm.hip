@@ -34,6 +34,8 @@ constexpr int kThreads = 256;
 constexpr int BN = 64;
 constexpr int BK = 32;
 constexpr int LDW = BN + 1;
+constexpr int KCH = 256;                 // k_eff entries per decode chunk (one entry per thread)
+constexpr int TPC = KCH / BK;            // tiles per chunk
 
 struct PConvArgs {
     const float* x;
@@ -52,11 +54,6 @@ struct PConvArgs {
     uint32_t k0, k1, call0, stream_id;
 };
 
-__device__ __forceinline__ float apply_act(float v, int act) {
-    if (act == 1) return fmaxf(v, 0.0f);
-    if (act == 2) return v > 20.0f ? v : log1pf(expf(v));
-    return v;
-}
 
 template <int BM, bool LRT>
 __global__ __launch_bounds__(kThreads) void pconv_gemm_kernel(const PConvArgs p) {
@@ -67,10 +64,14 @@ __global__ __launch_bounds__(kThreads) void pconv_gemm_kernel(const PConvArgs p)
     constexpr int XRPP = kThreads / XL;        // X rows per pass
     constexpr int XPASS = BK / XRPP;
 
-    __shared__ __attribute__((aligned(16))) float Xs[2][BK * LDX];
-    __shared__ float Ws[2][WSETS][BK * LDW];
-    __shared__ int32_t kt_w[2][BK];
-    __shared__ int32_t kt_x[2][BK];
+    // ONE LDS stage per operand; the second stage of the pipeline is the register file (loads for tile t+1 are
+    // issued before tile t's MFMAs and written to LDS after them, inside one loop iteration: no loop-carried
+    // in-flight registers, which hipcc would otherwise "fix" with copies behind a vmcnt(0)).  Small LDS + modest
+    // VGPR use => 4 workgroups per CU; latency is hidden by occupancy, not by prefetch depth.
+    __shared__ __attribute__((aligned(16))) float Xs[1][BK * LDX];
+    __shared__ float Ws[1][WSETS][BK * LDW];
+    __shared__ int32_t kt_w[2][KCH];   // (k_eff -> weight offset, x row) for a chunk of 256 k_eff = 8 tiles,
+    __shared__ int32_t kt_x[2][KCH];   // filled by all 256 threads at once, double buffered
 
     // ---- block -> (draw, channel tile, pixel, batch tile); weight-tile sharers on one XCD ----
     const int bid = blockIdx.x;
@@ -105,57 +106,74 @@ __global__ __launch_bounds__(kThreads) void pconv_gemm_kernel(const PConvArgs p)
     const int wn = (BM == 128) ? 0 : (wave >> 1) * 32;
     const int wm = (BM == 128) ? wave * 32 : (wave & 1) * 32;
 
-    const float* __restrict__ xg = p.x + (int64_t)e * p.x_ds + b0;
-    const float* __restrict__ wg = p.w + (int64_t)e * p.w_ds;
-    const float* __restrict__ w2g = LRT ? p.w2 + (int64_t)e * p.w_ds : nullptr;
+    // Buffer descriptors (wave-uniform): out-of-range offsets read as 0, which is how invalid k / channel / image
+    // lanes are masked without a branch around every load (a branch would make hipcc wait vmcnt(0) per element).
+    constexpr uint32_t kOOB = 0xFFFFFFF0u;
+    constexpr uint32_t kWInv = 0x7FFFFFF0u;    // invalid weight k: slab bytes < 2^30, so row + kWInv is out of range
+    constexpr uint32_t kXInv = 0xFFFF0000u;    // invalid x row: + column bytes (< 64 KiB) neither wraps nor lands in range
+    const int64_t w_elems = (int64_t)p.Cout * p.K;
+    const int64_t x_elems = (int64_t)p.Cin * p.H * p.W * p.B;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x + (int64_t)e * p.x_ds), 0, (int)(x_elems * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.w + (int64_t)e * p.w_ds), 0, (int)(w_elems * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t w2rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(LRT ? p.w2 + (int64_t)e * p.w_ds : p.w), 0, (int)(w_elems * 4), 0x00020000);
 
     // loaders
     const int wkl = tid & 31, wnl = tid >> 5;            // weights: lane -> k, 8 channel rows per pass
     const int xb4 = (tid % XL) * 4, xkr = tid / XL;      // x: lane -> 4 images, XRPP k rows per pass
-    const bool xb_ok = (b0 + xb4) < p.B;
+    // No per-lane masking of channels >= Cout or images >= B: such rows / columns of D are never stored, GEMM
+    // columns do not mix, and reads past a slab come back as 0 from the buffer unit.  Only invalid k must be zero
+    // (on both operands), which the table encodes as out-of-range offsets.
+    const uint32_t xcol = (uint32_t)(b0 + xb4) * 4u;                 // byte offset of this lane's 4 images in a row
+    uint32_t wrow[8];                                                // byte offset of this lane's 8 channel rows
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) wrow[ps] = (uint32_t)(n0 + wnl + ps * 8) * (uint32_t)p.K * 4u;
 
-    float wreg[WSETS][8];
-    f32x4 xreg[XPASS];
+    float wregA[WSETS][8];
+    f32x4 xregA[XPASS];
 
-    auto fill_ktab = [&](int tile, int buf) {
-        if (tid < BK) {
-            const int k = tile * BK + tid;
-            int wo = -1, xo = -1;
-            if (k < Keff) {
-                const int ci = k / nrq;
-                const int rq = k - ci * nrq;
-                const int rr = rq / nq;
-                const int r = r_lo + rr;
-                const int q = q_lo + (rq - rr * nq);
-                wo = ci * p.khkw + r * p.kw + q;
-                xo = (ci * p.H + ihb + r * p.dh) * p.W + iwb + q * p.dw;     // row index; * B at use
-            }
-            kt_w[buf][tid] = wo;
-            kt_x[buf][tid] = xo;
+    // k_eff -> (ci, r, q) with float-reciprocal division + fix-up (exact for k_eff < 2^24)
+    const float inv_nrq = nrq > 0 ? 1.0f / (float)nrq : 0.0f;
+    const float inv_nq = nq > 0 ? 1.0f / (float)nq : 0.0f;
+    auto fill_chunk = [&](int chunk) {
+        const int k = chunk * KCH + tid;
+        uint32_t wo = kWInv, xo = kXInv;
+        if (k < Keff) {
+            int ci = (int)((float)k * inv_nrq);
+            int rq = k - ci * nrq;
+            if (rq < 0) { --ci; rq += nrq; } else if (rq >= nrq) { ++ci; rq -= nrq; }
+            int rr = (int)((float)rq * inv_nq);
+            int qq = rq - rr * nq;
+            if (qq < 0) { --rr; qq += nq; } else if (qq >= nq) { ++rr; qq -= nq; }
+            const int r = r_lo + rr, q = q_lo + qq;
+            wo = (uint32_t)(ci * p.khkw + r * p.kw + q) * 4u;                                    // byte offset in a row
+            xo = (uint32_t)((ci * p.H + ihb + r * p.dh) * p.W + iwb + q * p.dw) * (uint32_t)p.B * 4u;   // row byte offset
         }
+        kt_w[chunk & 1][tid] = (int32_t)wo;
+        kt_x[chunk & 1][tid] = (int32_t)xo;
     };
 
-    auto load_tile = [&](int buf) {
-        const int wo = kt_w[buf][wkl];
+    auto load_tile = [&](int tile, float (&wreg)[WSETS][8], f32x4 (&xreg)[XPASS]) {
+        const int buf = (tile / TPC) & 1;
+        const int kb = (tile % TPC) * BK;
+        const uint32_t wob = (uint32_t)kt_w[buf][kb + wkl];
 #pragma unroll
-        for (int s = 0; s < WSETS; ++s) {
-            const float* __restrict__ src = (s == 0) ? wg : w2g;
-#pragma unroll
-            for (int ps = 0; ps < 8; ++ps) {
-                const int n = n0 + wnl + ps * 8;
-                wreg[s][ps] = (wo >= 0 && n < p.Cout) ? src[(int64_t)n * p.K + wo] : 0.0f;
-            }
+        for (int ps = 0; ps < 8; ++ps) {
+            const uint32_t off = wrow[ps] + wob;
+            wreg[0][ps] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrs, off, 0, 0));
+            if (LRT) wreg[WSETS - 1][ps] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(w2rs, off, 0, 0));
         }
 #pragma unroll
         for (int ps = 0; ps < XPASS; ++ps) {
-            const int xo = kt_x[buf][xkr + ps * XRPP];
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (xo >= 0 && xb_ok) v = *reinterpret_cast<const f32x4*>(xg + (int64_t)xo * p.B + xb4);
-            xreg[ps] = v;
+            const uint32_t off = (uint32_t)kt_x[buf][kb + xkr + ps * XRPP] + xcol;
+            xreg[ps] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0));
         }
     };
 
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int, float (&wreg)[WSETS][8], f32x4 (&xreg)[XPASS]) {
+        constexpr int buf = 0;
 #pragma unroll
         for (int s = 0; s < WSETS; ++s)
 #pragma unroll
@@ -173,44 +191,74 @@ __global__ __launch_bounds__(kThreads) void pconv_gemm_kernel(const PConvArgs p)
         for (int r = 0; r < 16; ++r) { acc[t][r] = 0.0f; accv[t][r] = 0.0f; }
 
     const int lrow = lane & 31, lk = lane >> 5;
-    if (ntiles > 0) {
-        fill_ktab(0, 0);
-        fill_ktab(1, 1);
-        __syncthreads();
-        load_tile(0);
-        store_tile(0);
-        __syncthreads();
-        for (int t = 0; t < ntiles; ++t) {
-            const int cur = t & 1;
-            const bool more = (t + 1) < ntiles;
-            if (more) load_tile(cur ^ 1);
-            if (t + 2 < ntiles) fill_ktab(t + 2, cur);   // kt[cur] was last read before the previous barrier
+
+    auto mma_tile = [&]() {
 #pragma unroll
-            for (int kk = 0; kk < BK / 2; ++kk) {
-                const int krow = kk * 2 + lk;
-                const float b = Xs[cur][krow * LDX + wm + lrow];
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            const int krow = kk * 2 + lk;
+            const float b = Xs[0][krow * LDX + wm + lrow];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const float a = Ws[cur][0][krow * LDW + wn + nt * 32 + lrow];
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[nt], 0, 0, 0);
-                    if (LRT) {
-                        const float a2 = Ws[cur][WSETS - 1][krow * LDW + wn + nt * 32 + lrow];
-                        accv[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b * b, accv[nt], 0, 0, 0);
-                    }
+            for (int nt = 0; nt < NT; ++nt) {
+                const float a = Ws[0][0][krow * LDW + wn + nt * 32 + lrow];
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[nt], 0, 0, 0);
+                if (LRT) {
+                    const float a2 = Ws[0][WSETS - 1][krow * LDW + wn + nt * 32 + lrow];
+                    accv[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b * b, accv[nt], 0, 0, 0);
                 }
             }
-            if (more) store_tile(cur ^ 1);
+        }
+    };
+
+    if (ntiles > 0) {
+        fill_chunk(0);
+        __syncthreads();
+        load_tile(0, wregA, xregA);
+        if (KCH < Keff) fill_chunk(1);
+        store_tile(0, wregA, xregA);
+        __syncthreads();
+        for (int t = 0; t < ntiles; ++t) {
+            const bool more = (t + 1) < ntiles;
+            if (more) load_tile(t + 1, wregA, xregA);                 // in flight during this tile's MFMAs
+            // decode chunk c+1 early in chunk c (c >= 1; chunk 1 is decoded in the prologue): its buffer was last
+            // read by load_tile(TPC*c - 1), several barriers ago
+            if ((t % TPC) == 1 && t / TPC >= 1 && (t / TPC + 1) * KCH < Keff) fill_chunk(t / TPC + 1);
+            mma_tile();
+            __syncthreads();                                          // every wave is done reading the LDS stage
+            if (more) store_tile(0, wregA, xregA);
             __syncthreads();
         }
     }
 
-    // ---- epilogue: rows = channels, lanes = images ----
+    // ---- epilogue: rows = channels, lanes = images; bias via buffer loads, stores via buffer stores
+    //      (out-of-range channel / image lanes get an out-of-range offset: no branches, no per-element waits) ----
     const int b = b0 + wm + lrow;
-    if (b < p.B) {
-        const int HoWo = p.Ho * p.Wo;
+    const bool b_ok = b < p.B;
+    const int HoWo = p.Ho * p.Wo;
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.bias ? p.bias + (int64_t)e * p.b_ds : p.w), 0, p.bias ? p.Cout * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
+        p.y + (int64_t)e * p.y_ds, 0, (int)((int64_t)p.Cout * HoWo * p.B * 4), 0x00020000);
+    float bv[NT][16];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = n0 + wn + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            bv[nt][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brs, (uint32_t)n * 4u, 0, 0));
+        }
+    if (!LRT) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wn + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                const uint32_t off = (b_ok & (n < p.Cout)) ? (uint32_t)(((int64_t)n * HoWo + pix) * p.B + b) * 4u : kOOB;
+                const float v = bbb::apply_act(acc[nt][r] + bv[nt][r], p.act);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), yrs, off, 0, 0);
+            }
+    } else if (b_ok) {
         const int64_t ybase = (int64_t)e * p.y_ds + (int64_t)pix * p.B + b;
-        const float* __restrict__ bg = p.bias ? p.bias + (int64_t)e * p.b_ds : nullptr;
-        const float* __restrict__ b2g = (LRT && p.bias2) ? p.bias2 + (int64_t)e * p.b_ds : nullptr;
+        const float* __restrict__ b2g = p.bias2 ? p.bias2 + (int64_t)e * p.b_ds : nullptr;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
@@ -218,26 +266,24 @@ __global__ __launch_bounds__(kThreads) void pconv_gemm_kernel(const PConvArgs p)
                 const int n = n0 + wn + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
                 if (n < p.Cout) {
                     const int64_t o = ybase + (int64_t)n * HoWo * p.B;
-                    float v = acc[nt][r] + (bg ? bg[n] : 0.0f);
-                    if (LRT) {
-                        const float var = 1e-16f + (accv[nt][r] + (b2g ? b2g[n] : 0.0f));
-                        if (p.y_mu) p.y_mu[o] = v;
-                        if (p.y_var) p.y_var[o] = var;
-                        if (p.sample) {
-                            float z;
-                            if (p.eps_ext) {
-                                z = p.eps_ext[o];
-                            } else {   // canonical NCHW element index of this draw's [B][Cout][Ho][Wo] slab
-                                const uint64_t idx = (uint64_t)(((int64_t)b * p.Cout + n) * HoWo + pix);
-                                float z4[4];
-                                bbb::normal4(idx >> 2, p.stream_id, p.call0 + (uint32_t)e, p.k0, p.k1, z4);
-                                const int c = (int)(idx & 3);
-                                z = c == 0 ? z4[0] : c == 1 ? z4[1] : c == 2 ? z4[2] : z4[3];
-                            }
-                            v = v + __builtin_amdgcn_sqrtf(var) * z;
+                    float v = acc[nt][r] + bv[nt][r];
+                    const float var = 1e-16f + (accv[nt][r] + (b2g ? b2g[n] : 0.0f));
+                    if (p.y_mu) p.y_mu[o] = v;
+                    if (p.y_var) p.y_var[o] = var;
+                    if (p.sample) {
+                        float z;
+                        if (p.eps_ext) {
+                            z = p.eps_ext[o];
+                        } else {   // canonical NCHW element index of this draw's [B][Cout][Ho][Wo] slab
+                            const uint64_t idx = (uint64_t)(((int64_t)b * p.Cout + n) * HoWo + pix);
+                            float z4[4];
+                            bbb::normal4(idx >> 2, p.stream_id, p.call0 + (uint32_t)e, p.k0, p.k1, z4);
+                            const int c = (int)(idx & 3);
+                            z = c == 0 ? z4[0] : c == 1 ? z4[1] : c == 2 ? z4[2] : z4[3];
                         }
+                        v = v + __builtin_amdgcn_sqrtf(var) * z;
                     }
-                    p.y[o] = apply_act(v, p.act);
+                    p.y[o] = bbb::apply_act(v, p.act);
                 }
             }
         }
@@ -277,6 +323,10 @@ int fill(const bbb_conv_desc_t* d, PConvArgs& a) {
     const int wo = (d->w + 2 * d->pad_w - d->dil_w * (d->kw - 1) - 1) / d->stride_w + 1;
     if (ho <= 0 || wo <= 0) return BBB_ESHAPE;
     if ((int64_t)d->cin * d->h * d->w > 0x7fffffffLL || (int64_t)d->cin * d->kh * d->kw > 0x7fffffffLL) return BBB_ESHAPE;
+    // per-draw slabs are addressed through 32-bit buffer offsets
+    if ((int64_t)d->cin * d->h * d->w * d->batch * 4 > 0xFFFE0000LL || (int64_t)d->cout * ho * wo * d->batch * 4 > 0xFFFE0000LL ||
+        ((int64_t)d->cout + 64) * d->cin * d->kh * d->kw * 4 > 0x3FFFFFFFLL || (int64_t)d->batch * 4 > 0xFFFFLL)
+        return BBB_ESHAPE;
     a.B = d->batch; a.Cin = d->cin; a.H = d->h; a.W = d->w; a.Cout = d->cout; a.kh = d->kh; a.kw = d->kw;
     a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w; a.dh = d->dil_h; a.dw = d->dil_w;
     a.Ho = ho; a.Wo = wo; a.K = d->cin * d->kh * d->kw; a.khkw = d->kh * d->kw; a.act = d->act;

@@ -179,7 +179,9 @@ def test_batched_ensemble_equals_loop(env, net_type, lt, B, hw, cin):
         batched, kl = env["ens"].mc_logits(net, x, E, 1234, 10, fuse_act=False)
         fused, _ = env["ens"].mc_logits(net, x, E, 1234, 10, fuse_act=True)
     assert torch.equal(loop, batched)                   # same kernels, same k order, same noise calls
-    np.testing.assert_allclose(fused.cpu().numpy(), loop.cpu().numpy(), rtol=1e-4, atol=1e-5)   # epilogue softplus vs torch's
+    # batch-innermost path: hardware exp2/log2 softplus in the GEMM epilogue vs torch's softplus between layers
+    scale = max(1.0, float(loop.abs().max()))
+    np.testing.assert_allclose(fused.cpu().numpy(), loop.cpu().numpy(), rtol=5e-4, atol=2e-5 * scale)
     assert abs(kl.item() - kl_loop.item()) <= 1e-6 * kl_loop.item()
     # the whole step
     env["rng"].manual_seed(1234, call=10)
