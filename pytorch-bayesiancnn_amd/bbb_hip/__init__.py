@@ -6,7 +6,7 @@
   ensemble  the num_ens Monte-Carlo loop of main_bayesian.py:43-53 / 73-80, batched over draws and
             sharded over GPUs
   zoo       BBBLeNet / BBBAlexNet / BBB3Conv3FC built from a topology table (same constructor surface as
-            the reference's models/BayesianModels/*.py, for hosts where /root/reference is absent)
+            the reference's models/BayesianModels/*.py, for hosts without the reference checkout)
 The drop-in boundary itself is the sibling package ``layers``.
 """
 from . import _lib, rng, ops  # noqa: F401

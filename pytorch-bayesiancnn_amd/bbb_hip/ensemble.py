@@ -373,8 +373,9 @@ def combine_ranks(lse_local, kl_local, num_ens, group, kl_mode="sum", shape=None
         kl_local = torch.zeros((), device=dev)
     B, C = lse_local.shape
     buf = torch.cat([lse_local.reshape(-1), kl_local.detach().reshape(1).to(lse_local.dtype)])
-    gathered = torch.empty((world, buf.numel()), dtype=buf.dtype, device=buf.device)
-    dist.all_gather_into_tensor(gathered, buf, group=group)
+    flat = torch.empty(world * buf.numel(), dtype=buf.dtype, device=buf.device)
+    dist.all_gather_into_tensor(flat, buf, group=group)       # ONE collective per MC step (RCCL on GPUs)
+    gathered = flat.view(world, buf.numel())
     blocks = gathered[:, :-1].reshape(world, B, C)
     log_outputs = torch.logsumexp(blocks, dim=0) - math.log(num_ens)
     kl = gathered[:, -1].sum()

@@ -1,0 +1,306 @@
+"""CPU-only checks of the host side: C-ABI library loads and exports every symbol of include/bbb_hip.h, the
+drop-in `layers` surface matches the reference's, the product path refuses to compute without a GPU, the
+noise/call-counter contract, draw sharding, and the N>1 combine over a world_size-2 gloo group."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import bbb_numpy as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "pytorch-bayesiancnn_amd")
+HEADER = os.path.join(ROOT, "include", "bbb_hip.h")
+
+
+@pytest.fixture(scope="module")
+def built():
+    so = os.path.join(PKG, "bbb_hip", "libbbb_hip.so")
+    if not os.path.exists(so):
+        subprocess.run(["bash", os.path.join(ROOT, "build.sh")], check=True)
+    return so
+
+
+def test_library_exports_every_declared_symbol(built):
+    from bbb_hip import _lib
+    decl = set(re.findall(r"^\s*(?:int|int64_t|const char\*)\s+(bbb_\w+)\s*\(", open(HEADER).read(), flags=re.M))
+    assert decl, "no declarations parsed from the header"
+    assert decl == set(_lib.EXPORTS), (decl ^ set(_lib.EXPORTS))
+    h = _lib.lib()                      # CDLL + argtypes for every symbol; raises if one is missing
+    for name in decl:
+        assert hasattr(h, name)
+    assert h.bbb_abi_version() == 1
+    assert b"gfx950" in h.bbb_build_info()
+
+
+def test_struct_layouts_match_the_header(built):
+    """ctypes mirrors vs a tiny C program compiled against the header (sizeof / offsetof)."""
+    from bbb_hip import _lib
+    src = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "bbb_hip.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu\n", sizeof(bbb_segment_t), offsetof(bbb_segment_t, n), offsetof(bbb_segment_t, stream_id),
+         sizeof(bbb_conv_desc_t), offsetof(bbb_conv_desc_t, x_draw_stride));
+  printf("%zu %zu\n", offsetof(bbb_conv_desc_t, act), offsetof(bbb_conv_desc_t, draws));
+  return 0; }
+'''
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "t.c")
+        open(c, "w").write(src)
+        exe = os.path.join(d, "t")
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe], check=True)
+        out = subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()
+    got = [int(v) for v in out]
+    S, C = _lib.Segment, _lib.ConvDesc
+    assert got == [ctypes.sizeof(S), S.n.offset, S.stream_id.offset, ctypes.sizeof(C), C.x_draw_stride.offset,
+                   C.act.offset, C.draws.offset]
+
+
+def test_argument_errors_without_a_gpu(built):
+    """Entry points validate before touching the device: error codes come back on a GPU-less host."""
+    from bbb_hip import _lib
+    h = _lib.lib()
+    seg = (_lib.Segment * 1)()
+    assert h.bbb_reparam_kl_fwd(seg, 1, 1, 0.0, 0.1, 0, 0, 0, None, None, None, None) == -1        # null mu
+    assert h.bbb_reparam_kl_fwd(seg, 0, 1, 0.0, 0.1, 0, 0, 0, None, None, None, None) == -1        # nseg = 0
+    assert h.bbb_reparam_kl_fwd(seg, 17, 1, 0.0, 0.1, 0, 0, 0, None, None, None, None) == -1       # > 16 segments
+    assert h.bbb_reparam_partials(seg, 0) == -1
+    d = _lib.ConvDesc()
+    assert h.bbb_conv2d_fwd(ctypes.byref(d), None, None, None, None, None) == -1                   # zero geometry
+    d.batch, d.cin, d.h, d.w, d.cout, d.kh, d.kw = 2, 3, 2, 2, 4, 3, 3
+    d.stride_h = d.stride_w = d.dil_h = d.dil_w = d.draws = 1
+    assert h.bbb_conv2d_fwd(ctypes.byref(d), None, None, None, None, None) == -3                   # kernel > image
+    d.batch = 6
+    d.h = d.w = 8
+    assert h.bbb_conv2d_chwn_fwd(ctypes.byref(d), None, None, None, None, None) == -3              # B % 4 != 0
+    assert h.bbb_mc_tail(None, 1, 1, 1, 0, None, None) == -1
+    assert h.bbb_eps_dump(None, 4, 0, 0, 0, 0, None) == -1
+    assert h.bbb_maxpool_chwn(None, None, 1, 4, 4, 4, 2, 2, None) == -1
+
+
+def test_product_path_refuses_cpu_tensors(built):
+    import layers
+    from bbb_hip import BBBHipError, ops
+    layer = layers.BBB_Conv2d(3, 4, 3)
+    if layer.W_mu.is_cuda:
+        pytest.skip("GPU present")
+    with pytest.raises(BBBHipError, match="MI355X only"):
+        layer(torch.randn(2, 3, 8, 8))
+    with pytest.raises(BBBHipError):
+        layers.BBB_LRT_Linear(8, 4)(torch.randn(2, 8))
+    with pytest.raises(BBBHipError):
+        layer.kl_loss()
+    with pytest.raises(BBBHipError):
+        ops.mc_tail(torch.zeros(2, 3, 4))
+
+
+def test_no_oracle_import_in_product():
+    """The shipped package must never import / call the oracle (or the reference)."""
+    bad = re.compile(r"bbb_numpy|ref_port_torch|/root/reference|import\s+oracle|from\s+oracle")
+    for base, _, files in os.walk(PKG):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cuh", ".h")):
+                txt = open(os.path.join(base, f)).read()
+                assert not bad.search(txt), f"{f} references the oracle"
+
+
+# ---------------------------------------------------------------- drop-in surface
+def test_layers_surface_matches_reference_contract():
+    import inspect
+    import layers
+    assert sorted(n for n in layers.__all__) == sorted(["BBB_Linear", "BBB_Conv2d", "BBB_LRT_Linear", "BBB_LRT_Conv2d",
+                                                        "FlattenLayer", "ModuleWrapper"])
+    sig = inspect.signature(layers.BBB_Conv2d.__init__)
+    assert list(sig.parameters)[1:] == ["in_channels", "out_channels", "kernel_size", "stride", "padding", "dilation", "bias", "priors"]
+    assert [sig.parameters[k].default for k in ("stride", "padding", "dilation", "bias", "priors")] == [1, 0, 1, True, None]
+    assert list(inspect.signature(layers.BBB_LRT_Conv2d.__init__).parameters)[1:] == list(sig.parameters)[1:]
+    for cls in (layers.BBB_Linear, layers.BBB_LRT_Linear):
+        assert list(inspect.signature(cls.__init__).parameters)[1:] == ["in_features", "out_features", "bias", "priors"]
+    for cls in (layers.BBB_Conv2d, layers.BBB_Linear, layers.BBB_LRT_Conv2d, layers.BBB_LRT_Linear):
+        p = inspect.signature(cls.forward).parameters
+        assert list(p)[2] == "sample" and p["sample"].default is True
+        assert issubclass(cls, layers.ModuleWrapper)
+    conv = layers.BBB_Conv2d(3, 5, (2, 3), stride=2, padding=1, bias=False)
+    assert conv.kernel_size == (2, 3) and conv.groups == 1 and conv.use_bias is False
+    assert list(conv.state_dict().keys()) == ["W_mu", "W_rho"] and conv.bias_mu is None
+    lin = layers.BBB_LRT_Linear(7, 3, priors={"prior_mu": 0.5, "prior_sigma": 0.2, "posterior_mu_initial": (1, 0.0),
+                                              "posterior_rho_initial": (-2, 0.0)})
+    assert list(lin.state_dict().keys()) == ["W_mu", "W_rho", "bias_mu", "bias_rho"]
+    assert lin.prior_mu == 0.5 and lin.prior_sigma == 0.2
+    assert torch.all(lin.W_mu == 1) and torch.all(lin.bias_rho == -2) and lin.W_mu.shape == (3, 7)
+    np.testing.assert_allclose(lin.W_sigma.detach().numpy(), O.sigma_from_rho(lin.W_rho.detach().numpy()), rtol=1e-6)
+    f = layers.FlattenLayer(12)
+    assert f(torch.zeros(5, 3, 2, 2)).shape == (5, 12) and f(torch.zeros(2, 6, 2, 2)).shape == (4, 12)
+    m = layers.ModuleWrapper()
+    m.child = layers.ModuleWrapper()
+    m.set_flag("foo", 3)
+    assert m.foo == 3 and m.child.foo == 3
+
+
+@pytest.mark.parametrize("name,cls_name,n_classes,cin", [("lenet", "BBBLeNet", 10, 1), ("alexnet", "BBBAlexNet", 100, 3),
+                                                          ("3conv3fc", "BBB3Conv3FC", 10, 3)])
+@pytest.mark.parametrize("lt", ["bbb", "lrt"])
+def test_zoo_models_have_reference_state_dict(golden, name, cls_name, n_classes, cin, lt):
+    """Same parameter names / shapes / init order as the upstream models: building under the seed the fixture
+    was made with reproduces the reference's parameter checksums."""
+    import ref_port_torch as P
+    from bbb_hip import zoo
+    torch.manual_seed(3)
+    net = getattr(zoo, cls_name)(n_classes, cin, P.CONFIG_PRIORS, lt, "softplus")
+    torch.manual_seed(3)
+    params = P.init_params(name, cin, n_classes, P.CONFIG_PRIORS)
+    sd = net.state_dict()
+    want = [f"{n}.{k}" for n in params if not n.startswith("_") for k in ("W_mu", "W_rho", "bias_mu", "bias_rho")]
+    assert list(sd.keys()) == want
+    if not next(iter(sd.values())).is_cuda:
+        for n in params:
+            if not n.startswith("_"):
+                for k in ("W_mu", "W_rho", "bias_mu", "bias_rho"):
+                    assert torch.equal(sd[f"{n}.{k}"], params[n][k])
+    assert net.num_classes == n_classes and net.layer_type == lt
+    with pytest.raises(ValueError):
+        getattr(zoo, cls_name)(10, 3, None, "nope", "softplus")
+    with pytest.raises(ValueError):
+        getattr(zoo, cls_name)(10, 3, None, "bbb", "tanh")
+
+
+@pytest.mark.reference
+def test_reference_models_build_unchanged_on_our_layers():
+    """Build-container only: the UNMODIFIED upstream model files import `layers` and get ours; structure and
+    state_dict equal the zoo's."""
+    code = r'''
+import sys; sys.dont_write_bytecode = True
+sys.path.insert(0, "/root/reference"); sys.path.insert(0, "%s")
+import layers, torch
+assert layers.__file__.startswith("%s"), layers.__file__
+from models.BayesianModels.BayesianAlexNet import BBBAlexNet
+from models.BayesianModels.BayesianLeNet import BBBLeNet
+from models.BayesianModels.Bayesian3Conv3FC import BBB3Conv3FC
+import config_bayesian as cfg
+from bbb_hip import zoo
+for ref, ours, cin in ((BBBAlexNet, zoo.BBBAlexNet, 3), (BBBLeNet, zoo.BBBLeNet, 1), (BBB3Conv3FC, zoo.BBB3Conv3FC, 3)):
+    for lt in ("bbb", "lrt"):
+        a, b = ref(10, cin, cfg.priors, lt, "softplus"), ours(10, cin, cfg.priors, lt, "softplus")
+        assert [type(m).__name__ for m in a.children()] == [type(m).__name__ for m in b.children()]
+        assert [n for n, _ in a.named_children()] == [n for n, _ in b.named_children()]
+        assert {k: tuple(v.shape) for k, v in a.state_dict().items()} == {k: tuple(v.shape) for k, v in b.state_dict().items()}
+        assert type(a.conv1).__module__.startswith("layers.")
+print("OK")
+''' % (PKG, PKG)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-3000:]
+
+
+# ---------------------------------------------------------------- rng / sharding logic
+def test_call_counter_contract():
+    from bbb_hip import rng
+    torch.manual_seed(123)
+    s, c = rng.get_state()
+    assert s == 123 and c == 0
+    assert rng.next_calls(3) == (123, 0) and rng.next_calls(1) == (123, 3)
+    torch.manual_seed(124)                       # reseeding torch restarts the noise stream
+    assert rng.get_state() == (124, 0)
+    rng.manual_seed(9, call=7)
+    assert rng.layer_call() == (9, 7)            # stand-alone layer: fresh call
+    sc = rng.push_forward_scope()                # model forward: one call shared by all layers
+    assert sc == (9, 8) and rng.layer_call() == (9, 8) and rng.layer_call() == (9, 8)
+    rng.pop_forward_scope()
+    assert rng.get_state() == (9, 9)
+
+
+def test_stream_ids_are_per_model():
+    import ref_port_torch as P
+    from bbb_hip import rng, zoo
+    a = zoo.BBBLeNet(10, 1, P.CONFIG_PRIORS, "bbb", "relu")
+    b = zoo.BBBLeNet(10, 1, P.CONFIG_PRIORS, "bbb", "relu")
+    assert a.conv1._stream_base != b.conv1._stream_base
+    assert rng.assign_stream_ids(a) == 5 and rng.assign_stream_ids(b) == 5
+    assert [m._stream_base for m in (a.conv1, a.conv2, a.fc1, a.fc2, a.fc3)] == [0, 4, 8, 12, 16]
+    assert b.fc3._stream_base == 16
+
+
+def test_draw_ranges_partition_the_ensemble():
+    from bbb_hip.ensemble import draw_range
+    for E in (1, 7, 10, 25, 80):
+        for world in (1, 2, 3, 4, 8, 16):
+            rs = [draw_range(E, r, world) for r in range(world)]
+            assert rs[0][0] == 0 and rs[-1][1] == E
+            assert all(rs[i][1] == rs[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in rs]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_conv_flops_accounting():
+    from bbb_hip.ensemble import conv_flops
+    # AlexNet/CIFAR bs=512 per draw: im2col 1.52 / 5.03 / 2.72 / 3.62 / 1.21 GFLOP
+    shapes = [(3, 32, 64, 11, 4, 5), (64, 4, 192, 5, 1, 2), (192, 2, 384, 3, 1, 1), (384, 2, 256, 3, 1, 1), (256, 2, 128, 3, 1, 1)]
+    tot_u = tot_i = 0.0
+    for cin, hw, cout, k, s, p in shapes:
+        u, i = conv_flops(512, cin, hw, hw, cout, k, k, s, p, 1, 1)
+        tot_u += u
+        tot_i += i
+        assert u <= i
+    assert abs(tot_i - 14.11e9) < 0.02e9
+    assert abs(tot_u - 7.08e9) < 0.02e9          # more than half of the im2col matrix is padding
+
+
+# ---------------------------------------------------------------- N > 1 combine over gloo (world_size 2 and 3)
+_WORKER = r'''
+import os, sys, math
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+import numpy as np, torch, torch.distributed as dist
+import bbb_numpy as O
+from bbb_hip import ensemble
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % os.environ["MASTER_PORT"], rank=rank, world_size=world)
+E, B, C = int(sys.argv[3]), 6, 5
+rng = np.random.default_rng(0)
+logits = (rng.standard_normal((E, B, C)) * 3).astype(np.float32)          # what the E draws would produce
+lo, hi = ensemble.draw_range(E, rank, world)
+if hi > lo:
+    ls = O.log_softmax(logits[lo:hi], axis=2).astype(np.float64)
+    m = ls.max(0)
+    lse = torch.tensor(m + np.log(np.exp(ls - m).sum(0)), dtype=torch.float32)   # what mc_tail(mean_over=0) returns
+    kl_local = torch.tensor(123.5 * (hi - lo))
+else:
+    lse, kl_local = None, None
+out, kl = ensemble.combine_ranks(lse, kl_local, E, dist.group.WORLD, "sum", shape=(B, C))
+want = O.mc_log_outputs(logits)
+assert np.allclose(out.numpy(), want, rtol=1e-5, atol=1e-6), np.abs(out.numpy() - want).max()
+assert abs(kl.item() - 123.5 * E) < 1e-3
+# every rank holds the same bits
+g = [torch.empty_like(out) for _ in range(world)]
+dist.all_gather(g, out)
+assert all(torch.equal(g[0], t) for t in g)
+_, klm = ensemble.combine_ranks(lse, kl_local, E, dist.group.WORLD, "mean", shape=(B, C))
+assert abs(klm.item() - 123.5) < 1e-4
+dist.destroy_process_group()
+print("RANK_OK", rank)
+'''
+
+
+@pytest.mark.parametrize("world,E", [(2, 10), (2, 1), (3, 7)])
+def test_ensemble_combine_over_gloo(tmp_path, world, E):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), PKG, os.path.join(ROOT, "oracle"), str(E)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for r, p in enumerate(procs):
+        out, err = p.communicate(timeout=120)
+        assert p.returncode == 0 and f"RANK_OK {r}" in out, err[-3000:]
