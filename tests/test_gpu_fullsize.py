@@ -1,0 +1,159 @@
+"""BASELINE.json's configurations at FULL size on the MI355X, checked through size-independent properties
+(the oracle would take minutes there): layout equivalence, batched-vs-loop identity, linearity, determinism,
+sharding invariance, moment identities.  Run with -m gpu."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import ref_port_torch as P
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import layers
+    from bbb_hip import ops, rng, ensemble, zoo
+    return dict(layers=layers, ops=ops, rng=rng, ens=ensemble, zoo=zoo)
+
+
+def build(env, net_type, lt, ncls, cin=3, seed=0):
+    torch.manual_seed(seed)
+    net = env["zoo"].getModel(net_type, cin, ncls, P.CONFIG_PRIORS, lt, "softplus").cuda()
+    env["rng"].assign_stream_ids(net)
+    return net
+
+
+def test_metric_config_alexnet_bs512_ens10(env):
+    """BayesianAlexNet CIFAR-10 bs=512 num_ens=10 (the headline): the batch-innermost fast path, the NCHW batched
+    path and the reference-style Python loop agree; KL is the sum of the layers' kl_loss(); reruns are bitwise equal."""
+    net = build(env, "alexnet", "bbb", 10)
+    x = torch.rand(512, 3, 32, 32, device="cuda")
+    E = 10
+    with torch.no_grad():
+        fast, kl_f = env["ens"].mc_logits(net, x, E, 99, 0)
+        nchw, kl_n = env["ens"].mc_logits(net, x, E, 99, 0, fuse_act=False, layout="nchw")
+        env["rng"].manual_seed(99, call=0)
+        loop = torch.stack([net(x)[0] for _ in range(3)])
+        fast2, _ = env["ens"].mc_logits(net, x, E, 99, 0)
+        other, _ = env["ens"].mc_logits(net, x, E, 100, 0)
+        kl_layers = sum(m.kl_loss() for m in net.modules() if hasattr(m, "kl_loss"))
+    assert fast.shape == (E, 512, 10)
+    assert torch.equal(nchw[:3], loop)
+    scale = float(nchw.abs().max())
+    assert float((fast - nchw).abs().max()) <= 5e-4 * scale        # hw softplus epilogue vs torch softplus, 6 layers
+    assert torch.equal(fast, fast2) and not torch.equal(fast, other)
+    assert kl_f.item() == kl_n.item()
+    assert abs(kl_f.item() - kl_layers.item()) <= 2e-6 * kl_f.item()
+    # step-level: logmeanexp is bounded by the per-draw extremes and averages to the arithmetic mean of probabilities
+    env["rng"].manual_seed(99, call=0)
+    with torch.no_grad():
+        lo, klsum = env["ens"].mc_forward(net, x, E)
+    ls = F.log_softmax(fast, dim=2)
+    assert torch.all(lo <= ls.max(0).values + 1e-5) and torch.all(lo >= ls.min(0).values - 1e-5)
+    np.testing.assert_allclose(lo.exp().cpu().numpy(), ls.exp().mean(0).cpu().numpy(), rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(lo.exp().sum(1).cpu().numpy(), 1.0, rtol=1e-5)
+    assert abs(klsum.item() - E * kl_f.item()) <= 2e-6 * E * kl_f.item()
+
+
+def test_config4_ens25_sharded_over_8_ranks_simulated(env):
+    """num_ens=25 over 8 ranks: every rank's block equals the matching slice of the single-device ensemble and the
+    rank-order log-sum-exp equals the unsharded result."""
+    net = build(env, "alexnet", "bbb", 10)
+    x = torch.rand(512, 3, 32, 32, device="cuda")
+    E, world = 25, 8
+    with torch.no_grad():
+        full, _ = env["ens"].mc_logits(net, x, E, 5, 40)
+        want = env["ops"].mc_tail(full, mean_over=E)
+        blocks = []
+        for r in range(world):
+            lo, hi = env["ens"].draw_range(E, r, world)
+            lg, _ = env["ens"].mc_logits(net, x, hi - lo, 5, 40 + lo)
+            assert torch.equal(lg, full[lo:hi])
+            blocks.append(env["ops"].mc_tail(lg, mean_over=0))
+        got = torch.logsumexp(torch.stack(blocks), 0) - float(np.log(E))
+    np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=3e-6, atol=3e-6)
+
+
+def test_config2_3conv3fc_bs256(env):
+    net = build(env, "3conv3fc", "bbb", 10)
+    x = torch.rand(256, 3, 32, 32, device="cuda")
+    with torch.no_grad():
+        fast, kl = env["ens"].mc_logits(net, x, 4, 7, 0)
+        nchw, kl2 = env["ens"].mc_logits(net, x, 4, 7, 0, fuse_act=False, layout="nchw")
+    assert fast.shape == (4, 256, 10) and kl.item() == kl2.item()
+    assert float((fast - nchw).abs().max()) <= 5e-4 * float(nchw.abs().max())
+
+
+def test_config3_alexnet_lrt_cifar100_bs512(env):
+    """LRT: layouts agree (same eps stream by canonical element index); the first layer's output over draws has the
+    LRT moments (mean act_mu, variance act_var)."""
+    net = build(env, "alexnet", "lrt", 100)
+    x = torch.rand(512, 3, 32, 32, device="cuda")
+    with torch.no_grad():
+        fast, kl = env["ens"].mc_logits(net, x, 2, 11, 0)
+        nchw, _ = env["ens"].mc_logits(net, x, 2, 11, 0, fuse_act=False, layout="nchw")
+        assert fast.shape == (2, 512, 100)
+        assert float((fast - nchw).abs().max()) <= 1e-3 * float(nchw.abs().max())
+        l1 = net.conv1
+        _, s2 = env["ops"].kl_only([l1.W_mu, l1.bias_mu], [l1.W_rho, l1.bias_rho], 0, 0.1, want_sigma=True, sigma_squared=True)
+        E = 48
+        xs = x[:64].unsqueeze(0).expand(E, -1, -1, -1, -1)
+        y, am, av = env["ops"].lrt_conv2d_forward(xs, l1.W_mu, s2[0], l1.bias_mu, s2[1], 3, 0, 2, 4, 5, 1, want_moments=True)
+    z = ((y.mean(0) - am[0]) / (av[0] / E).sqrt()).abs()
+    assert z.max().item() < 6.0 and z.mean().item() < 1.0
+    r = y.var(0) / av[0]
+    assert abs(r.mean().item() - 1) < 0.02
+
+
+def test_config5_alexnet_224_flatten_quirk(env):
+    """3x224x224 input: FlattenLayer(128) turns [B,128,7,7] into [B*49,128]; the ensemble path must fall
+    back to the reference layout there and equal the Python loop."""
+    net = build(env, "alexnet", "bbb", 10)
+    x = torch.rand(8, 3, 224, 224, device="cuda")
+    with torch.no_grad():
+        batched, _ = env["ens"].mc_logits(net, x, 2, 21, 0, fuse_act=False)
+        env["rng"].manual_seed(21, call=0)
+        loop = torch.stack([net(x)[0] for _ in range(2)])
+    assert batched.shape == (2, 8 * 49, 10)
+    assert torch.equal(batched, loop)
+
+
+def test_conv_linearity_and_shift_at_full_size(env):
+    """conv is linear in x and in w; checked on AlexNet conv2 at bs=512 in the batch-innermost layout."""
+    ops = env["ops"]
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x1 = torch.randn(1, 64, 4, 4, 512, device="cuda", generator=g)
+    x2 = torch.randn(1, 64, 4, 4, 512, device="cuda", generator=g)
+    w = torch.randn(2, 192, 64, 5, 5, device="cuda", generator=g) * 0.05
+    y1 = ops.conv2d_chwn_forward(x1, w, None, 1, 2, 1)
+    y2 = ops.conv2d_chwn_forward(x2, w, None, 1, 2, 1)
+    y12 = ops.conv2d_chwn_forward(x1 + 2 * x2, w, None, 1, 2, 1)
+    assert float((y12 - (y1 + 2 * y2)).abs().max()) <= 2e-4 * float(y12.abs().max())
+    b = torch.randn(2, 192, device="cuda", generator=g)
+    yb = ops.conv2d_chwn_forward(x1, w, b, 1, 2, 1)
+    np.testing.assert_allclose((yb - y1).cpu().numpy(), np.broadcast_to(b.cpu().numpy()[:, :, None, None, None], yb.shape), rtol=0, atol=2e-5)
+
+
+def test_reparam_at_full_alexnet_size_is_consistent(env):
+    """All 12 AlexNet tensors, E=10: mean/variance of (w - mu)/sigma over draws and elements ~ N(0,1); KL equals the
+    per-tensor sum; one multi-tensor launch == twelve single-tensor launches (bitwise)."""
+    net = build(env, "alexnet", "bbb", 10)
+    layers_ = env["ens"].bayesian_layers(net)
+    mus, rhos, ids = [], [], []
+    for l in layers_:
+        m, r, i = l._param_lists()
+        mus += m
+        rhos += r
+        ids += i
+    with torch.no_grad():
+        ws, _, kl = env["ops"].reparam_kl_forward(mus, rhos, 0, 0.1, ids, 17, 3, draws=10)
+        tot = 0.0
+        for m, r, i, w in zip(mus, rhos, ids, ws):
+            w1, _, k1 = env["ops"].reparam_kl_forward([m], [r], 0, 0.1, [i], 17, 3, draws=10)
+            assert torch.equal(w1[0], w)
+            tot += k1.double().item()
+        assert abs(kl.item() - tot) <= 1e-6 * tot
+        z = (ws[4] - mus[4].unsqueeze(0)) / torch.log1p(torch.exp(rhos[4])).unsqueeze(0)     # conv3 weights, 6.6M samples
+    assert abs(z.mean().item()) < 2e-3 and abs(z.var().item() - 1) < 3e-3
