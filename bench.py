@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layer-type", default="bbb", choices=["bbb", "lrt"])
     ap.add_argument("--no-kernel-timers", action="store_true")
+    ap.add_argument("--streams", type=int, default=2, help="independent sub-ensembles on separate HIP streams")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -129,16 +131,32 @@ def main():
             torch.distributed.barrier(group=group)
         torch.cuda.synchronize(dev)
 
+    use_graph = (not args.no_graph) and world == 1
     with torch.no_grad():
+        if use_graph:
+            # the whole step (E draws x all layers on `streams` HIP streams + tail) is one captured hipGraph; a device-side
+            # call counter inside the graph gives every replay fresh Philox noise (no cached outputs)
+            gstep = ensemble.GraphedMC(net, x, total_ens, streams=args.streams)
+            step = gstep.step
+        else:
+            step = lambda: ensemble.mc_forward(net, x, total_ens, group=group, streams=args.streams)
         for _ in range(args.warmup):
-            ensemble.mc_forward(net, x, total_ens, group=group)
-        timers = None if args.no_kernel_timers else ensemble.Timers()
+            step()
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            lo, kl = ensemble.mc_forward(net, x, total_ens, group=group, timers=timers)
+            lo, kl = step()
         barrier()
         elapsed = time.perf_counter() - t0
+        lo, kl = lo.clone(), kl.clone()
+        # per-kernel HIP-event brackets: the same step launched eagerly on one stream (events cannot sit inside a graph)
+        timers = None
+        if not args.no_kernel_timers:
+            timers = ensemble.Timers()
+            for _ in range(min(args.steps, 20)):
+                ensemble.mc_forward(net, x, total_ens, group=group, timers=timers)
+            torch.cuda.synchronize(dev)
+            timer_steps = min(args.steps, 20)
 
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -159,7 +177,8 @@ def main():
                                    f"softplus, bs={BATCH}, num_ens={NUM_ENS} per GPU ({total_ens} draws total), "
                                    "forward only (main_bayesian.py:73-80)",
                        "global_batch": BATCH, "num_ens_total": total_ens,
-                       "parallelism": f"mc-ensemble x{world}" if world > 1 else "single"},
+                       "parallelism": f"mc-ensemble x{world}" if world > 1 else "single",
+                       "launch": ("hipGraph replay, %d streams" % args.streams) if use_graph else ("eager, %d streams" % args.streams)},
         }
         if timers is not None:
             agg = timers.summary()
@@ -170,8 +189,10 @@ def main():
                                    "unit": "TFLOP/s", "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
                                    "kernel": "conv_gemm_kernel (fp32 v_mfma_f32_32x32x2_f32), all conv/linear launches",
                                    "launches": g["n"], "avg_us": round(1e3 * g["ms"] / g["n"], 2),
-                                   "flop_per_step": g["work"] / args.steps,
-                                   "share_of_step": round(g["ms"] / (1e3 * elapsed), 4)}
+                                   "flop_per_step": g["work"] / timer_steps,
+                                   "im2col_flop_per_step": g["work_im2col"] / timer_steps,
+                                   "timed_by": "HIP events around every launch, %d eager single-stream steps of the same workload right after the timed region" % timer_steps,
+                                   "share_of_eager_step": None}
             r = agg.get("reparam_kl")
             if r:
                 e_loc = NUM_ENS

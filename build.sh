@@ -8,7 +8,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wall -Wno-unused
 objs=()
 for f in csrc/*.hip; do
   o=build/$(basename "${f%.hip}").o
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ csrc/bbb_common.cuh -nt "$o" ] || [ ../include/bbb_hip.h -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ csrc/bbb_common.cuh -nt "$o" ] || [ ../include/bbb_hip.h -nt "$o" ] || [ csrc/pconv_args.h -nt "$o" ]; then
     "$HIPCC" $FLAGS -c "$f" -o "$o" &
   fi
   objs+=("$o")

@@ -64,12 +64,15 @@ typedef struct bbb_segment {
  *   kl_partials device scratch, at least bbb_reparam_partials(segs, nseg) doubles
  *   kl_out      device float: sum over all segments of the KL term (NULL = no KL)
  *   kl_out64    optional device double with the same sum (NULL = skip)
+ *   call_dev    optional DEVICE uint32 added to call0 when the kernel runs (NULL = 0).  This is what lets a
+ *               captured hipGraph draw fresh noise on every replay: the graph also contains the increment.
  * KL does not depend on eps; the sum is reduced in a fixed order in fp64 (bitwise reproducible).
  */
 int bbb_reparam_kl_fwd(const bbb_segment_t* segs, int nseg, int draws,
                        float prior_mu, float prior_sigma,
                        uint64_t seed, uint32_t call0, uint32_t flags,
-                       double* kl_partials, float* kl_out, double* kl_out64, void* stream);
+                       double* kl_partials, float* kl_out, double* kl_out64,
+                       const uint32_t* call_dev, void* stream);
 
 /* Number of doubles of scratch bbb_reparam_kl_fwd needs for these segments (host-only helper). */
 int64_t bbb_reparam_partials(const bbb_segment_t* segs, int nseg);
@@ -126,7 +129,8 @@ int bbb_conv2d_fwd(const bbb_conv_desc_t* d, const float* x, const float* w, con
 int bbb_lrt_conv2d_fwd(const bbb_conv_desc_t* d, const float* x, const float* w_mu, const float* w_var,
                        const float* b_mu, const float* b_var, float* y,
                        float* act_mu_out, float* act_var_out, const float* eps_ext,
-                       uint64_t seed, uint32_t call0, uint32_t stream_id, int sample, void* stream);
+                       uint64_t seed, uint32_t call0, uint32_t stream_id, int sample,
+                       const uint32_t* call_dev, void* stream);
 
 /*
  * Batch-innermost ("CHWN") variants used by the batched Monte-Carlo ensemble path.
@@ -141,7 +145,8 @@ int bbb_conv2d_chwn_fwd(const bbb_conv_desc_t* d, const float* x, const float* w
 int bbb_lrt_conv2d_chwn_fwd(const bbb_conv_desc_t* d, const float* x, const float* w_mu, const float* w_var,
                             const float* b_mu, const float* b_var, float* y,
                             float* act_mu_out, float* act_var_out, const float* eps_ext,
-                            uint64_t seed, uint32_t call0, uint32_t stream_id, int sample, void* stream);
+                            uint64_t seed, uint32_t call0, uint32_t stream_id, int sample,
+                            const uint32_t* call_dev, void* stream);
 
 /* nn.MaxPool2d(kernel_size=k, stride=s) (no padding, floor mode; models/BayesianModels/BayesianAlexNet.py:37)
  * on batch-innermost planes: x [planes][h][w][B] -> y [planes][(h-k)/s+1][(w-k)/s+1][B]. */

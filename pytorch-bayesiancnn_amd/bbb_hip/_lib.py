@@ -35,17 +35,17 @@ class ConvDesc(ctypes.Structure):
 
 _SIGNATURES = {
     "bbb_reparam_kl_fwd": (c_int, [ctypes.POINTER(Segment), c_int, c_int, c_float, c_float, c_u64, c_u32, c_u32,
-                                   c_void_p, c_void_p, c_void_p, c_void_p]),
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "bbb_reparam_partials": (c_i64, [ctypes.POINTER(Segment), c_int]),
     "bbb_reparam_kl_bwd": (c_int, [ctypes.POINTER(Segment), c_int, c_int, c_float, c_float, c_u64, c_u32, c_u32,
                                    c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), c_void_p]),
     "bbb_eps_dump": (c_int, [c_void_p, c_i64, c_i64, c_u64, c_u32, c_u32, c_void_p]),
     "bbb_conv2d_fwd": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "bbb_lrt_conv2d_fwd": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                   c_void_p, c_void_p, c_void_p, c_u64, c_u32, c_u32, c_int, c_void_p]),
+                                   c_void_p, c_void_p, c_void_p, c_u64, c_u32, c_u32, c_int, c_void_p, c_void_p]),
     "bbb_conv2d_chwn_fwd": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "bbb_lrt_conv2d_chwn_fwd": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                        c_void_p, c_void_p, c_void_p, c_u64, c_u32, c_u32, c_int, c_void_p]),
+                                        c_void_p, c_void_p, c_void_p, c_u64, c_u32, c_u32, c_int, c_void_p, c_void_p]),
     "bbb_maxpool_chwn": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "bbb_mc_tail": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "bbb_abi_version": (c_int, []),

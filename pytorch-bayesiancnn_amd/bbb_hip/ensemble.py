@@ -181,7 +181,7 @@ def _chwn_ok(net, x):
     return True
 
 
-def _mc_logits_chwn(net, x, draws, seed, call0, timers=None):
+def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1):
     """Inference path of mc_logits in the batch-innermost layout ([E, C, H, W, B]): pixel-major GEMMs that
     skip padding taps, activation fused into the GEMM epilogue, pooling on contiguous image vectors."""
     layers = bayesian_layers(net)
@@ -194,60 +194,101 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None):
         variances, k2 = _variances_all(lrt, timers)
         kl = k2 if kl is None else kl + k2
     E, B = draws, x.shape[0]
-    h = x.permute(1, 2, 3, 0).contiguous().unsqueeze(0)          # [1, C, H, W, B], shared by all draws
+    xt = x.permute(1, 2, 3, 0).contiguous().unsqueeze(0)         # [1, C, H, W, B], shared by all draws
     children = list(net.children())
-    i = 0
-    while i < len(children):
-        mod = children[i]
-        nxt = children[i + 1] if i + 1 < len(children) else None
-        act = _act_name(nxt) if nxt is not None else None
-        if isinstance(mod, (_BBBLayer, _LRTLayer)):
-            is_conv = isinstance(mod, (_BBBConv, _LRTConv))
-            geom = (mod.stride, mod.padding, mod.dilation) if is_conv else (1, 0, 1)
-            h5 = h if is_conv else h.reshape(h.shape[0], mod.in_features, 1, 1, -1)
-            if h5.dim() != 5 or h5.shape[-1] != B:
-                return None                                      # flatten quirk etc.: caller falls back
-            if isinstance(mod, _BBBLayer):
-                w, b = sampled[mod]
-                if not is_conv:
-                    w = w.reshape(E, mod.out_features, mod.in_features, 1, 1)
-                fl = conv_flops(B, h5.shape[1], h5.shape[2], h5.shape[3], w.shape[1], w.shape[3], w.shape[4], *geom, E) \
-                    if timers is not None else None
-                y = _run(timers, "conv_gemm", fl, lambda: ops.conv2d_chwn_forward(h5, w, b, *geom, act=act))
+
+    def run(e0, e1):
+        """Layers for draws [e0, e1) on the current stream -> logits [e1-e0, C, B] (or None: fall back)."""
+        Es = e1 - e0
+        h = xt
+        i = 0
+        while i < len(children):
+            mod = children[i]
+            nxt = children[i + 1] if i + 1 < len(children) else None
+            act = _act_name(nxt) if nxt is not None else None
+            if isinstance(mod, (_BBBLayer, _LRTLayer)):
+                is_conv = isinstance(mod, (_BBBConv, _LRTConv))
+                geom = (mod.stride, mod.padding, mod.dilation) if is_conv else (1, 0, 1)
+                h5 = h if is_conv else h.reshape(h.shape[0], mod.in_features, 1, 1, -1)
+                if h5.dim() != 5 or h5.shape[-1] != B:
+                    return None                                  # flatten quirk etc.: caller falls back
+                if isinstance(mod, _BBBLayer):
+                    w, b = sampled[mod]
+                    w = w[e0:e1]
+                    b = None if b is None else b[e0:e1]
+                    if not is_conv:
+                        w = w.reshape(Es, mod.out_features, mod.in_features, 1, 1)
+                    fl = conv_flops(B, h5.shape[1], h5.shape[2], h5.shape[3], w.shape[1], w.shape[3], w.shape[4], *geom, Es) \
+                        if timers is not None else None
+                    y = _run(timers, "conv_gemm", fl, lambda: ops.conv2d_chwn_forward(h5, w, b, *geom, act=act))
+                else:
+                    w_var, b_var = variances[mod]
+                    w_mu = mod.W_mu
+                    if not is_conv:
+                        shp = (mod.out_features, mod.in_features, 1, 1)
+                        w_mu, w_var = w_mu.reshape(shp), w_var.reshape(shp)
+                    if h5.shape[0] == 1 and Es > 1:
+                        h5 = h5.expand(Es, *h5.shape[1:])
+                    fl = conv_flops(B, h5.shape[1], h5.shape[2], h5.shape[3], w_mu.shape[0], w_mu.shape[2], w_mu.shape[3],
+                                    *geom, Es, 2) if timers is not None else None
+                    y = _run(timers, "lrt_gemm", fl,
+                             lambda: ops.lrt_conv2d_chwn_forward(h5, w_mu, w_var, mod.bias_mu if mod.use_bias else None, b_var,
+                                                                 seed, call0 + e0, mod._stream_base + 2, *geom, sample=True,
+                                                                 act=act)[0])
+                h = y
+                if act is not None:
+                    i += 1
+            elif isinstance(mod, FlattenLayer):
+                if h.dim() != 5 or h.shape[1] * h.shape[2] * h.shape[3] != mod.num_features:
+                    return None
+                h = h.reshape(h.shape[0], mod.num_features, 1, 1, B)
+            elif isinstance(mod, nn.MaxPool2d):
+                h = _run(timers, "maxpool", None, lambda: ops.maxpool_chwn(h, mod.kernel_size, mod.stride))
+            elif isinstance(mod, nn.ReLU):
+                h = torch.relu(h)
             else:
-                w_var, b_var = variances[mod]
-                w_mu = mod.W_mu
-                if not is_conv:
-                    shp = (mod.out_features, mod.in_features, 1, 1)
-                    w_mu, w_var = w_mu.reshape(shp), w_var.reshape(shp)
-                if h5.shape[0] == 1 and E > 1:
-                    h5 = h5.expand(E, *h5.shape[1:])
-                fl = conv_flops(B, h5.shape[1], h5.shape[2], h5.shape[3], w_mu.shape[0], w_mu.shape[2], w_mu.shape[3],
-                                *geom, E, 2) if timers is not None else None
-                y = _run(timers, "lrt_gemm", fl,
-                         lambda: ops.lrt_conv2d_chwn_forward(h5, w_mu, w_var, mod.bias_mu if mod.use_bias else None, b_var,
-                                                             seed, call0, mod._stream_base + 2, *geom, sample=True, act=act)[0])
-            h = y
-            if act is not None:
-                i += 1
-        elif isinstance(mod, FlattenLayer):
-            if h.dim() != 5 or h.shape[1] * h.shape[2] * h.shape[3] != mod.num_features:
-                return None
-            h = h.reshape(h.shape[0], mod.num_features, 1, 1, B)
-        elif isinstance(mod, nn.MaxPool2d):
-            h = _run(timers, "maxpool", None, lambda: ops.maxpool_chwn(h, mod.kernel_size, mod.stride))
-        elif isinstance(mod, nn.ReLU):
-            h = torch.relu(h)
-        else:
-            h = F.softplus(h)
-        i += 1
-    if h.shape[0] == 1 and E > 1:
-        h = h.expand(E, *h.shape[1:])
-    logits = h.reshape(E, -1, B).permute(0, 2, 1).contiguous()   # [E, B, C] for the tail kernel
+                h = F.softplus(h)
+            i += 1
+        if h.shape[0] == 1 and Es > 1:
+            h = h.expand(Es, *h.shape[1:])
+        return h.reshape(Es, -1, B)
+
+    nsplit = max(1, min(int(streams), E))
+    if nsplit == 1 or timers is not None:
+        out = run(0, E)
+        if out is None:
+            return None
+    else:
+        # Independent sub-ensembles on separate HIP streams: each GEMM launch is one wave of workgroups with a ramp
+        # and a tail, and the other stream's kernels fill those bubbles (and the launch gaps).
+        main = torch.cuda.current_stream(x.device)
+        pool = _side_streams(x.device, nsplit)
+        bounds = [draw_range(E, r, nsplit) for r in range(nsplit)]
+        parts = []
+        for st, (e0, e1) in zip(pool, bounds):
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                parts.append(run(e0, e1))
+        for st in pool:
+            main.wait_stream(st)
+        if any(pt is None for pt in parts):
+            return None
+        out = torch.cat(parts, dim=0)
+    logits = out.permute(0, 2, 1).contiguous()                   # [E, B, C] for the tail kernel
     return logits, kl
 
 
-def mc_logits(net, x, draws, seed, call0, fuse_act=True, timers=None, eps=None, layout="auto"):
+_stream_pool = {}
+
+
+def _side_streams(device, n):
+    key = (torch.device(device).index, n)
+    if key not in _stream_pool:
+        _stream_pool[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
+    return _stream_pool[key]
+
+
+def mc_logits(net, x, draws, seed, call0, fuse_act=True, timers=None, eps=None, layout="auto", streams=1):
     """E stochastic forwards of `net` on the same batch x -> (logits [E, B', C], kl of ONE forward).
 
     Equivalent to `[net(x)[0] for _ in range(E)]` under noise calls call0 .. call0+E-1 (B' = B except for
@@ -255,7 +296,7 @@ def mc_logits(net, x, draws, seed, call0, fuse_act=True, timers=None, eps=None, 
     when it applies (inference, B % 4 == 0, known module kinds), "nchw" forces the reference layout."""
     _lib.require_device(x)
     if layout != "nchw" and eps is None and fuse_act and _chwn_ok(net, x):
-        out = _mc_logits_chwn(net, x, draws, seed, call0, timers)
+        out = _mc_logits_chwn(net, x, draws, seed, call0, timers, streams)
         if out is not None:
             return out
     layers = bayesian_layers(net)
@@ -333,7 +374,7 @@ def mc_logits(net, x, draws, seed, call0, fuse_act=True, timers=None, eps=None, 
     return h, kl
 
 
-def mc_forward(net, x, num_ens, group=None, fuse_act=True, timers=None, kl_mode="sum"):
+def mc_forward(net, x, num_ens, group=None, fuse_act=True, timers=None, kl_mode="sum", streams=1):
     """One Monte-Carlo step: -> (log_outputs [B, C], kl).
 
     kl_mode "sum": kl summed over the num_ens calls as validate_model does (main_bayesian.py:76-77);
@@ -345,7 +386,7 @@ def mc_forward(net, x, num_ens, group=None, fuse_act=True, timers=None, kl_mode=
     seed, call0 = rng.next_calls(num_ens)            # all ranks advance identically
     lo, hi = draw_range(num_ens, rank, world)
     if hi > lo:
-        logits, kl1 = mc_logits(net, x, hi - lo, seed, call0 + lo, fuse_act=fuse_act, timers=timers)
+        logits, kl1 = mc_logits(net, x, hi - lo, seed, call0 + lo, fuse_act=fuse_act, timers=timers, streams=streams)
         if torch.is_grad_enabled() and logits.requires_grad:
             # training extension: differentiable tail through torch ops
             lse = torch.logsumexp(F.log_softmax(logits, dim=2), dim=0) - (0.0 if world > 1 else math.log(num_ens))
@@ -382,3 +423,45 @@ def combine_ranks(lse_local, kl_local, num_ens, group, kl_mode="sum", shape=None
     if kl_mode != "sum":
         kl = kl / num_ens
     return log_outputs, kl
+
+
+class GraphedMC:
+    """One Monte-Carlo step captured as a hipGraph (launch-bound inner loop -> one graph launch per step).
+
+    The step is `mc_forward(net, x, num_ens, streams=...)` for a FIXED input buffer `x` (copy new batches into
+    `self.x`) on one GPU, inference only.  Fresh noise on every replay: the kernels add a device-side counter to their
+    call index and the graph itself increments that counter by num_ens, so replay r uses calls call0 + r*num_ens ..
+    exactly what r eager steps would have used; the Python-side counter is advanced in step().
+    Results land in `self.log_outputs` [B, C] and `self.kl` (overwritten by every replay)."""
+
+    def __init__(self, net, x, num_ens, streams=1, kl_mode="sum"):
+        _lib.require_device(x)
+        self.net, self.x, self.num_ens = net, x, int(num_ens)
+        dev = x.device
+        self.counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.seed, self.call0 = rng.next_calls(0)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.no_grad(), torch.cuda.stream(side), rng.device_call_offset(self.counter):
+            for _ in range(2):                       # warm-up on the capture stream (allocator, lazy module state)
+                self._step_body(streams, kl_mode)
+            self.counter.zero_()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), rng.device_call_offset(self.counter), torch.cuda.graph(self.graph):
+            self.log_outputs, self.kl = self._step_body(streams, kl_mode)
+        self.replays = 0
+
+    def _step_body(self, streams, kl_mode):
+        logits, kl1 = mc_logits(self.net, self.x, self.num_ens, self.seed, self.call0, streams=streams)
+        lo = ops.mc_tail(logits, mean_over=self.num_ens)
+        kl = kl1 * float(self.num_ens) if kl_mode == "sum" else kl1
+        self.counter.add_(self.num_ens)              # part of the graph: next replay = next num_ens calls
+        return lo, kl
+
+    def step(self):
+        self.graph.replay()
+        self.replays += 1
+        rng.next_calls(self.num_ens)                 # keep the host-side counter in step with the device's
+        return self.log_outputs, self.kl

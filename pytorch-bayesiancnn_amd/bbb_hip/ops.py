@@ -9,7 +9,7 @@ import ctypes
 
 import torch
 
-from . import _lib
+from . import _lib, rng
 from ._lib import Segment, ConvDesc, check, ptr, require_device, cur_stream
 
 _scratch = {}
@@ -65,7 +65,7 @@ def reparam_kl_forward(mus, rhos, prior_mu, prior_sigma, stream_ids, seed, call0
     flags = (_lib.SIGMA_SQUARED if sigma_squared else 0) | (_lib.KL_TEXTBOOK if textbook_kl else 0)
     with torch.cuda.device(dev):
         rc = L.bbb_reparam_kl_fwd(segs, len(mus), draws, float(prior_mu), float(prior_sigma), seed, call0 & 0xFFFFFFFF,
-                                  flags, ptr(parts), ptr(kl), 0, cur_stream(dev))
+                                  flags, ptr(parts), ptr(kl), 0, rng.call_dev_ptr(dev), cur_stream(dev))
     check(rc, "bbb_reparam_kl_fwd")
     return ws, sigmas, kl
 
@@ -174,7 +174,8 @@ def lrt_conv2d_forward(x, w_mu, w_var, b_mu, b_var, seed, call0, stream_id, stri
     with torch.cuda.device(x.device):
         check(_lib.lib().bbb_lrt_conv2d_fwd(ctypes.byref(d), x.data_ptr(), w_mu.data_ptr(), w_var.data_ptr(), ptr(b_mu),
                                             ptr(b_var), y.data_ptr(), ptr(am), ptr(av), ptr(eps), seed,
-                                            call0 & 0xFFFFFFFF, stream_id, 1 if sample else 0, cur_stream(x.device)),
+                                            call0 & 0xFFFFFFFF, stream_id, 1 if sample else 0, rng.call_dev_ptr(x.device),
+                                            cur_stream(x.device)),
               "bbb_lrt_conv2d_fwd")
     return y, am, av
 
@@ -225,7 +226,8 @@ def lrt_conv2d_chwn_forward(x, w_mu, w_var, b_mu, b_var, seed, call0, stream_id,
     with torch.cuda.device(x.device):
         check(_lib.lib().bbb_lrt_conv2d_chwn_fwd(ctypes.byref(d), x.data_ptr(), w_mu.data_ptr(), w_var.data_ptr(), ptr(b_mu),
                                                  ptr(b_var), y.data_ptr(), ptr(am), ptr(av), ptr(eps), seed,
-                                                 call0 & 0xFFFFFFFF, stream_id, 1 if sample else 0, cur_stream(x.device)),
+                                                 call0 & 0xFFFFFFFF, stream_id, 1 if sample else 0,
+                                                 rng.call_dev_ptr(x.device), cur_stream(x.device)),
               "bbb_lrt_conv2d_chwn_fwd")
     return y, am, av
 

@@ -82,3 +82,30 @@ def assign_stream_ids(net):
             m._stream_base = 4 * i
             i += 1
     return i
+
+
+# ---- device-side call offset (hipGraph replay) ---------------------------------------------------------------
+_graph_counter = {"tensor": None}
+
+
+def call_dev_ptr(device):
+    """Pointer handed to the kernels as `call_dev`: 0 (NULL) in eager mode; while a GraphedMC step is being captured or
+    exists, the address of its device counter so that every replay draws fresh noise."""
+    t = _graph_counter["tensor"]
+    return 0 if t is None else t.data_ptr()
+
+
+class device_call_offset:
+    """Context: kernels launched inside add `counter` (a 1-element int32 device tensor) to their call index."""
+
+    def __init__(self, counter):
+        self.counter = counter
+
+    def __enter__(self):
+        self.prev = _graph_counter["tensor"]
+        _graph_counter["tensor"] = self.counter
+        return self
+
+    def __exit__(self, *exc):
+        _graph_counter["tensor"] = self.prev
+        return False

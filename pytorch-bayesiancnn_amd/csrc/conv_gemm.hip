@@ -49,6 +49,7 @@ struct ConvArgs {
     int32_t B, Cin, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, Ho, Wo;
     int32_t M, K, HoWo, khkw, act, sample;
     uint32_t k0, k1, call0, stream_id;
+    const uint32_t* call_dev;
 };
 
 
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const ConvArgs p) {
                                 // element index inside this draw's [B][Cout][Ho][Wo] slab
                                 const uint64_t idx = (uint64_t)((int64_t)b * p.Cout * p.HoWo + (int64_t)n * p.HoWo + pix);
                                 float z4[4];
-                                bbb::normal4(idx >> 2, p.stream_id, p.call0 + (uint32_t)e, p.k0, p.k1, z4);
+                                bbb::normal4(idx >> 2, p.stream_id, p.call0 + (p.call_dev ? *p.call_dev : 0u) + (uint32_t)e, p.k0, p.k1, z4);
                                 const int c = (int)(idx & 3);
                                 z = c == 0 ? z4[0] : c == 1 ? z4[1] : c == 2 ? z4[2] : z4[3];
                             }
@@ -357,7 +358,7 @@ extern "C" int bbb_conv2d_fwd(const bbb_conv_desc_t* d, const float* x, const fl
 extern "C" int bbb_lrt_conv2d_fwd(const bbb_conv_desc_t* d, const float* x, const float* w_mu, const float* w_var,
                                   const float* b_mu, const float* b_var, float* y, float* act_mu_out, float* act_var_out,
                                   const float* eps_ext, uint64_t seed, uint32_t call0, uint32_t stream_id, int sample,
-                                  void* stream) {
+                                  const uint32_t* call_dev, void* stream) {
     ConvArgs a = {};
     const int rc = check_desc(d, a);
     if (rc != 0) return rc;
@@ -371,5 +372,6 @@ extern "C" int bbb_lrt_conv2d_fwd(const bbb_conv_desc_t* d, const float* x, cons
     a.y_mu = act_mu_out; a.y_var = act_var_out; a.eps_ext = eps_ext;
     a.k0 = (uint32_t)seed; a.k1 = (uint32_t)(seed >> 32); a.call0 = call0; a.stream_id = stream_id;
     a.sample = sample ? 1 : 0;
+    a.call_dev = call_dev;
     return launch<true>(a, d->draws, (hipStream_t)stream);
 }

@@ -1,0 +1,27 @@
+// Kernel-argument block shared by the two pixel-major GEMM variants (pconv_gemm.hip, pconv_dma.hip).
+#pragma once
+#include <stdint.h>
+
+struct PConvArgs {
+    const float* x;
+    const float* w;
+    const float* w2;
+    const float* bias;
+    const float* bias2;
+    float* y;
+    float* y_mu;
+    float* y_var;
+    const float* eps_ext;
+    int64_t x_ds, w_ds, b_ds, y_ds;
+    int32_t B, Cin, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, Ho, Wo;
+    int32_t K, khkw, act, sample;
+    int32_t Mtiles, nbt, Ntiles, G, per_xcd;
+#ifdef BBB_TIMESTAMPS
+    long long* ts;
+#endif
+    uint32_t k0, k1, call0, stream_id;
+    const uint32_t* call_dev;
+};
+
+// pconv_dma.hip: LDS-DMA pipelined variant; returns -1000 when it does not apply.
+int bbb_pconv_dma_launch(const void* args, int lrt, int bm, int64_t blocks, void* stream);

@@ -21,9 +21,11 @@
 // indexed by the canonical NCHW element index (identical stream to the NCHW kernel and the oracle).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/bbb_hip.h"
 #include "bbb_common.cuh"
+#include "pconv_args.h"
 
 namespace {
 
@@ -37,28 +39,13 @@ constexpr int LDW = BN + 1;
 constexpr int KCH = 256;                 // k_eff entries per decode chunk (one entry per thread)
 constexpr int TPC = KCH / BK;            // tiles per chunk
 
-struct PConvArgs {
-    const float* x;
-    const float* w;
-    const float* w2;
-    const float* bias;
-    const float* bias2;
-    float* y;
-    float* y_mu;
-    float* y_var;
-    const float* eps_ext;
-    int64_t x_ds, w_ds, b_ds, y_ds;
-    int32_t B, Cin, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, Ho, Wo;
-    int32_t K, khkw, act, sample;
-    int32_t Mtiles, nbt, Ntiles, G;
-    uint32_t k0, k1, call0, stream_id;
-};
 
 
 template <int BM, bool LRT>
 __global__ __launch_bounds__(kThreads) void pconv_gemm_kernel(const PConvArgs p) {
     constexpr int LDX = BM + 4;
-    constexpr int NT = (BM == 128) ? 2 : 1;
+    constexpr int NT = (BM >= 128) ? 2 : 1;              // 32-channel MFMA tiles per wave
+    constexpr int MT = (BM == 256) ? 2 : 1;              // 32-image MFMA tiles per wave
     constexpr int WSETS = LRT ? 2 : 1;
     constexpr int XL = BM / 4;                 // lanes per X row (float4 each)
     constexpr int XRPP = kThreads / XL;        // X rows per pass
@@ -74,13 +61,17 @@ __global__ __launch_bounds__(kThreads) void pconv_gemm_kernel(const PConvArgs p)
     __shared__ int32_t kt_x[2][KCH];   // filled by all 256 threads at once, double buffered
 
     // ---- block -> (draw, channel tile, pixel, batch tile); weight-tile sharers on one XCD ----
+    // Work items (group g = (draw, channel tile), m-tile j) in g-major order are cut into 8 equal contiguous chunks,
+    // one per XCD (workgroup id mod 8 is the XCD the dispatcher places it on): perfectly balanced, and the
+    // workgroups that share a weight tile run on the same XCD at the same time.  (A wrong placement guess costs
+    // L2 hits, never correctness.)
     const int bid = blockIdx.x;
     const int xcd = bid & 7;
-    const int slot = bid >> 3;
-    const int tg = slot / p.Mtiles;
-    const int j = slot - tg * p.Mtiles;
-    const int g = xcd + 8 * tg;
-    if (g >= p.G) return;
+    const int64_t item = (int64_t)xcd * p.per_xcd + (bid >> 3);
+    const int64_t item_end = (int64_t)(xcd + 1) * p.per_xcd;
+    if (item >= item_end || item >= (int64_t)p.G * p.Mtiles) return;
+    const int g = (int)(item / p.Mtiles);
+    const int j = (int)(item - (int64_t)g * p.Mtiles);
     const int e = g / p.Ntiles;
     const int n0 = (g - e * p.Ntiles) * BN;
     const int pix = j / p.nbt;
@@ -103,8 +94,8 @@ __global__ __launch_bounds__(kThreads) void pconv_gemm_kernel(const PConvArgs p)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = (BM == 128) ? 0 : (wave >> 1) * 32;
-    const int wm = (BM == 128) ? wave * 32 : (wave & 1) * 32;
+    const int wn = (BM >= 128) ? 0 : (wave >> 1) * 32;
+    const int wm = (BM >= 128) ? wave * 32 * MT : (wave & 1) * 32;
 
     // Buffer descriptors (wave-uniform): out-of-range offsets read as 0, which is how invalid k / channel / image
     // lanes are masked without a branch around every load (a branch would make hipcc wait vmcnt(0) per element).
@@ -183,27 +174,43 @@ __global__ __launch_bounds__(kThreads) void pconv_gemm_kernel(const PConvArgs p)
             *reinterpret_cast<f32x4*>(&Xs[buf][(xkr + ps * XRPP) * LDX + xb4]) = xreg[ps];
     };
 
-    f32x16 acc[NT];
-    f32x16 accv[NT];
+    f32x16 acc[NT][MT];
+    f32x16 accv[NT][MT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[t][r] = 0.0f; accv[t][r] = 0.0f; }
+        for (int u = 0; u < MT; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[t][u][r] = 0.0f; accv[t][u][r] = 0.0f; }
 
     const int lrow = lane & 31, lk = lane >> 5;
 
+#ifdef BBB_TIMESTAMPS   // debugging aid: s_memtime stamps of wave 0 of two workgroups (see profiles/r01_notes.md)
+    __shared__ long long tsbuf[112];
+    const bool tson = p.ts && (bid == 8 * 40 || bid == 8 * 100) && tid == 0;
+    int tsi = 0;
+#define TS() do { if (tson && tsi < 112) tsbuf[tsi++] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define TS() do { } while (0)
+#endif
+    TS();
     auto mma_tile = [&]() {
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
             const int krow = kk * 2 + lk;
-            const float b = Xs[0][krow * LDX + wm + lrow];
+            float b[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) b[mt] = Xs[0][krow * LDX + wm + mt * 32 + lrow];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const float a = Ws[0][0][krow * LDW + wn + nt * 32 + lrow];
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[nt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[mt], acc[nt][mt], 0, 0, 0);
                 if (LRT) {
                     const float a2 = Ws[0][WSETS - 1][krow * LDW + wn + nt * 32 + lrow];
-                    accv[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b * b, accv[nt], 0, 0, 0);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        accv[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b[mt] * b[mt], accv[nt][mt], 0, 0, 0);
                 }
             }
         }
@@ -216,23 +223,30 @@ __global__ __launch_bounds__(kThreads) void pconv_gemm_kernel(const PConvArgs p)
         if (KCH < Keff) fill_chunk(1);
         store_tile(0, wregA, xregA);
         __syncthreads();
+        TS();
         for (int t = 0; t < ntiles; ++t) {
             const bool more = (t + 1) < ntiles;
             if (more) load_tile(t + 1, wregA, xregA);                 // in flight during this tile's MFMAs
             // decode chunk c+1 early in chunk c (c >= 1; chunk 1 is decoded in the prologue): its buffer was last
             // read by load_tile(TPC*c - 1), several barriers ago
             if ((t % TPC) == 1 && t / TPC >= 1 && (t / TPC + 1) * KCH < Keff) fill_chunk(t / TPC + 1);
+            TS();
             mma_tile();
+            TS();
             __syncthreads();                                          // every wave is done reading the LDS stage
+            TS();
             if (more) store_tile(0, wregA, xregA);
+            TS();
             __syncthreads();
         }
     }
 
+    TS();
+#ifdef BBB_TIMESTAMPS
+    if (tson) { long long* o = p.ts + (bid == 8 * 40 ? 0 : 128); for (int i = 0; i < tsi; ++i) o[i] = tsbuf[i]; }
+#endif
     // ---- epilogue: rows = channels, lanes = images; bias via buffer loads, stores via buffer stores
     //      (out-of-range channel / image lanes get an out-of-range offset: no branches, no per-element waits) ----
-    const int b = b0 + wm + lrow;
-    const bool b_ok = b < p.B;
     const int HoWo = p.Ho * p.Wo;
     const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.bias ? p.bias + (int64_t)e * p.b_ds : p.w), 0, p.bias ? p.Cout * 4 : 0, 0x00020000);
@@ -246,44 +260,49 @@ __global__ __launch_bounds__(kThreads) void pconv_gemm_kernel(const PConvArgs p)
             const int n = n0 + wn + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
             bv[nt][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brs, (uint32_t)n * 4u, 0, 0));
         }
-    if (!LRT) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+    for (int mt = 0; mt < MT; ++mt) {
+        const int b = b0 + wm + mt * 32 + lrow;
+        const bool b_ok = b < p.B;
+        if (!LRT) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int n = n0 + wn + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                const uint32_t off = (b_ok & (n < p.Cout)) ? (uint32_t)(((int64_t)n * HoWo + pix) * p.B + b) * 4u : kOOB;
-                const float v = bbb::apply_act(acc[nt][r] + bv[nt][r], p.act);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), yrs, off, 0, 0);
-            }
-    } else if (b_ok) {
-        const int64_t ybase = (int64_t)e * p.y_ds + (int64_t)pix * p.B + b;
-        const float* __restrict__ b2g = p.bias2 ? p.bias2 + (int64_t)e * p.b_ds : nullptr;
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
+                for (int r = 0; r < 16; ++r) {
+                    const int n = n0 + wn + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                    const uint32_t off = (b_ok & (n < p.Cout)) ? (uint32_t)(((int64_t)n * HoWo + pix) * p.B + b) * 4u : kOOB;
+                    const float v = bbb::apply_act(acc[nt][mt][r] + bv[nt][r], p.act);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), yrs, off, 0, 0);
+                }
+        } else if (b_ok) {
+            const int64_t ybase = (int64_t)e * p.y_ds + (int64_t)pix * p.B + b;
+            const float* __restrict__ b2g = p.bias2 ? p.bias2 + (int64_t)e * p.b_ds : nullptr;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int n = n0 + wn + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                if (n < p.Cout) {
-                    const int64_t o = ybase + (int64_t)n * HoWo * p.B;
-                    float v = acc[nt][r] + bv[nt][r];
-                    const float var = 1e-16f + (accv[nt][r] + (b2g ? b2g[n] : 0.0f));
-                    if (p.y_mu) p.y_mu[o] = v;
-                    if (p.y_var) p.y_var[o] = var;
-                    if (p.sample) {
-                        float z;
-                        if (p.eps_ext) {
-                            z = p.eps_ext[o];
-                        } else {   // canonical NCHW element index of this draw's [B][Cout][Ho][Wo] slab
-                            const uint64_t idx = (uint64_t)(((int64_t)b * p.Cout + n) * HoWo + pix);
-                            float z4[4];
-                            bbb::normal4(idx >> 2, p.stream_id, p.call0 + (uint32_t)e, p.k0, p.k1, z4);
-                            const int c = (int)(idx & 3);
-                            z = c == 0 ? z4[0] : c == 1 ? z4[1] : c == 2 ? z4[2] : z4[3];
+            for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = n0 + wn + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                    if (n < p.Cout) {
+                        const int64_t o = ybase + (int64_t)n * HoWo * p.B;
+                        float v = acc[nt][mt][r] + bv[nt][r];
+                        const float var = 1e-16f + (accv[nt][mt][r] + (b2g ? b2g[n] : 0.0f));
+                        if (p.y_mu) p.y_mu[o] = v;
+                        if (p.y_var) p.y_var[o] = var;
+                        if (p.sample) {
+                            float z;
+                            if (p.eps_ext) {
+                                z = p.eps_ext[o];
+                            } else {   // canonical NCHW element index of this draw's [B][Cout][Ho][Wo] slab
+                                const uint64_t idx = (uint64_t)(((int64_t)b * p.Cout + n) * HoWo + pix);
+                                float z4[4];
+                                bbb::normal4(idx >> 2, p.stream_id, p.call0 + (p.call_dev ? *p.call_dev : 0u) + (uint32_t)e, p.k0, p.k1, z4);
+                                const int c = (int)(idx & 3);
+                                z = c == 0 ? z4[0] : c == 1 ? z4[1] : c == 2 ? z4[2] : z4[3];
+                            }
+                            v = v + __builtin_amdgcn_sqrtf(var) * z;
                         }
-                        v = v + __builtin_amdgcn_sqrtf(var) * z;
+                        p.y[o] = bbb::apply_act(v, p.act);
                     }
-                    p.y[o] = bbb::apply_act(v, p.act);
                 }
             }
         }
@@ -340,17 +359,39 @@ int launch(PConvArgs& a, int draws, hipStream_t st) {
     a.Ntiles = (a.Cout + BN - 1) / BN;
     a.G = a.Ntiles * draws;
     const int64_t pixels = (int64_t)a.Ho * a.Wo;
-    // tile choice: fewest "rounds x tile width" over the 256 CUs
-    const int64_t nb128 = pixels * ((a.B + 127) / 128) * a.G, nb64 = pixels * ((a.B + 63) / 64) * a.G;
-    const int64_t c128 = ((nb128 + 255) / 256) * 128, c64 = ((nb64 + 255) / 256) * 64;
-    const int bm = (LRT || c64 < c128) ? 64 : 128;   // LRT stages two weight tiles: 64-wide only (LDS budget)
+    // tile choice: 128 images per workgroup (two accumulator chains per wave) unless that leaves fewer than 3
+    // workgroups per CU, then 64.  A 256-image tile (64x64 per wave) exists but measured 5-10 % slower on every
+    // AlexNet layer (3 instead of 4 workgroups per CU); it is kept for BBB_FORCE_BM experiments only.
+    // LRT stages two weight tiles and keeps two accumulator sets: 64-wide only.
+    const int64_t nb128 = pixels * ((a.B + 127) / 128) * a.G;
+    int bm = (LRT || nb128 < 768) ? 64 : 128;
+    if (const char* f = getenv("BBB_FORCE_BM")) { if (!LRT) bm = atoi(f); }
+#ifdef BBB_TIMESTAMPS
+    { const char* tv = getenv("BBB_TS"); a.ts = tv ? (long long*)strtoull(tv, nullptr, 0) : nullptr; }
+#endif
     a.nbt = (a.B + bm - 1) / bm;
     const int64_t mt = pixels * a.nbt;
     if (mt > 0x7fffffffLL) return BBB_ESHAPE;
     a.Mtiles = (int)mt;
-    const int64_t blocks = (int64_t)8 * ((a.G + 7) / 8) * mt;
+    const int64_t items = (int64_t)a.G * mt;
+    const int64_t per = (items + 7) / 8;
+    const int64_t blocks = 8 * per;
     if (blocks > 0x7fffffffLL) return BBB_ESHAPE;
+    a.per_xcd = (int32_t)per;
+    {   // BBB_PCONV=dma selects the LDS-DMA pipelined variant (pconv_dma.hip: 3-stage ring, 2 workgroups per CU).  It
+        // measured 20-30 % SLOWER than this register-staged kernel at 4 workgroups per CU on every AlexNet layer, so it
+        // is opt-in, kept for comparison on other shapes.
+        const char* v = getenv("BBB_PCONV");
+        if (v && v[0] == 'd' && bm != 256) {
+            const int rc = bbb_pconv_dma_launch(&a, LRT ? 1 : 0, bm, blocks, st);
+            if (rc != -1000) return rc;
+        }
+    }
     if constexpr (!LRT) {
+        if (bm == 256) {
+            hipLaunchKernelGGL((pconv_gemm_kernel<256, false>), dim3((unsigned)blocks), dim3(kThreads), 0, st, a);
+            return (int)hipGetLastError();
+        }
         if (bm == 128) {
             hipLaunchKernelGGL((pconv_gemm_kernel<128, false>), dim3((unsigned)blocks), dim3(kThreads), 0, st, a);
             return (int)hipGetLastError();
@@ -376,7 +417,7 @@ extern "C" int bbb_conv2d_chwn_fwd(const bbb_conv_desc_t* d, const float* x, con
 extern "C" int bbb_lrt_conv2d_chwn_fwd(const bbb_conv_desc_t* d, const float* x, const float* w_mu, const float* w_var,
                                        const float* b_mu, const float* b_var, float* y, float* act_mu_out,
                                        float* act_var_out, const float* eps_ext, uint64_t seed, uint32_t call0,
-                                       uint32_t stream_id, int sample, void* stream) {
+                                       uint32_t stream_id, int sample, const uint32_t* call_dev, void* stream) {
     PConvArgs a = {};
     const int rc = fill(d, a);
     if (rc != 0) return rc;
@@ -391,6 +432,7 @@ extern "C" int bbb_lrt_conv2d_chwn_fwd(const bbb_conv_desc_t* d, const float* x,
     a.y_mu = act_mu_out; a.y_var = act_var_out; a.eps_ext = eps_ext;
     a.k0 = (uint32_t)seed; a.k1 = (uint32_t)(seed >> 32); a.call0 = call0; a.stream_id = stream_id;
     a.sample = sample ? 1 : 0;
+    a.call_dev = call_dev;
     return launch<true>(a, d->draws, (hipStream_t)stream);
 }
 

@@ -34,6 +34,7 @@ struct ReparamArgs {
     uint32_t k0, k1, call0, flags;
     double* partials;
     const float* gkl;
+    const uint32_t* call_dev;
 };
 
 // KL term exactly in the reference's operator order (metrics.py:28 with the call-site argument
@@ -69,6 +70,7 @@ __global__ __launch_bounds__(kThreads) void reparam_kl_fwd_kernel(const ReparamA
     const bool textbook = (a.flags & BBB_KL_TEXTBOOK) != 0;
     const bool sq = (a.flags & BBB_SIGMA_SQUARED) != 0;
     const bool want_kl = a.partials != nullptr;
+    const uint32_t call0 = a.call0 + (a.call_dev ? *a.call_dev : 0u);
     // vector path needs 16-byte aligned rows for every draw
     const bool aligned = ((((uintptr_t)sg.mu | (uintptr_t)sg.rho | (uintptr_t)sg.w | (uintptr_t)sg.sigma |
                             (uintptr_t)sg.eps) & 15u) == 0) && ((sg.draw_stride & 3) == 0);
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(kThreads) void reparam_kl_fwd_kernel(const ReparamA
 #pragma unroll
                     for (int j = 0; j < 4; ++j) z[j] = j < cnt ? sg.eps[o + j] : 0.0f;
                 } else {
-                    bbb::normal4(g, sg.stream_id, a.call0 + (uint32_t)e, a.k0, a.k1, z);
+                    bbb::normal4(g, sg.stream_id, call0 + (uint32_t)e, a.k0, a.k1, z);
                 }
                 if (aligned && cnt == 4) {
                     f32x4 w4;
@@ -289,7 +291,7 @@ extern "C" int64_t bbb_reparam_partials(const bbb_segment_t* segs, int nseg) {
 
 extern "C" int bbb_reparam_kl_fwd(const bbb_segment_t* segs, int nseg, int draws, float prior_mu, float prior_sigma,
                                   uint64_t seed, uint32_t call0, uint32_t flags, double* kl_partials, float* kl_out,
-                                  double* kl_out64, void* stream) {
+                                  double* kl_out64, const uint32_t* call_dev, void* stream) {
     ReparamArgs a = {};
     const int chunks = fill_args(a, segs, nseg, draws, false);
     if (chunks < 0) return chunks;
@@ -303,6 +305,7 @@ extern "C" int bbb_reparam_kl_fwd(const bbb_segment_t* segs, int nseg, int draws
     a.call0 = call0;
     a.flags = flags;
     a.partials = want_kl ? kl_partials : nullptr;
+    a.call_dev = call_dev;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(reparam_kl_fwd_kernel, dim3(chunks), dim3(kThreads), 0, st, a);
     hipError_t err = hipGetLastError();

@@ -256,3 +256,41 @@ def test_train_step_runs_and_learns(env):
         opt.step()
         losses.append(loss.item())
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+
+
+def test_graphed_step_replays_draw_fresh_noise_and_match_eager(env):
+    """hipGraph replay r of GraphedMC == eager mc_forward at noise calls call0 + r*E (device-side call counter)."""
+    torch.manual_seed(2)
+    net = env["zoo"].BBBAlexNet(10, 3, P.CONFIG_PRIORS, "bbb", "softplus").cuda()
+    env["rng"].assign_stream_ids(net)
+    x = torch.rand(64, 3, 32, 32, device="cuda")
+    E = 4
+    env["rng"].manual_seed(77, call=100)
+    g = env["ens"].GraphedMC(net, x, E, streams=2)
+    outs = []
+    for r in range(3):
+        lo, kl = g.step()
+        outs.append((lo.clone(), kl.clone()))
+    assert env["rng"].get_state() == (77, 100 + 3 * E)
+    assert not torch.equal(outs[0][0], outs[1][0]) and not torch.equal(outs[1][0], outs[2][0])
+    with torch.no_grad():
+        for r in range(3):
+            env["rng"].manual_seed(77, call=100 + r * E)
+            lo, kl = env["ens"].mc_forward(net, x, E)
+            assert torch.equal(lo, outs[r][0]) and kl.item() == outs[r][1].item()
+
+
+def test_lrt_graphed_step(env):
+    torch.manual_seed(2)
+    net = env["zoo"].BBBLeNet(10, 1, P.CONFIG_PRIORS, "lrt", "relu").cuda()
+    env["rng"].assign_stream_ids(net)
+    x = torch.rand(16, 1, 32, 32, device="cuda")
+    env["rng"].manual_seed(5, call=0)
+    g = env["ens"].GraphedMC(net, x, 3)
+    a = g.step()[0].clone()
+    b = g.step()[0].clone()
+    assert not torch.equal(a, b)
+    with torch.no_grad():
+        env["rng"].manual_seed(5, call=3)
+        lo, _ = env["ens"].mc_forward(net, x, 3)
+    assert torch.equal(lo, b)
