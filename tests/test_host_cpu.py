@@ -69,9 +69,9 @@ def test_argument_errors_without_a_gpu(built):
     from bbb_hip import _lib
     h = _lib.lib()
     seg = (_lib.Segment * 1)()
-    assert h.bbb_reparam_kl_fwd(seg, 1, 1, 0.0, 0.1, 0, 0, 0, None, None, None, None) == -1        # null mu
-    assert h.bbb_reparam_kl_fwd(seg, 0, 1, 0.0, 0.1, 0, 0, 0, None, None, None, None) == -1        # nseg = 0
-    assert h.bbb_reparam_kl_fwd(seg, 17, 1, 0.0, 0.1, 0, 0, 0, None, None, None, None) == -1       # > 16 segments
+    assert h.bbb_reparam_kl_fwd(seg, 1, 1, 0.0, 0.1, 0, 0, 0, None, None, None, None, None) == -1        # null mu
+    assert h.bbb_reparam_kl_fwd(seg, 0, 1, 0.0, 0.1, 0, 0, 0, None, None, None, None, None) == -1        # nseg = 0
+    assert h.bbb_reparam_kl_fwd(seg, 17, 1, 0.0, 0.1, 0, 0, 0, None, None, None, None, None) == -1       # > 16 segments
     assert h.bbb_reparam_partials(seg, 0) == -1
     d = _lib.ConvDesc()
     assert h.bbb_conv2d_fwd(ctypes.byref(d), None, None, None, None, None) == -1                   # zero geometry
