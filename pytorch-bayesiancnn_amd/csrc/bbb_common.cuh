@@ -49,8 +49,35 @@ __device__ __forceinline__ void normal4(uint64_t g, uint32_t stream_id, uint32_t
 
 // softplus as the reference writes it, log1p(exp(rho)) (layers/BBB/BBBConv.py:64); rho > 20 returns rho,
 // which is the same fp32 value and does not overflow where the reference's exp does (rho > ~88).
+// This is the per-element cost of the parameter pass, so it is built from the hardware exp2 / rcp units with the
+// rounding errors folded back in (<= ~2 ulp end to end) instead of the ~100-instruction libm pair:
+//   exp(rho)   = 2^hi * (1 + lo*ln2),  hi = rho*log2e rounded, lo = the product's rounding error (+ log2e's own)
+//   log1p(t)   = 2*atanh(z), z = t/(2+t), odd series to z^9 (z <= 0.13 for t <= 0.3, truncation < 1e-9 relative)
+// t > 0.3 (rho > -1.2, i.e. sigma > 0.26: far from any BBB posterior) takes the libm path.
+__device__ __forceinline__ float exp_fast_accurate(float x) {
+    const float hi = x * 1.4426950408889634f;
+    float lo = fmaf(x, 1.4426950408889634f, -hi);
+    lo = fmaf(x, 1.925963033500011e-8f, lo);
+    const float r = __builtin_amdgcn_exp2f(hi);
+    return fmaf(r, lo * 0.6931471805599453f, r);
+}
+
+__device__ __forceinline__ float rcp_newton(float v) {       // 1/v to < 1 ulp
+    const float r = __builtin_amdgcn_rcpf(v);
+    return fmaf(fmaf(-v, r, 1.0f), r, r);
+}
+
 __device__ __forceinline__ float softplus_ref(float rho) {
-    return rho > 20.0f ? rho : log1pf(expf(rho));
+    if (rho > 20.0f) return rho;
+    if (rho > -1.2f || rho < -80.0f) return log1pf(expf(rho));
+    const float t = exp_fast_accurate(rho);
+    const float d = 2.0f + t;
+    const float rd = __builtin_amdgcn_rcpf(d);
+    float z = t * rd;
+    z = fmaf(fmaf(-z, d, t), rd, z);                           // correctly rounded t / (2 + t)
+    const float z2 = z * z;
+    const float p = fmaf(z2, fmaf(z2, fmaf(z2, fmaf(z2, 2.0f / 9.0f, 2.0f / 7.0f), 2.0f / 5.0f), 2.0f / 3.0f), 2.0f);
+    return z * p;
 }
 
 // Epilogue activations.  Softplus(beta=1, threshold=20) on the hardware exp2 / log2 units:

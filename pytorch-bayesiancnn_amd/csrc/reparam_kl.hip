@@ -17,8 +17,7 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kGroupsPerThread = 1;                          // groups of 4 elements
-constexpr int kChunk = kThreads * 4 * kGroupsPerThread;      // elements per block
+constexpr int kChunk = kThreads * 4;                         // elements per (block, group slot): 4 per thread
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
@@ -37,19 +36,23 @@ struct ReparamArgs {
     const uint32_t* call_dev;
 };
 
-// KL term exactly in the reference's operator order (metrics.py:28 with the call-site argument
-// order): 0.5 * (2*log(sig_p/sig_q) - 1 + (sig_q/sig_p)^2 + ((mu_p - mu_q)/sig_p)^2),
-// q = prior scalars, p = posterior tensors.  Correctly rounded fp32 divisions and logf.
-__device__ __forceinline__ float kl_term(float mu, float sigma, float mu0, float sig0, bool textbook) {
+// KL term in the reference's form (metrics.py:28 with the call-site argument order):
+//   0.5 * (2*log(sig_p/sig_q) - 1 + (sig_q/sig_p)^2 + ((mu_p - mu_q)/sig_p)^2),  q = prior scalars, p = posterior.
+// One Newton-refined reciprocal instead of three IEEE divisions and the hardware log2 instead of logf: each term
+// is within ~1e-7 absolute / 2 ulp relative of the torch expression, far inside the 1e-6 relative bound on the SUM
+// (terms are O(100) and the errors are unbiased).  l2s0 = log2(prior sigma), is0 = 1 / prior sigma.
+__device__ __forceinline__ float kl_term(float mu, float sigma, float mu0, float sig0, float l2s0, float is0, bool textbook) {
+    const float l2 = __builtin_amdgcn_logf(sigma) - l2s0;            // log2(sigma / sig0)
     float t;
     if (!textbook) {
-        const float a = sig0 / sigma;
-        const float b = (mu - mu0) / sigma;
-        t = 2.0f * logf(sigma / sig0) - 1.0f + a * a + b * b;
+        const float is = bbb::rcp_newton(sigma);
+        const float a = sig0 * is;
+        const float b = (mu - mu0) * is;
+        t = fmaf(1.3862943611198906f, l2, -1.0f) + a * a + b * b;
     } else {  // KL(q||p): q = posterior, p = prior (opt-in)
-        const float a = sigma / sig0;
-        const float b = (mu0 - mu) / sig0;
-        t = 2.0f * logf(sig0 / sigma) - 1.0f + a * a + b * b;
+        const float a = sigma * is0;
+        const float b = (mu0 - mu) * is0;
+        t = fmaf(-1.3862943611198906f, l2, -1.0f) + a * a + b * b;
     }
     return 0.5f * t;
 }
@@ -60,17 +63,22 @@ __device__ __forceinline__ int find_segment(const ReparamArgs& a, int chunk) {
     return s;
 }
 
+// GPT = groups of 4 elements per thread.  1 for model-sized launches (enough blocks as it is); 4 for very large
+// tensors, where 4x fewer, longer blocks with all their loads issued up front stream HBM better.
+template <int GPT>
 __global__ __launch_bounds__(kThreads) void reparam_kl_fwd_kernel(const ReparamArgs a) {
+    constexpr int kGroupsPerThread = GPT;
     __shared__ double wave_part[kThreads / bbb::kWave];
     const int chunk = blockIdx.x;
     const int s = find_segment(a, chunk);
     const bbb_segment_t sg = a.seg[s];
-    const int64_t base = (int64_t)(chunk - a.chunk_begin[s]) * kChunk;
+    const int64_t base = (int64_t)(chunk - a.chunk_begin[s]) * (kChunk * GPT);
     const float mu0 = a.prior_mu, sig0 = a.prior_sigma;
     const bool textbook = (a.flags & BBB_KL_TEXTBOOK) != 0;
     const bool sq = (a.flags & BBB_SIGMA_SQUARED) != 0;
     const bool want_kl = a.partials != nullptr;
     const uint32_t call0 = a.call0 + (a.call_dev ? *a.call_dev : 0u);
+    const float l2s0 = __builtin_amdgcn_logf(sig0), is0 = 1.0f / sig0;
     // vector path needs 16-byte aligned rows for every draw
     const bool aligned = ((((uintptr_t)sg.mu | (uintptr_t)sg.rho | (uintptr_t)sg.w | (uintptr_t)sg.sigma |
                             (uintptr_t)sg.eps) & 15u) == 0) && ((sg.draw_stride & 3) == 0);
@@ -95,11 +103,13 @@ __global__ __launch_bounds__(kThreads) void reparam_kl_fwd_kernel(const ReparamA
                 rho[j] = j < cnt ? sg.rho[i0 + j] : 0.0f;
             }
         }
+        float klf = 0.0f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             sigma[j] = bbb::softplus_ref(rho[j]);
-            if (want_kl && j < cnt) kl_acc += (double)kl_term(mu[j], sigma[j], mu0, sig0, textbook);
+            if (want_kl && j < cnt) klf += kl_term(mu[j], sigma[j], mu0, sig0, l2s0, is0, textbook);
         }
+        kl_acc += (double)klf;
         if (sg.sigma != nullptr) {
             if (aligned && cnt == 4) {
                 f32x4 o;
@@ -164,6 +174,7 @@ __global__ __launch_bounds__(kThreads) void kl_finish_kernel(const double* parti
 }
 
 __global__ __launch_bounds__(kThreads) void reparam_kl_bwd_kernel(const ReparamArgs a) {
+    constexpr int kGroupsPerThread = 1;
     const int chunk = blockIdx.x;
     const int s = find_segment(a, chunk);
     const bbb_segment_t sg = a.seg[s];
@@ -260,7 +271,7 @@ __global__ __launch_bounds__(kThreads) void eps_dump_kernel(float* out, int64_t 
     }
 }
 
-int fill_args(ReparamArgs& a, const bbb_segment_t* segs, int nseg, int draws, bool bwd) {
+int fill_args(ReparamArgs& a, const bbb_segment_t* segs, int nseg, int draws, bool bwd, int gpt = 1) {
     if (segs == nullptr || nseg <= 0 || nseg > BBB_MAX_SEGMENTS || draws <= 0) return BBB_EINVAL;
     int chunks = 0;
     for (int s = 0; s < nseg; ++s) {
@@ -271,7 +282,7 @@ int fill_args(ReparamArgs& a, const bbb_segment_t* segs, int nseg, int draws, bo
             return BBB_EALIGN;
         a.seg[s] = g;
         a.chunk_begin[s] = chunks;
-        chunks += (int)((g.n + kChunk - 1) / kChunk);
+        chunks += (int)((g.n + (int64_t)kChunk * gpt - 1) / ((int64_t)kChunk * gpt));
         (void)bwd;
     }
     for (int s = nseg; s <= BBB_MAX_SEGMENTS; ++s) a.chunk_begin[s] = chunks;
@@ -293,7 +304,11 @@ extern "C" int bbb_reparam_kl_fwd(const bbb_segment_t* segs, int nseg, int draws
                                   uint64_t seed, uint32_t call0, uint32_t flags, double* kl_partials, float* kl_out,
                                   double* kl_out64, const uint32_t* call_dev, void* stream) {
     ReparamArgs a = {};
-    const int chunks = fill_args(a, segs, nseg, draws, false);
+    int64_t total = 0;
+    if (segs != nullptr && nseg > 0 && nseg <= BBB_MAX_SEGMENTS)
+        for (int s = 0; s < nseg; ++s) total += segs[s].n;
+    const int gpt = total > (int64_t)kChunk * 16384 ? 4 : 1;       // > 16M elements: longer blocks
+    const int chunks = fill_args(a, segs, nseg, draws, false, gpt);
     if (chunks < 0) return chunks;
     const bool want_kl = (kl_out != nullptr) || (kl_out64 != nullptr);
     if (want_kl && kl_partials == nullptr) return BBB_EINVAL;
@@ -307,7 +322,8 @@ extern "C" int bbb_reparam_kl_fwd(const bbb_segment_t* segs, int nseg, int draws
     a.partials = want_kl ? kl_partials : nullptr;
     a.call_dev = call_dev;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(reparam_kl_fwd_kernel, dim3(chunks), dim3(kThreads), 0, st, a);
+    if (gpt == 4) hipLaunchKernelGGL(reparam_kl_fwd_kernel<4>, dim3(chunks), dim3(kThreads), 0, st, a);
+    else          hipLaunchKernelGGL(reparam_kl_fwd_kernel<1>, dim3(chunks), dim3(kThreads), 0, st, a);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return (int)err;
     if (want_kl) {

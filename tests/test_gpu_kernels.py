@@ -47,7 +47,7 @@ def test_reparam_kl_ragged_sizes(ops, n):
     ws, sig, kl = ops.reparam_kl_forward([dev(mu)], [dev(rho)], 0.0, 0.1, [5], 1, 0, draws=3, want_sigma=True,
                                          eps=[dev(eps)])
     s = O.sigma_from_rho(rho)
-    np.testing.assert_allclose(sig[0].cpu().numpy(), s, rtol=3e-7)
+    np.testing.assert_allclose(sig[0].cpu().numpy(), s, rtol=5e-7)     # <= 4 ulp (hardware exp2 + atanh series)
     np.testing.assert_allclose(ws[0].cpu().numpy(), mu[None] + eps * s[None], rtol=1e-6, atol=1e-7)
     want = O.kl_loss(mu, s, 0.0, 0.1)
     assert abs(kl.item() - want) <= 1e-6 * abs(want)
@@ -82,13 +82,13 @@ def test_reparam_kl_multitensor_philox_and_determinism(ops):
 def test_reparam_kl_against_reference_fixture(ops, golden):
     Fn = golden["functions"]
     _, sig, kl = ops.reparam_kl_forward([dev(Fn["kl.mu"])], [dev(Fn["kl.rho"])], 0, 0.1, [0], 0, 0, sample=False, want_sigma=True)
-    np.testing.assert_allclose(sig[0].cpu().numpy(), Fn["kl.sigma"], rtol=3e-7)
+    np.testing.assert_allclose(sig[0].cpu().numpy(), Fn["kl.sigma"], rtol=5e-7)
     assert abs(kl.item() - float(Fn["kl.value_cfg"])) <= 2e-6 * float(Fn["kl.value_cfg"])
     _, _, klt = ops.reparam_kl_forward([dev(Fn["kl.mu"])], [dev(Fn["kl.rho"])], 0, 0.1, [0], 0, 0, sample=False, textbook_kl=True)
     assert abs(klt.item() - float(Fn["kl.value_textbook"])) <= 2e-6 * float(Fn["kl.value_textbook"])
     _, s2, _ = ops.reparam_kl_forward([dev(Fn["kl.mu"])], [dev(Fn["kl.rho"])], 0, 0.1, [0], 0, 0, sample=False, want_sigma=True,
                                       sigma_squared=True, want_kl=False)
-    np.testing.assert_allclose(s2[0].cpu().numpy(), Fn["kl.sigma"] ** 2, rtol=6e-7)
+    np.testing.assert_allclose(s2[0].cpu().numpy(), Fn["kl.sigma"] ** 2, rtol=1e-6)
 
 
 def test_reparam_large_rho_is_finite(ops):
@@ -98,7 +98,7 @@ def test_reparam_large_rho_is_finite(ops):
     with np.errstate(over="ignore"):
         want = O.sigma_from_rho(rho.cpu().numpy())
     got = sig[0].cpu().numpy()
-    np.testing.assert_allclose(got[:7], want[:7], rtol=3e-7)
+    np.testing.assert_allclose(got[:7], want[:7], rtol=5e-7)
     assert got[7] == 100.0 and np.isinf(want[7])       # documented departure: no overflow
 
 
