@@ -162,6 +162,13 @@ int bbb_maxpool_chwn(const float* x, float* y, int64_t planes, int h, int w, int
 int bbb_mc_tail(const float* logits, int draws, int batch, int classes, int mean_over,
                 float* lse_out, void* stream);
 
+/* bbb_mc_tail for logits stored batch-innermost, [draws][C][B] (output of the batched ensemble path); lse_out is [B][C]. */
+int bbb_mc_tail_cb(const float* logits, int draws, int batch, int classes, int mean_over,
+                   float* lse_out, void* stream);
+
+/* [rows][cols] -> [cols][rows] (e.g. an NCHW batch [B][C*H*W] into the batch-innermost [C*H*W][B] layout). */
+int bbb_transpose2d(const float* in, float* out, int64_t rows, int64_t cols, void* stream);
+
 /* Library / device introspection (host-only). */
 int bbb_abi_version(void);
 const char* bbb_build_info(void);

@@ -194,8 +194,12 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1):
         variances, k2 = _variances_all(lrt, timers)
         kl = k2 if kl is None else kl + k2
     E, B = draws, x.shape[0]
-    xt = x.permute(1, 2, 3, 0).contiguous().unsqueeze(0)         # [1, C, H, W, B], shared by all draws
+    xt = ops.to_batch_innermost(x).unsqueeze(0)                  # [1, C, H, W, B], shared by all draws
     children = list(net.children())
+    last_bayes = max((i for i, m in enumerate(children) if isinstance(m, (_BBBLayer, _LRTLayer))), default=-1)
+    tail_is_last = last_bayes == len(children) - 1
+    n_out = getattr(children[last_bayes], "out_features", None) if tail_is_last else None
+    logits_buf = torch.empty((E, n_out, B), dtype=torch.float32, device=x.device) if n_out is not None else None
 
     def run(e0, e1):
         """Layers for draws [e0, e1) on the current stream -> logits [e1-e0, C, B] (or None: fall back)."""
@@ -220,7 +224,8 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1):
                         w = w.reshape(Es, mod.out_features, mod.in_features, 1, 1)
                     fl = conv_flops(B, h5.shape[1], h5.shape[2], h5.shape[3], w.shape[1], w.shape[3], w.shape[4], *geom, Es) \
                         if timers is not None else None
-                    y = _run(timers, "conv_gemm", fl, lambda: ops.conv2d_chwn_forward(h5, w, b, *geom, act=act))
+                    dst = logits_buf[e0:e1] if (logits_buf is not None and i == last_bayes and not is_conv) else None
+                    y = _run(timers, "conv_gemm", fl, lambda: ops.conv2d_chwn_forward(h5, w, b, *geom, act=act, out=dst))
                 else:
                     w_var, b_var = variances[mod]
                     w_mu = mod.W_mu
@@ -251,7 +256,13 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1):
             i += 1
         if h.shape[0] == 1 and Es > 1:
             h = h.expand(Es, *h.shape[1:])
-        return h.reshape(Es, -1, B)
+        h = h.reshape(Es, -1, B)
+        if logits_buf is not None and h.shape[1] == logits_buf.shape[1]:
+            dst = logits_buf[e0:e1]
+            if h.data_ptr() != dst.data_ptr():
+                dst.copy_(h)
+            return dst
+        return h
 
     nsplit = max(1, min(int(streams), E))
     if nsplit == 1 or timers is not None:
@@ -273,9 +284,10 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1):
             main.wait_stream(st)
         if any(pt is None for pt in parts):
             return None
-        out = torch.cat(parts, dim=0)
-    logits = out.permute(0, 2, 1).contiguous()                   # [E, B, C] for the tail kernel
-    return logits, kl
+        out = logits_buf if (logits_buf is not None and all(pt.data_ptr() == logits_buf[b0:b1].data_ptr()
+                                                            for pt, (b0, b1) in zip(parts, bounds))) \
+            else torch.cat(parts, dim=0)
+    return out, kl                                               # logits stay batch-innermost: [E, C, B]
 
 
 _stream_pool = {}
@@ -298,7 +310,7 @@ def mc_logits(net, x, draws, seed, call0, fuse_act=True, timers=None, eps=None, 
     if layout != "nchw" and eps is None and fuse_act and _chwn_ok(net, x):
         out = _mc_logits_chwn(net, x, draws, seed, call0, timers, streams)
         if out is not None:
-            return out
+            return out[0].permute(0, 2, 1).contiguous(), out[1]      # API layout [E, B, C]
     layers = bayesian_layers(net)
     bbb = [l for l in layers if isinstance(l, _BBBLayer)]
     lrt = [l for l in layers if isinstance(l, _LRTLayer)]
@@ -374,6 +386,23 @@ def mc_logits(net, x, draws, seed, call0, fuse_act=True, timers=None, eps=None, 
     return h, kl
 
 
+def _local_lse(net, x, draws, seed, call0, mean_over, fuse_act=True, timers=None, streams=1):
+    """(log-sum-exp over `draws` local draws of the per-draw log_softmax [B, C], kl of one forward), staying in the
+    batch-innermost layout end to end when the fast path applies."""
+    if fuse_act and _chwn_ok(net, x):
+        out = _mc_logits_chwn(net, x, draws, seed, call0, timers, streams)
+        if out is not None:
+            lse = _run(timers, "mc_tail", 0, lambda: ops.mc_tail_cb(out[0], mean_over=mean_over))
+            return lse, out[1]
+    logits, kl1 = mc_logits(net, x, draws, seed, call0, fuse_act=fuse_act, timers=timers, layout="nchw")
+    if torch.is_grad_enabled() and logits.requires_grad:
+        # training extension (SURVEY.md section 8f N1): differentiable tail through torch ops
+        lse = torch.logsumexp(F.log_softmax(logits, dim=2), dim=0) - (math.log(mean_over) if mean_over > 0 else 0.0)
+    else:
+        lse = _run(timers, "mc_tail", 0, lambda: ops.mc_tail(logits, mean_over=mean_over))
+    return lse, kl1
+
+
 def mc_forward(net, x, num_ens, group=None, fuse_act=True, timers=None, kl_mode="sum", streams=1):
     """One Monte-Carlo step: -> (log_outputs [B, C], kl).
 
@@ -386,12 +415,8 @@ def mc_forward(net, x, num_ens, group=None, fuse_act=True, timers=None, kl_mode=
     seed, call0 = rng.next_calls(num_ens)            # all ranks advance identically
     lo, hi = draw_range(num_ens, rank, world)
     if hi > lo:
-        logits, kl1 = mc_logits(net, x, hi - lo, seed, call0 + lo, fuse_act=fuse_act, timers=timers, streams=streams)
-        if torch.is_grad_enabled() and logits.requires_grad:
-            # training extension: differentiable tail through torch ops
-            lse = torch.logsumexp(F.log_softmax(logits, dim=2), dim=0) - (0.0 if world > 1 else math.log(num_ens))
-        else:
-            lse = _run(timers, "mc_tail", 0, lambda: ops.mc_tail(logits, mean_over=0 if world > 1 else num_ens))
+        lse, kl1 = _local_lse(net, x, hi - lo, seed, call0 + lo, 0 if world > 1 else num_ens, fuse_act=fuse_act,
+                              timers=timers, streams=streams)
         kl_local = kl1 * float(hi - lo)
     else:                                            # more ranks than draws
         lse, kl_local = None, None
@@ -454,8 +479,7 @@ class GraphedMC:
         self.replays = 0
 
     def _step_body(self, streams, kl_mode):
-        logits, kl1 = mc_logits(self.net, self.x, self.num_ens, self.seed, self.call0, streams=streams)
-        lo = ops.mc_tail(logits, mean_over=self.num_ens)
+        lo, kl1 = _local_lse(self.net, self.x, self.num_ens, self.seed, self.call0, self.num_ens, streams=streams)
         kl = kl1 * float(self.num_ens) if kl_mode == "sum" else kl1
         self.counter.add_(self.num_ens)              # part of the graph: next replay = next num_ens calls
         return lo, kl

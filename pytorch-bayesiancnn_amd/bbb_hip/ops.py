@@ -188,7 +188,7 @@ def _desc_chwn(x, w, stride, padding, dilation, draws, x_shared, w_shared, act):
     return d, ho, wo
 
 
-def conv2d_chwn_forward(x, w, bias, stride=1, padding=0, dilation=1, act=None):
+def conv2d_chwn_forward(x, w, bias, stride=1, padding=0, dilation=1, act=None, out=None):
     """Batch-innermost conv for the ensemble path.  x: [E|1, Cin, H, W, B] (B % 4 == 0); w: [E|1, Cout, Cin, kh, kw];
     bias [E|1, Cout] or None -> y [E, Cout, Ho, Wo, B].  Padding taps are skipped, not multiplied."""
     require_device(x, w, bias)
@@ -198,7 +198,13 @@ def conv2d_chwn_forward(x, w, bias, stride=1, padding=0, dilation=1, act=None):
     if x.shape[0] not in (1, E) or w.shape[0] not in (1, E):
         raise _lib.BBBHipError("leading (draw) dims of x and w must be 1 or equal")
     d, ho, wo = _desc_chwn(x, w, stride, padding, dilation, E, x.shape[0] == 1 and E > 1, w.shape[0] == 1 and E > 1, act)
-    y = torch.empty((E, w.shape[1], ho, wo, x.shape[4]), dtype=torch.float32, device=x.device)
+    shape = (E, w.shape[1], ho, wo, x.shape[4])
+    if out is None:
+        y = torch.empty(shape, dtype=torch.float32, device=x.device)
+    else:
+        if out.numel() != E * w.shape[1] * ho * wo * x.shape[4] or not out.is_contiguous() or out.dtype != torch.float32:
+            raise _lib.BBBHipError("out= must be a contiguous fp32 tensor of the output's size")
+        y = out.view(shape)
     with torch.cuda.device(x.device):
         check(_lib.lib().bbb_conv2d_chwn_fwd(ctypes.byref(d), x.data_ptr(), w.data_ptr(), ptr(bias), y.data_ptr(),
                                              cur_stream(x.device)), "bbb_conv2d_chwn_fwd")
@@ -246,6 +252,29 @@ def maxpool_chwn(x, k, s):
         check(_lib.lib().bbb_maxpool_chwn(x.data_ptr(), y.data_ptr(), planes, H, W, B, int(k), int(s), cur_stream(x.device)),
               "bbb_maxpool_chwn")
     return y
+
+
+def mc_tail_cb(logits, mean_over=0):
+    """mc_tail for batch-innermost logits [E, C, B] -> [B, C]."""
+    require_device(logits)
+    logits = logits.contiguous()
+    E, C, B = logits.shape
+    out = torch.empty((B, C), dtype=torch.float32, device=logits.device)
+    with torch.cuda.device(logits.device):
+        check(_lib.lib().bbb_mc_tail_cb(logits.data_ptr(), E, B, C, int(mean_over), out.data_ptr(), cur_stream(logits.device)),
+              "bbb_mc_tail_cb")
+    return out
+
+
+def to_batch_innermost(x):
+    """[B, C, H, W] -> [C, H, W, B] (LDS-tiled transpose)."""
+    require_device(x)
+    x = x.contiguous()
+    B = x.shape[0]
+    out = torch.empty(tuple(x.shape[1:]) + (B,), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.lib().bbb_transpose2d(x.data_ptr(), out.data_ptr(), B, x.numel() // B, cur_stream(x.device)), "bbb_transpose2d")
+    return out
 
 
 def mc_tail(logits, mean_over=0):

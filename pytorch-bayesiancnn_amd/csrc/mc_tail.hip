@@ -58,7 +58,76 @@ __global__ __launch_bounds__(64) void mc_tail_kernel(const float* __restrict__ l
     }
 }
 
+// Same reduction for logits stored batch-innermost, [E][C][B] (what the batched ensemble path produces): one thread
+// per image, lanes = consecutive images so every read is coalesced; the per-draw log-partition values sit in LDS.
+constexpr int kCbThreads = 64;
+__global__ __launch_bounds__(kCbThreads) void mc_tail_cb_kernel(const float* __restrict__ logits, int E, int B, int C, float sub,
+                                                                float* __restrict__ out) {
+    extern __shared__ float lz[];                       // [E][64]
+    const int b = blockIdx.x * kCbThreads + threadIdx.x;
+    const bool ok = b < B;
+    const int bb = ok ? b : B - 1;
+    for (int e = 0; e < E; ++e) {
+        const float* p = logits + (int64_t)e * C * B + bb;
+        float mx = -INFINITY;
+        for (int c = 0; c < C; ++c) mx = fmaxf(mx, p[(int64_t)c * B]);
+        float se = 0.0f;
+        for (int c = 0; c < C; ++c) se += expf(p[(int64_t)c * B] - mx);
+        lz[e * kCbThreads + threadIdx.x] = mx + logf(se);
+    }
+    for (int c = 0; c < C; ++c) {
+        float m = -INFINITY, s = 0.0f;
+        for (int e = 0; e < E; ++e) {
+            const float ls = logits[((int64_t)e * C + c) * B + bb] - lz[e * kCbThreads + threadIdx.x];
+            const float nm = fmaxf(m, ls);
+            s = s * expf(m - nm) + expf(ls - nm);
+            m = nm;
+        }
+        if (ok) out[(int64_t)b * C + c] = m + logf(s) - sub;
+    }
+}
+
+// [R][Ccols] -> [Ccols][R] through a padded 32x32 LDS tile (NCHW batch -> batch-innermost: R = B, Ccols = C*H*W).
+__global__ __launch_bounds__(256) void transpose2d_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int Cc) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + i * 8, c = c0 + tx;
+        if (r < R && c < Cc) tile[ty + i * 8][tx] = in[(int64_t)r * Cc + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + i * 8, r = r0 + tx;
+        if (r < R && c < Cc) out[(int64_t)c * R + r] = tile[tx][ty + i * 8];
+    }
+}
+
 }  // namespace
+
+extern "C" int bbb_mc_tail_cb(const float* logits, int draws, int batch, int classes, int mean_over, float* lse_out,
+                              void* stream) {
+    if (logits == nullptr || lse_out == nullptr || draws <= 0 || batch <= 0 || classes <= 0 || mean_over < 0 || draws > 512)
+        return BBB_EINVAL;
+    if ((((uintptr_t)logits | (uintptr_t)lse_out) & 3u) != 0) return BBB_EALIGN;
+    const float sub = mean_over > 0 ? logf((float)mean_over) : 0.0f;
+    const int blocks = (batch + kCbThreads - 1) / kCbThreads;
+    hipLaunchKernelGGL(mc_tail_cb_kernel, dim3(blocks), dim3(kCbThreads), (size_t)draws * kCbThreads * sizeof(float),
+                       (hipStream_t)stream, logits, draws, batch, classes, sub, lse_out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int bbb_transpose2d(const float* in, float* out, int64_t rows, int64_t cols, void* stream) {
+    if (in == nullptr || out == nullptr || rows <= 0 || cols <= 0 || rows > 0x7fffffffLL || cols > 0x7fffffffLL) return BBB_EINVAL;
+    if ((((uintptr_t)in | (uintptr_t)out) & 3u) != 0) return BBB_EALIGN;
+    const int64_t gx = (cols + 31) / 32, gy = (rows + 31) / 32;
+    if (gy > 65535) return BBB_ESHAPE;
+    hipLaunchKernelGGL(transpose2d_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, (hipStream_t)stream, in, out, (int)rows,
+                       (int)cols);
+    return (int)hipGetLastError();
+}
 
 extern "C" int bbb_mc_tail(const float* logits, int draws, int batch, int classes, int mean_over, float* lse_out,
                            void* stream) {

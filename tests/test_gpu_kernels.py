@@ -298,3 +298,18 @@ def test_maxpool_chwn(ops, k, s, H, W):
     want = O.maxpool2d(np.ascontiguousarray(x.transpose(0, 4, 1, 2, 3)).reshape(-1, 5, H, W), k, s)
     want = want.reshape(3, 8, 5, *want.shape[2:]).transpose(0, 2, 3, 4, 1)
     np.testing.assert_array_equal(y, want)
+
+
+@pytest.mark.parametrize("E,B,C", [(1, 4, 10), (10, 512, 10), (3, 70, 100), (80, 16, 7)])
+def test_mc_tail_batch_innermost(ops, E, B, C):
+    rng = np.random.default_rng(E + B + C)
+    z = (rng.standard_normal((E, B, C)) * 4).astype(np.float32)
+    zcb = dev(np.ascontiguousarray(z.transpose(0, 2, 1)))
+    np.testing.assert_allclose(ops.mc_tail_cb(zcb, mean_over=E).cpu().numpy(), O.mc_log_outputs(z), rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(ops.mc_tail_cb(zcb).cpu().numpy(), ops.mc_tail(dev(z)).cpu().numpy(), rtol=2e-6, atol=2e-6)
+
+
+@pytest.mark.parametrize("shape", [(512, 3, 32, 32), (4, 1, 5, 7), (33, 2, 3, 3)])
+def test_to_batch_innermost(ops, shape):
+    x = torch.randn(*shape, device="cuda")
+    assert torch.equal(ops.to_batch_innermost(x), x.permute(1, 2, 3, 0).contiguous())
