@@ -148,8 +148,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layer-type", default="bbb", choices=["bbb", "lrt"])
     ap.add_argument("--no-kernel-timers", action="store_true")
-    ap.add_argument("--streams", type=int, default=2, help="independent sub-ensembles on separate HIP streams")
+    ap.add_argument("--streams", type=int, default=1, help="independent sub-ensembles on separate HIP streams")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
+    ap.add_argument("--pipeline", type=int, default=3, help="independent MC steps in flight (hipGraph lanes on separate streams)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -186,12 +187,15 @@ def main():
             torch.distributed.barrier(group=group)
         torch.cuda.synchronize(dev)
 
-    use_graph = (not args.no_graph) and world == 1
+    use_graph = not args.no_graph
     with torch.no_grad():
         if use_graph:
             # the whole step (E draws x all layers on `streams` HIP streams + tail) is one captured hipGraph; a device-side
             # call counter inside the graph gives every replay fresh Philox noise (no cached outputs)
-            gstep = ensemble.GraphedMC(net, x, total_ens, streams=args.streams)
+            if args.pipeline > 1:
+                gstep = ensemble.GraphedPipeline(net, x, total_ens, depth=args.pipeline, streams=args.streams, group=group)
+            else:
+                gstep = ensemble.GraphedMC(net, x, total_ens, streams=args.streams, group=group)
             step = gstep.step
         else:
             step = lambda: ensemble.mc_forward(net, x, total_ens, group=group, streams=args.streams)
@@ -236,7 +240,8 @@ def main():
                                    "forward only (main_bayesian.py:73-80)",
                        "global_batch": BATCH, "num_ens_total": total_ens,
                        "parallelism": f"mc-ensemble x{world}" if world > 1 else "single",
-                       "launch": ("hipGraph replay, %d streams" % args.streams) if use_graph else ("eager, %d streams" % args.streams)},
+                       "launch": ("hipGraph replay, %d step(s) in flight x %d draw streams" % (max(1, args.pipeline), args.streams))
+                       if use_graph else ("eager, %d streams" % args.streams)},
         }
         if timers is not None:
             agg = timers.summary()

@@ -453,39 +453,100 @@ def combine_ranks(lse_local, kl_local, num_ens, group, kl_mode="sum", shape=None
 class GraphedMC:
     """One Monte-Carlo step captured as a hipGraph (launch-bound inner loop -> one graph launch per step).
 
-    The step is `mc_forward(net, x, num_ens, streams=...)` for a FIXED input buffer `x` (copy new batches into
-    `self.x`) on one GPU, inference only.  Fresh noise on every replay: the kernels add a device-side counter to their
-    call index and the graph itself increments that counter by num_ens, so replay r uses calls call0 + r*num_ens ..
-    exactly what r eager steps would have used; the Python-side counter is advanced in step().
-    Results land in `self.log_outputs` [B, C] and `self.kl` (overwritten by every replay)."""
+    The step is `mc_forward(net, x, num_ens, group=..., streams=...)` for a FIXED input buffer `x` (copy new batches
+    into `self.x`), inference only.  Fresh noise on every replay: the kernels add a device-side counter to their call
+    index and the graph itself increments that counter, so replay r uses exactly the calls r eager steps would have
+    used; the Python-side counter is advanced in step().
+    `lane` / `lanes`: this graph is lane `lane` of `lanes` graphs replayed round-robin (GraphedPipeline): its counter
+    starts at lane*num_ens and advances by lanes*num_ens.
+    With a process group the graph holds this rank's draws (draw_range) and the one all_gather per step is issued
+    eagerly after the replay, on the lane's stream (collectives stay outside the graph).
+    step() returns (log_outputs [B, C], kl); with world == 1 these are buffers overwritten by the next replay."""
 
-    def __init__(self, net, x, num_ens, streams=1, kl_mode="sum"):
+    def __init__(self, net, x, num_ens, streams=1, kl_mode="sum", lane=0, lanes=1, stream=None, seed_call=None, group=None):
         _lib.require_device(x)
-        self.net, self.x, self.num_ens = net, x, int(num_ens)
+        self.net, self.x, self.num_ens, self.group, self.kl_mode = net, x, int(num_ens), group, kl_mode
+        self.world = 1 if group is None else torch.distributed.get_world_size(group)
+        rank = 0 if group is None else torch.distributed.get_rank(group)
+        self.lo, self.hi = draw_range(self.num_ens, rank, self.world)
         dev = x.device
-        self.counter = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.seed, self.call0 = rng.next_calls(0)
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.no_grad(), torch.cuda.stream(side), rng.device_call_offset(self.counter):
-            for _ in range(2):                       # warm-up on the capture stream (allocator, lazy module state)
-                self._step_body(streams, kl_mode)
-            self.counter.zero_()
-        torch.cuda.current_stream(dev).wait_stream(side)
-        torch.cuda.synchronize(dev)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), rng.device_call_offset(self.counter), torch.cuda.graph(self.graph):
-            self.log_outputs, self.kl = self._step_body(streams, kl_mode)
+        self.stride = int(lanes) * self.num_ens
+        self.start = int(lane) * self.num_ens
+        self.counter = torch.full((1,), self.start, dtype=torch.int32, device=dev)
+        self.seed, self.call0 = seed_call if seed_call is not None else rng.next_calls(0)
+        self.own_stream = stream is not None
+        self.stream = stream if stream is not None else torch.cuda.Stream(device=dev)
+        self.lse = self.kl_local = None
+        if self.hi > self.lo:
+            self.stream.wait_stream(torch.cuda.current_stream(dev))
+            with torch.no_grad(), torch.cuda.stream(self.stream), rng.device_call_offset(self.counter):
+                for _ in range(2):                   # warm-up on the capture stream (allocator, lazy module state)
+                    self._step_body(streams)
+                self.counter.fill_(self.start)
+            torch.cuda.current_stream(dev).wait_stream(self.stream)
+            torch.cuda.synchronize(dev)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.no_grad(), rng.device_call_offset(self.counter), torch.cuda.graph(self.graph, stream=self.stream):
+                self.lse, self.kl_local = self._step_body(streams)
+        else:
+            self.graph = None                        # more ranks than draws: this rank only joins the collective
+        self.shape = (x.shape[0], getattr(net, "num_classes", None))
         self.replays = 0
 
-    def _step_body(self, streams, kl_mode):
-        lo, kl1 = _local_lse(self.net, self.x, self.num_ens, self.seed, self.call0, self.num_ens, streams=streams)
-        kl = kl1 * float(self.num_ens) if kl_mode == "sum" else kl1
-        self.counter.add_(self.num_ens)              # part of the graph: next replay = next num_ens calls
-        return lo, kl
+    def _step_body(self, streams):
+        n_loc = self.hi - self.lo
+        lse, kl1 = _local_lse(self.net, self.x, n_loc, self.seed, self.call0 + self.lo,
+                              self.num_ens if self.world == 1 else 0, streams=streams)
+        if self.world == 1:
+            kl = kl1 * float(self.num_ens) if self.kl_mode == "sum" else kl1 * 1.0
+        else:
+            kl = kl1 * float(n_loc)
+        self.counter.add_(self.stride)               # part of the graph: next replay of this lane
+        return lse, kl
 
     def step(self):
-        self.graph.replay()
-        self.replays += 1
-        rng.next_calls(self.num_ens)                 # keep the host-side counter in step with the device's
-        return self.log_outputs, self.kl
+        ctx = torch.cuda.stream(self.stream) if self.own_stream else _null_ctx()
+        with ctx:
+            if self.graph is not None:
+                self.graph.replay()
+            self.replays += 1
+            rng.next_calls(self.num_ens)             # keep the host-side counter in step with the device's
+            if self.world == 1:
+                return self.lse, self.kl_local
+            with torch.no_grad():
+                return combine_ranks(self.lse, self.kl_local, self.num_ens, self.group, self.kl_mode, shape=self.shape)
+
+
+class _null_ctx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+class GraphedPipeline:
+    """`depth` independent Monte-Carlo steps in flight: GraphedMC lanes on their own HIP streams, replayed round-robin.
+    Consecutive steps of an inference / validation loop do not depend on each other, so step i+1's kernels may run
+    while step i's are still draining: each layer launch of an E=10 step is a single wave of workgroups, and the other
+    step's kernels fill its ramp, its tail and the CUs its imbalance leaves idle.  Every step still does all of its
+    work with its own noise (lane l, replay r = noise calls of step r*depth + l).
+    step() returns the (log_outputs, kl) buffers of the lane just enqueued; call sync() (or synchronize the device)
+    before reading them."""
+
+    def __init__(self, net, x, num_ens, depth=2, streams=1, kl_mode="sum", group=None):
+        seed_call = rng.next_calls(0)
+        self.lanes = [GraphedMC(net, x, num_ens, streams=streams, kl_mode=kl_mode, lane=l, lanes=depth,
+                                stream=torch.cuda.Stream(device=x.device), seed_call=seed_call, group=group)
+                      for l in range(depth)]
+        self.i = 0
+        self.dev = x.device
+
+    def step(self):
+        lane = self.lanes[self.i % len(self.lanes)]
+        self.i += 1
+        return lane.step()
+
+    def sync(self):
+        for lane in self.lanes:
+            lane.stream.synchronize()

@@ -15,7 +15,7 @@ struct PConvArgs {
     int64_t x_ds, w_ds, b_ds, y_ds;
     int32_t B, Cin, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, Ho, Wo;
     int32_t K, khkw, act, sample;
-    int32_t Mtiles, nbt, Ntiles, G, per_xcd;
+    int32_t Mtiles, nbt, Ntiles, G, per_xcd, stagger;
 #ifdef BBB_TIMESTAMPS
     long long* ts;
 #endif

@@ -48,7 +48,7 @@ typedef PConvArgs DmaArgs;
 template <int BM, bool LRT>
 constexpr int stage_floats() { return BK * BM + (LRT ? 2 : 1) * BN * BK; }
 template <int BM, bool LRT>
-constexpr int smem_bytes() { return (NSTAGE * stage_floats<BM, LRT>() + 4 * KCH) * 4; }
+constexpr int smem_bytes() { return (NSTAGE * stage_floats<BM, LRT>() + 4 * KCH) * 4 + 1024; }
 
 template <int BM, bool LRT>
 __global__ __launch_bounds__(kThreads) void pconv_dma_kernel(const DmaArgs p) {
@@ -167,6 +167,15 @@ __global__ __launch_bounds__(kThreads) void pconv_dma_kernel(const DmaArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc[t][r] = 0.0f; accv[t][r] = 0.0f; }
 
+#ifdef BBB_TIMESTAMPS
+    long long* tsb = reinterpret_cast<long long*>(kt_x + 2 * KCH);
+    const bool tson = p.ts && (bid == 8 * 40 || bid == 8 * 100) && tid == 0;
+    int tsi = 0;
+#define TS() do { if (tson && tsi < 112) tsb[tsi++] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define TS() do { } while (0)
+#endif
+    TS();
     auto mma_tile = [&](int tile) {
         const float* const xs = smem + (tile % NSTAGE) * SF;
         const float* const ws = xs + BK * BM;
@@ -193,18 +202,26 @@ __global__ __launch_bounds__(kThreads) void pconv_dma_kernel(const DmaArgs p) {
         __builtin_amdgcn_s_barrier();
         issue(0);
         if (ntiles > 1) issue(1);
+        TS();
         for (int t = 0; t < ntiles; ++t) {
             // tile t has landed once at most one tile's worth of DMA (tile t+1) is still outstanding
             if (t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS) : "memory");
             else                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // table writes / fragment reads of this wave retired
             __builtin_amdgcn_s_barrier();
+            TS();
             if (t + 2 < ntiles) issue(t + 2);
+            TS();
             // decode chunk c+1 early in chunk c (chunk 1 was decoded in the prologue); visible after the next barriers
             if ((t % TPC) == 1 && t / TPC >= 1 && (t / TPC + 1) * KCH < Keff) fill_chunk(t / TPC + 1);
             mma_tile(t);
+            TS();
         }
     }
+    TS();
+#ifdef BBB_TIMESTAMPS
+    if (tson) { long long* o = p.ts + (bid == 8 * 40 ? 0 : 128); for (int i = 0; i < tsi; ++i) o[i] = tsb[i]; }
+#endif
 
     // ---- epilogue (same as the register-staged kernel) ----
     constexpr uint32_t kOOB = 0xFFFFFFF0u;

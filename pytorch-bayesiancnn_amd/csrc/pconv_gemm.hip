@@ -216,6 +216,10 @@ __global__ __launch_bounds__(kThreads) void pconv_gemm_kernel(const PConvArgs p)
         }
     };
 
+    {   // de-phase the co-resident workgroups of a CU (experiment: BBB_STAGGER = units of 64 cycles per slot)
+        const int slot = (bid >> 8) & 3;
+        for (int i = 0; i < slot * p.stagger; ++i) __builtin_amdgcn_s_sleep(1);
+    }
     if (ntiles > 0) {
         fill_chunk(0);
         __syncthreads();
@@ -366,6 +370,7 @@ int launch(PConvArgs& a, int draws, hipStream_t st) {
     const int64_t nb128 = pixels * ((a.B + 127) / 128) * a.G;
     int bm = (LRT || nb128 < 768) ? 64 : 128;
     if (const char* f = getenv("BBB_FORCE_BM")) { if (!LRT) bm = atoi(f); }
+    { const char* sv = getenv("BBB_STAGGER"); a.stagger = sv ? atoi(sv) : 0; }
 #ifdef BBB_TIMESTAMPS
     { const char* tv = getenv("BBB_TS"); a.ts = tv ? (long long*)strtoull(tv, nullptr, 0) : nullptr; }
 #endif

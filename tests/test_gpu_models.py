@@ -294,3 +294,26 @@ def test_lrt_graphed_step(env):
         env["rng"].manual_seed(5, call=3)
         lo, _ = env["ens"].mc_forward(net, x, 3)
     assert torch.equal(lo, b)
+
+
+def test_graphed_pipeline_steps_match_eager_sequence(env):
+    """Three steps in flight on three streams: step i of the round-robin pipeline == the i-th eager mc_forward."""
+    torch.manual_seed(4)
+    net = env["zoo"].BBBAlexNet(10, 3, P.CONFIG_PRIORS, "bbb", "softplus").cuda()
+    env["rng"].assign_stream_ids(net)
+    x = torch.rand(64, 3, 32, 32, device="cuda")
+    E, depth, nsteps = 4, 3, 7
+    env["rng"].manual_seed(31, call=8)
+    pipe = env["ens"].GraphedPipeline(net, x, E, depth=depth)
+    got = []
+    for i in range(nsteps):
+        lo, kl = pipe.step()
+        pipe.lanes[i % depth].stream.synchronize()
+        got.append((lo.clone(), kl.clone()))
+    pipe.sync()
+    assert env["rng"].get_state() == (31, 8 + nsteps * E)
+    with torch.no_grad():
+        env["rng"].manual_seed(31, call=8)
+        for i in range(nsteps):
+            lo, kl = env["ens"].mc_forward(net, x, E)
+            assert torch.equal(lo, got[i][0]) and kl.item() == got[i][1].item(), i
