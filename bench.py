@@ -9,6 +9,9 @@ layers' own reset_parameters with config_bayesian.priors, x ~ U[0,1).
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
+Launch structure: each step is one captured hipGraph (a device-side call counter inside it advances the Philox
+noise on every replay) and `--pipeline` (default 3) independent steps are in flight on separate HIP streams.
+
 N > 1 (weak scaling): every rank runs num_ens=10 draws of the same 512-image batch -- a 10*N-draw ensemble
 sharded over the GPUs (draw j is noise call call0 + j on whichever rank owns it) -- and the ranks combine
 their log-sum-exp blocks and KL sums with ONE all_gather over RCCL per step.  value = B * 10 * N / step time.
@@ -129,7 +132,10 @@ def reparam_probe(net, dev, n_params):
         del mu, rho, dst
     gbs = byts / t_model / 1e9
     return {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
-            "traffic": None, "kernel": "reparam_kl_fwd_kernel + kl_finish_kernel, 12 tensors x 10 draws in one launch",
+            "traffic": 104.2e6 if abs(byts - 104445408) < 1 else None,
+            "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 wide-load correction) + WRITE_SIZE, separate passes: "
+                              "profiles/r01_pmc_hbm_traffic.txt (17.1 MB + 87.1 MB per launch)",
+            "kernel": "reparam_kl_fwd_kernel + kl_finish_kernel, 12 tensors x 10 draws in one launch",
             "bytes_per_launch": byts, "avg_us": round(t_model * 1e6, 2),
             "note": "(8 + 4E) B per weight element; the 17 MB of (mu,rho) and 87 MB of w are Infinity-Cache resident here",
             "hbm_resident_probe": {

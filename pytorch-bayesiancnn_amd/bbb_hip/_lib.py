@@ -11,7 +11,7 @@ import os
 import torch  # noqa: F401  (must precede CDLL: shares torch's HIP runtime)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbbb_hip.so")
+LIB_PATH = os.environ.get("BBB_HIP_LIB") or os.path.join(_HERE, "libbbb_hip.so")   # env override: experiments only
 
 MAX_SEGMENTS = 16
 SIGMA_SQUARED = 1

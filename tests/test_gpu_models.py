@@ -317,3 +317,43 @@ def test_graphed_pipeline_steps_match_eager_sequence(env):
         for i in range(nsteps):
             lo, kl = env["ens"].mc_forward(net, x, E)
             assert torch.equal(lo, got[i][0]) and kl.item() == got[i][1].item(), i
+
+
+def test_graphed_step_multirank_logic_simulated(env, monkeypatch):
+    """World-size-2 graphed steps simulated on one GPU: each "rank" captures its own draw block; their (lse, kl)
+    blocks combined as combine_ranks does must equal the single-device step at the same noise calls, replay after replay."""
+    import torch.distributed as dist
+    ens = env["ens"]
+    torch.manual_seed(6)
+    net = env["zoo"].BBBLeNet(10, 1, P.CONFIG_PRIORS, "bbb", "softplus").cuda()
+    env["rng"].assign_stream_ids(net)
+    x = torch.rand(32, 1, 32, 32, device="cuda")
+    E, world = 5, 2
+    captured = {}
+
+    def fake_combine(lse, kl_local, num_ens, group, kl_mode="sum", shape=None):
+        captured[group] = (lse.clone(), kl_local.clone())
+        return lse, kl_local
+
+    monkeypatch.setattr(ens, "combine_ranks", fake_combine)
+    monkeypatch.setattr(dist, "get_world_size", lambda group=None: world)
+    steps = {}
+    for rank in range(world):
+        monkeypatch.setattr(dist, "get_rank", lambda group=None, r=rank: r)
+        env["rng"].manual_seed(11, call=20)
+        g = ens.GraphedMC(net, x, E, group=f"rank{rank}")
+        assert (g.lo, g.hi) == ens.draw_range(E, rank, world)
+        outs = []
+        for r in range(3):
+            g.step()
+            torch.cuda.synchronize()
+            outs.append(captured[f"rank{rank}"])
+        steps[rank] = outs
+    monkeypatch.undo()
+    with torch.no_grad():
+        for r in range(3):
+            env["rng"].manual_seed(11, call=20 + r * E)
+            want, kl = ens.mc_forward(net, x, E)
+            got = torch.logsumexp(torch.stack([steps[0][r][0], steps[1][r][0]]), 0) - float(np.log(E))
+            np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=3e-6, atol=3e-6)
+            assert abs((steps[0][r][1] + steps[1][r][1]).item() - kl.item()) <= 2e-6 * kl.item()
