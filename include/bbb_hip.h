@@ -166,6 +166,14 @@ int bbb_mc_tail(const float* logits, int draws, int batch, int classes, int mean
 int bbb_mc_tail_cb(const float* logits, int draws, int batch, int classes, int mean_over,
                    float* lse_out, void* stream);
 
+/*
+ * Uncertainty decomposition over `draws` stochastic forwards (uncertainty_estimation.py:37-58 per image, :61-102 per
+ * batch): logits [draws][B][C] -> pred = mean logits, epistemic = mean (p_hat - p_bar)^2, aleatoric = p_bar - mean p_hat^2,
+ * each [B][C]; p_hat = softmax(logits), or softplus(logits)/sum when `normalized`.
+ */
+int bbb_uncertainty(const float* logits, int draws, int batch, int classes, int normalized,
+                    float* pred, float* epistemic, float* aleatoric, void* stream);
+
 /* [rows][cols] -> [cols][rows] (e.g. an NCHW batch [B][C*H*W] into the batch-innermost [C*H*W][B] layout). */
 int bbb_transpose2d(const float* in, float* out, int64_t rows, int64_t cols, void* stream);
 

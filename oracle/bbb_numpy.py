@@ -303,6 +303,26 @@ def get_beta(batch_idx, m, beta_type, epoch=None, num_epochs=None):
     return 0
 
 
+def uncertainty(logits_tbc, normalized=False):
+    """Aleatoric / epistemic decomposition from T stochastic forwards, uncertainty_estimation.py:37-58 (per image: T
+    rows of one batch) and :61-102 (per batch: T forwards).  logits [T, B, C] -> (pred, epistemic, aleatoric), each [B, C]:
+      p_hat = softmax(logits)                       (normalized: softplus(logits) / sum softplus(logits))
+      pred = mean_T logits;  p_bar = mean_T p_hat
+      epistemic = diag((p_hat - p_bar)^T (p_hat - p_bar)) / T;   aleatoric = diag(diag(p_bar) - p_hat^T p_hat / T)"""
+    z = np.asarray(logits_tbc, np.float64)
+    if normalized:
+        sp = np.where(z > 20, z, np.log1p(np.exp(np.minimum(z, 20))))
+        p = sp / sp.sum(axis=2, keepdims=True)
+    else:
+        m = z.max(axis=2, keepdims=True)
+        e = np.exp(z - m)
+        p = e / e.sum(axis=2, keepdims=True)
+    pbar = p.mean(axis=0)
+    epi = ((p - pbar[None]) ** 2).mean(axis=0)
+    ale = pbar - (p ** 2).mean(axis=0)
+    return z.mean(axis=0).astype(F32), epi.astype(F32), ale.astype(F32)
+
+
 # ----------------------------------------------------------------------------------------------
 # Model topologies as data (facts read from models/BayesianModels/*.py; attribute order there is
 # the graph because ModuleWrapper.forward walks children(), layers/misc.py:16-18).

@@ -49,6 +49,7 @@ _SIGNATURES = {
     "bbb_maxpool_chwn": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "bbb_mc_tail": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "bbb_mc_tail_cb": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "bbb_uncertainty": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "bbb_transpose2d": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_void_p]),
     "bbb_abi_version": (c_int, []),
     "bbb_build_info": (ctypes.c_char_p, []),

@@ -266,6 +266,18 @@ def mc_tail_cb(logits, mean_over=0):
     return out
 
 
+def uncertainty(logits, normalized=False):
+    """logits [T, B, C] -> (pred, epistemic, aleatoric), each [B, C] (see bbb_uncertainty)."""
+    require_device(logits)
+    logits = logits.contiguous()
+    T, B, C = logits.shape
+    outs = [torch.empty((B, C), dtype=torch.float32, device=logits.device) for _ in range(3)]
+    with torch.cuda.device(logits.device):
+        check(_lib.lib().bbb_uncertainty(logits.data_ptr(), T, B, C, 1 if normalized else 0, outs[0].data_ptr(),
+                                         outs[1].data_ptr(), outs[2].data_ptr(), cur_stream(logits.device)), "bbb_uncertainty")
+    return tuple(outs)
+
+
 def to_batch_innermost(x):
     """[B, C, H, W] -> [C, H, W, B] (LDS-tiled transpose)."""
     require_device(x)

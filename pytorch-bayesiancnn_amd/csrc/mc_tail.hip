@@ -87,6 +87,66 @@ __global__ __launch_bounds__(kCbThreads) void mc_tail_cb_kernel(const float* __r
     }
 }
 
+// Aleatoric / epistemic decomposition over T stochastic forwards (uncertainty_estimation.py:37-58, 61-102 upstream):
+// one wave per image, lanes over classes.  Pass 1: per draw p_hat = softmax(logits) (or softplus-normalised),
+// accumulate sum logits, sum p, sum p^2.  Pass 2 recomputes p_hat to sum (p - p_bar)^2 without cancellation.
+__global__ __launch_bounds__(64) void uncertainty_kernel(const float* __restrict__ logits, int T, int B, int C, int normalized,
+                                                         float* __restrict__ pred, float* __restrict__ epi,
+                                                         float* __restrict__ ale) {
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
+    float s_l[kMaxPerLane], s_p[kMaxPerLane], s_p2[kMaxPerLane], s_d2[kMaxPerLane];
+#pragma unroll
+    for (int i = 0; i < kMaxPerLane; ++i) { s_l[i] = 0.f; s_p[i] = 0.f; s_p2[i] = 0.f; s_d2[i] = 0.f; }
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int t = 0; t < T; ++t) {
+            const float* row = logits + ((int64_t)t * B + b) * C;
+            float v[kMaxPerLane], q[kMaxPerLane];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < kMaxPerLane; ++i) {
+                const int c = lane + i * 64;
+                v[i] = c < C ? row[c] : -INFINITY;
+                mx = fmaxf(mx, v[i]);
+            }
+            mx = bbb::wave_max(mx);
+            float z = 0.0f;
+#pragma unroll
+            for (int i = 0; i < kMaxPerLane; ++i) {
+                const int c = lane + i * 64;
+                q[i] = 0.0f;
+                if (c < C) q[i] = normalized ? (v[i] > 20.0f ? v[i] : log1pf(expf(v[i]))) : expf(v[i] - mx);
+                z += q[i];
+            }
+            z = bbb::wave_sum_all(z);
+            const float iz = 1.0f / z;
+#pragma unroll
+            for (int i = 0; i < kMaxPerLane; ++i) {
+                const int c = lane + i * 64;
+                if (c < C) {
+                    const float ph = q[i] * iz;
+                    if (pass == 0) { s_l[i] += v[i]; s_p[i] += ph; s_p2[i] += ph * ph; }
+                    else { const float d = ph - s_p[i]; s_d2[i] += d * d; }       // s_p holds p_bar in pass 1
+                }
+            }
+        }
+        if (pass == 0) {
+#pragma unroll
+            for (int i = 0; i < kMaxPerLane; ++i) s_p[i] /= (float)T;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < kMaxPerLane; ++i) {
+        const int c = lane + i * 64;
+        if (c < C) {
+            const int64_t o = (int64_t)b * C + c;
+            pred[o] = s_l[i] / (float)T;
+            epi[o] = s_d2[i] / (float)T;
+            ale[o] = s_p[i] - s_p2[i] / (float)T;
+        }
+    }
+}
+
 // [R][Ccols] -> [Ccols][R] through a padded 32x32 LDS tile (NCHW batch -> batch-innermost: R = B, Ccols = C*H*W).
 __global__ __launch_bounds__(256) void transpose2d_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int Cc) {
     __shared__ float tile[32][33];
@@ -116,6 +176,17 @@ extern "C" int bbb_mc_tail_cb(const float* logits, int draws, int batch, int cla
     const int blocks = (batch + kCbThreads - 1) / kCbThreads;
     hipLaunchKernelGGL(mc_tail_cb_kernel, dim3(blocks), dim3(kCbThreads), (size_t)draws * kCbThreads * sizeof(float),
                        (hipStream_t)stream, logits, draws, batch, classes, sub, lse_out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int bbb_uncertainty(const float* logits, int draws, int batch, int classes, int normalized, float* pred,
+                               float* epistemic, float* aleatoric, void* stream) {
+    if (logits == nullptr || pred == nullptr || epistemic == nullptr || aleatoric == nullptr || draws <= 0 || batch <= 0 ||
+        classes <= 0 || classes > 64 * kMaxPerLane)
+        return BBB_EINVAL;
+    if ((((uintptr_t)logits | (uintptr_t)pred | (uintptr_t)epistemic | (uintptr_t)aleatoric) & 3u) != 0) return BBB_EALIGN;
+    hipLaunchKernelGGL(uncertainty_kernel, dim3(batch), dim3(64), 0, (hipStream_t)stream, logits, draws, batch, classes,
+                       normalized ? 1 : 0, pred, epistemic, aleatoric);
     return (int)hipGetLastError();
 }
 

@@ -28,4 +28,4 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden():
     import numpy as np
-    return {n: np.load(os.path.join(GOLDEN, n + ".npz")) for n in ("layers_small", "functions", "models")}
+    return {n: np.load(os.path.join(GOLDEN, n + ".npz")) for n in ("layers_small", "functions", "models", "uncertainty")}

@@ -213,9 +213,37 @@ def make_models():
     np.savez_compressed(os.path.join(HERE, "models.npz"), **out)
 
 
+def make_uncertainty():
+    """uncertainty_estimation.get_uncertainty_per_image on CPU (its module imports data/torchvision/seaborn at the top,
+    so the function is executed from its source text with those imports stubbed; the function body is untouched)."""
+    import types
+    src = open(os.path.join(REF, "uncertainty_estimation.py")).read()
+    start = src.index("def get_uncertainty_per_image")
+    end = src.index("def get_uncertainty_per_batch")
+    ns = {"torch": torch, "np": np, "F": F}
+    exec(compile(src[start:end], "uncertainty_estimation.py", "exec"), ns)
+    fn = ns["get_uncertainty_per_image"]
+    out = {}
+    for tag, lt, seed in (("lrt", "lrt", 31), ("bbb", "bbb", 32)):
+        torch.manual_seed(seed)
+        net = BBBLeNet(10, 1, ref_cfg.priors, lt, "softplus")
+        img = torch.rand(1, 32, 32)
+        T = 15
+        for norm in (False, True):
+            torch.manual_seed(seed + 1)
+            logits, _ = net(img.unsqueeze(0).repeat(T, 1, 1, 1))
+            torch.manual_seed(seed + 1)
+            pred, epi, ale = fn(net, img, T=T, normalized=norm)
+            k = f"unc_{tag}_{int(norm)}"
+            out[k + ".logits"] = npy(logits)
+            out[k + ".pred"], out[k + ".epistemic"], out[k + ".aleatoric"] = pred, epi, ale
+    np.savez_compressed(os.path.join(HERE, "uncertainty.npz"), **out)
+
+
 if __name__ == "__main__":
+    make_uncertainty()
     make_layers()
     make_functions()
     make_models()
-    for f in ("layers_small.npz", "functions.npz", "models.npz"):
+    for f in ("layers_small.npz", "functions.npz", "models.npz", "uncertainty.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

@@ -357,3 +357,42 @@ def test_graphed_step_multirank_logic_simulated(env, monkeypatch):
             got = torch.logsumexp(torch.stack([steps[0][r][0], steps[1][r][0]]), 0) - float(np.log(E))
             np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=3e-6, atol=3e-6)
             assert abs((steps[0][r][1] + steps[1][r][1]).item() - kl.item()) <= 2e-6 * kl.item()
+
+
+# ---------------------------------------------------------------- uncertainty estimation (N2)
+def test_uncertainty_kernel_vs_reference_fixture(env, golden):
+    U = golden["uncertainty"]
+    for tag in ("lrt", "bbb"):
+        for norm in (0, 1):
+            k = f"unc_{tag}_{norm}"
+            logits = torch.from_numpy(U[k + ".logits"]).cuda().unsqueeze(1)          # [T, 1, C]
+            pred, epi, ale = env["ops"].uncertainty(logits, normalized=bool(norm))
+            np.testing.assert_allclose(pred[0].cpu().numpy(), U[k + ".pred"], rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(epi[0].cpu().numpy(), U[k + ".epistemic"], rtol=1e-3, atol=1e-9)
+            np.testing.assert_allclose(ale[0].cpu().numpy(), U[k + ".aleatoric"], rtol=1e-4, atol=1e-8)
+
+
+def test_uncertainty_per_batch_and_per_image(env):
+    from bbb_hip import uncertainty as unc
+    torch.manual_seed(8)
+    net = env["zoo"].BBBLeNet(10, 1, P.DEFAULT_PRIORS, "bbb", "softplus").cuda()
+    env["rng"].assign_stream_ids(net)
+    batch = torch.rand(12, 1, 32, 32)
+    T = 9
+    env["rng"].manual_seed(3, call=0)
+    pred, epi, ale = unc.get_uncertainty_per_batch(net, batch, T=T, normalized=False)
+    with torch.no_grad():
+        logits, _ = env["ens"].mc_logits(net, batch.cuda(), T, 3, 0)
+    wp, we, wa = O.uncertainty(logits.cpu().numpy(), False)
+    np.testing.assert_allclose(pred, wp, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(epi, we, rtol=1e-3, atol=1e-9)
+    np.testing.assert_allclose(ale, wa, rtol=1e-4, atol=1e-8)
+    assert pred.shape == (12, 10) and (epi >= 0).all() and (ale >= -1e-7).all() and epi.max() > 1e-8
+    # per image: T copies in ONE batch -> one weight draw for BBB layers -> no epistemic spread; LRT decorrelates rows
+    p1, e1, a1 = unc.get_uncertainty_per_image(net, batch[0].cuda(), T=T)
+    assert p1.shape == (10,) and e1.max() < 1e-10
+    lrt = env["zoo"].BBBLeNet(10, 1, P.DEFAULT_PRIORS, "lrt", "softplus").cuda()
+    p2, e2, a2 = unc.get_uncertainty_per_image(lrt, batch[0].cuda(), T=T, normalized=True)
+    assert e2.max() > 1e-9 and np.isfinite(a2).all() and (a2 > -1e-7).all()
+    # softmax identity: epistemic + aleatoric = p_bar - p_bar^2 per class, so the class sums stay below 1
+    assert 0 < (e1 + a1).sum() < 1 and 0 < (e2 + a2).sum() < 1

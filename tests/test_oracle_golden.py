@@ -182,3 +182,18 @@ print("OK")
 ''' % os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:]
+
+
+def test_numpy_uncertainty_vs_reference(golden):
+    """oracle.uncertainty == uncertainty_estimation.get_uncertainty_per_image of the reference (softmax and normalized)."""
+    U = golden["uncertainty"]
+    for tag in ("lrt", "bbb"):
+        for norm in (0, 1):
+            k = f"unc_{tag}_{norm}"
+            logits = U[k + ".logits"]                       # [T, C]: T rows of one batch = T "draws" of one image
+            pred, epi, ale = O.uncertainty(logits[:, None, :], normalized=bool(norm))
+            np.testing.assert_allclose(pred[0], U[k + ".pred"], rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(epi[0], U[k + ".epistemic"], rtol=2e-4, atol=1e-9)
+            np.testing.assert_allclose(ale[0], U[k + ".aleatoric"], rtol=2e-5, atol=1e-8)
+    # with BBB layers all T rows share one weight draw: epistemic is (numerically) zero -- SURVEY.md section 8f N2
+    assert U["unc_bbb_0.epistemic"].max() < 1e-10 and U["unc_lrt_0.epistemic"].max() > 1e-8
