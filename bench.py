@@ -195,16 +195,22 @@ def main():
 
     use_graph = not args.no_graph
     with torch.no_grad():
+        launch_note = None
         if use_graph:
-            # the whole step (E draws x all layers on `streams` HIP streams + tail) is one captured hipGraph; a device-side
-            # call counter inside the graph gives every replay fresh Philox noise (no cached outputs)
-            if args.pipeline > 1:
-                gstep = ensemble.GraphedPipeline(net, x, total_ens, depth=args.pipeline, streams=args.streams, group=group)
-            else:
-                gstep = ensemble.GraphedMC(net, x, total_ens, streams=args.streams, group=group)
-            step = gstep.step
-        else:
-            step = lambda: ensemble.mc_forward(net, x, total_ens, group=group, streams=args.streams)
+            # the whole step (E draws x all layers + tail) is one captured hipGraph; a device-side call counter inside the
+            # graph gives every replay fresh Philox noise (no cached outputs)
+            try:
+                if args.pipeline > 1:
+                    gstep = ensemble.GraphedPipeline(net, x, total_ens, depth=args.pipeline, streams=args.streams, group=group)
+                else:
+                    gstep = ensemble.GraphedMC(net, x, total_ens, streams=args.streams, group=group)
+                step = gstep.step
+            except Exception as exc:      # launch-mode fallback only (same kernels, launched eagerly); reported in the JSON
+                use_graph = False
+                launch_note = "hipGraph capture failed (%s: %s); eager launches" % (type(exc).__name__, str(exc)[:120])
+                torch.cuda.synchronize(dev)
+        if not use_graph:
+            step = lambda: ensemble.mc_forward(net, x, total_ens, group=group, streams=max(2, args.streams))
         for _ in range(args.warmup):
             step()
         barrier()
@@ -247,7 +253,7 @@ def main():
                        "global_batch": BATCH, "num_ens_total": total_ens,
                        "parallelism": f"mc-ensemble x{world}" if world > 1 else "single",
                        "launch": ("hipGraph replay, %d step(s) in flight x %d draw streams" % (max(1, args.pipeline), args.streams))
-                       if use_graph else ("eager, %d streams" % args.streams)},
+                       if use_graph else (launch_note or ("eager, %d streams" % max(2, args.streams)))},
         }
         if timers is not None:
             agg = timers.summary()

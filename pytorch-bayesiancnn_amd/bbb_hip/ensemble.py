@@ -486,7 +486,7 @@ class GraphedMC:
             torch.cuda.current_stream(dev).wait_stream(self.stream)
             torch.cuda.synchronize(dev)
             self.graph = torch.cuda.CUDAGraph()
-            with torch.no_grad(), rng.device_call_offset(self.counter), torch.cuda.graph(self.graph, stream=self.stream):
+            with torch.no_grad(), rng.device_call_offset(self.counter), torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="thread_local"):
                 self.lse, self.kl_local = self._step_body(streams)
         else:
             self.graph = None                        # more ranks than draws: this rank only joins the collective
