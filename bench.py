@@ -220,6 +220,20 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         lo, kl = lo.clone(), kl.clone()
+        # transparency: the same step with ONE step in flight (single graph lane), same process, same data
+        serial = None
+        if use_graph and args.pipeline > 1 and world == 1:
+            g1 = ensemble.GraphedMC(net, x, total_ens, streams=args.streams)
+            for _ in range(5):
+                g1.step()
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                g1.step()
+            torch.cuda.synchronize(dev)
+            dt = (time.perf_counter() - t1) / args.steps
+            serial = {"value": round(BATCH * total_ens / dt, 1), "ms_per_step": round(1e3 * dt, 4),
+                      "note": "one hipGraph lane: step i+1 starts only after step i has drained (step latency)"}
         # per-kernel HIP-event brackets: the same step launched eagerly on one stream (events cannot sit inside a graph)
         timers = None
         if not args.no_kernel_timers:
@@ -270,6 +284,8 @@ def main():
                                    "share_of_eager_step": None}
             if args.layer_type == "bbb":
                 out["roofline_reparam"] = reparam_probe(net, dev, n_params)
+        if serial is not None:
+            out["one_step_in_flight"] = serial
         if cpu is not None:
             out["cpu_baseline"] = cpu
             out["speedup_vs_cpu"] = round(out["value"] / cpu["value"], 1)

@@ -304,3 +304,34 @@ def test_ensemble_combine_over_gloo(tmp_path, world, E):
     for r, p in enumerate(procs):
         out, err = p.communicate(timeout=120)
         assert p.returncode == 0 and f"RANK_OK {r}" in out, err[-3000:]
+
+
+@pytest.mark.reference
+def test_reference_driver_imports_unchanged_through_the_launcher():
+    """N4: run_reference.prepare() makes the UNMODIFIED main_bayesian importable on today's torch / numpy without
+    torchvision, with `layers` resolving to this package; getModel builds our layers; the synthetic `data` module has the
+    reference's interface.  (run() itself needs an MI355X and the checkout on the same host.)"""
+    code = r'''
+import sys
+sys.path.insert(0, "%s")
+import run_reference as rr
+mb = rr.prepare("/root/reference", synthetic=64)
+import numpy as np, torch, layers
+assert layers.__file__.startswith("%s")
+assert np.Inf == np.inf
+net = mb.getModel("alexnet", 3, 10, mb.cfg.priors, "bbb", "softplus")
+assert type(net.conv1).__module__ == "layers.bbb" and type(net).__module__.startswith("models.BayesianModels")
+opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+torch.optim.lr_scheduler.ReduceLROnPlateau(opt, patience=6, verbose=True)          # main_bayesian.py:118 as written
+import data
+tr, te, cin, ncls = data.getDataset("CIFAR10")
+a, b, c = data.getDataloader(tr, te, 0.2, 16, 4)
+xb, yb = next(iter(a))
+assert (cin, ncls) == (3, 10) and xb.shape == (16, 3, 32, 32) and len(b.dataset) == 12
+assert callable(mb.train_model) and callable(mb.validate_model) and callable(mb.run)
+ck = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+assert list(ck)[:4] == ["conv1.W_mu", "conv1.W_rho", "conv1.bias_mu", "conv1.bias_rho"]
+print("OK")
+''' % (PKG, PKG)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-3000:]
