@@ -41,7 +41,7 @@ constexpr int TPC = KCH / BK;            // tiles per chunk
 
 
 
-template <int BM, bool LRT>
+template <int BM, bool LRT, bool ILV>
 __global__ __launch_bounds__(kThreads) void pconv_gemm_kernel(const PConvArgs p) {
     constexpr int LDX = BM + 4;
     constexpr int NT = (BM >= 128) ? 2 : 1;              // 32-channel MFMA tiles per wave
@@ -146,21 +146,36 @@ __global__ __launch_bounds__(kThreads) void pconv_gemm_kernel(const PConvArgs p)
         kt_x[chunk & 1][tid] = (int32_t)xo;
     };
 
-    auto load_tile = [&](int tile, float (&wreg)[WSETS][8], f32x4 (&xreg)[XPASS]) {
+    // Staging loads are split into an address phase (table lookups + adds, before the tile's MFMAs) and the individual
+    // buffer loads.  ILV = true: mma_tile() interleaves the loads BETWEEN the MFMAs of the current tile - a VMEM
+    // instruction costs the issuing wave 100-200 cycles, and among MFMAs that time hides in the 64-cycle shadows of the
+    // matrix pipe (s_memtime: the load phase of a lone workgroup was as long as its MFMA phase).  Measured: +8-10 % on
+    // launches of <= ~1.5 workgroup rounds (latency-bound), -5-15 % on multi-round launches where four co-resident
+    // workgroups already keep the pipe busy and the interleaved loads only delay MFMA issue.  The launcher picks.
+    constexpr int NLOADS = 8 + XPASS;
+    uint32_t loff[NLOADS];
+    auto load_addr = [&](int tile) {
         const int buf = (tile / TPC) & 1;
         const int kb = (tile % TPC) * BK;
         const uint32_t wob = (uint32_t)kt_w[buf][kb + wkl];
 #pragma unroll
-        for (int ps = 0; ps < 8; ++ps) {
-            const uint32_t off = wrow[ps] + wob;
-            wreg[0][ps] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrs, off, 0, 0));
-            if (LRT) wreg[WSETS - 1][ps] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(w2rs, off, 0, 0));
-        }
+        for (int ps = 0; ps < 8; ++ps) loff[ps] = wrow[ps] + wob;
 #pragma unroll
-        for (int ps = 0; ps < XPASS; ++ps) {
-            const uint32_t off = (uint32_t)kt_x[buf][kb + xkr + ps * XRPP] + xcol;
-            xreg[ps] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0));
+        for (int ps = 0; ps < XPASS; ++ps) loff[8 + ps] = (uint32_t)kt_x[buf][kb + xkr + ps * XRPP] + xcol;
+    };
+    auto load_one = [&](int i, float (&wreg)[WSETS][8], f32x4 (&xreg)[XPASS]) {
+        if (i < XPASS) {          // x rows first: they are the wider transfers
+            xreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, loff[8 + i], 0, 0));
+        } else {
+            const int ps = i - XPASS;
+            wreg[0][ps] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrs, loff[ps], 0, 0));
+            if (LRT) wreg[WSETS - 1][ps] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(w2rs, loff[ps], 0, 0));
         }
+    };
+    auto load_tile = [&](int tile, float (&wreg)[WSETS][8], f32x4 (&xreg)[XPASS]) {
+        load_addr(tile);
+#pragma unroll
+        for (int i = 0; i < NLOADS; ++i) load_one(i, wreg, xreg);
     };
 
     auto store_tile = [&](int, float (&wreg)[WSETS][8], f32x4 (&xreg)[XPASS]) {
@@ -194,9 +209,13 @@ __global__ __launch_bounds__(kThreads) void pconv_gemm_kernel(const PConvArgs p)
 #define TS() do { } while (0)
 #endif
     TS();
-    auto mma_tile = [&]() {
+    auto mma_tile = [&](bool more) {
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
+            if (ILV && kk < NLOADS) {
+                if (more) load_one(kk, wregA, xregA);
+                __builtin_amdgcn_sched_barrier(0);     // keep this load ahead of k-step kk's MFMAs, behind kk-1's
+            }
             const int krow = kk * 2 + lk;
             float b[MT];
 #pragma unroll
@@ -230,12 +249,16 @@ __global__ __launch_bounds__(kThreads) void pconv_gemm_kernel(const PConvArgs p)
         TS();
         for (int t = 0; t < ntiles; ++t) {
             const bool more = (t + 1) < ntiles;
-            if (more) load_tile(t + 1, wregA, xregA);                 // in flight during this tile's MFMAs
+            TS();
+            if (more) {
+                if (ILV) load_addr(t + 1);                            // loads themselves are issued inside mma_tile()
+                else     load_tile(t + 1, wregA, xregA);              // all loads up front (large launches)
+            }
             // decode chunk c+1 early in chunk c (c >= 1; chunk 1 is decoded in the prologue): its buffer was last
             // read by load_tile(TPC*c - 1), several barriers ago
             if ((t % TPC) == 1 && t / TPC >= 1 && (t / TPC + 1) * KCH < Keff) fill_chunk(t / TPC + 1);
             TS();
-            mma_tile();
+            mma_tile(more);
             TS();
             __syncthreads();                                          // every wave is done reading the LDS stage
             TS();
@@ -392,17 +415,22 @@ int launch(PConvArgs& a, int draws, hipStream_t st) {
             if (rc != -1000) return rc;
         }
     }
+    bool ilv = items <= 1536;      // <= 1.5 rounds of 4 workgroups x 256 CUs: latency-bound launch
+    if (const char* f = getenv("BBB_ILV")) ilv = atoi(f) != 0;
+    const dim3 grid((unsigned)blocks), block(kThreads);
     if constexpr (!LRT) {
         if (bm == 256) {
-            hipLaunchKernelGGL((pconv_gemm_kernel<256, false>), dim3((unsigned)blocks), dim3(kThreads), 0, st, a);
+            hipLaunchKernelGGL((pconv_gemm_kernel<256, false, false>), grid, block, 0, st, a);
             return (int)hipGetLastError();
         }
         if (bm == 128) {
-            hipLaunchKernelGGL((pconv_gemm_kernel<128, false>), dim3((unsigned)blocks), dim3(kThreads), 0, st, a);
+            if (ilv) hipLaunchKernelGGL((pconv_gemm_kernel<128, false, true>), grid, block, 0, st, a);
+            else     hipLaunchKernelGGL((pconv_gemm_kernel<128, false, false>), grid, block, 0, st, a);
             return (int)hipGetLastError();
         }
     }
-    hipLaunchKernelGGL((pconv_gemm_kernel<64, LRT>), dim3((unsigned)blocks), dim3(kThreads), 0, st, a);
+    if (ilv) hipLaunchKernelGGL((pconv_gemm_kernel<64, LRT, true>), grid, block, 0, st, a);
+    else     hipLaunchKernelGGL((pconv_gemm_kernel<64, LRT, false>), grid, block, 0, st, a);
     return (int)hipGetLastError();
 }
 
