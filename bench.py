@@ -205,6 +205,8 @@ def main():
                 else:
                     gstep = ensemble.GraphedMC(net, x, total_ens, streams=args.streams, group=group)
                 step = gstep.step
+                step()                    # first replay (+ first collective when N > 1) inside the guarded region
+                torch.cuda.synchronize(dev)
             except Exception as exc:      # launch-mode fallback only (same kernels, launched eagerly); reported in the JSON
                 use_graph = False
                 launch_note = "hipGraph capture failed (%s: %s); eager launches" % (type(exc).__name__, str(exc)[:120])
