@@ -1,9 +1,10 @@
 """Tensor-level entry points over the C ABI + their autograd wiring.
 
-Forward math is entirely in the HIP kernels.  Backward: the parameter pass has its own fused HIP kernel
-(eps regenerated from the counter, never stored); the conv/linear data and weight gradients currently go
-through ATen's convolution_backward (MIOpen/rocBLAS) -- a declared stop-gap for the training extension
-(SURVEY.md section 8f N1), not part of the forward metric path.
+Forward math is entirely in the HIP kernels.  Backward (training extension): the parameter pass
+has its own fused HIP kernel (eps regenerated from the counter, never stored); conv / linear weight gradients and
+stride-1 input gradients run on the SAME fp32-MFMA implicit-GEMM kernel as the forward (wgrad = the axis-swapped
+convolution, dgrad = the flipped-weight convolution); only the input gradient of strided / dilated layers still goes
+through ATen's convolution_backward.  Activations, pooling and the loss tail use torch autograd in this mode.
 """
 import ctypes
 
@@ -367,7 +368,42 @@ class _KLOnly(torch.autograd.Function):
         return tuple(out)
 
 
+def conv2d_input_grad(gy, w, x_shape, stride, padding, dilation):
+    """d loss / d x of y = conv2d(x, w) on the same fp32-MFMA kernel: for stride 1 / dilation 1 it is a convolution of
+    gy with the spatially flipped, channel-transposed weights and padding k-1-p.  gy [E,B,Cout,Ho,Wo], w [E|1,Cout,Cin,kh,kw].
+    Returns None when the geometry is not covered (strided / dilated layers: caller falls back)."""
+    (sh, sw), (ph, pw), (dh, dw) = _pair(stride), _pair(padding), _pair(dilation)
+    kh, kw = w.shape[3], w.shape[4]
+    if (sh, sw, dh, dw) != (1, 1, 1, 1) or ph > kh - 1 or pw > kw - 1:
+        return None
+    w_t = w.flip(3, 4).transpose(1, 2).contiguous()                     # [E|1, Cin, Cout, kh, kw]
+    gx = conv2d_forward(gy, w_t, None, 1, (kh - 1 - ph, kw - 1 - pw), 1)
+    return gx if tuple(gx.shape[1:]) == tuple(x_shape[1:]) else None
+
+
+def conv2d_weight_grad(gy, x, w_shape, stride, padding, dilation):
+    """d loss / d w on the same kernel: with batch and channel axes swapped, wgrad is itself a convolution --
+    input x^T [Cin as batch, B as channels, H, W], "weights" gy^T [Cout, B, Ho, Wo], stride = the layer's dilation,
+    dilation = the layer's stride -> [Cin, Cout, kh(+), kw(+)], cropped and transposed back.  One GEMM per draw, batched
+    over draws; when the weights are shared by all draws (LRT) the draw axis is folded into the batch."""
+    (sh, sw), (ph, pw), (dh, dw) = _pair(stride), _pair(padding), _pair(dilation)
+    Ew, Cout, Cin, kh, kw = w_shape
+    E = gy.shape[0]
+    if x.shape[0] == 1 and E > 1:
+        x = x.expand(E, *x.shape[1:])
+    if Ew == 1 and E > 1:                                                # shared weights: sum over draws = bigger batch
+        x = x.reshape(1, E * x.shape[1], *x.shape[2:])
+        gy = gy.reshape(1, E * gy.shape[1], *gy.shape[2:])
+    x_t = x.transpose(1, 2).contiguous()                                 # [E, Cin, B, H, W]
+    gy_t = gy.transpose(1, 2).contiguous()                               # [E, Cout, B, Ho, Wo]
+    g = conv2d_forward(x_t, gy_t, None, (dh, dw), (ph, pw), (sh, sw))    # [E, Cin, Cout, kh', kw'], kh' >= kh
+    return g[:, :, :, :kh, :kw].transpose(1, 2).contiguous()
+
+
 class _Conv2d(torch.autograd.Function):
+    """y = conv2d(x, w, bias) batched over draws.  Backward runs on the same HIP GEMM (dgrad as a flipped-weight conv,
+    wgrad as the axis-swapped conv); only strided / dilated dgrad falls back to ATen's convolution_backward."""
+
     @staticmethod
     def forward(ctx, x, w, bias, stride, padding, dilation):
         y = conv2d_forward(x, w, bias, stride, padding, dilation)
@@ -379,30 +415,26 @@ class _Conv2d(torch.autograd.Function):
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
         stride, padding, dilation, has_bias = ctx.geom
+        gy = gy.contiguous()
         E = gy.shape[0]
-        gx = torch.zeros_like(x) if ctx.needs_input_grad[0] else None
-        gw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
-        gb = gy.sum(dim=(1, 3, 4)) if has_bias and ctx.needs_input_grad[2] else None
-        if gb is not None and w.shape[0] == 1 and E > 1:
-            gb = gb.sum(0, keepdim=True)
-        for e in range(E):   # stop-gap: ATen (MIOpen) dgrad / wgrad per draw
-            xe = x[e if x.shape[0] > 1 else 0]
-            we = w[e if w.shape[0] > 1 else 0]
-            gxe, gwe, _ = torch.ops.aten.convolution_backward(
-                gy[e], xe, we, None, list(stride), list(padding), list(dilation), False, [0, 0], 1,
-                [gx is not None, gw is not None, False])
-            if gx is not None:
-                if x.shape[0] > 1:
-                    gx[e] = gxe
-                else:
-                    gx[0] += gxe
-            if gw is not None:
-                if w.shape[0] > 1:
-                    gw[e] = gwe
-                elif e == 0:
-                    gw[0] = gwe
-                else:
-                    gw[0] += gwe
+        gx = gw = gb = None
+        if has_bias and ctx.needs_input_grad[2]:
+            gb = gy.sum(dim=(1, 3, 4))
+            if w.shape[0] == 1 and E > 1:
+                gb = gb.sum(0, keepdim=True)
+        if ctx.needs_input_grad[1]:
+            gw = conv2d_weight_grad(gy, x, tuple(w.shape), stride, padding, dilation)
+        if ctx.needs_input_grad[0]:
+            gx = conv2d_input_grad(gy, w, (E,) + tuple(x.shape[1:]), stride, padding, dilation)
+            if gx is None:                                               # strided / dilated layer: ATen stop-gap
+                gx = torch.empty((E,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+                for e in range(E):
+                    xe = x[e if x.shape[0] > 1 else 0]
+                    we = w[e if w.shape[0] > 1 else 0]
+                    gx[e] = torch.ops.aten.convolution_backward(gy[e], xe, we, None, list(stride), list(padding),
+                                                                list(dilation), False, [0, 0], 1, [True, False, False])[0]
+            if x.shape[0] == 1 and E > 1:
+                gx = gx.sum(0, keepdim=True)
         return gx, gw, gb, None, None, None
 
 
@@ -421,20 +453,28 @@ class _LrtConv2d(torch.autograd.Function):
     def backward(ctx, gy):
         x, w_mu, w_var, y, am, av = ctx.saved_tensors
         cfg = ctx.cfg
-        st, pd, dl = list(_pair(cfg["stride"])), list(_pair(cfg["padding"])), list(_pair(cfg["dilation"]))
-        E, B = x.shape[0], x.shape[1]
-        x4 = x.reshape((E * B,) + tuple(x.shape[2:]))
-        g4 = gy.reshape((E * B,) + tuple(gy.shape[2:]))
+        geom = (cfg["stride"], cfg["padding"], cfg["dilation"])
+        gy = gy.contiguous()
         # out = am + sqrt(av) * eps  ->  d/d am = g ;  d/d av = g * eps / (2 sqrt(av)) = g * (y - am) / (2 av)
-        if cfg["sample"]:
-            gv4 = (g4 * (y - am).reshape_as(g4) / (2.0 * av.reshape_as(g4)))
-        else:
-            gv4 = torch.zeros_like(g4)
-        gx1, gwm, _ = torch.ops.aten.convolution_backward(g4, x4, w_mu, None, st, pd, dl, False, [0, 0], 1, [True, True, False])
-        gx2, gwv, _ = torch.ops.aten.convolution_backward(gv4, x4 * x4, w_var, None, st, pd, dl, False, [0, 0], 1, [True, True, False])
-        gx = (gx1 + gx2 * 2.0 * x4).reshape_as(x)
-        gbm = g4.sum(dim=(0, 2, 3)) if ctx.has_bias else None
-        gbv = gv4.sum(dim=(0, 2, 3)) if ctx.has_bias else None
+        gv = gy * (y - am) / (2.0 * av) if cfg["sample"] else torch.zeros_like(gy)
+        x2 = x * x
+        wm5, wv5 = w_mu.unsqueeze(0), w_var.unsqueeze(0)
+        gwm = conv2d_weight_grad(gy, x, tuple(wm5.shape), *geom)[0]
+        gwv = conv2d_weight_grad(gv, x2, tuple(wv5.shape), *geom)[0]
+        gx = None
+        if ctx.needs_input_grad[0]:
+            g1 = conv2d_input_grad(gy, wm5, tuple(x.shape), *geom)
+            g2 = conv2d_input_grad(gv, wv5, tuple(x.shape), *geom)
+            if g1 is None or g2 is None:                                 # strided / dilated layer: ATen stop-gap
+                st, pd, dl = list(_pair(geom[0])), list(_pair(geom[1])), list(_pair(geom[2]))
+                E, B = x.shape[0], x.shape[1]
+                x4 = x.reshape((E * B,) + tuple(x.shape[2:]))
+                f = lambda g, xx, ww: torch.ops.aten.convolution_backward(
+                    g.reshape((E * B,) + tuple(g.shape[2:])), xx, ww, None, st, pd, dl, False, [0, 0], 1, [True, False, False])[0]
+                g1, g2 = f(gy, x4, w_mu).reshape_as(x), f(gv, x4 * x4, w_var).reshape_as(x)
+            gx = g1 + g2 * 2.0 * x
+        gbm = gy.sum(dim=(0, 1, 3, 4)) if ctx.has_bias else None
+        gbv = gv.sum(dim=(0, 1, 3, 4)) if ctx.has_bias else None
         return gx, gwm, gwv, gbm, gbv, None
 
 

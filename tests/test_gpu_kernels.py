@@ -313,3 +313,43 @@ def test_mc_tail_batch_innermost(ops, E, B, C):
 def test_to_batch_innermost(ops, shape):
     x = torch.randn(*shape, device="cuda")
     assert torch.equal(ops.to_batch_innermost(x), x.permute(1, 2, 3, 0).contiguous())
+
+
+# ---------------------------------------------------------------- backward on the same GEMM kernel (training extension)
+@pytest.mark.parametrize("case", [
+    # B, Cin, H, W, Cout, kh, kw, stride, pad, dil, E, w_shared
+    (6, 5, 9, 8, 7, 3, 3, 1, 1, 1, 2, False),
+    (4, 3, 12, 12, 6, 5, 5, 2, 2, 1, 1, False),      # strided: wgrad via dilation = stride (with cropping), dgrad -> ATen
+    (5, 4, 10, 9, 3, 3, 2, 3, 1, 1, 2, False),       # stride 3, (H + 2p - k) % s != 0
+    (8, 16, 4, 4, 12, 3, 3, 1, 1, 1, 3, True),       # weights shared by the draws (LRT-style): grads summed over draws
+    (4, 6, 7, 7, 5, 3, 3, 1, 0, 2, 1, False),        # dilated
+    (16, 40, 1, 1, 10, 1, 1, 1, 0, 1, 2, False),     # linear as 1x1
+])
+def test_conv_backward_helpers_vs_autograd(ops, case):
+    B, Cin, H, W, Cout, kh, kw, s, p, d, E, shared = case
+    g = torch.Generator(device="cuda").manual_seed(sum(case[:11]))
+    x = torch.randn(E, B, Cin, H, W, device="cuda", generator=g)
+    w = torch.randn(1 if shared else E, Cout, Cin, kh, kw, device="cuda", generator=g) * 0.2
+    ys = [torch.nn.functional.conv2d(x[e], w[0 if shared else e], None, s, p, d) for e in range(E)]
+    gy = torch.randn(E, *ys[0].shape, device="cuda", generator=g)
+    # reference gradients from ATen in float64
+    xd = x.double().requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    loss = sum((torch.nn.functional.conv2d(xd[e], wd[0 if shared else e], None, s, p, d) * gy[e].double()).sum() for e in range(E))
+    loss.backward()
+    gw = ops.conv2d_weight_grad(gy, x, tuple(w.shape), s, p, d)
+    np.testing.assert_allclose(gw.cpu().numpy(), wd.grad.float().cpu().numpy(), rtol=2e-4, atol=2e-4)
+    gx = ops.conv2d_input_grad(gy, w, tuple(x.shape), s, p, d)
+    if s == 1 and d == 1:
+        np.testing.assert_allclose(gx.cpu().numpy(), xd.grad.float().cpu().numpy(), rtol=2e-4, atol=2e-4)
+    else:
+        assert gx is None                             # not covered: the autograd Function falls back to ATen
+    # through the autograd Function (bias included)
+    xa = x.clone().requires_grad_(True)
+    wa = w.clone().requires_grad_(True)
+    ba = torch.randn(w.shape[0], Cout, device="cuda", generator=g).requires_grad_(True)
+    (ops.conv2d(xa, wa, ba, s, p, d) * gy).sum().backward()
+    np.testing.assert_allclose(xa.grad.cpu().numpy(), xd.grad.float().cpu().numpy(), rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(wa.grad.cpu().numpy(), wd.grad.float().cpu().numpy(), rtol=2e-4, atol=2e-4)
+    want_gb = gy.sum(dim=(1, 3, 4))
+    np.testing.assert_allclose(ba.grad.cpu().numpy(), (want_gb.sum(0, keepdim=True) if shared else want_gb).cpu().numpy(), rtol=1e-4, atol=1e-4)
