@@ -394,10 +394,23 @@ def conv2d_weight_grad(gy, x, w_shape, stride, padding, dilation):
     if Ew == 1 and E > 1:                                                # shared weights: sum over draws = bigger batch
         x = x.reshape(1, E * x.shape[1], *x.shape[2:])
         gy = gy.reshape(1, E * gy.shape[1], *gy.shape[2:])
+    # split-K: the reduction runs over batch x output pixels while the result is only Cin*kh*kw x Cout, so a layer
+    # with a large feature map would occupy a handful of workgroups.  Batch chunks become extra "draws", summed after.
+    E1, Bt = x.shape[0], x.shape[1]
+    tiles = E1 * -(-Cin * kh * kw // 64) * -(-Cout // 64)
+    split = 1
+    while Bt % (2 * split) == 0 and Bt // (2 * split) >= 4 and tiles * 2 * split <= 1024:
+        split *= 2
+    if split > 1:
+        x = x.reshape(E1 * split, Bt // split, *x.shape[2:])
+        gy = gy.reshape(E1 * split, Bt // split, *gy.shape[2:])
     x_t = x.transpose(1, 2).contiguous()                                 # [E, Cin, B, H, W]
     gy_t = gy.transpose(1, 2).contiguous()                               # [E, Cout, B, Ho, Wo]
     g = conv2d_forward(x_t, gy_t, None, (dh, dw), (ph, pw), (sh, sw))    # [E, Cin, Cout, kh', kw'], kh' >= kh
-    return g[:, :, :, :kh, :kw].transpose(1, 2).contiguous()
+    g = g[:, :, :, :kh, :kw]
+    if split > 1:
+        g = g.reshape(E1, split, *g.shape[1:]).sum(1)
+    return g.transpose(1, 2).contiguous()
 
 
 class _Conv2d(torch.autograd.Function):
