@@ -37,6 +37,7 @@ import torch  # noqa: E402
 PRIORS = {"prior_mu": 0, "prior_sigma": 0.1, "posterior_mu_initial": (0, 0.1), "posterior_rho_initial": (-5, 0.1)}
 BATCH, NUM_ENS, CLASSES = 512, 10, 10
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense v_mfma_f32_32x32x16_bf16 peak (same guide)
 PEAK_HBM_GBS = 8000.0             # HBM3E spec (6.3 TB/s achievable)
 
 
@@ -146,6 +147,21 @@ def reparam_probe(net, dev, n_params):
                         "the achievable streaming rate on this box"}}
 
 
+def gemm_roofline(g, timer_steps, dtype):
+    """Dominant kernel of the step: all conv / linear launches.  FLOPs counted = in-bounds taps only (what the fp32 kernel
+    multiplies; the bf16 kernel also multiplies the zero taps, which is not counted as useful work)."""
+    tf = g["work"] / (g["ms"] * 1e-3) / 1e12
+    peak = PEAK_BF16_MFMA_TFLOPS if dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
+    kern = ("pconv_bf16_kernel (v_mfma_f32_32x32x16_bf16, batch-innermost, LDS transpose reads)" if dtype == "bf16" else
+            "pconv_gemm_kernel (fp32 v_mfma_f32_32x32x2_f32, batch-innermost, in-bounds taps only)")
+    return {"bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
+            "traffic": None, "kernel": kern + ", all conv/linear launches of a step",
+            "launches": g["n"], "avg_us": round(1e3 * g["ms"] / g["n"], 2),
+            "flop_per_step": g["work"] / timer_steps, "im2col_flop_per_step": g["work_im2col"] / timer_steps,
+            "timed_by": "HIP events around every launch, %d eager single-stream steps of the same workload right after "
+                        "the timed region" % timer_steps}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -157,6 +173,10 @@ def main():
     ap.add_argument("--streams", type=int, default=1, help="independent sub-ensembles on separate HIP streams")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
     ap.add_argument("--pipeline", type=int, default=3, help="independent MC steps in flight (hipGraph lanes on separate streams)")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="f32: the reference's arithmetic on the exact fp32 matrix cores (headline).  bf16: sampled weights and "
+                         "hidden activations stored as bf16, fp32 accumulate (BASELINE.json configs[1] precision)")
+    ap.add_argument("--no-bf16-extra", action="store_true", help="skip the secondary bf16 measurement of the default run")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -194,6 +214,9 @@ def main():
         torch.cuda.synchronize(dev)
 
     use_graph = not args.no_graph
+    precision = "bf16" if args.dtype == "bf16" else "fp32"
+    if precision == "bf16" and args.layer_type != "bbb":
+        raise SystemExit("--dtype bf16 covers BBB layers only")
     with torch.no_grad():
         launch_note = None
         if use_graph:
@@ -201,9 +224,10 @@ def main():
             # graph gives every replay fresh Philox noise (no cached outputs)
             try:
                 if args.pipeline > 1:
-                    gstep = ensemble.GraphedPipeline(net, x, total_ens, depth=args.pipeline, streams=args.streams, group=group)
+                    gstep = ensemble.GraphedPipeline(net, x, total_ens, depth=args.pipeline, streams=args.streams, group=group,
+                                                     precision=precision)
                 else:
-                    gstep = ensemble.GraphedMC(net, x, total_ens, streams=args.streams, group=group)
+                    gstep = ensemble.GraphedMC(net, x, total_ens, streams=args.streams, group=group, precision=precision)
                 step = gstep.step
                 step()                    # first replay (+ first collective when N > 1) inside the guarded region
                 torch.cuda.synchronize(dev)
@@ -212,7 +236,7 @@ def main():
                 launch_note = "hipGraph capture failed (%s: %s); eager launches" % (type(exc).__name__, str(exc)[:120])
                 torch.cuda.synchronize(dev)
         if not use_graph:
-            step = lambda: ensemble.mc_forward(net, x, total_ens, group=group, streams=max(2, args.streams))
+            step = lambda: ensemble.mc_forward(net, x, total_ens, group=group, streams=max(2, args.streams), precision=precision)
         for _ in range(args.warmup):
             step()
         barrier()
@@ -225,7 +249,7 @@ def main():
         # transparency: the same step with ONE step in flight (single graph lane), same process, same data
         serial = None
         if use_graph and args.pipeline > 1 and world == 1:
-            g1 = ensemble.GraphedMC(net, x, total_ens, streams=args.streams)
+            g1 = ensemble.GraphedMC(net, x, total_ens, streams=args.streams, precision=precision)
             for _ in range(5):
                 g1.step()
             torch.cuda.synchronize(dev)
@@ -245,8 +269,30 @@ def main():
             # the event brackets then hold kernel time only, not host launch latency
             torch.cuda._sleep(int(1.0e8))
             for _ in range(timer_steps):
-                ensemble.mc_forward(net, x, total_ens, group=group, timers=timers)
+                ensemble.mc_forward(net, x, total_ens, group=group, timers=timers, precision=precision)
             torch.cuda.synchronize(dev)
+        # secondary measurement: the same workload under the bf16 storage model (never the headline value)
+        bf16_extra = None
+        if precision == "fp32" and args.layer_type == "bbb" and use_graph and not args.no_bf16_extra:
+            try:
+                gb = ensemble.GraphedPipeline(net, x, total_ens, depth=max(1, args.pipeline), streams=args.streams, group=group,
+                                              precision="bf16")
+                for _ in range(max(3, args.warmup)):
+                    gb.step()
+                barrier()
+                tb = time.perf_counter()
+                for _ in range(args.steps):
+                    gb.step()
+                barrier()
+                tb = time.perf_counter() - tb
+                tmb = ensemble.Timers()
+                torch.cuda._sleep(int(1.0e8))
+                for _ in range(5):
+                    ensemble.mc_forward(net, x, total_ens, group=group, timers=tmb, precision="bf16")
+                torch.cuda.synchronize(dev)
+                bf16_extra = (tb, tmb.summary())
+            except Exception as exc:
+                bf16_extra = "bf16 measurement failed: %s: %s" % (type(exc).__name__, str(exc)[:160])
 
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -262,7 +308,7 @@ def main():
             "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"BayesianAlexNet 3x32x32 -> {CLASSES} classes, layer_type={args.layer_type}, "
                                    f"softplus, bs={BATCH}, num_ens={NUM_ENS} per GPU ({total_ens} draws total), "
                                    "forward only (main_bayesian.py:73-80)",
@@ -275,19 +321,21 @@ def main():
             agg = timers.summary()
             g = agg.get("conv_gemm") or agg.get("lrt_gemm")
             if g:
-                tf = g["work"] / (g["ms"] * 1e-3) / 1e12
-                out["roofline"] = {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                                   "unit": "TFLOP/s", "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                                   "kernel": "pconv_gemm_kernel (fp32 v_mfma_f32_32x32x2_f32, batch-innermost, in-bounds taps only), all conv/linear launches of a step",
-                                   "launches": g["n"], "avg_us": round(1e3 * g["ms"] / g["n"], 2),
-                                   "flop_per_step": g["work"] / timer_steps,
-                                   "im2col_flop_per_step": g["work_im2col"] / timer_steps,
-                                   "timed_by": "HIP events around every launch, %d eager single-stream steps of the same workload right after the timed region" % timer_steps,
-                                   "share_of_eager_step": None}
+                out["roofline"] = gemm_roofline(g, timer_steps, args.dtype)
             if args.layer_type == "bbb":
                 out["roofline_reparam"] = reparam_probe(net, dev, n_params)
         if serial is not None:
             out["one_step_in_flight"] = serial
+        if isinstance(bf16_extra, tuple):
+            tb, aggb = bf16_extra
+            out["bf16"] = {"value": round(BATCH * total_ens / (tb / args.steps), 1), "unit": "samples/s",
+                           "ms_per_step": round(1e3 * tb / args.steps, 4),
+                           "note": "same workload, launch structure and noise streams with sampled weights + hidden activations "
+                                   "stored as bf16 (fp32 accumulate / bias / activation / KL); parity: tests/test_gpu_bf16.py; "
+                                   "not the headline value",
+                           "roofline": gemm_roofline(aggb["conv_gemm"], 5, "bf16") if "conv_gemm" in aggb else None}
+        elif bf16_extra is not None:
+            out["bf16"] = {"error": bf16_extra}
         if cpu is not None:
             out["cpu_baseline"] = cpu
             out["speedup_vs_cpu"] = round(out["value"] / cpu["value"], 1)

@@ -4,7 +4,7 @@ set -euo pipefail
 cd "$(dirname "$0")/pytorch-bayesiancnn_amd"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 mkdir -p build
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wall -Wno-unused-variable"
+FLAGS="${BBB_EXTRA_FLAGS:-} --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wall -Wno-unused-variable"
 objs=()
 for f in csrc/*.hip; do
   o=build/$(basename "${f%.hip}").o

@@ -47,7 +47,11 @@ typedef struct bbb_segment {
     int64_t n;            /* elements */
     int64_t draw_stride;  /* elements between consecutive draws of w / eps (>= n) */
     uint32_t stream_id;   /* noise stream of this tensor */
-    uint32_t reserved;
+    uint32_t w_row_len;   /* 0: w is fp32, dense.  > 0: w is BF16 (round-to-nearest-even), a matrix with rows of
+                             w_row_len elements stored at a pitch of w_row_len rounded up to 8 elements -- the operand
+                             layout of bbb_conv2d_chwn_bf16_fwd; draw_stride then counts bf16 elements, the pad columns
+                             are written as zeros, and `eps` (fp32) keeps the dense [draws][n] layout
+                             with stride n */
 } bbb_segment_t;
 
 #define BBB_SIGMA_SQUARED 1u   /* flags: write sigma^2 (the LRT variance operand) instead of sigma */
@@ -151,6 +155,23 @@ int bbb_lrt_conv2d_chwn_fwd(const bbb_conv_desc_t* d, const float* x, const floa
 /* nn.MaxPool2d(kernel_size=k, stride=s) (no padding, floor mode; models/BayesianModels/BayesianAlexNet.py:37)
  * on batch-innermost planes: x [planes][h][w][B] -> y [planes][(h-k)/s+1][(w-k)/s+1][B]. */
 int bbb_maxpool_chwn(const float* x, float* y, int64_t planes, int h, int w, int batch, int k, int s, void* stream);
+
+/*
+ * BF16 storage variants of the batch-innermost path (BASELINE.json configs[1]: "BBB layers, bf16"); fp32 accumulation,
+ * fp32 bias and fp32 epilogue (bias + activation), one rounding (nearest-even) when a value is stored as bf16.
+ *   x: [draws|1][cin][h][w][B] bf16   (B % 8 == 0, 16-byte aligned, draw strides multiples of 8 elements)
+ *   w: [draws|1][cout][Kp] bf16       K = cin*kh*kw in the reference's (ci, r, q) order, Kp = K rounded up to 8, pad
+ *                                     columns zero -- what bbb_reparam_kl_fwd writes for a segment with w_row_len = K
+ *   y: [draws][cout][ho][wo][B]       bf16, or fp32 when out_f32 != 0 (the logits layer feeding bbb_mc_tail)
+ * d->w_draw_stride counts bf16 elements (cout*Kp per draw when dense).  Same contraction as bbb_conv2d_chwn_fwd
+ * (layers/BBB/BBBConv.py:77, BBBLinear.py:70) on v_mfma_f32_32x32x16_bf16.  BBB layers only (no LRT variant).
+ */
+int bbb_conv2d_chwn_bf16_fwd(const bbb_conv_desc_t* d, const void* x, const void* w, const float* bias, void* y,
+                             int out_f32, void* stream);
+/* nn.MaxPool2d(k, s) on [planes][h][w][B] bf16 (B % 8 == 0); exact (max commutes with the rounding). */
+int bbb_maxpool_chwn_bf16(const void* x, void* y, int64_t planes, int h, int w, int batch, int k, int s, void* stream);
+/* fp32 [batch][plane] (an NCHW tensor, plane = C*H*W) -> bf16 [plane][batch] (batch-innermost), nearest-even. */
+int bbb_nchw_to_chwn_bf16(const float* x, void* y, int batch, int64_t plane, void* stream);
 
 /*
  * Monte-Carlo tail (main_bayesian.py:49,53 / :78,80 + utils.py:14-22): per draw log_softmax over

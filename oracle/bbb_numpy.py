@@ -384,3 +384,50 @@ def model_forward(net_type, params, x, layer_type, activation, eps_fn):
             kl += kl_loss(p["W_mu"], Ws, params["_prior_mu"], params["_prior_sigma"])
             kl += kl_loss(p["bias_mu"], bs, params["_prior_mu"], params["_prior_sigma"])
     return h, kl
+
+
+# ----------------------------------------------------------------------------------------------
+# bf16 STORAGE model (BASELINE.json configs[1]).  The reference has no reduced-precision mode: this is the same
+# algorithm (layers/BBB/BBBConv.py:61-77, models/BayesianModels/*.py) with the rounding points the HIP bf16 path
+# documents in include/bbb_hip.h -- sampled weight matrices, the input image and every hidden activation are rounded
+# once to bf16 (nearest-even) where they are stored; biases, accumulation, the epilogue (bias + activation), KL and
+# the logits stay fp32.
+# ----------------------------------------------------------------------------------------------
+def bf16_round(a):
+    """fp32 -> nearest-even bf16, returned as fp32 values."""
+    u = np.ascontiguousarray(np.asarray(a, F32)).view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return r.astype(np.uint32).view(F32).reshape(np.shape(a))
+
+
+def model_forward_bf16(net_type, params, x, activation, eps_fn):
+    """model_forward(layer_type='bbb') under the bf16 storage model.  Returns (logits fp32, kl)."""
+    act = softplus_act if activation == "softplus" else relu_act
+    ops_ = TOPOLOGY[net_type]
+    last = max(i for i, op in enumerate(ops_) if op[0] in ("conv", "fc"))
+    h = bf16_round(x)
+    kl = 0.0
+    i = 0
+    while i < len(ops_):
+        op = ops_[i]
+        if op[0] == "act":
+            h = bf16_round(act(h))                       # unfused activation (not produced by the topologies above)
+        elif op[0] == "pool":
+            h = maxpool2d(h, op[1], op[2])
+        elif op[0] == "flatten":
+            h = h.reshape(-1, op[1])
+        else:
+            p = params[op[1]]
+            Ws, bs = sigma_from_rho(p["W_rho"]), sigma_from_rho(p["bias_rho"])
+            w = bf16_round(reparam(p["W_mu"], Ws, eps_fn(op[1], "W", p["W_mu"].shape)))
+            b = reparam(p["bias_mu"], bs, eps_fn(op[1], "bias", p["bias_mu"].shape))
+            y = conv2d(h, w, b, op[4], op[5], 1) if op[0] == "conv" else linear(h, w, b)
+            fused = i + 1 < len(ops_) and ops_[i + 1][0] == "act"
+            if fused:                                    # activation is part of the GEMM epilogue, applied in fp32
+                y = act(y)
+                i += 1
+            h = y if i >= last else bf16_round(y)
+            kl += kl_loss(p["W_mu"], Ws, params["_prior_mu"], params["_prior_sigma"])
+            kl += kl_loss(p["bias_mu"], bs, params["_prior_mu"], params["_prior_sigma"])
+        i += 1
+    return h, kl

@@ -23,7 +23,7 @@ c_u64, c_u32, c_i64, c_i32 = ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int64, c
 
 class Segment(ctypes.Structure):
     _fields_ = [("mu", c_void_p), ("rho", c_void_p), ("w", c_void_p), ("sigma", c_void_p), ("eps", c_void_p),
-                ("n", c_i64), ("draw_stride", c_i64), ("stream_id", c_u32), ("reserved", c_u32)]
+                ("n", c_i64), ("draw_stride", c_i64), ("stream_id", c_u32), ("w_row_len", c_u32)]
 
 
 class ConvDesc(ctypes.Structure):
@@ -47,6 +47,9 @@ _SIGNATURES = {
     "bbb_lrt_conv2d_chwn_fwd": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_u64, c_u32, c_u32, c_int, c_void_p, c_void_p]),
     "bbb_maxpool_chwn": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "bbb_conv2d_chwn_bf16_fwd": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "bbb_maxpool_chwn_bf16": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "bbb_nchw_to_chwn_bf16": (c_int, [c_void_p, c_void_p, c_int, c_i64, c_void_p]),
     "bbb_mc_tail": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "bbb_mc_tail_cb": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "bbb_uncertainty": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -94,7 +97,7 @@ def ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
-def require_device(*tensors):
+def require_device(*tensors, dtype=torch.float32):
     """Every compute entry point works on MI355X memory only; fail loudly otherwise."""
     for t in tensors:
         if t is None:
@@ -102,8 +105,8 @@ def require_device(*tensors):
         if not t.is_cuda:
             raise BBBHipError("bbb_hip computes on an MI355X only (tensor is on %s); there is no CPU path. "
                               "Move the module / input to 'cuda'." % t.device)
-        if t.dtype != torch.float32:
-            raise BBBHipError(f"bbb_hip expects float32 tensors, got {t.dtype}")
+        if t.dtype != dtype:
+            raise BBBHipError(f"bbb_hip expects {dtype} tensors here, got {t.dtype}")
 
 
 def cur_stream(device):

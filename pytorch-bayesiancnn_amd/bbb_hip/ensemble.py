@@ -113,6 +113,32 @@ def _sample_all(layers, draws, seed, call0, timers=None, eps=None):
     return out, kl_total
 
 
+def _sample_all_bf16(layers, draws, seed, call0, timers=None):
+    """_sample_all for the bf16 storage path: weight matrices come back bf16 in the GEMM's padded-row layout."""
+    mus, rhos, ids = [], [], []
+    for l in layers:
+        m, r, i = l._param_lists()
+        mus += m
+        rhos += r
+        ids += i
+    pri = {(l.prior_mu, l.prior_sigma) for l in layers}
+    if len(pri) != 1:
+        raise _lib.BBBHipError("bf16 path: all layers must share one prior")
+    pm, ps = next(iter(pri))
+    kl_total, ws_all = None, []
+    for s in range(0, len(mus), _lib.MAX_SEGMENTS):
+        sl = slice(s, s + _lib.MAX_SEGMENTS)
+        kl, ws = _run(timers, "reparam_kl", sum(m.numel() for m in mus[sl]),
+                      lambda: ops.sample_weights_bf16(mus[sl], rhos[sl], pm, ps, ids[sl], seed, call0, draws))
+        kl_total = kl if kl_total is None else kl_total + kl
+        ws_all += ws
+    out, k = {}, 0
+    for l in layers:
+        out[l] = (ws_all[k], ws_all[k + 1] if l.use_bias else None)
+        k += 2 if l.use_bias else 1
+    return out, kl_total
+
+
 def _variances_all(layers, timers=None):
     """One fused launch for every LRT layer: sigma^2 tensors + KL."""
     mus, rhos = [], []
@@ -181,20 +207,35 @@ def _chwn_ok(net, x):
     return True
 
 
-def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1):
+def _check_precision(precision, net, x, fast_path_allowed):
+    """precision: "fp32" (the reference's arithmetic, default) or "bf16" (bf16 storage of sampled weights and
+    activations, fp32 accumulate; inference on the batch-innermost path only -- anything else fails loudly)."""
+    if precision == "fp32":
+        return
+    if precision != "bf16":
+        raise _lib.BBBHipError(f"precision must be 'fp32' or 'bf16', got {precision!r}")
+    if not fast_path_allowed or not _chwn_ok(net, x):
+        raise _lib.BBBHipError("bf16 runs on the batch-innermost inference path only (no autograd, no external eps, "
+                               "4-d input with B % 8 == 0, BBB layers + ReLU/Softplus/MaxPool2d/FlattenLayer)")
+
+
+def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precision="fp32"):
     """Inference path of mc_logits in the batch-innermost layout ([E, C, H, W, B]): pixel-major GEMMs that
     skip padding taps, activation fused into the GEMM epilogue, pooling on contiguous image vectors."""
     layers = bayesian_layers(net)
     bbb = [l for l in layers if isinstance(l, _BBBLayer)]
     lrt = [l for l in layers if isinstance(l, _LRTLayer)]
     kl, sampled, variances = None, {}, {}
+    bf16 = precision == "bf16"
+    if bf16 and (lrt or x.shape[0] % 8 != 0):
+        raise _lib.BBBHipError("the bf16 path covers BBB (non-LRT) layers and batch sizes that are multiples of 8")
     if bbb:
-        sampled, kl = _sample_all(bbb, draws, seed, call0, timers)
+        sampled, kl = _sample_all_bf16(bbb, draws, seed, call0, timers) if bf16 else _sample_all(bbb, draws, seed, call0, timers)
     if lrt:
         variances, k2 = _variances_all(lrt, timers)
         kl = k2 if kl is None else kl + k2
     E, B = draws, x.shape[0]
-    xt = ops.to_batch_innermost(x).unsqueeze(0)                  # [1, C, H, W, B], shared by all draws
+    xt = (ops.to_batch_innermost_bf16(x) if bf16 else ops.to_batch_innermost(x)).unsqueeze(0)   # [1, C, H, W, B], shared
     children = list(net.children())
     last_bayes = max((i for i, m in enumerate(children) if isinstance(m, (_BBBLayer, _LRTLayer))), default=-1)
     tail_is_last = last_bayes == len(children) - 1
@@ -216,7 +257,18 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1):
                 h5 = h if is_conv else h.reshape(h.shape[0], mod.in_features, 1, 1, -1)
                 if h5.dim() != 5 or h5.shape[-1] != B:
                     return None                                  # flatten quirk etc.: caller falls back
-                if isinstance(mod, _BBBLayer):
+                if isinstance(mod, _BBBLayer) and bf16:
+                    w, b = sampled[mod]
+                    w = w[e0:e1]
+                    b = None if b is None else b[e0:e1]
+                    ckk = (mod.in_channels, *mod.kernel_size) if is_conv else (mod.in_features, 1, 1)
+                    fl = conv_flops(B, h5.shape[1], h5.shape[2], h5.shape[3], w.shape[1], ckk[1], ckk[2], *geom, Es) \
+                        if timers is not None else None
+                    is_logits = logits_buf is not None and i == last_bayes and not is_conv
+                    dst = logits_buf[e0:e1] if is_logits else None
+                    y = _run(timers, "conv_gemm", fl,
+                             lambda: ops.conv2d_chwn_bf16_forward(h5, w, b, ckk, *geom, act=act, out_f32=(i == last_bayes and tail_is_last), out=dst))
+                elif isinstance(mod, _BBBLayer):
                     w, b = sampled[mod]
                     w = w[e0:e1]
                     b = None if b is None else b[e0:e1]
@@ -248,7 +300,8 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1):
                     return None
                 h = h.reshape(h.shape[0], mod.num_features, 1, 1, B)
             elif isinstance(mod, nn.MaxPool2d):
-                h = _run(timers, "maxpool", None, lambda: ops.maxpool_chwn(h, mod.kernel_size, mod.stride))
+                pool = ops.maxpool_chwn_bf16 if bf16 else ops.maxpool_chwn
+                h = _run(timers, "maxpool", None, lambda: pool(h, mod.kernel_size, mod.stride))
             elif isinstance(mod, nn.ReLU):
                 h = torch.relu(h)
             else:
@@ -300,17 +353,20 @@ def _side_streams(device, n):
     return _stream_pool[key]
 
 
-def mc_logits(net, x, draws, seed, call0, fuse_act=True, timers=None, eps=None, layout="auto", streams=1):
+def mc_logits(net, x, draws, seed, call0, fuse_act=True, timers=None, eps=None, layout="auto", streams=1, precision="fp32"):
     """E stochastic forwards of `net` on the same batch x -> (logits [E, B', C], kl of ONE forward).
 
     Equivalent to `[net(x)[0] for _ in range(E)]` under noise calls call0 .. call0+E-1 (B' = B except for
     the 224x224 AlexNet flatten quirk, where B' = B*49).  layout "auto" takes the batch-innermost fast path
     when it applies (inference, B % 4 == 0, known module kinds), "nchw" forces the reference layout."""
     _lib.require_device(x)
+    _check_precision(precision, net, x, layout != "nchw" and eps is None and fuse_act)
     if layout != "nchw" and eps is None and fuse_act and _chwn_ok(net, x):
-        out = _mc_logits_chwn(net, x, draws, seed, call0, timers, streams)
+        out = _mc_logits_chwn(net, x, draws, seed, call0, timers, streams, precision)
         if out is not None:
             return out[0].permute(0, 2, 1).contiguous(), out[1]      # API layout [E, B, C]
+    if precision != "fp32":
+        raise _lib.BBBHipError("this model / input does not fit the batch-innermost path, which is the only bf16 path")
     layers = bayesian_layers(net)
     bbb = [l for l in layers if isinstance(l, _BBBLayer)]
     lrt = [l for l in layers if isinstance(l, _LRTLayer)]
@@ -386,14 +442,17 @@ def mc_logits(net, x, draws, seed, call0, fuse_act=True, timers=None, eps=None, 
     return h, kl
 
 
-def _local_lse(net, x, draws, seed, call0, mean_over, fuse_act=True, timers=None, streams=1):
+def _local_lse(net, x, draws, seed, call0, mean_over, fuse_act=True, timers=None, streams=1, precision="fp32"):
     """(log-sum-exp over `draws` local draws of the per-draw log_softmax [B, C], kl of one forward), staying in the
     batch-innermost layout end to end when the fast path applies."""
+    _check_precision(precision, net, x, fuse_act)
     if fuse_act and _chwn_ok(net, x):
-        out = _mc_logits_chwn(net, x, draws, seed, call0, timers, streams)
+        out = _mc_logits_chwn(net, x, draws, seed, call0, timers, streams, precision)
         if out is not None:
             lse = _run(timers, "mc_tail", 0, lambda: ops.mc_tail_cb(out[0], mean_over=mean_over))
             return lse, out[1]
+    if precision != "fp32":
+        raise _lib.BBBHipError("this model / input does not fit the batch-innermost path, which is the only bf16 path")
     logits, kl1 = mc_logits(net, x, draws, seed, call0, fuse_act=fuse_act, timers=timers, layout="nchw")
     if torch.is_grad_enabled() and logits.requires_grad:
         # training extension (SURVEY.md section 8f N1): differentiable tail through torch ops
@@ -403,7 +462,7 @@ def _local_lse(net, x, draws, seed, call0, mean_over, fuse_act=True, timers=None
     return lse, kl1
 
 
-def mc_forward(net, x, num_ens, group=None, fuse_act=True, timers=None, kl_mode="sum", streams=1):
+def mc_forward(net, x, num_ens, group=None, fuse_act=True, timers=None, kl_mode="sum", streams=1, precision="fp32"):
     """One Monte-Carlo step: -> (log_outputs [B, C], kl).
 
     kl_mode "sum": kl summed over the num_ens calls as validate_model does (main_bayesian.py:76-77);
@@ -416,7 +475,7 @@ def mc_forward(net, x, num_ens, group=None, fuse_act=True, timers=None, kl_mode=
     lo, hi = draw_range(num_ens, rank, world)
     if hi > lo:
         lse, kl1 = _local_lse(net, x, hi - lo, seed, call0 + lo, 0 if world > 1 else num_ens, fuse_act=fuse_act,
-                              timers=timers, streams=streams)
+                              timers=timers, streams=streams, precision=precision)
         kl_local = kl1 * float(hi - lo)
     else:                                            # more ranks than draws
         lse, kl_local = None, None
@@ -463,9 +522,11 @@ class GraphedMC:
     eagerly after the replay, on the lane's stream (collectives stay outside the graph).
     step() returns (log_outputs [B, C], kl); with world == 1 these are buffers overwritten by the next replay."""
 
-    def __init__(self, net, x, num_ens, streams=1, kl_mode="sum", lane=0, lanes=1, stream=None, seed_call=None, group=None):
+    def __init__(self, net, x, num_ens, streams=1, kl_mode="sum", lane=0, lanes=1, stream=None, seed_call=None, group=None,
+                 precision="fp32"):
         _lib.require_device(x)
         self.net, self.x, self.num_ens, self.group, self.kl_mode = net, x, int(num_ens), group, kl_mode
+        self.precision = precision
         self.world = 1 if group is None else torch.distributed.get_world_size(group)
         rank = 0 if group is None else torch.distributed.get_rank(group)
         self.lo, self.hi = draw_range(self.num_ens, rank, self.world)
@@ -496,7 +557,7 @@ class GraphedMC:
     def _step_body(self, streams):
         n_loc = self.hi - self.lo
         lse, kl1 = _local_lse(self.net, self.x, n_loc, self.seed, self.call0 + self.lo,
-                              self.num_ens if self.world == 1 else 0, streams=streams)
+                              self.num_ens if self.world == 1 else 0, streams=streams, precision=self.precision)
         if self.world == 1:
             kl = kl1 * float(self.num_ens) if self.kl_mode == "sum" else kl1 * 1.0
         else:
@@ -534,10 +595,11 @@ class GraphedPipeline:
     step() returns the (log_outputs, kl) buffers of the lane just enqueued; call sync() (or synchronize the device)
     before reading them."""
 
-    def __init__(self, net, x, num_ens, depth=2, streams=1, kl_mode="sum", group=None):
+    def __init__(self, net, x, num_ens, depth=2, streams=1, kl_mode="sum", group=None, precision="fp32"):
         seed_call = rng.next_calls(0)
         self.lanes = [GraphedMC(net, x, num_ens, streams=streams, kl_mode=kl_mode, lane=l, lanes=depth,
-                                stream=torch.cuda.Stream(device=x.device), seed_call=seed_call, group=group)
+                                stream=torch.cuda.Stream(device=x.device), seed_call=seed_call, group=group,
+                                precision=precision)
                       for l in range(depth)]
         self.i = 0
         self.dev = x.device

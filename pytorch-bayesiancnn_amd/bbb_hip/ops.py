@@ -255,6 +255,119 @@ def maxpool_chwn(x, k, s):
     return y
 
 
+# ---- bf16 storage path (BASELINE.json configs[1]) -------------------------------------------------------------------
+
+def bf16_row_pitch(k):
+    return (int(k) + 7) & ~7
+
+
+def sample_weights_bf16(mus, rhos, prior_mu, prior_sigma, stream_ids, seed, call0, draws, eps=None):
+    """The fused reparam + KL pass with the sampled WEIGHT matrices written as bf16 in the bf16 GEMM's operand layout
+    ([draws, rows, pitch], pitch = row length rounded up to 8, pad zero) and 1-d tensors (biases) kept fp32.
+    Inference only.  Returns (kl, [tensors])."""
+    if len(mus) == 0 or len(mus) > _lib.MAX_SEGMENTS:
+        raise _lib.BBBHipError(f"1..{_lib.MAX_SEGMENTS} tensors per launch, got {len(mus)}")
+    require_device(*mus, *rhos)
+    dev = mus[0].device
+    mus = [m.detach().contiguous() for m in mus]
+    rhos = [r.detach().contiguous() for r in rhos]
+    outs, row_lens = [], []
+    for m in mus:
+        if m.dim() >= 2:
+            rows, k = m.shape[0], m.numel() // m.shape[0]
+            kp = bf16_row_pitch(k)
+            o = torch.empty((draws, rows, kp), dtype=torch.bfloat16, device=dev)    # the kernel also writes the zero pad
+            outs.append(o)
+            row_lens.append(k)
+        else:
+            outs.append(torch.empty((draws,) + tuple(m.shape), dtype=torch.float32, device=dev))
+            row_lens.append(0)
+    if eps is not None:
+        eps = [e.contiguous() for e in eps]
+        require_device(*eps)
+    segs = _segments(mus, rhos, outs, None, eps, stream_ids, draws)
+    for i, (o, rl) in enumerate(zip(outs, row_lens)):
+        if rl:
+            segs[i].w_row_len = rl
+            segs[i].draw_stride = o.shape[1] * o.shape[2]
+    kl = torch.empty((), dtype=torch.float32, device=dev)
+    L = _lib.lib()
+    parts = _partials(dev, L.bbb_reparam_partials(segs, len(mus)))
+    with torch.cuda.device(dev):
+        rc = L.bbb_reparam_kl_fwd(segs, len(mus), draws, float(prior_mu), float(prior_sigma), seed, call0 & 0xFFFFFFFF,
+                                  0, ptr(parts), ptr(kl), 0, rng.call_dev_ptr(dev), cur_stream(dev))
+    check(rc, "bbb_reparam_kl_fwd")
+    return kl, outs
+
+
+def to_batch_innermost_bf16(x):
+    """fp32 [B, C, H, W] -> bf16 [C, H, W, B] (one rounding, nearest-even)."""
+    require_device(x)
+    x = x.contiguous()
+    B = x.shape[0]
+    plane = x.numel() // B
+    y = torch.empty(tuple(x.shape[1:]) + (B,), dtype=torch.bfloat16, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.lib().bbb_nchw_to_chwn_bf16(x.data_ptr(), y.data_ptr(), B, plane, cur_stream(x.device)), "bbb_nchw_to_chwn_bf16")
+    return y
+
+
+def conv2d_chwn_bf16_forward(x, w, bias, cin_khkw, stride=1, padding=0, dilation=1, act=None, out_f32=False, out=None):
+    """bf16 batch-innermost conv.  x: [E|1, Cin, H, W, B] bf16 (B % 8 == 0); w: [E|1, Cout, Kp] bf16 as written by
+    sample_weights_bf16; cin_khkw = (Cin, kh, kw); bias [E|1, Cout] fp32 or None -> y [E, Cout, Ho, Wo, B] bf16 (fp32
+    when out_f32)."""
+    require_device(x, w, dtype=torch.bfloat16)
+    require_device(bias)
+    x, w = x.contiguous(), w.contiguous()
+    bias = None if bias is None else bias.contiguous()
+    cin, kh, kw = cin_khkw
+    E = max(x.shape[0], w.shape[0])
+    if x.shape[0] not in (1, E) or w.shape[0] not in (1, E):
+        raise _lib.BBBHipError("leading (draw) dims of x and w must be 1 or equal")
+    Ex, Cin, H, W, B = x.shape
+    if Cin != cin or w.shape[2] != bf16_row_pitch(cin * kh * kw):
+        raise _lib.BBBHipError("weight pitch / channel count do not match the geometry")
+    (sh, sw), (ph, pw), (dh, dw) = _pair(stride), _pair(padding), _pair(dilation)
+    d = ConvDesc()
+    d.batch, d.cin, d.h, d.w, d.cout, d.kh, d.kw = B, Cin, H, W, w.shape[1], kh, kw
+    d.stride_h, d.stride_w, d.pad_h, d.pad_w, d.dil_h, d.dil_w = sh, sw, ph, pw, dh, dw
+    d.draws = E
+    d.x_draw_stride = 0 if (Ex == 1 and E > 1) else Cin * H * W * B
+    d.w_draw_stride = 0 if (w.shape[0] == 1 and E > 1) else w.shape[1] * w.shape[2]
+    d.b_draw_stride = 0 if (bias is None or (bias.shape[0] == 1 and E > 1)) else w.shape[1]
+    d.act = {None: 0, "relu": 1, "softplus": 2}[act]
+    ho = (H + 2 * ph - dh * (kh - 1) - 1) // sh + 1
+    wo = (W + 2 * pw - dw * (kw - 1) - 1) // sw + 1
+    shape = (E, w.shape[1], ho, wo, B)
+    dt = torch.float32 if out_f32 else torch.bfloat16
+    if out is None:
+        y = torch.empty(shape, dtype=dt, device=x.device)
+    else:
+        if out.numel() != E * w.shape[1] * ho * wo * B or not out.is_contiguous() or out.dtype != dt:
+            raise _lib.BBBHipError("out= must be a contiguous tensor of the output's size and dtype")
+        y = out.view(shape)
+    with torch.cuda.device(x.device):
+        check(_lib.lib().bbb_conv2d_chwn_bf16_fwd(ctypes.byref(d), x.data_ptr(), w.data_ptr(), ptr(bias), y.data_ptr(),
+                                                  1 if out_f32 else 0, cur_stream(x.device)), "bbb_conv2d_chwn_bf16_fwd")
+    return y
+
+
+def maxpool_chwn_bf16(x, k, s):
+    """MaxPool2d(k, s) on bf16 [..., H, W, B] (B % 8 == 0)."""
+    require_device(x, dtype=torch.bfloat16)
+    x = x.contiguous()
+    *lead, H, W, B = x.shape
+    planes = 1
+    for v in lead:
+        planes *= v
+    ho, wo = (H - k) // s + 1, (W - k) // s + 1
+    y = torch.empty((*lead, ho, wo, B), dtype=torch.bfloat16, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.lib().bbb_maxpool_chwn_bf16(x.data_ptr(), y.data_ptr(), planes, H, W, B, int(k), int(s), cur_stream(x.device)),
+              "bbb_maxpool_chwn_bf16")
+    return y
+
+
 def mc_tail_cb(logits, mean_over=0):
     """mc_tail for batch-innermost logits [E, C, B] -> [B, C]."""
     require_device(logits)

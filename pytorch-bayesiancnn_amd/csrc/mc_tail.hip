@@ -61,24 +61,29 @@ __global__ __launch_bounds__(64) void mc_tail_kernel(const float* __restrict__ l
 // Same reduction for logits stored batch-innermost, [E][C][B] (what the batched ensemble path produces): one thread
 // per image, lanes = consecutive images so every read is coalesced; the per-draw log-partition values sit in LDS.
 constexpr int kCbThreads = 64;
-__global__ __launch_bounds__(kCbThreads) void mc_tail_cb_kernel(const float* __restrict__ logits, int E, int B, int C, float sub,
-                                                                float* __restrict__ out) {
+constexpr int kCbRows = 16;
+// blockDim = (64 images, ny <= 16): phase 1 spreads the draws over y (log-partition of each draw), phase 2 spreads the
+// classes over y (log-sum-exp over draws) -- the serial chain per thread is E*C/ny long instead of E*C.
+__global__ __launch_bounds__(kCbThreads * kCbRows) void mc_tail_cb_kernel(const float* __restrict__ logits, int E, int B, int C,
+                                                                          float sub, float* __restrict__ out) {
     extern __shared__ float lz[];                       // [E][64]
-    const int b = blockIdx.x * kCbThreads + threadIdx.x;
+    const int tx = threadIdx.x, ty = threadIdx.y, ny = blockDim.y;
+    const int b = blockIdx.x * kCbThreads + tx;
     const bool ok = b < B;
     const int bb = ok ? b : B - 1;
-    for (int e = 0; e < E; ++e) {
+    for (int e = ty; e < E; e += ny) {
         const float* p = logits + (int64_t)e * C * B + bb;
         float mx = -INFINITY;
         for (int c = 0; c < C; ++c) mx = fmaxf(mx, p[(int64_t)c * B]);
         float se = 0.0f;
         for (int c = 0; c < C; ++c) se += expf(p[(int64_t)c * B] - mx);
-        lz[e * kCbThreads + threadIdx.x] = mx + logf(se);
+        lz[e * kCbThreads + tx] = mx + logf(se);
     }
-    for (int c = 0; c < C; ++c) {
+    __syncthreads();
+    for (int c = ty; c < C; c += ny) {
         float m = -INFINITY, s = 0.0f;
         for (int e = 0; e < E; ++e) {
-            const float ls = logits[((int64_t)e * C + c) * B + bb] - lz[e * kCbThreads + threadIdx.x];
+            const float ls = logits[((int64_t)e * C + c) * B + bb] - lz[e * kCbThreads + tx];
             const float nm = fmaxf(m, ls);
             s = s * expf(m - nm) + expf(ls - nm);
             m = nm;
@@ -174,7 +179,9 @@ extern "C" int bbb_mc_tail_cb(const float* logits, int draws, int batch, int cla
     if ((((uintptr_t)logits | (uintptr_t)lse_out) & 3u) != 0) return BBB_EALIGN;
     const float sub = mean_over > 0 ? logf((float)mean_over) : 0.0f;
     const int blocks = (batch + kCbThreads - 1) / kCbThreads;
-    hipLaunchKernelGGL(mc_tail_cb_kernel, dim3(blocks), dim3(kCbThreads), (size_t)draws * kCbThreads * sizeof(float),
+    const int mx = draws > classes ? draws : classes;
+    const int ny = mx < kCbRows ? mx : kCbRows;
+    hipLaunchKernelGGL(mc_tail_cb_kernel, dim3(blocks), dim3(kCbThreads, ny), (size_t)draws * kCbThreads * sizeof(float),
                        (hipStream_t)stream, logits, draws, batch, classes, sub, lse_out);
     return (int)hipGetLastError();
 }

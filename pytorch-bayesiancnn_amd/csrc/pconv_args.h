@@ -1,4 +1,4 @@
-// Kernel-argument block shared by the two pixel-major GEMM variants (pconv_gemm.hip, pconv_dma.hip).
+// Kernel-argument block shared by the pixel-major GEMM variants (pconv_gemm.hip, pconv_dma.hip, pconv_bf16.hip).
 #pragma once
 #include <stdint.h>
 
@@ -14,7 +14,7 @@ struct PConvArgs {
     const float* eps_ext;
     int64_t x_ds, w_ds, b_ds, y_ds;
     int32_t B, Cin, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, Ho, Wo;
-    int32_t K, khkw, act, sample;
+    int32_t K, Kp, khkw, act, sample;   // Kp: bf16 weight row pitch (pconv_bf16.hip)
     int32_t Mtiles, nbt, Ntiles, G, per_xcd, stagger;
 #ifdef BBB_TIMESTAMPS
     long long* ts;

@@ -1,0 +1,427 @@
+// bf16 pixel-major implicit GEMM (v_mfma_f32_32x32x16_bf16, fp32 accumulate) for the batch-innermost ensemble path.
+//
+// Same decomposition as pconv_gemm.hip -- one workgroup = (output pixel, 64 channels, 128 images), weights as the MFMA
+// "A" operand, images as the lanes -- with bf16 storage on both sides:
+//   activations  [draw][C][H][W][B]  bf16, B % 8 == 0 (rows move as 16-byte vectors)
+//   weights      [draw][Cout][Kp]    bf16, Kp = K rounded up to 8 (rows start 16-byte aligned; the pad is zero),
+//                                    K = Cin*kh*kw in the reference's (ci, r, q) order, written by the reparam kernel
+//   output       bf16 (hidden layers) or fp32 (the logits layer), bias fp32, fp32 accumulation and epilogue.
+// At 16x the fp32 matrix rate the contraction is no longer the bound; feeding it is.  So, unlike the fp32 kernel:
+//   * k runs over the FULL (ci, r, q) range: a weight k-tile is then one contiguous 128-byte run per channel (two
+//     16-byte loads per thread, no table), and taps that fall into the padding are zeroed on the image side only
+//     (their row offset is out of range for the buffer unit);
+//   * image rows are loaded 8 images per lane and stored to LDS as they are ([k][b]); the k-contiguous operand layout
+//     the bf16 MFMA wants comes from the LDS transpose read (ds_read_b64_tr_b16), not from a register shuffle.
+// The launches of a 10-draw CIFAR step are small (320-2560 workgroups of work) and a k-tile's operands come from the
+// Infinity Cache (the weights were written by the kernel before), ~1 us away: one workgroup walking its k range tile
+// by tile is latency-bound (measured 1.0-1.3 us per 64-k tile, 256 cycles of which are MFMA).  So the k range is also
+// split INSIDE the workgroup: KG groups of 4 waves each own every KG-th 64-k tile, with their own LDS stage and their
+// own loads in flight, and the partial accumulators are summed through LDS in a fixed order (deterministic).
+// LDS pitches: image rows 320 B (= 64 B mod 256: the four rows of a transpose read and the two 16-column halves of a
+// 32-lane group land on disjoint banks), weight rows 144 B (conflict-free for the 16-byte reads).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "../../include/bbb_hip.h"
+#include "bbb_common.cuh"
+#include "pconv_args.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 64;
+constexpr int LDWB = BK + 8;             // weight row pitch (elements): 144 B
+constexpr int KCH = 256;                 // k entries per decode chunk and k-group
+constexpr int TPC = KCH / BK;
+
+__device__ __forceinline__ uint16_t f2bf(float v) {              // round to nearest even (v_cvt_pk_bf16_f32)
+    return __builtin_bit_cast(uint16_t, (__bf16)v);
+}
+
+// Workgroup = KG k-groups x (WN x WM) waves; every wave owns a 64-channel x 64-image block of D (2 x 2 MFMA tiles, so
+// each LDS operand read feeds two MFMAs: the LDS pipe, not the matrix pipe, is what this kernel saturates first).
+//   (WN, WM) = (2, 2): 128 channels x 128 images    (1, 4): 64 x 256    (1, 2): 64 x 128, two waves
+template <bool OUT_F32, int WN, int WM, int KG>
+__global__ __launch_bounds__(64 * WN * WM * KG) void pconv_bf16_kernel(const PConvArgs p) {
+    constexpr int GT = 64 * WN * WM;                              // threads per k-group
+    constexpr int BN = 64 * WN, BM = 64 * WM;
+    constexpr int LDXB = BM + 32;                                 // image row pitch: = 64 B mod 256 for BM = 128, 256
+    constexpr int WPASS = BN * 8 / GT, WROWS = GT / 8;            // weight tile: 8 lanes x 16 B per 128-byte row
+    constexpr int XL = BM / 8, XROWS = GT / XL, XPASS = BK / XROWS;   // image tile: XL lanes x 16 B per row
+    constexpr int KCHG = KCH * KG;
+    constexpr int kStage = BK * LDXB + BN * LDWB;                 // elements per k-group stage
+    // dynamic LDS only (a static array in front would shift the 16-byte alignment of the carve)
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+    const int kg = __builtin_amdgcn_readfirstlane((int)threadIdx.x / GT);
+    uint16_t* Xs = smem + kg * kStage;
+    uint16_t* Ws = Xs + BK * LDXB;
+    int32_t* kt_all = reinterpret_cast<int32_t*>(smem + KG * kStage);      // [2][KCHG], filled by the first KCHG threads
+
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7;
+    const int64_t item = (int64_t)xcd * p.per_xcd + (bid >> 3);
+    const int64_t item_end = (int64_t)(xcd + 1) * p.per_xcd;
+    if (item >= item_end || item >= (int64_t)p.G * p.Mtiles) return;
+    const int g = (int)(item / p.Mtiles);
+    const int j = (int)(item - (int64_t)g * p.Mtiles);
+    const int e = g / p.Ntiles;
+    const int n0 = (g - e * p.Ntiles) * BN;
+    const int pix = j / p.nbt;
+    const int b0 = (j - pix * p.nbt) * BM;
+    const int oh = pix / p.Wo, ow = pix - oh * p.Wo;
+    const int ihb = oh * p.sh - p.ph, iwb = ow * p.sw - p.pw;
+    const int K = p.K, Kp = p.Kp;
+    const int niter = (K + BK * KG - 1) / (BK * KG);              // every group runs the same number of iterations
+
+    const int tid = (int)threadIdx.x - kg * GT;                   // thread within its k-group
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = (wave / WM) * 64, wm = (wave % WM) * 64;
+
+    constexpr uint32_t kOOB = 0xFFFFFFF0u;
+    constexpr uint32_t kXInv = 0xFFFF0000u;
+    const uint16_t* xb = reinterpret_cast<const uint16_t*>(p.x) + (int64_t)e * p.x_ds;
+    const uint16_t* wb = reinterpret_cast<const uint16_t*>(p.w) + (int64_t)e * p.w_ds;
+    const int64_t x_bytes = (int64_t)p.Cin * p.H * p.W * p.B * 2;
+    const int64_t w_bytes = (int64_t)p.Cout * Kp * 2;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(xb), 0, (int)x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(wb), 0, (int)w_bytes, 0x00020000);
+
+    const int wr = tid >> 3, wseg = (tid & 7) * 8;
+    const uint32_t wbase = (uint32_t)(n0 + wr) * (uint32_t)Kp * 2u + (uint32_t)wseg * 2u;
+    const uint32_t wstep = (uint32_t)WROWS * (uint32_t)Kp * 2u;
+    const int xkr = tid / XL, xb8 = (tid % XL) * 8;
+    const uint32_t xcol = (uint32_t)(b0 + xb8) * 2u;
+
+    const float inv_khkw = 1.0f / (float)p.khkw, inv_kw = 1.0f / (float)p.kw;
+    auto fill_chunk = [&](int chunk) {
+        for (int i = (int)threadIdx.x; i < KCHG; i += GT * KG) {
+            const int k = chunk * KCHG + i;
+            uint32_t xo = kXInv;
+            if (k < K) {
+                int ci = (int)((float)k * inv_khkw);
+                int rq = k - ci * p.khkw;
+                if (rq < 0) { --ci; rq += p.khkw; } else if (rq >= p.khkw) { ++ci; rq -= p.khkw; }
+                int r = (int)((float)rq * inv_kw);
+                int q = rq - r * p.kw;
+                if (q < 0) { --r; q += p.kw; } else if (q >= p.kw) { ++r; q -= p.kw; }
+                const int ih = ihb + r * p.dh, iw = iwb + q * p.dw;
+                if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W)
+                    xo = (uint32_t)((ci * p.H + ih) * p.W + iw) * (uint32_t)p.B * 2u;
+            }
+            kt_all[(chunk & 1) * KCHG + i] = (int32_t)xo;
+        }
+    };
+
+    u32x4 wreg[WPASS], xreg[XPASS];
+    auto load_tile = [&](int it) {                       // iteration `it`: this group's 64-k tile is it*KG + kg
+        const int buf = (it / TPC) & 1;
+        const int kb = ((it % TPC) * KG + kg) * BK;
+        uint32_t wo = wbase + (uint32_t)(it * KG + kg) * (BK * 2u);
+        uint32_t xo[XPASS];
+#pragma unroll
+        for (int ps = 0; ps < XPASS; ++ps) xo[ps] = (uint32_t)kt_all[buf * KCHG + kb + xkr + ps * XROWS] + xcol;
+#ifdef BBB_BF16_PROBE
+        if (p.stagger & 1) { for (int ps = 0; ps < XPASS; ++ps) xo[ps] = kOOB; }
+        if (p.stagger & 2) wo = 0x7FFFFF00u;
+#endif
+#pragma unroll
+        for (int ps = 0; ps < XPASS; ++ps) xreg[ps] = __builtin_amdgcn_raw_buffer_load_b128(xrs, xo[ps], 0, 0);
+#pragma unroll
+        for (int ps = 0; ps < WPASS; ++ps) wreg[ps] = __builtin_amdgcn_raw_buffer_load_b128(wrs, wo + (uint32_t)ps * wstep, 0, 0);
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int ps = 0; ps < WPASS; ++ps) *reinterpret_cast<u32x4*>(&Ws[(wr + ps * WROWS) * LDWB + wseg]) = wreg[ps];
+#pragma unroll
+        for (int ps = 0; ps < XPASS; ++ps) *reinterpret_cast<u32x4*>(&Xs[(xkr + ps * XROWS) * LDXB + xb8]) = xreg[ps];
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.0f;
+
+    const int lrow = lane & 31, lk = lane >> 5;
+    // transpose-read address of this lane inside a 16-k step: 16-lane group -> (k half, 16-column block); the lane
+    // supplies row (t >> 2) of 4, columns 4*(t & 3)..+3, and receives column t, rows 0..3
+    const int tg = lane >> 4, tt = lane & 15;
+    const int tr_off = ((8 * (tg >> 1) + (tt >> 2)) * LDXB + wm + 16 * (tg & 1) + 4 * (tt & 3));
+    typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+
+    auto mma_tile = [&]() {
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            bf16x8 b[2], a[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const s16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(&Xs[tr_off + mt * 32 + kk * 16 * LDXB]));
+                const s16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(&Xs[tr_off + mt * 32 + (kk * 16 + 4) * LDXB]));
+                b[mt] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+                a[nt] = *reinterpret_cast<const bf16x8*>(&Ws[(wn + nt * 32 + lrow) * LDWB + kk * 16 + lk * 8]);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[nt], b[mt], acc[nt][mt], 0, 0, 0);
+        }
+    };
+
+#ifdef BBB_TIMESTAMPS   // debugging aid: s_memtime stamps of wave 0 of two workgroups
+    __shared__ long long tsbuf[120];
+    const bool tson = p.ts && (bid == 8 * 3 || bid == 8 * 20) && threadIdx.x == 0;
+    int tsi = 0;
+#define TS() do { if (tson && tsi < 120) tsbuf[tsi++] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define TS() do { } while (0)
+#endif
+    {
+        TS();
+        fill_chunk(0);
+        __syncthreads();
+        load_tile(0);
+        if (KCHG < K) fill_chunk(1);
+        store_tile();
+        __syncthreads();
+        TS();
+        for (int t = 0; t < niter; ++t) {
+            const bool more = (t + 1) < niter;
+            if (more) load_tile(t + 1);
+            if ((t % TPC) == 1 && t / TPC >= 1 && (t / TPC + 1) * KCHG < K) fill_chunk(t / TPC + 1);
+            TS();
+            mma_tile();
+            TS();
+            __syncthreads();
+            TS();
+            if (more) store_tile();
+            TS();
+            __syncthreads();
+            TS();
+        }
+    }
+#ifdef BBB_TIMESTAMPS
+    if (tson) { long long* o = p.ts + (bid == 8 * 3 ? 0 : 128); for (int i = 0; i < tsi; ++i) o[i] = tsbuf[i]; }
+#endif
+
+    // ---- cross-group reduction (fixed order: group 0 + 1 + ...), through the now idle stage memory ----
+    if (KG > 1) {
+        float* red = reinterpret_cast<float*>(smem);               // [KG-1][64][GT] floats
+        if (kg > 0) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[((kg - 1) * 64 + (nt * 2 + mt) * 16 + r) * GT + tid] = acc[nt][mt][r];
+        }
+        __syncthreads();
+        if (kg > 0) return;
+#pragma unroll
+        for (int g2 = 1; g2 < KG; ++g2)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[nt][mt][r] += red[((g2 - 1) * 64 + (nt * 2 + mt) * 16 + r) * GT + tid];
+    }
+
+    // ---- epilogue: rows = channels, lanes = images ----
+    const int HoWo = p.Ho * p.Wo;
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.bias ? p.bias + (int64_t)e * p.b_ds : p.w), 0, p.bias ? p.Cout * 4 : 0, 0x00020000);
+    constexpr int OSZ = OUT_F32 ? 4 : 2;
+    char* yb = reinterpret_cast<char*>(p.y) + (int64_t)e * p.y_ds * OSZ;
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(yb, 0, (int)((int64_t)p.Cout * HoWo * p.B * OSZ), 0x00020000);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = n0 + wn + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            const float bv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brs, (uint32_t)n * 4u, 0, 0));
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int b = b0 + wm + mt * 32 + lrow;
+                const uint32_t off = ((b < p.B) & (n < p.Cout)) ? (uint32_t)(((int64_t)n * HoWo + pix) * p.B + b) * (uint32_t)OSZ : kOOB;
+                const float v = bbb::apply_act(acc[nt][mt][r] + bv, p.act);
+                if (OUT_F32) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), yrs, off, 0, 0);
+                else         __builtin_amdgcn_raw_buffer_store_b16(f2bf(v), yrs, off, 0, 0);
+            }
+        }
+}
+
+template <bool OUT_F32, int WN, int WM, int KG>
+int launch_cfg(const PConvArgs& a, int64_t blocks, hipStream_t st) {
+    constexpr int kSmem = KG * (BK * (64 * WM + 32) + 64 * WN * LDWB) * 2 + 2 * KCH * KG * 4;
+    constexpr int kRed = (KG - 1) * 64 * (64 * WN * WM) * 4;
+    static_assert(kRed <= KG * (BK * (64 * WM + 32) + 64 * WN * LDWB) * 2, "reduction buffer must fit in the stage memory");
+    static_assert(kSmem <= 160 * 1024, "LDS");
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(&pconv_bf16_kernel<OUT_F32, WN, WM, KG>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, kSmem);
+        if (er != hipSuccess) return (int)er;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((pconv_bf16_kernel<OUT_F32, WN, WM, KG>), dim3((unsigned)blocks), dim3(64 * WN * WM * KG), kSmem, st, a);
+    return (int)hipGetLastError();
+}
+
+template <bool OUT_F32>
+int launch_shape(const PConvArgs& a, int shape, int kgs, int64_t blocks, hipStream_t st) {
+    if (shape == 22) return kgs == 2 ? launch_cfg<OUT_F32, 2, 2, 2>(a, blocks, st) : launch_cfg<OUT_F32, 2, 2, 1>(a, blocks, st);
+    if (shape == 14) return kgs == 2 ? launch_cfg<OUT_F32, 1, 4, 2>(a, blocks, st) : launch_cfg<OUT_F32, 1, 4, 1>(a, blocks, st);
+    return kgs == 2 ? launch_cfg<OUT_F32, 1, 2, 2>(a, blocks, st) : launch_cfg<OUT_F32, 1, 2, 1>(a, blocks, st);
+}
+
+// maxpool over [planes][H][W][B] bf16, 8 images per thread (bf16 order = fp32 order of the widened values: exact)
+__global__ __launch_bounds__(256) void maxpool_chwn_bf16_kernel(const u32x4* __restrict__ x, u32x4* __restrict__ y, int64_t total8,
+                                                                int H, int W, int Ho, int Wo, int B8, int k, int s) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total8) return;
+    const int b8 = (int)(i % B8);
+    int64_t t = i / B8;
+    const int ow = (int)(t % Wo);
+    t /= Wo;
+    const int oh = (int)(t % Ho);
+    const int64_t pl = t / Ho;
+    const u32x4* xp = x + ((pl * H + (int64_t)oh * s) * W + (int64_t)ow * s) * B8 + b8;
+    float m[8];
+    {
+        const u32x4 v = xp[0];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            m[2 * u] = __builtin_bit_cast(float, v[u] << 16);
+            m[2 * u + 1] = __builtin_bit_cast(float, v[u] & 0xFFFF0000u);
+        }
+    }
+    for (int a = 0; a < k; ++a)
+        for (int c = 0; c < k; ++c) {
+            const u32x4 v = xp[((int64_t)a * W + c) * B8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                m[2 * u] = fmaxf(m[2 * u], __builtin_bit_cast(float, v[u] << 16));
+                m[2 * u + 1] = fmaxf(m[2 * u + 1], __builtin_bit_cast(float, v[u] & 0xFFFF0000u));
+            }
+        }
+    u32x4 o;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        o[u] = (__builtin_bit_cast(uint32_t, m[2 * u]) >> 16) | (__builtin_bit_cast(uint32_t, m[2 * u + 1]) & 0xFFFF0000u);
+    y[i] = o;
+}
+
+// fp32 NCHW [B][C][H][W] -> bf16 [C][H][W][B]: 32x32 tile transpose through LDS (planes = C*H*W)
+__global__ __launch_bounds__(256) void nchw_to_chwn_bf16_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, int B, int P) {
+    __shared__ float tile[32][33];
+    const int p0 = blockIdx.x * 32, bb0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int bi = bb0 + r, pi = p0 + tx;
+        tile[r][tx] = (bi < B && pi < P) ? x[(int64_t)bi * P + pi] : 0.0f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int pi = p0 + r, bi = bb0 + tx;
+        if (pi < P && bi < B) y[(int64_t)pi * B + bi] = f2bf(tile[tx][r]);
+    }
+}
+
+}  // namespace
+
+extern "C" int bbb_conv2d_chwn_bf16_fwd(const bbb_conv_desc_t* d, const void* x, const void* w, const float* bias, void* y,
+                                        int out_f32, void* stream) {
+    if (d == nullptr || x == nullptr || w == nullptr || y == nullptr) return BBB_EINVAL;
+    if (d->batch <= 0 || d->cin <= 0 || d->h <= 0 || d->w <= 0 || d->cout <= 0 || d->kh <= 0 || d->kw <= 0 ||
+        d->stride_h <= 0 || d->stride_w <= 0 || d->pad_h < 0 || d->pad_w < 0 || d->dil_h <= 0 || d->dil_w <= 0 ||
+        d->draws <= 0 || d->act < 0 || d->act > 2)
+        return BBB_EINVAL;
+    if (d->batch % 8 != 0) return BBB_ESHAPE;        // rows of 16-byte vectors of 8 bf16 images
+    const int ho = (d->h + 2 * d->pad_h - d->dil_h * (d->kh - 1) - 1) / d->stride_h + 1;
+    const int wo = (d->w + 2 * d->pad_w - d->dil_w * (d->kw - 1) - 1) / d->stride_w + 1;
+    if (ho <= 0 || wo <= 0) return BBB_ESHAPE;
+    const int64_t K = (int64_t)d->cin * d->kh * d->kw;
+    const int64_t Kp = (K + 7) & ~(int64_t)7;
+    if (K >= (1 << 24)) return BBB_ESHAPE;           // float-reciprocal k decode is exact below 2^24
+    if ((int64_t)d->cin * d->h * d->w * d->batch * 2 > 0xFFFE0000LL || (int64_t)d->cout * ho * wo * d->batch * 4 > 0xFFFE0000LL ||
+        ((int64_t)d->cout + 64) * Kp * 2 > 0x7FFFFFFFLL || (int64_t)d->batch * 2 > 0xFFFFLL)
+        return BBB_ESHAPE;
+    if ((((uintptr_t)x | (uintptr_t)w) & 15u) != 0 || ((uintptr_t)y & (out_f32 ? 3u : 1u)) != 0 || ((uintptr_t)bias & 3u) != 0)
+        return BBB_EALIGN;
+    if ((d->x_draw_stride & 7) != 0 || (d->w_draw_stride & 7) != 0) return BBB_EALIGN;
+    PConvArgs a = {};
+    a.B = d->batch; a.Cin = d->cin; a.H = d->h; a.W = d->w; a.Cout = d->cout; a.kh = d->kh; a.kw = d->kw;
+    a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w; a.dh = d->dil_h; a.dw = d->dil_w;
+    a.Ho = ho; a.Wo = wo; a.K = (int32_t)K; a.Kp = (int32_t)Kp; a.khkw = d->kh * d->kw; a.act = d->act;
+    a.x_ds = d->x_draw_stride; a.w_ds = d->w_draw_stride; a.b_ds = d->b_draw_stride;
+    a.y_ds = (int64_t)d->cout * ho * wo * d->batch;
+    a.x = reinterpret_cast<const float*>(x); a.w = reinterpret_cast<const float*>(w); a.bias = bias;
+    a.y = reinterpret_cast<float*>(y);
+    // tile shape: LDS-pipe cycles per unit of useful work (see the kernel comment), including the waste of ragged
+    // channel / image tiles: 128x128 -> 256, 64x256 -> 288, 64x128 (two waves) -> 320
+    auto waste = [](int n, int t) { return (double)(((n + t - 1) / t) * t) / (double)n; };
+    const double c22 = 256.0 * waste(a.Cout, 128) * waste(a.B, 128);
+    const double c14 = 288.0 * waste(a.Cout, 64) * waste(a.B, 256);
+    const double c12 = 320.0 * waste(a.Cout, 64) * waste(a.B, 128);
+    int shape = (c22 <= c14 && c22 <= c12) ? 22 : (c14 <= c12 ? 14 : 12);
+    if (const char* f = getenv("BBB_BF16_SHAPE")) { const int v = atoi(f); if (v == 22 || v == 14 || v == 12) shape = v; }
+    const int bn = shape == 22 ? 128 : 64, bm = shape == 14 ? 256 : 128;
+    a.Ntiles = (a.Cout + bn - 1) / bn;
+    a.G = a.Ntiles * d->draws;
+    a.nbt = (a.B + bm - 1) / bm;
+    const int64_t mt = (int64_t)ho * wo * a.nbt;
+    if (mt > 0x7fffffffLL) return BBB_ESHAPE;
+    a.Mtiles = (int)mt;
+    const int64_t items = (int64_t)a.G * mt;
+    const int64_t per = (items + 7) / 8;
+    const int64_t blocks = 8 * per;
+    if (blocks > 0x7fffffffLL) return BBB_ESHAPE;
+    a.per_xcd = (int32_t)per;
+    // a second k-group (its own stage, its own loads in flight, deterministic LDS reduction) when the launch cannot
+    // fill the chip with workgroups and the k loop is long: then per-tile latency, not LDS throughput, sets the pace
+    const int t64 = (int)((K + BK - 1) / BK);
+    int kgs = (items < 512 && t64 >= 8) ? 2 : 1;
+    if (const char* f = getenv("BBB_BF16_KG")) { const int v = atoi(f); if (v == 1 || v == 2) kgs = v; }
+#ifdef BBB_BF16_PROBE
+    if (const char* f = getenv("BBB_BF16_PROBE")) a.stagger = atoi(f);
+#endif
+#ifdef BBB_TIMESTAMPS
+    { const char* tv = getenv("BBB_TS"); a.ts = tv ? (long long*)strtoull(tv, nullptr, 0) : nullptr; }
+#endif
+    hipStream_t st = (hipStream_t)stream;
+    return out_f32 ? launch_shape<true>(a, shape, kgs, blocks, st) : launch_shape<false>(a, shape, kgs, blocks, st);
+}
+
+extern "C" int bbb_maxpool_chwn_bf16(const void* x, void* y, int64_t planes, int h, int w, int batch, int k, int s, void* stream) {
+    if (x == nullptr || y == nullptr || planes <= 0 || h <= 0 || w <= 0 || batch <= 0 || k <= 0 || s <= 0) return BBB_EINVAL;
+    if (batch % 8 != 0 || h < k || w < k) return BBB_ESHAPE;
+    if ((((uintptr_t)x | (uintptr_t)y) & 15u) != 0) return BBB_EALIGN;
+    const int ho = (h - k) / s + 1, wo = (w - k) / s + 1;
+    const int64_t total8 = planes * ho * wo * (batch / 8);
+    const int64_t blocks = (total8 + 255) / 256;
+    if (blocks > 0x7fffffffLL) return BBB_ESHAPE;
+    hipLaunchKernelGGL(maxpool_chwn_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const u32x4*>(x), reinterpret_cast<u32x4*>(y), total8, h, w, ho, wo, batch / 8, k, s);
+    return (int)hipGetLastError();
+}
+
+extern "C" int bbb_nchw_to_chwn_bf16(const float* x, void* y, int batch, int64_t plane, void* stream) {
+    if (x == nullptr || y == nullptr || batch <= 0 || plane <= 0 || plane > 0x7fffffffLL) return BBB_EINVAL;
+    if (((uintptr_t)x & 3u) != 0 || ((uintptr_t)y & 1u) != 0) return BBB_EALIGN;
+    const dim3 grid((unsigned)((plane + 31) / 32), (unsigned)((batch + 31) / 32));
+    if (grid.y > 65535u) return BBB_ESHAPE;
+    hipLaunchKernelGGL(nchw_to_chwn_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, reinterpret_cast<uint16_t*>(y), batch,
+                       (int)plane);
+    return (int)hipGetLastError();
+}

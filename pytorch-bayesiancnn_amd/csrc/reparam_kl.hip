@@ -57,6 +57,8 @@ __device__ __forceinline__ float kl_term(float mu, float sigma, float mu0, float
     return 0.5f * t;
 }
 
+__device__ __forceinline__ uint16_t bf16_bits(float v) { return __builtin_bit_cast(uint16_t, (__bf16)v); }
+
 __device__ __forceinline__ int find_segment(const ReparamArgs& a, int chunk) {
     int s = 0;
     while (s + 1 < a.nseg && chunk >= a.chunk_begin[s + 1]) ++s;
@@ -125,12 +127,37 @@ __global__ __launch_bounds__(kThreads) void reparam_kl_fwd_kernel(const ReparamA
                 float z[4];
                 const int64_t o = (int64_t)e * sg.draw_stride + i0;
                 if (sg.eps != nullptr) {
+                    const int64_t oe = sg.w_row_len != 0 ? (int64_t)e * sg.n + i0 : o;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) z[j] = j < cnt ? sg.eps[o + j] : 0.0f;
+                    for (int j = 0; j < 4; ++j) z[j] = j < cnt ? sg.eps[oe + j] : 0.0f;
                 } else {
                     bbb::normal4(g, sg.stream_id, call0 + (uint32_t)e, a.k0, a.k1, z);
                 }
-                if (aligned && cnt == 4) {
+                if (sg.w_row_len != 0) {
+                    // bf16 weights for the bf16 GEMM: rows of w_row_len elements at a pitch rounded up to 8 (the pad is
+                    // written as zeros by whoever holds the row's last element), round-to-nearest-even from the fp32 sample
+                    uint16_t* wb = reinterpret_cast<uint16_t*>(sg.w) + (int64_t)e * sg.draw_stride;
+                    const int64_t rl = sg.w_row_len, pitch = (rl + 7) & ~(int64_t)7;
+                    const int64_t row = i0 / rl, col = i0 - row * rl;
+                    if (cnt == 4 && col + 4 <= rl && ((rl & 3) == 0) && (((uintptr_t)wb & 7u) == 0) && ((sg.draw_stride & 3) == 0)) {
+                        uint32_t lo = (uint32_t)bf16_bits(mu[0] + z[0] * sigma[0]) | ((uint32_t)bf16_bits(mu[1] + z[1] * sigma[1]) << 16);
+                        uint32_t hi = (uint32_t)bf16_bits(mu[2] + z[2] * sigma[2]) | ((uint32_t)bf16_bits(mu[3] + z[3] * sigma[3]) << 16);
+                        *reinterpret_cast<uint2*>(wb + row * pitch + col) = make_uint2(lo, hi);
+                    } else {
+                        for (int j = 0; j < cnt; ++j) {
+                            const int64_t ij = i0 + j, rj = ij / rl;
+                            wb[rj * pitch + (ij - rj * rl)] = bf16_bits(mu[j] + z[j] * sigma[j]);
+                        }
+                    }
+                    // whoever writes the last element of a row also zeroes the row's pad (pitch - rl < 8 elements)
+                    if (pitch != rl) {
+                        for (int j = 0; j < cnt; ++j) {
+                            const int64_t ij = i0 + j, rj = ij / rl;
+                            if (ij - rj * rl == rl - 1)
+                                for (int64_t c = rl; c < pitch; ++c) wb[rj * pitch + c] = 0;
+                        }
+                    }
+                } else if (aligned && cnt == 4) {
                     f32x4 w4;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) w4[j] = mu[j] + z[j] * sigma[j];   // mul then add, like the reference
@@ -278,8 +305,9 @@ int fill_args(ReparamArgs& a, const bbb_segment_t* segs, int nseg, int draws, bo
         const bbb_segment_t& g = segs[s];
         if (g.mu == nullptr || g.rho == nullptr || g.n <= 0) return BBB_EINVAL;
         if (g.draw_stride < g.n && draws > 1 && (g.w || g.eps)) return BBB_EINVAL;
-        if ((((uintptr_t)g.mu | (uintptr_t)g.rho | (uintptr_t)g.w | (uintptr_t)g.sigma | (uintptr_t)g.eps) & 3u) != 0)
+        if ((((uintptr_t)g.mu | (uintptr_t)g.rho | (g.w_row_len ? 0 : (uintptr_t)g.w) | (uintptr_t)g.sigma | (uintptr_t)g.eps) & 3u) != 0)
             return BBB_EALIGN;
+        if (g.w_row_len != 0 && (bwd || g.w == nullptr || g.n % g.w_row_len != 0 || ((uintptr_t)g.w & 1u))) return BBB_EINVAL;
         a.seg[s] = g;
         a.chunk_begin[s] = chunks;
         chunks += (int)((g.n + (int64_t)kChunk * gpt - 1) / ((int64_t)kChunk * gpt));

@@ -1,0 +1,189 @@
+"""bf16 storage path (BASELINE.json configs[1]: "Bayesian3Conv3FC CIFAR-10, BBB layers, bf16, batch 256") on the MI355X
+against the oracle's bf16 storage model and against the fp32 path.  Stated tolerances:
+  * one GEMM launch, fp32 output, same bf16 operands: 2e-5 relative to sum_k |w||x| (fp32 accumulation order only);
+  * one GEMM launch, bf16 output: half a bf16 ulp of the result (2^-9 relative) on top of that;
+  * whole model vs the oracle's bf16 model (same rounding points, fp64 accumulate): a hidden activation that lands
+    within accumulation error of a rounding boundary flips by one bf16 ulp (0.4 %) and the flips spread through the
+    next layers -> logits within 2e-2 * max|logit|;
+  * whole Monte-Carlo step vs the fp32 path (the reference's arithmetic): log-probabilities within 2e-2 of their
+    largest magnitude (measured: 0.5 %), KL identical (it never touches bf16).
+Run with -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+import bbb_numpy as O
+import ref_port_torch as P
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import layers  # noqa: F401
+    from bbb_hip import ops, rng, ensemble, zoo
+    return dict(ops=ops, rng=rng, ens=ensemble, zoo=zoo)
+
+
+def _bf(t):
+    return t.to(torch.bfloat16)
+
+
+def _pack_w(w):
+    """[E, Cout, Cin, kh, kw] fp32 -> the kernel's operand: bf16 [E, Cout, Kp], zero pad."""
+    E, Cout = w.shape[:2]
+    K = w[0, 0].numel()
+    Kp = (K + 7) & ~7
+    out = torch.zeros(E, Cout, Kp, dtype=torch.bfloat16, device=w.device)
+    out[:, :, :K] = _bf(w.reshape(E, Cout, K))
+    return out
+
+
+CONV_CASES = [
+    # B, Cin, H, W, Cout, k, stride, pad, dil, E, x_shared
+    (16, 3, 32, 32, 64, 11, 4, 5, 1, 2, True),      # AlexNet conv1: K = 363 (padded rows), one channel tile
+    (24, 3, 16, 16, 32, 5, 1, 2, 1, 1, True),       # 3Conv3FC conv1: K = 75, B not a multiple of 128
+    (136, 6, 9, 7, 70, 3, 1, 1, 1, 2, False),       # two batch tiles + ragged tile, Cout not a multiple of 64
+    (8, 16, 6, 6, 130, 3, 2, 1, 2, 3, False),       # stride + dilation, three channel tiles
+    (8, 1, 12, 12, 6, 5, 1, 0, 1, 1, True),         # LeNet conv1: K = 25
+    (40, 520, 1, 1, 10, 1, 1, 0, 1, 2, False),      # linear layer, K = 520 (more than two 256-entry decode chunks)
+    (8, 64, 4, 4, 64, 5, 1, 2, 1, 1, True),         # K = 1600: seven decode chunks
+]
+
+
+@pytest.mark.parametrize("B,Cin,H,W,Cout,k,s,p,d,E,xs", CONV_CASES)
+@pytest.mark.parametrize("out_f32", [True, False])
+def test_conv_bf16_vs_oracle(env, B, Cin, H, W, Cout, k, s, p, d, E, xs, out_f32):
+    torch.manual_seed(B * 7 + Cout)
+    x = torch.randn(1 if xs else E, B, Cin, H, W, device="cuda")
+    w = torch.randn(E, Cout, Cin, k, k, device="cuda") * 0.2
+    bias = torch.randn(E, Cout, device="cuda")
+    xb = _bf(x.permute(0, 2, 3, 4, 1).contiguous())                       # [E|1, C, H, W, B]
+    y = env["ops"].conv2d_chwn_bf16_forward(xb, _pack_w(w), bias, (Cin, k, k), s, p, d, act="softplus", out_f32=out_f32)
+    assert y.dtype == (torch.float32 if out_f32 else torch.bfloat16)
+    got = y.float().permute(0, 4, 1, 2, 3).cpu().numpy()                 # [E, B, Cout, Ho, Wo]
+    xr = xb.float().permute(0, 4, 1, 2, 3).cpu().numpy()
+    wr = _bf(w).float().cpu().numpy()
+    for e in range(E):
+        xe = xr[0 if xs else e]
+        pre = O.conv2d(xe, wr[e], bias[e].cpu().numpy(), s, p, d)
+        mag = O.conv2d(np.abs(xe), np.abs(wr[e]), np.abs(bias[e].cpu().numpy()), s, p, d)
+        want = O.softplus_act(pre)
+        tol = 2e-5 * mag + 2e-6                                          # softplus is 1-Lipschitz
+        if not out_f32:
+            tol = tol + np.abs(want) * 2.0 ** -8
+        assert got[e].shape == want.shape
+        err = np.abs(got[e] - want)
+        assert (err <= tol).all(), f"draw {e}: max excess {(err - tol).max():.3e}"
+
+
+def test_sampled_weights_bf16_are_the_rounded_fp32_samples(env):
+    """Same Philox stream, same fp32 arithmetic, one nearest-even rounding; pad columns untouched (zero); biases fp32."""
+    torch.manual_seed(0)
+    shapes = [(64, 3, 11, 11), (64,), (10, 33), (10,), (16, 8, 3, 3), (16,), (7, 5), (7,)]
+    mus = [torch.randn(s, device="cuda") * 0.1 for s in shapes]
+    rhos = [torch.randn(s, device="cuda") * 0.3 - 4 for s in shapes]
+    ids = list(range(len(shapes)))
+    E = 3
+    ws, _, kl32 = env["ops"].reparam_kl_forward(mus, rhos, 0.0, 0.1, ids, 99, 5, draws=E)
+    kl16, outs = env["ops"].sample_weights_bf16(mus, rhos, 0.0, 0.1, ids, 99, 5, E)
+    assert torch.equal(kl16, kl32)
+    for w32, o, s in zip(ws, outs, shapes):
+        if len(s) == 1:
+            assert o.dtype == torch.float32 and torch.equal(o, w32)
+            continue
+        K = int(np.prod(s[1:]))
+        assert o.dtype == torch.bfloat16 and o.shape == (E, s[0], (K + 7) & ~7)
+        assert torch.equal(o[:, :, :K], _bf(w32.reshape(E, s[0], K)))
+        assert not o[:, :, K:].any()
+
+
+def test_layout_and_pool_bf16_exact(env):
+    torch.manual_seed(1)
+    x = torch.randn(24, 5, 9, 11, device="cuda")
+    xb = env["ops"].to_batch_innermost_bf16(x)
+    assert torch.equal(xb, _bf(x).permute(1, 2, 3, 0).contiguous())
+    for k, s in ((2, 2), (3, 2), (3, 1)):
+        got = env["ops"].maxpool_chwn_bf16(xb.unsqueeze(0), k, s)[0]
+        want = torch.nn.functional.max_pool2d(_bf(x).float(), k, s).to(torch.bfloat16).permute(1, 2, 3, 0)
+        assert torch.equal(got, want.contiguous())
+
+
+def _oracle_eps_fn(names, seed, call):
+    idx = {n: i for i, n in enumerate(names)}
+
+    def fn(name, kind, shape):
+        stream = 4 * idx[name] + {"W": 0, "bias": 1}[kind]
+        return O.normal_eps(seed, call, stream, int(np.prod(shape))).reshape(shape)
+    return fn
+
+
+@pytest.mark.parametrize("net_type,B,cin,hw", [("3conv3fc", 256, 3, 32), ("alexnet", 64, 3, 32), ("lenet", 32, 1, 32)])
+def test_model_bf16_vs_oracle_bf16_model(env, net_type, B, cin, hw):
+    """configs[1] shape (3Conv3FC, batch 256) + the other two topologies: every draw of the bf16 path vs the oracle's
+    bf16 storage model under the same Philox noise."""
+    torch.manual_seed(11)
+    params = P.init_params(net_type, cin, 10, P.CONFIG_PRIORS)
+    net = env["zoo"].getModel(net_type, cin, 10, P.CONFIG_PRIORS, "bbb", "softplus")
+    sd = {f"{n}.{k}": v for n, p in params.items() if not n.startswith("_") for k, v in p.items()}
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda()
+    env["rng"].assign_stream_ids(net)
+    x = torch.rand(B, cin, hw, hw)
+    E, seed, call0 = 2, 4242, 7
+    with torch.no_grad():
+        logits, kl = env["ens"].mc_logits(net, x.cuda(), E, seed, call0, precision="bf16")
+        logits32, kl32 = env["ens"].mc_logits(net, x.cuda(), E, seed, call0)
+    assert torch.equal(kl, kl32)
+    names = [op[1] for op in O.TOPOLOGY[net_type] if op[0] in ("conv", "fc")]
+    npar = {n: {k: v.numpy() for k, v in p.items()} for n, p in params.items() if not n.startswith("_")}
+    npar["_prior_mu"], npar["_prior_sigma"] = params["_prior_mu"], params["_prior_sigma"]
+    for e in range(E):
+        want, kl_o = O.model_forward_bf16(net_type, npar, x.numpy(), "softplus", _oracle_eps_fn(names, seed, call0 + e))
+        got = logits[e].cpu().numpy()
+        scale = float(np.abs(want).max())
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-2 * scale)
+        assert abs(kl.item() - kl_o) <= 2e-6 * kl_o
+        # and the bf16 result is a perturbation of the fp32 one, not something else
+        np.testing.assert_allclose(got, logits32[e].cpu().numpy(), rtol=0, atol=6e-2 * scale)
+
+
+def test_mc_step_bf16_close_to_fp32_and_graph_replays(env):
+    """The whole step (sample -> layers -> log_softmax -> logmeanexp) in bf16 vs fp32 with the same noise; the captured
+    graph reproduces the eager bf16 step bit for bit and draws fresh noise per replay."""
+    torch.manual_seed(2)
+    net = env["zoo"].BBBAlexNet(10, 3, P.CONFIG_PRIORS, "bbb", "softplus").cuda()
+    env["rng"].assign_stream_ids(net)
+    x = torch.rand(64, 3, 32, 32, device="cuda")
+    E = 10
+    with torch.no_grad():
+        env["rng"].manual_seed(7, call=0)
+        lo32, kl32 = env["ens"].mc_forward(net, x, E)
+        env["rng"].manual_seed(7, call=0)
+        lo16, kl16 = env["ens"].mc_forward(net, x, E, precision="bf16")
+        lo16b, _ = env["ens"].mc_forward(net, x, E, precision="bf16")        # next step: calls E .. 2E-1
+    assert torch.equal(kl16, kl32)
+    scale = max(1.0, float(lo32.abs().max()))           # random-init logits are O(100): compare on that scale
+    assert float((lo16 - lo32).abs().max()) <= 2e-2 * scale
+    assert float(lo16.exp().sum(1).sub(1).abs().max()) < 1e-4 * E            # still a mixture of distributions
+    env["rng"].manual_seed(7, call=0)
+    g = env["ens"].GraphedMC(net, x, E, precision="bf16")
+    a, _ = g.step()
+    a = a.clone()
+    b, _ = g.step()
+    torch.cuda.synchronize()
+    assert torch.equal(a, lo16) and torch.equal(b, lo16b)
+
+
+def test_bf16_refuses_what_it_does_not_cover(env):
+    from bbb_hip._lib import BBBHipError
+    net = env["zoo"].BBBLeNet(10, 1, P.CONFIG_PRIORS, "lrt", "softplus").cuda()
+    env["rng"].assign_stream_ids(net)
+    with torch.no_grad(), pytest.raises(BBBHipError):
+        env["ens"].mc_forward(net, torch.rand(8, 1, 32, 32, device="cuda"), 2, precision="bf16")      # LRT layers
+    net = env["zoo"].BBBLeNet(10, 1, P.CONFIG_PRIORS, "bbb", "softplus").cuda()
+    env["rng"].assign_stream_ids(net)
+    with torch.no_grad(), pytest.raises(BBBHipError):
+        env["ens"].mc_forward(net, torch.rand(12, 1, 32, 32, device="cuda"), 2, precision="bf16")     # B % 8 != 0
+    with pytest.raises(BBBHipError):
+        env["ens"].mc_forward(net, torch.rand(8, 1, 32, 32, device="cuda"), 2, precision="bf16")      # autograd on

@@ -197,3 +197,28 @@ def test_numpy_uncertainty_vs_reference(golden):
             np.testing.assert_allclose(ale[0], U[k + ".aleatoric"], rtol=2e-5, atol=1e-8)
     # with BBB layers all T rows share one weight draw: epistemic is (numerically) zero -- SURVEY.md section 8f N2
     assert U["unc_bbb_0.epistemic"].max() < 1e-10 and U["unc_lrt_0.epistemic"].max() > 1e-8
+
+
+# ---------------------------------------------------------------- bf16 storage model (no upstream counterpart)
+def test_bf16_storage_model_is_a_small_perturbation_of_the_fp32_oracle():
+    """oracle.model_forward_bf16 = the pinned fp32 oracle with documented rounding points: rounding is torch's
+    nearest-even, and the logits stay within 2e-2 of the fp32 oracle's scale under the same noise."""
+    import torch
+    rs = np.random.RandomState(0)
+    a = (rs.randn(20000) * 10 ** rs.uniform(-6, 6, 20000)).astype(np.float32)
+    assert np.array_equal(O.bf16_round(a), torch.from_numpy(a).to(torch.bfloat16).float().numpy())
+    assert np.array_equal(O.bf16_round(O.bf16_round(a)), O.bf16_round(a))
+    torch.manual_seed(5)
+    params = P.init_params("lenet", 1, 10, P.CONFIG_PRIORS)
+    npar = {n: {k: v.numpy() for k, v in p.items()} for n, p in params.items() if not n.startswith("_")}
+    npar["_prior_mu"], npar["_prior_sigma"] = params["_prior_mu"], params["_prior_sigma"]
+    x = rs.rand(4, 1, 32, 32).astype(np.float32)
+    names = [op[1] for op in O.TOPOLOGY["lenet"] if op[0] in ("conv", "fc")]
+
+    def eps_fn(name, kind, shape):
+        return O.normal_eps(77, 3, 4 * names.index(name) + (0 if kind == "W" else 1), int(np.prod(shape))).reshape(shape)
+    want, kl = O.model_forward("lenet", npar, x, "bbb", "softplus", eps_fn)
+    got, kl16 = O.model_forward_bf16("lenet", npar, x, "softplus", eps_fn)
+    assert kl16 == kl
+    assert np.abs(got - want).max() <= 2e-2 * np.abs(want).max()
+    assert np.abs(got - want).max() > 0
