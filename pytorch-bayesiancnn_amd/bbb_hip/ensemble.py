@@ -244,6 +244,8 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
 
     def run(e0, e1):
         """Layers for draws [e0, e1) on the current stream -> logits [e1-e0, C, B] (or None: fall back)."""
+        nonlocal logits_buf
+        B = x.shape[0]
         Es = e1 - e0
         h = xt
         i = 0
@@ -296,9 +298,24 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
                 if act is not None:
                     i += 1
             elif isinstance(mod, FlattenLayer):
-                if h.dim() != 5 or h.shape[1] * h.shape[2] * h.shape[3] != mod.num_features:
+                if h.dim() != 5:
                     return None
-                h = h.reshape(h.shape[0], mod.num_features, 1, 1, B)
+                chw = h.shape[1] * h.shape[2] * h.shape[3]
+                if chw == mod.num_features:
+                    h = h.reshape(h.shape[0], mod.num_features, 1, 1, B)
+                else:
+                    # the reference's view(-1, num_features) on a larger map (AlexNet on 224x224: [B,128,7,7] -> [B*49,128])
+                    # cuts each image's NCHW memory into rows of num_features: go through the NCHW order once, on this
+                    # small tensor, and continue batch-innermost with B' = B*chw/num_features "images"
+                    if chw % mod.num_features != 0 or bf16:
+                        return None
+                    rows = h.permute(0, 4, 1, 2, 3).reshape(h.shape[0], -1, mod.num_features)     # [E|1, B', F]
+                    B = rows.shape[1]
+                    if B % 4 != 0:
+                        return None
+                    h = rows.permute(0, 2, 1).contiguous().reshape(h.shape[0], mod.num_features, 1, 1, B)
+                    if logits_buf is not None and logits_buf.shape[2] != B:
+                        logits_buf = torch.empty((E, n_out, B), dtype=torch.float32, device=x.device)
             elif isinstance(mod, nn.MaxPool2d):
                 pool = ops.maxpool_chwn_bf16 if bf16 else ops.maxpool_chwn
                 h = _run(timers, "maxpool", None, lambda: pool(h, mod.kernel_size, mod.stride))

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(64 * WN * WM * KG) void pconv_bf16_kernel(const PCo
     const int wn = (wave / WM) * 64, wm = (wave % WM) * 64;
 
     constexpr uint32_t kOOB = 0xFFFFFFF0u;
-    constexpr uint32_t kXInv = 0xFFFF0000u;
+    const uint32_t kXInv = p.x_inv;
     const uint16_t* xb = reinterpret_cast<const uint16_t*>(p.x) + (int64_t)e * p.x_ds;
     const uint16_t* wb = reinterpret_cast<const uint16_t*>(p.w) + (int64_t)e * p.w_ds;
     const int64_t x_bytes = (int64_t)p.Cin * p.H * p.W * p.B * 2;
@@ -355,8 +355,10 @@ extern "C" int bbb_conv2d_chwn_bf16_fwd(const bbb_conv_desc_t* d, const void* x,
     const int64_t Kp = (K + 7) & ~(int64_t)7;
     if (K >= (1 << 24)) return BBB_ESHAPE;           // float-reciprocal k decode is exact below 2^24
     if ((int64_t)d->cin * d->h * d->w * d->batch * 2 > 0xFFFE0000LL || (int64_t)d->cout * ho * wo * d->batch * 4 > 0xFFFE0000LL ||
-        ((int64_t)d->cout + 64) * Kp * 2 > 0x7FFFFFFFLL || (int64_t)d->batch * 2 > 0xFFFFLL)
+        ((int64_t)d->cout + 64) * Kp * 2 > 0x7FFFFFFFLL || (int64_t)d->batch * 2 > 0x0FFFFFFFLL)
         return BBB_ESHAPE;
+    const uint32_t x_inv = (0xFFFFFFF0u - ((uint32_t)d->batch + 512u) * 2u) & ~15u;   // a ragged last tile reaches < 512 columns past the row
+    if ((int64_t)d->cin * d->h * d->w * d->batch * 2 > (int64_t)x_inv) return BBB_ESHAPE;
     if ((((uintptr_t)x | (uintptr_t)w) & 15u) != 0 || ((uintptr_t)y & (out_f32 ? 3u : 1u)) != 0 || ((uintptr_t)bias & 3u) != 0)
         return BBB_EALIGN;
     if ((d->x_draw_stride & 7) != 0 || (d->w_draw_stride & 7) != 0) return BBB_EALIGN;
@@ -368,6 +370,7 @@ extern "C" int bbb_conv2d_chwn_bf16_fwd(const bbb_conv_desc_t* d, const void* x,
     a.y_ds = (int64_t)d->cout * ho * wo * d->batch;
     a.x = reinterpret_cast<const float*>(x); a.w = reinterpret_cast<const float*>(w); a.bias = bias;
     a.y = reinterpret_cast<float*>(y);
+    a.x_inv = x_inv;
     // tile shape: LDS-pipe cycles per unit of useful work (see the kernel comment), including the waste of ragged
     // channel / image tiles: 128x128 -> 256, 64x256 -> 288, 64x128 (two waves) -> 320
     auto waste = [](int n, int t) { return (double)(((n + t - 1) / t) * t) / (double)n; };

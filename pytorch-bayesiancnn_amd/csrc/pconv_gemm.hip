@@ -101,7 +101,7 @@ __global__ __launch_bounds__(kThreads) void pconv_gemm_kernel(const PConvArgs p)
     // lanes are masked without a branch around every load (a branch would make hipcc wait vmcnt(0) per element).
     constexpr uint32_t kOOB = 0xFFFFFFF0u;
     constexpr uint32_t kWInv = 0x7FFFFFF0u;    // invalid weight k: slab bytes < 2^30, so row + kWInv is out of range
-    constexpr uint32_t kXInv = 0xFFFF0000u;    // invalid x row: + column bytes (< 64 KiB) neither wraps nor lands in range
+    const uint32_t kXInv = p.x_inv;            // invalid x row: + column bytes (< one row) neither wraps nor lands in range
     const int64_t w_elems = (int64_t)p.Cout * p.K;
     const int64_t x_elems = (int64_t)p.Cin * p.H * p.W * p.B;
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
@@ -371,8 +371,10 @@ int fill(const bbb_conv_desc_t* d, PConvArgs& a) {
     if ((int64_t)d->cin * d->h * d->w > 0x7fffffffLL || (int64_t)d->cin * d->kh * d->kw > 0x7fffffffLL) return BBB_ESHAPE;
     // per-draw slabs are addressed through 32-bit buffer offsets
     if ((int64_t)d->cin * d->h * d->w * d->batch * 4 > 0xFFFE0000LL || (int64_t)d->cout * ho * wo * d->batch * 4 > 0xFFFE0000LL ||
-        ((int64_t)d->cout + 64) * d->cin * d->kh * d->kw * 4 > 0x3FFFFFFFLL || (int64_t)d->batch * 4 > 0xFFFFLL)
+        ((int64_t)d->cout + 64) * d->cin * d->kh * d->kw * 4 > 0x3FFFFFFFLL || (int64_t)d->batch * 4 > 0x0FFFFFFFLL)
         return BBB_ESHAPE;
+    a.x_inv = (0xFFFFFFF0u - ((uint32_t)d->batch + 512u) * 4u) & ~15u;   /* a ragged last tile reaches < 512 columns past the row */
+    if ((int64_t)d->cin * d->h * d->w * d->batch * 4 > (int64_t)a.x_inv) return BBB_ESHAPE;
     a.B = d->batch; a.Cin = d->cin; a.H = d->h; a.W = d->w; a.Cout = d->cout; a.kh = d->kh; a.kw = d->kw;
     a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w; a.dh = d->dil_h; a.dw = d->dil_w;
     a.Ho = ho; a.Wo = wo; a.K = d->cin * d->kh * d->kw; a.khkw = d->kh * d->kw; a.act = d->act;

@@ -118,6 +118,14 @@ def test_config5_alexnet_224_flatten_quirk(env):
         loop = torch.stack([net(x)[0] for _ in range(2)])
     assert batched.shape == (2, 8 * 49, 10)
     assert torch.equal(batched, loop)
+    # the batch-innermost fast path handles the quirk too (one pass through the NCHW order at the flatten) and agrees
+    # with the reference layout to the tolerance of the fused softplus epilogue
+    with torch.no_grad():
+        fast, _ = env["ens"].mc_logits(net, x, 2, 21, 0)
+        lo, _ = env["ens"].mc_forward(net, x, 2)
+    assert fast.shape == loop.shape and lo.shape == (8 * 49, 10)
+    scale = max(1.0, float(loop.abs().max()))
+    np.testing.assert_allclose(fast.cpu().numpy(), loop.cpu().numpy(), rtol=5e-4, atol=2e-5 * scale)
 
 
 def test_conv_linearity_and_shift_at_full_size(env):
