@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define BBB_ABI_VERSION 1
+#define BBB_ABI_VERSION 2
 #define BBB_MAX_SEGMENTS 16
 
 #define BBB_EINVAL (-1)   /* bad argument (null pointer, non-positive size, too many segments) */
@@ -50,8 +50,11 @@ typedef struct bbb_segment {
     uint32_t w_row_len;   /* 0: w is fp32, dense.  > 0: w is BF16 (round-to-nearest-even), a matrix with rows of
                              w_row_len elements stored at a pitch of w_row_len rounded up to 8 elements -- the operand
                              layout of bbb_conv2d_chwn_bf16_fwd; draw_stride then counts bf16 elements, the pad columns
-                             are written as zeros, and `eps` (fp32) keeps the dense [draws][n] layout
-                             with stride n */
+                             are written as zeros, and `eps` (fp32) keeps the dense [draws][n] layout with stride n */
+    uint32_t w_taps;      /* bf16 rows only.  0 / 1: row elements keep the tensor's own order ([cin][kh][kw]).  T > 1: the
+                             row is a [cin][T] matrix (T = kh*kw) and is written TRANSPOSED, [T][cin] ("tap-major":
+                             element (ci, t) lands at column t*cin + ci), the BBB_BF16_W_TAP_MAJOR operand layout */
+    uint32_t reserved;
 } bbb_segment_t;
 
 #define BBB_SIGMA_SQUARED 1u   /* flags: write sigma^2 (the LRT variance operand) instead of sigma */
@@ -160,14 +163,20 @@ int bbb_maxpool_chwn(const float* x, float* y, int64_t planes, int h, int w, int
  * BF16 storage variants of the batch-innermost path (BASELINE.json configs[1]: "BBB layers, bf16"); fp32 accumulation,
  * fp32 bias and fp32 epilogue (bias + activation), one rounding (nearest-even) when a value is stored as bf16.
  *   x: [draws|1][cin][h][w][B] bf16   (B % 8 == 0, 16-byte aligned, draw strides multiples of 8 elements)
- *   w: [draws|1][cout][Kp] bf16       K = cin*kh*kw in the reference's (ci, r, q) order, Kp = K rounded up to 8, pad
- *                                     columns zero -- what bbb_reparam_kl_fwd writes for a segment with w_row_len = K
- *   y: [draws][cout][ho][wo][B]       bf16, or fp32 when out_f32 != 0 (the logits layer feeding bbb_mc_tail)
+ *   w: [draws|1][cout][Kp] bf16       K = cin*kh*kw, Kp = K rounded up to 8, pad columns zero -- what bbb_reparam_kl_fwd
+ *                                     writes for a segment with w_row_len = K.  Column order inside a row: the reference's
+ *                                     (ci, r, q), or with BBB_BF16_W_TAP_MAJOR (needs cin % 8 == 0) (r, q, ci) = a segment
+ *                                     written with w_taps = kh*kw.  Tap-major rows let the kernel skip the kernel taps
+ *                                     that fall into the zero padding (as the fp32 kernel does) and still move weights as
+ *                                     16-byte vectors; with the reference order those taps are multiplied by zeros.
+ *   y: [draws][cout][ho][wo][B]       bf16, or fp32 with BBB_BF16_OUT_F32 (the logits layer feeding bbb_mc_tail)
  * d->w_draw_stride counts bf16 elements (cout*Kp per draw when dense).  Same contraction as bbb_conv2d_chwn_fwd
  * (layers/BBB/BBBConv.py:77, BBBLinear.py:70) on v_mfma_f32_32x32x16_bf16.  BBB layers only (no LRT variant).
  */
+#define BBB_BF16_OUT_F32      1u
+#define BBB_BF16_W_TAP_MAJOR  2u
 int bbb_conv2d_chwn_bf16_fwd(const bbb_conv_desc_t* d, const void* x, const void* w, const float* bias, void* y,
-                             int out_f32, void* stream);
+                             uint32_t flags, void* stream);
 /* nn.MaxPool2d(k, s) on [planes][h][w][B] bf16 (B % 8 == 0); exact (max commutes with the rounding). */
 int bbb_maxpool_chwn_bf16(const void* x, void* y, int64_t planes, int h, int w, int batch, int k, int s, void* stream);
 /* fp32 [batch][plane] (an NCHW tensor, plane = C*H*W) -> bf16 [plane][batch] (batch-innermost), nearest-even. */

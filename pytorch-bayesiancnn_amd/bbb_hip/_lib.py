@@ -23,7 +23,7 @@ c_u64, c_u32, c_i64, c_i32 = ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int64, c
 
 class Segment(ctypes.Structure):
     _fields_ = [("mu", c_void_p), ("rho", c_void_p), ("w", c_void_p), ("sigma", c_void_p), ("eps", c_void_p),
-                ("n", c_i64), ("draw_stride", c_i64), ("stream_id", c_u32), ("w_row_len", c_u32)]
+                ("n", c_i64), ("draw_stride", c_i64), ("stream_id", c_u32), ("w_row_len", c_u32), ("w_taps", c_u32), ("reserved", c_u32)]
 
 
 class ConvDesc(ctypes.Structure):
@@ -47,7 +47,7 @@ _SIGNATURES = {
     "bbb_lrt_conv2d_chwn_fwd": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_u64, c_u32, c_u32, c_int, c_void_p, c_void_p]),
     "bbb_maxpool_chwn": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "bbb_conv2d_chwn_bf16_fwd": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "bbb_conv2d_chwn_bf16_fwd": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_u32, c_void_p]),
     "bbb_maxpool_chwn_bf16": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "bbb_nchw_to_chwn_bf16": (c_int, [c_void_p, c_void_p, c_int, c_i64, c_void_p]),
     "bbb_mc_tail": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
@@ -79,8 +79,8 @@ def lib():
             fn = getattr(h, name)          # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if h.bbb_abi_version() != 1:
-            raise BBBHipError(f"ABI mismatch: library reports {h.bbb_abi_version()}, binding expects 1")
+        if h.bbb_abi_version() != 2:
+            raise BBBHipError(f"ABI mismatch: library reports {h.bbb_abi_version()}, binding expects 2")
         _lib = h
     return _lib
 

@@ -269,7 +269,8 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
                     is_logits = logits_buf is not None and i == last_bayes and not is_conv
                     dst = logits_buf[e0:e1] if is_logits else None
                     y = _run(timers, "conv_gemm", fl,
-                             lambda: ops.conv2d_chwn_bf16_forward(h5, w, b, ckk, *geom, act=act, out_f32=(i == last_bayes and tail_is_last), out=dst))
+                             lambda: ops.conv2d_chwn_bf16_forward(h5, w, b, ckk, *geom, act=act, out_f32=(i == last_bayes and tail_is_last),
+                                                                  out=dst, tap_major=is_conv and ops.bf16_tap_major(tuple(mod.W_mu.shape))))
                 elif isinstance(mod, _BBBLayer):
                     w, b = sampled[mod]
                     w = w[e0:e1]

@@ -261,34 +261,41 @@ def bf16_row_pitch(k):
     return (int(k) + 7) & ~7
 
 
+def bf16_tap_major(shape):
+    """Conv weights [Cout, Cin, kh, kw] with Cin % 8 == 0 and more than one tap are stored tap-major ((r, q, ci) order
+    inside a row): the bf16 GEMM can then skip the taps that fall into the padding."""
+    return len(shape) == 4 and shape[1] % 8 == 0 and shape[2] * shape[3] > 1
+
+
 def sample_weights_bf16(mus, rhos, prior_mu, prior_sigma, stream_ids, seed, call0, draws, eps=None):
     """The fused reparam + KL pass with the sampled WEIGHT matrices written as bf16 in the bf16 GEMM's operand layout
-    ([draws, rows, pitch], pitch = row length rounded up to 8, pad zero) and 1-d tensors (biases) kept fp32.
-    Inference only.  Returns (kl, [tensors])."""
+    ([draws, rows, pitch], pitch = row length rounded up to 8, pad zero; tap-major column order where bf16_tap_major says
+    so) and 1-d tensors (biases) kept fp32.  Inference only.  Returns (kl, [tensors])."""
     if len(mus) == 0 or len(mus) > _lib.MAX_SEGMENTS:
         raise _lib.BBBHipError(f"1..{_lib.MAX_SEGMENTS} tensors per launch, got {len(mus)}")
     require_device(*mus, *rhos)
     dev = mus[0].device
     mus = [m.detach().contiguous() for m in mus]
     rhos = [r.detach().contiguous() for r in rhos]
-    outs, row_lens = [], []
+    outs, row_lens, taps = [], [], []
     for m in mus:
         if m.dim() >= 2:
             rows, k = m.shape[0], m.numel() // m.shape[0]
-            kp = bf16_row_pitch(k)
-            o = torch.empty((draws, rows, kp), dtype=torch.bfloat16, device=dev)    # the kernel also writes the zero pad
-            outs.append(o)
+            outs.append(torch.empty((draws, rows, bf16_row_pitch(k)), dtype=torch.bfloat16, device=dev))   # pad written by the kernel
             row_lens.append(k)
+            taps.append(m.shape[2] * m.shape[3] if bf16_tap_major(tuple(m.shape)) else 0)
         else:
             outs.append(torch.empty((draws,) + tuple(m.shape), dtype=torch.float32, device=dev))
             row_lens.append(0)
+            taps.append(0)
     if eps is not None:
         eps = [e.contiguous() for e in eps]
         require_device(*eps)
     segs = _segments(mus, rhos, outs, None, eps, stream_ids, draws)
-    for i, (o, rl) in enumerate(zip(outs, row_lens)):
+    for i, (o, rl, tp) in enumerate(zip(outs, row_lens, taps)):
         if rl:
             segs[i].w_row_len = rl
+            segs[i].w_taps = tp
             segs[i].draw_stride = o.shape[1] * o.shape[2]
     kl = torch.empty((), dtype=torch.float32, device=dev)
     L = _lib.lib()
@@ -312,10 +319,11 @@ def to_batch_innermost_bf16(x):
     return y
 
 
-def conv2d_chwn_bf16_forward(x, w, bias, cin_khkw, stride=1, padding=0, dilation=1, act=None, out_f32=False, out=None):
+def conv2d_chwn_bf16_forward(x, w, bias, cin_khkw, stride=1, padding=0, dilation=1, act=None, out_f32=False, out=None,
+                             tap_major=False):
     """bf16 batch-innermost conv.  x: [E|1, Cin, H, W, B] bf16 (B % 8 == 0); w: [E|1, Cout, Kp] bf16 as written by
-    sample_weights_bf16; cin_khkw = (Cin, kh, kw); bias [E|1, Cout] fp32 or None -> y [E, Cout, Ho, Wo, B] bf16 (fp32
-    when out_f32)."""
+    sample_weights_bf16 (tap_major = its column order, see bf16_tap_major); cin_khkw = (Cin, kh, kw); bias [E|1, Cout]
+    fp32 or None -> y [E, Cout, Ho, Wo, B] bf16 (fp32 when out_f32)."""
     require_device(x, w, dtype=torch.bfloat16)
     require_device(bias)
     x, w = x.contiguous(), w.contiguous()
@@ -348,7 +356,8 @@ def conv2d_chwn_bf16_forward(x, w, bias, cin_khkw, stride=1, padding=0, dilation
         y = out.view(shape)
     with torch.cuda.device(x.device):
         check(_lib.lib().bbb_conv2d_chwn_bf16_fwd(ctypes.byref(d), x.data_ptr(), w.data_ptr(), ptr(bias), y.data_ptr(),
-                                                  1 if out_f32 else 0, cur_stream(x.device)), "bbb_conv2d_chwn_bf16_fwd")
+                                                  (1 if out_f32 else 0) | (2 if tap_major else 0), cur_stream(x.device)),
+              "bbb_conv2d_chwn_bf16_fwd")
     return y
 
 

@@ -20,6 +20,7 @@ struct PConvArgs {
     long long* ts;
 #endif
     uint32_t k0, k1, call0, stream_id;
+    int32_t wtap;        // bf16: weight rows are tap-major ((r, q, ci) order)
     uint32_t x_inv;      // byte offset that marks an invalid image row: x_inv + any column offset is out of range and does not wrap
     const uint32_t* call_dev;
 };

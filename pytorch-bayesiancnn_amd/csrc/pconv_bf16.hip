@@ -7,9 +7,11 @@
 //                                    K = Cin*kh*kw in the reference's (ci, r, q) order, written by the reparam kernel
 //   output       bf16 (hidden layers) or fp32 (the logits layer), bias fp32, fp32 accumulation and epilogue.
 // At 16x the fp32 matrix rate the contraction is no longer the bound; feeding it is.  So, unlike the fp32 kernel:
-//   * k runs over the FULL (ci, r, q) range: a weight k-tile is then one contiguous 128-byte run per channel (two
-//     16-byte loads per thread, no table), and taps that fall into the padding are zeroed on the image side only
-//     (their row offset is out of range for the buffer unit);
+//   * weights must move as 16-byte vectors of 8 consecutive k.  With rows in the reference's (ci, r, q) order that forces
+//     k to run over the FULL range (taps that fall into the padding are zeroed on the image side only: their row offset
+//     is out of range for the buffer unit) -- twice the work on AlexNet's 2x2 / 4x4 maps.  With TAP-MAJOR rows
+//     ((r, q, ci) order, written that way by the reparam kernel when cin % 8 == 0) the in-bounds taps of a pixel are
+//     runs of cin consecutive k, so padding taps are skipped exactly as in the fp32 kernel;
 //   * image rows are loaded 8 images per lane and stored to LDS as they are ([k][b]); the k-contiguous operand layout
 //     the bf16 MFMA wants comes from the LDS transpose read (ds_read_b64_tr_b16), not from a register shuffle.
 // The launches of a 10-draw CIFAR step are small (320-2560 workgroups of work) and a k-tile's operands come from the
@@ -31,6 +33,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -61,7 +64,8 @@ __global__ __launch_bounds__(64 * WN * WM * KG) void pconv_bf16_kernel(const PCo
     const int kg = __builtin_amdgcn_readfirstlane((int)threadIdx.x / GT);
     uint16_t* Xs = smem + kg * kStage;
     uint16_t* Ws = Xs + BK * LDXB;
-    int32_t* kt_all = reinterpret_cast<int32_t*>(smem + KG * kStage);      // [2][KCHG], filled by the first KCHG threads
+    int32_t* kt_all = reinterpret_cast<int32_t*>(smem + KG * kStage);      // [2][KCHG] image-row offsets per k
+    int32_t* kw_all = kt_all + 2 * KCHG;                                   // [2][KCHG] weight-column offsets per k
 
     const int bid = blockIdx.x;
     const int xcd = bid & 7;
@@ -76,7 +80,20 @@ __global__ __launch_bounds__(64 * WN * WM * KG) void pconv_bf16_kernel(const PCo
     const int b0 = (j - pix * p.nbt) * BM;
     const int oh = pix / p.Wo, ow = pix - oh * p.Wo;
     const int ihb = oh * p.sh - p.ph, iwb = ow * p.sw - p.pw;
-    const int K = p.K, Kp = p.Kp;
+    const int Kp = p.Kp;
+    // in-bounds tap rectangle of this pixel (tap-major rows only; otherwise every tap is enumerated)
+    int r_lo = 0, q_lo = 0, nr = p.kh, nq = p.kw;
+    if (p.wtap) {
+        r_lo = ihb < 0 ? (-ihb + p.dh - 1) / p.dh : 0;
+        q_lo = iwb < 0 ? (-iwb + p.dw - 1) / p.dw : 0;
+        int r_hi = (p.H - 1 - ihb) >= 0 ? (p.H - 1 - ihb) / p.dh + 1 : 0;
+        int q_hi = (p.W - 1 - iwb) >= 0 ? (p.W - 1 - iwb) / p.dw + 1 : 0;
+        r_hi = r_hi < p.kh ? r_hi : p.kh;
+        q_hi = q_hi < p.kw ? q_hi : p.kw;
+        nr = r_hi > r_lo ? r_hi - r_lo : 0;
+        nq = q_hi > q_lo ? q_hi - q_lo : 0;
+    }
+    const int K = p.wtap ? p.Cin * nr * nq : p.K;                 // contraction length of this pixel
     const int niter = (K + BK * KG - 1) / (BK * KG);              // every group runs the same number of iterations
 
     const int tid = (int)threadIdx.x - kg * GT;                   // thread within its k-group
@@ -85,6 +102,7 @@ __global__ __launch_bounds__(64 * WN * WM * KG) void pconv_bf16_kernel(const PCo
     const int wn = (wave / WM) * 64, wm = (wave % WM) * 64;
 
     constexpr uint32_t kOOB = 0xFFFFFFF0u;
+    constexpr uint32_t kWInv = 0x7FFFFFF0u;                       // + a row offset (< 2^31): out of range, no wrap
     const uint32_t kXInv = p.x_inv;
     const uint16_t* xb = reinterpret_cast<const uint16_t*>(p.x) + (int64_t)e * p.x_ds;
     const uint16_t* wb = reinterpret_cast<const uint16_t*>(p.w) + (int64_t)e * p.w_ds;
@@ -94,28 +112,46 @@ __global__ __launch_bounds__(64 * WN * WM * KG) void pconv_bf16_kernel(const PCo
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(wb), 0, (int)w_bytes, 0x00020000);
 
     const int wr = tid >> 3, wseg = (tid & 7) * 8;
-    const uint32_t wbase = (uint32_t)(n0 + wr) * (uint32_t)Kp * 2u + (uint32_t)wseg * 2u;
+    const uint32_t wbase = (uint32_t)(n0 + wr) * (uint32_t)Kp * 2u;
     const uint32_t wstep = (uint32_t)WROWS * (uint32_t)Kp * 2u;
     const int xkr = tid / XL, xb8 = (tid % XL) * 8;
     const uint32_t xcol = (uint32_t)(b0 + xb8) * 2u;
 
+    // k -> (weight column offset, image row offset), float-reciprocal division + fix-up (exact below 2^24)
     const float inv_khkw = 1.0f / (float)p.khkw, inv_kw = 1.0f / (float)p.kw;
+    const float inv_cin = 1.0f / (float)p.Cin, inv_nq = nq > 0 ? 1.0f / (float)nq : 0.0f;
     auto fill_chunk = [&](int chunk) {
         for (int i = (int)threadIdx.x; i < KCHG; i += GT * KG) {
             const int k = chunk * KCHG + i;
-            uint32_t xo = kXInv;
-            if (k < K) {
-                int ci = (int)((float)k * inv_khkw);
-                int rq = k - ci * p.khkw;
-                if (rq < 0) { --ci; rq += p.khkw; } else if (rq >= p.khkw) { ++ci; rq -= p.khkw; }
-                int r = (int)((float)rq * inv_kw);
-                int q = rq - r * p.kw;
-                if (q < 0) { --r; q += p.kw; } else if (q >= p.kw) { ++r; q -= p.kw; }
-                const int ih = ihb + r * p.dh, iw = iwb + q * p.dw;
-                if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W)
-                    xo = (uint32_t)((ci * p.H + ih) * p.W + iw) * (uint32_t)p.B * 2u;
+            uint32_t xo = kXInv, wo = kWInv;
+            if (p.wtap) {
+                if (k < K) {
+                    int t = (int)((float)k * inv_cin);
+                    int ci = k - t * p.Cin;
+                    if (ci < 0) { --t; ci += p.Cin; } else if (ci >= p.Cin) { ++t; ci -= p.Cin; }
+                    int rr = (int)((float)t * inv_nq);
+                    int qq = t - rr * nq;
+                    if (qq < 0) { --rr; qq += nq; } else if (qq >= nq) { ++rr; qq -= nq; }
+                    const int r = r_lo + rr, q = q_lo + qq;
+                    wo = (uint32_t)((r * p.kw + q) * p.Cin + ci) * 2u;
+                    xo = (uint32_t)((ci * p.H + ihb + r * p.dh) * p.W + iwb + q * p.dw) * (uint32_t)p.B * 2u;
+                }
+            } else {
+                if (k < Kp) wo = (uint32_t)k * 2u;                 // the zero pad columns K..Kp-1 are part of the row
+                if (k < K) {
+                    int ci = (int)((float)k * inv_khkw);
+                    int rq = k - ci * p.khkw;
+                    if (rq < 0) { --ci; rq += p.khkw; } else if (rq >= p.khkw) { ++ci; rq -= p.khkw; }
+                    int r = (int)((float)rq * inv_kw);
+                    int q = rq - r * p.kw;
+                    if (q < 0) { --r; q += p.kw; } else if (q >= p.kw) { ++r; q -= p.kw; }
+                    const int ih = ihb + r * p.dh, iw = iwb + q * p.dw;
+                    if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W)
+                        xo = (uint32_t)((ci * p.H + ih) * p.W + iw) * (uint32_t)p.B * 2u;
+                }
             }
             kt_all[(chunk & 1) * KCHG + i] = (int32_t)xo;
+            kw_all[(chunk & 1) * KCHG + i] = (int32_t)wo;
         }
     };
 
@@ -123,7 +159,7 @@ __global__ __launch_bounds__(64 * WN * WM * KG) void pconv_bf16_kernel(const PCo
     auto load_tile = [&](int it) {                       // iteration `it`: this group's 64-k tile is it*KG + kg
         const int buf = (it / TPC) & 1;
         const int kb = ((it % TPC) * KG + kg) * BK;
-        uint32_t wo = wbase + (uint32_t)(it * KG + kg) * (BK * 2u);
+        uint32_t wo = wbase + (uint32_t)kw_all[buf * KCHG + kb + wseg];   // 8 consecutive k of one tap / one row
         uint32_t xo[XPASS];
 #pragma unroll
         for (int ps = 0; ps < XPASS; ++ps) xo[ps] = (uint32_t)kt_all[buf * KCHG + kb + xkr + ps * XROWS] + xcol;
@@ -132,9 +168,9 @@ __global__ __launch_bounds__(64 * WN * WM * KG) void pconv_bf16_kernel(const PCo
         if (p.stagger & 2) wo = 0x7FFFFF00u;
 #endif
 #pragma unroll
-        for (int ps = 0; ps < XPASS; ++ps) xreg[ps] = __builtin_amdgcn_raw_buffer_load_b128(xrs, xo[ps], 0, 0);
+        for (int ps = 0; ps < XPASS; ++ps) xreg[ps] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xo[ps], 0, 0));
 #pragma unroll
-        for (int ps = 0; ps < WPASS; ++ps) wreg[ps] = __builtin_amdgcn_raw_buffer_load_b128(wrs, wo + (uint32_t)ps * wstep, 0, 0);
+        for (int ps = 0; ps < WPASS; ++ps) wreg[ps] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, wo + (uint32_t)ps * wstep, 0, 0));
     };
     auto store_tile = [&]() {
 #pragma unroll
@@ -210,9 +246,6 @@ __global__ __launch_bounds__(64 * WN * WM * KG) void pconv_bf16_kernel(const PCo
             TS();
         }
     }
-#ifdef BBB_TIMESTAMPS
-    if (tson) { long long* o = p.ts + (bid == 8 * 3 ? 0 : 128); for (int i = 0; i < tsi; ++i) o[i] = tsbuf[i]; }
-#endif
 
     // ---- cross-group reduction (fixed order: group 0 + 1 + ...), through the now idle stage memory ----
     if (KG > 1) {
@@ -237,36 +270,83 @@ __global__ __launch_bounds__(64 * WN * WM * KG) void pconv_bf16_kernel(const PCo
                     for (int r = 0; r < 16; ++r) acc[nt][mt][r] += red[((g2 - 1) * 64 + (nt * 2 + mt) * 16 + r) * GT + tid];
     }
 
-    // ---- epilogue: rows = channels, lanes = images ----
+    // ---- epilogue ----
     const int HoWo = p.Ho * p.Wo;
     const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.bias ? p.bias + (int64_t)e * p.b_ds : p.w), 0, p.bias ? p.Cout * 4 : 0, 0x00020000);
+        const_cast<float*>(p.bias ? p.bias + (int64_t)e * p.b_ds : reinterpret_cast<const float*>(p.w)), 0, p.bias ? p.Cout * 4 : 0, 0x00020000);
     constexpr int OSZ = OUT_F32 ? 4 : 2;
     char* yb = reinterpret_cast<char*>(p.y) + (int64_t)e * p.y_ds * OSZ;
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(yb, 0, (int)((int64_t)p.Cout * HoWo * p.B * OSZ), 0x00020000);
+    if constexpr (OUT_F32) {
+        // logits layer (a handful of channels): rows = channels, lanes = images, straight from the accumulators
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int n = n0 + wn + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-            const float bv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brs, (uint32_t)n * 4u, 0, 0));
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wn + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                const float bv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brs, (uint32_t)n * 4u, 0, 0));
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                const int b = b0 + wm + mt * 32 + lrow;
-                const uint32_t off = ((b < p.B) & (n < p.Cout)) ? (uint32_t)(((int64_t)n * HoWo + pix) * p.B + b) * (uint32_t)OSZ : kOOB;
-                const float v = bbb::apply_act(acc[nt][mt][r] + bv, p.act);
-                if (OUT_F32) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), yrs, off, 0, 0);
-                else         __builtin_amdgcn_raw_buffer_store_b16(f2bf(v), yrs, off, 0, 0);
+                for (int mt = 0; mt < 2; ++mt) {
+                    const int b = b0 + wm + mt * 32 + lrow;
+                    const uint32_t off = ((b < p.B) & (n < p.Cout)) ? (uint32_t)(((int64_t)n * HoWo + pix) * p.B + b) * 4u : kOOB;
+                    const float v = bbb::apply_act(acc[nt][mt][r] + bv, p.act);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), yrs, off, 0, 0);
+                }
             }
+    } else {
+        // 64 two-byte stores per lane cost ~340 cycles each (s_memtime: the epilogue was as long as 8 k-iterations).
+        // Instead every wave transposes its 64x64 block through LDS -- bias + activation + rounding in registers,
+        // ds_write_b16 into a [channel][image] image -- and stores 16-byte vectors of 8 images: 8 stores per lane, each
+        // wave-store covering 8 channels x 128 contiguous bytes.
+        constexpr int TP = 64 + 8;                                  // staging row pitch (elements): 144 B
+        __syncthreads();                                            // stage / reduction memory is free from here on
+        uint16_t* T = smem + wave * (64 * TP);
+        auto stage_block = [&](auto act) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int nl = nt * 32 + 8 * r4 + 4 * lk;           // 4 consecutive channels: accumulator rows r4*4 .. r4*4+3
+                // (bit_cast of the WHOLE result: indexing the builtin's return value directly reads element 0 four times
+                // with this hipcc -- caught by the parity tests)
+                const f32x4 bq = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, (uint32_t)(n0 + wn + nl) * 4u, 0, 0));
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+                        T[(nl + i) * TP + mt * 32 + lrow] = f2bf(act(acc[nt][mt][r4 * 4 + i] + bq[i]));
+            }
+        };
+        // one branch on the activation kind instead of one per element
+        if (p.act == 2)      stage_block([](float v) { return bbb::apply_act(v, 2); });
+        else if (p.act == 1) stage_block([](float v) { return fmaxf(v, 0.0f); });
+        else                 stage_block([](float v) { return v; });
+        // same-wave LDS accesses complete in order, so no s_barrier is needed between the writes above and the reads
+        // below -- but the compiler must not move the (differently typed) vector reads above the 2-byte writes
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+            const int v = ps * 64 + lane;
+            const int row = v >> 3, grp = v & 7;
+            const u32x4 q = *reinterpret_cast<const u32x4*>(&T[row * TP + grp * 8]);
+            const int n = n0 + wn + row, b = b0 + wm + grp * 8;
+            const uint32_t off = ((b < p.B) & (n < p.Cout)) ? (uint32_t)(((int64_t)n * HoWo + pix) * p.B + b) * 2u : kOOB;
+            __builtin_amdgcn_raw_buffer_store_b128(q, yrs, off, 0, 0);
         }
+    }
+#ifdef BBB_TIMESTAMPS
+    TS();
+    if (tson) { long long* o = p.ts + (bid == 8 * 3 ? 0 : 128); o[127] = tsi; for (int i = 0; i < tsi && i < 127; ++i) o[i] = tsbuf[i]; }
+#endif
 }
 
 template <bool OUT_F32, int WN, int WM, int KG>
 int launch_cfg(const PConvArgs& a, int64_t blocks, hipStream_t st) {
-    constexpr int kSmem = KG * (BK * (64 * WM + 32) + 64 * WN * LDWB) * 2 + 2 * KCH * KG * 4;
+    constexpr int kSmem = KG * (BK * (64 * WM + 32) + 64 * WN * LDWB) * 2 + 4 * KCH * KG * 4;
     constexpr int kRed = (KG - 1) * 64 * (64 * WN * WM) * 4;
     static_assert(kRed <= KG * (BK * (64 * WM + 32) + 64 * WN * LDWB) * 2, "reduction buffer must fit in the stage memory");
     static_assert(kSmem <= 160 * 1024, "LDS");
+    static_assert(WN * WM * 64 * 72 * 2 <= (BK * (64 * WM + 32) + 64 * WN * LDWB) * 2, "epilogue staging must fit in one stage");
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(&pconv_bf16_kernel<OUT_F32, WN, WM, KG>),
@@ -341,13 +421,17 @@ __global__ __launch_bounds__(256) void nchw_to_chwn_bf16_kernel(const float* __r
 }  // namespace
 
 extern "C" int bbb_conv2d_chwn_bf16_fwd(const bbb_conv_desc_t* d, const void* x, const void* w, const float* bias, void* y,
-                                        int out_f32, void* stream) {
+                                        uint32_t flags, void* stream) {
+    const int out_f32 = (flags & BBB_BF16_OUT_F32) ? 1 : 0;
+    const bool tap_major = (flags & BBB_BF16_W_TAP_MAJOR) != 0;
     if (d == nullptr || x == nullptr || w == nullptr || y == nullptr) return BBB_EINVAL;
     if (d->batch <= 0 || d->cin <= 0 || d->h <= 0 || d->w <= 0 || d->cout <= 0 || d->kh <= 0 || d->kw <= 0 ||
         d->stride_h <= 0 || d->stride_w <= 0 || d->pad_h < 0 || d->pad_w < 0 || d->dil_h <= 0 || d->dil_w <= 0 ||
         d->draws <= 0 || d->act < 0 || d->act > 2)
         return BBB_EINVAL;
     if (d->batch % 8 != 0) return BBB_ESHAPE;        // rows of 16-byte vectors of 8 bf16 images
+    if (tap_major && d->cin % 8 != 0) return BBB_ESHAPE;   // a 16-byte weight vector must not straddle two taps
+    if ((flags & ~(BBB_BF16_OUT_F32 | BBB_BF16_W_TAP_MAJOR)) != 0) return BBB_EINVAL;
     const int ho = (d->h + 2 * d->pad_h - d->dil_h * (d->kh - 1) - 1) / d->stride_h + 1;
     const int wo = (d->w + 2 * d->pad_w - d->dil_w * (d->kw - 1) - 1) / d->stride_w + 1;
     if (ho <= 0 || wo <= 0) return BBB_ESHAPE;
@@ -371,6 +455,7 @@ extern "C" int bbb_conv2d_chwn_bf16_fwd(const bbb_conv_desc_t* d, const void* x,
     a.x = reinterpret_cast<const float*>(x); a.w = reinterpret_cast<const float*>(w); a.bias = bias;
     a.y = reinterpret_cast<float*>(y);
     a.x_inv = x_inv;
+    a.wtap = tap_major ? 1 : 0;
     // tile shape: LDS-pipe cycles per unit of useful work (see the kernel comment), including the waste of ragged
     // channel / image tiles: 128x128 -> 256, 64x256 -> 288, 64x128 (two waves) -> 320
     auto waste = [](int n, int t) { return (double)(((n + t - 1) / t) * t) / (double)n; };

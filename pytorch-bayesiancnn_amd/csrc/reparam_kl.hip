@@ -122,6 +122,28 @@ __global__ __launch_bounds__(kThreads) void reparam_kl_fwd_kernel(const ReparamA
                 for (int j = 0; j < cnt; ++j) sg.sigma[i0 + j] = sq ? sigma[j] * sigma[j] : sigma[j];
             }
         }
+        // bf16 weight rows (w_row_len != 0): destination of each of the 4 elements inside one draw's matrix -- rows of rl
+        // elements at a pitch rounded up to 8, optionally transposed to tap-major order; the element that ends a row also
+        // zeroes the row's pad.  Independent of the draw, so computed once.
+        int64_t bf_dst[4] = {0, 0, 0, 0}, bf_rl = 0, bf_pitch = 0, bf_pad_row = -1;
+        bool bf_vec = false;
+        if (sg.w != nullptr && sg.w_row_len != 0) {
+            bf_rl = sg.w_row_len;
+            bf_pitch = (bf_rl + 7) & ~(int64_t)7;
+            const uint32_t taps = sg.w_taps > 1 ? sg.w_taps : 1u, cin = (uint32_t)bf_rl / taps;
+            const int64_t row0 = i0 / bf_rl;
+            uint32_t col = (uint32_t)(i0 - row0 * bf_rl);
+            int64_t row = row0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t ci = col / taps, tp = col - ci * taps;            // taps == 1: ci = col, tp = 0
+                bf_dst[j] = row * bf_pitch + (int64_t)(tp * cin + ci);
+                if (j < cnt && col == (uint32_t)bf_rl - 1 && bf_pitch != bf_rl) bf_pad_row = row;
+                if (++col == (uint32_t)bf_rl) { col = 0; ++row; }
+            }
+            bf_vec = taps == 1 && cnt == 4 && bf_dst[3] == bf_dst[0] + 3 && ((bf_rl & 3) == 0) &&
+                     (((uintptr_t)sg.w & 7u) == 0) && ((sg.draw_stride & 3) == 0);
+        }
         if (sg.w != nullptr) {
             for (int e = 0; e < a.draws; ++e) {
                 float z[4];
@@ -134,29 +156,17 @@ __global__ __launch_bounds__(kThreads) void reparam_kl_fwd_kernel(const ReparamA
                     bbb::normal4(g, sg.stream_id, call0 + (uint32_t)e, a.k0, a.k1, z);
                 }
                 if (sg.w_row_len != 0) {
-                    // bf16 weights for the bf16 GEMM: rows of w_row_len elements at a pitch rounded up to 8 (the pad is
-                    // written as zeros by whoever holds the row's last element), round-to-nearest-even from the fp32 sample
+                    // bf16 weights for the bf16 GEMM (destinations computed once, above the draw loop)
                     uint16_t* wb = reinterpret_cast<uint16_t*>(sg.w) + (int64_t)e * sg.draw_stride;
-                    const int64_t rl = sg.w_row_len, pitch = (rl + 7) & ~(int64_t)7;
-                    const int64_t row = i0 / rl, col = i0 - row * rl;
-                    if (cnt == 4 && col + 4 <= rl && ((rl & 3) == 0) && (((uintptr_t)wb & 7u) == 0) && ((sg.draw_stride & 3) == 0)) {
+                    if (bf_vec) {
                         uint32_t lo = (uint32_t)bf16_bits(mu[0] + z[0] * sigma[0]) | ((uint32_t)bf16_bits(mu[1] + z[1] * sigma[1]) << 16);
                         uint32_t hi = (uint32_t)bf16_bits(mu[2] + z[2] * sigma[2]) | ((uint32_t)bf16_bits(mu[3] + z[3] * sigma[3]) << 16);
-                        *reinterpret_cast<uint2*>(wb + row * pitch + col) = make_uint2(lo, hi);
+                        *reinterpret_cast<uint2*>(wb + bf_dst[0]) = make_uint2(lo, hi);
                     } else {
-                        for (int j = 0; j < cnt; ++j) {
-                            const int64_t ij = i0 + j, rj = ij / rl;
-                            wb[rj * pitch + (ij - rj * rl)] = bf16_bits(mu[j] + z[j] * sigma[j]);
-                        }
+                        for (int j = 0; j < cnt; ++j) wb[bf_dst[j]] = bf16_bits(mu[j] + z[j] * sigma[j]);
                     }
-                    // whoever writes the last element of a row also zeroes the row's pad (pitch - rl < 8 elements)
-                    if (pitch != rl) {
-                        for (int j = 0; j < cnt; ++j) {
-                            const int64_t ij = i0 + j, rj = ij / rl;
-                            if (ij - rj * rl == rl - 1)
-                                for (int64_t c = rl; c < pitch; ++c) wb[rj * pitch + c] = 0;
-                        }
-                    }
+                    if (bf_pad_row >= 0)
+                        for (int64_t c = bf_rl; c < bf_pitch; ++c) wb[bf_pad_row * bf_pitch + c] = 0;
                 } else if (aligned && cnt == 4) {
                     f32x4 w4;
 #pragma unroll
@@ -308,6 +318,7 @@ int fill_args(ReparamArgs& a, const bbb_segment_t* segs, int nseg, int draws, bo
         if ((((uintptr_t)g.mu | (uintptr_t)g.rho | (g.w_row_len ? 0 : (uintptr_t)g.w) | (uintptr_t)g.sigma | (uintptr_t)g.eps) & 3u) != 0)
             return BBB_EALIGN;
         if (g.w_row_len != 0 && (bwd || g.w == nullptr || g.n % g.w_row_len != 0 || ((uintptr_t)g.w & 1u))) return BBB_EINVAL;
+        if (g.w_taps > 1 && (g.w_row_len == 0 || g.w_row_len % g.w_taps != 0)) return BBB_EINVAL;
         a.seg[s] = g;
         a.chunk_begin[s] = chunks;
         chunks += (int)((g.n + (int64_t)kChunk * gpt - 1) / ((int64_t)kChunk * gpt));

@@ -29,13 +29,14 @@ def _bf(t):
     return t.to(torch.bfloat16)
 
 
-def _pack_w(w):
-    """[E, Cout, Cin, kh, kw] fp32 -> the kernel's operand: bf16 [E, Cout, Kp], zero pad."""
+def _pack_w(w, tap_major=False):
+    """[E, Cout, Cin, kh, kw] fp32 -> the kernel's operand: bf16 [E, Cout, Kp], zero pad; tap-major = (r, q, ci) columns."""
     E, Cout = w.shape[:2]
     K = w[0, 0].numel()
     Kp = (K + 7) & ~7
     out = torch.zeros(E, Cout, Kp, dtype=torch.bfloat16, device=w.device)
-    out[:, :, :K] = _bf(w.reshape(E, Cout, K))
+    src = w.permute(0, 1, 3, 4, 2) if tap_major else w
+    out[:, :, :K] = _bf(src.reshape(E, Cout, K))
     return out
 
 
@@ -48,18 +49,23 @@ CONV_CASES = [
     (8, 1, 12, 12, 6, 5, 1, 0, 1, 1, True),         # LeNet conv1: K = 25
     (40, 520, 1, 1, 10, 1, 1, 0, 1, 2, False),      # linear layer, K = 520 (more than two 256-entry decode chunks)
     (8, 64, 4, 4, 64, 5, 1, 2, 1, 1, True),         # K = 1600: seven decode chunks
+    (16, 24, 5, 7, 40, 3, 1, 1, 1, 2, False),       # cin = 24: 64-k tiles straddle taps in the tap-major order
+    (264, 384, 2, 2, 256, 3, 1, 1, 1, 1, False),    # AlexNet conv4 shape: 4 of 9 taps in bounds
 ]
 
 
 @pytest.mark.parametrize("B,Cin,H,W,Cout,k,s,p,d,E,xs", CONV_CASES)
-@pytest.mark.parametrize("out_f32", [True, False])
-def test_conv_bf16_vs_oracle(env, B, Cin, H, W, Cout, k, s, p, d, E, xs, out_f32):
+@pytest.mark.parametrize("out_f32,tap_major", [(True, False), (False, False), (False, True)])
+def test_conv_bf16_vs_oracle(env, B, Cin, H, W, Cout, k, s, p, d, E, xs, out_f32, tap_major):
+    if tap_major and Cin % 8 != 0:
+        pytest.skip("tap-major rows need cin % 8 == 0")
     torch.manual_seed(B * 7 + Cout)
     x = torch.randn(1 if xs else E, B, Cin, H, W, device="cuda")
     w = torch.randn(E, Cout, Cin, k, k, device="cuda") * 0.2
     bias = torch.randn(E, Cout, device="cuda")
     xb = _bf(x.permute(0, 2, 3, 4, 1).contiguous())                       # [E|1, C, H, W, B]
-    y = env["ops"].conv2d_chwn_bf16_forward(xb, _pack_w(w), bias, (Cin, k, k), s, p, d, act="softplus", out_f32=out_f32)
+    y = env["ops"].conv2d_chwn_bf16_forward(xb, _pack_w(w, tap_major), bias, (Cin, k, k), s, p, d, act="softplus", out_f32=out_f32,
+                                            tap_major=tap_major)
     assert y.dtype == (torch.float32 if out_f32 else torch.bfloat16)
     got = y.float().permute(0, 4, 1, 2, 3).cpu().numpy()                 # [E, B, Cout, Ho, Wo]
     xr = xb.float().permute(0, 4, 1, 2, 3).cpu().numpy()
@@ -94,7 +100,8 @@ def test_sampled_weights_bf16_are_the_rounded_fp32_samples(env):
             continue
         K = int(np.prod(s[1:]))
         assert o.dtype == torch.bfloat16 and o.shape == (E, s[0], (K + 7) & ~7)
-        assert torch.equal(o[:, :, :K], _bf(w32.reshape(E, s[0], K)))
+        src = w32.permute(0, 1, 3, 4, 2) if env["ops"].bf16_tap_major(s) else w32      # (r, q, ci) columns when cin % 8 == 0
+        assert torch.equal(o[:, :, :K], _bf(src.reshape(E, s[0], K)))
         assert not o[:, :, K:].any()
 
 

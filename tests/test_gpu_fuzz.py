@@ -68,11 +68,17 @@ def test_random_geometry_all_kernels(c):
     wb = torch.zeros(E, Cout, Kp, dtype=torch.bfloat16, device="cuda")
     wb[:, :, :K] = w.reshape(E, Cout, K).to(torch.bfloat16)
     xb = xc.to(torch.bfloat16)
-    y16 = ops.conv2d_chwn_bf16_forward(xb, wb, b, (Cin, kh, kw), *geom, act=a).float().permute(0, 4, 1, 2, 3)
+    outs = [("bf16", ops.conv2d_chwn_bf16_forward(xb, wb, b, (Cin, kh, kw), *geom, act=a))]
+    if Cin % 8 == 0:                               # tap-major rows: padding taps skipped instead of multiplied by zeros
+        wt = torch.zeros_like(wb)
+        wt[:, :, :K] = w.permute(0, 1, 3, 4, 2).reshape(E, Cout, K).to(torch.bfloat16)
+        outs.append(("bf16-tap-major", ops.conv2d_chwn_bf16_forward(xb, wt, b, (Cin, kh, kw), *geom, act=a, tap_major=True)))
     xr = xb.float().permute(0, 4, 1, 2, 3).cpu().numpy()
     wr = w.to(torch.bfloat16).float().cpu().numpy()
-    for e in range(E):
-        want, mag = _ref(xr, wr, bn, c, e, xs, act)
-        tol = 2e-5 * mag + 2e-6 + np.abs(want) * 2.0 ** -8
-        err = np.abs(y16[e].cpu().numpy() - want)
-        assert (err <= tol).all(), f"bf16 draw {e}: excess {(err - tol).max():.3e}"
+    for name, y16 in outs:
+        y16 = y16.float().permute(0, 4, 1, 2, 3)
+        for e in range(E):
+            want, mag = _ref(xr, wr, bn, c, e, xs, act)
+            tol = 2e-5 * mag + 2e-6 + np.abs(want) * 2.0 ** -8
+            err = np.abs(y16[e].cpu().numpy() - want)
+            assert (err <= tol).all(), f"{name} draw {e}: excess {(err - tol).max():.3e}"
