@@ -98,6 +98,25 @@ int bbb_reparam_kl_bwd(const bbb_segment_t* segs, int nseg, int draws,
                        uint64_t seed, uint32_t call0, uint32_t flags,
                        const float* gkl, float* const* grad_mu, float* const* grad_rho, void* stream);
 
+/* One parameter tensor of an Adam step: all four arrays hold n fp32 elements on the device. */
+typedef struct bbb_adam_segment {
+    float* param;        /* updated in place */
+    const float* grad;
+    float* exp_avg;      /* first moment, updated in place */
+    float* exp_avg_sq;   /* second moment, updated in place */
+    int64_t n;
+} bbb_adam_segment_t;
+
+/*
+ * Multi-tensor Adam (training extension): the optimizer.step() of main_bayesian.py:58 for up to BBB_MAX_SEGMENTS
+ * tensors in one launch, torch.optim.Adam semantics (amsgrad off, no weight decay), operation order as torch's:
+ *   m += (g - m)(1 - beta1);  v = v*beta2 + (1 - beta2) g^2;  p -= lr/(1 - beta1^step) * m / (sqrt(v)/sqrt(1 - beta2^step) + eps)
+ * `step` is the 1-based count of this update.  Hyper-parameters are doubles: derived scalars (1 - beta, the bias
+ * corrections) are formed in double and rounded to fp32 once, as torch does.
+ */
+int bbb_adam_step(const bbb_adam_segment_t* segs, int nseg, double lr, double beta1, double beta2, double eps,
+                  int64_t step, void* stream);
+
 /* Test entry: materialise n elements of a noise stream starting at element `start`. */
 int bbb_eps_dump(float* out, int64_t n, int64_t start, uint64_t seed, uint32_t call, uint32_t stream_id, void* stream);
 

@@ -148,3 +148,34 @@ def mc_step(net_type, params, x, n_classes, num_ens, layer_type="bbb", activatio
         kl += _kl_j
         outputs[:, :, j] = F.log_softmax(net_out, dim=1)
     return logmeanexp(outputs, 2), kl
+
+
+def train_steps(net_type, params, batches, n_classes, num_ens, lr, beta, train_size, layer_type="bbb", activation="softplus"):
+    """The batch loop of train_model (main_bayesian.py:36-62) on the functional port, CPU autograd + torch.optim.Adam
+    (main_bayesian.py:103): for each (x, y): zero_grad; num_ens forwards; kl / num_ens; logmeanexp; ELBO
+    (metrics.py:19-24: nll_loss(mean) * train_size + beta * kl); backward; step.  Mutates `params` in place
+    (leaf tensors get requires_grad).  Returns the list of losses."""
+    leaves = []
+    for name, p in params.items():
+        if name.startswith("_"):
+            continue
+        for k in ("W_mu", "W_rho", "bias_mu", "bias_rho"):
+            p[k].requires_grad_(True)
+            leaves.append(p[k])
+    opt = torch.optim.Adam(leaves, lr=lr)
+    losses = []
+    for x, y in batches:
+        opt.zero_grad()
+        outputs = torch.zeros(x.shape[0], n_classes, num_ens)
+        kl = 0.0
+        for j in range(num_ens):
+            net_out, _kl_j = forward(net_type, params, x, layer_type, activation)
+            kl = kl + _kl_j
+            outputs[:, :, j] = F.log_softmax(net_out, dim=1)
+        kl = kl / num_ens
+        log_outputs = logmeanexp(outputs, 2)
+        loss = F.nll_loss(log_outputs, y, reduction="mean") * train_size + beta * kl
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    return losses

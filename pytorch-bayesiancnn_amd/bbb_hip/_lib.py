@@ -26,6 +26,10 @@ class Segment(ctypes.Structure):
                 ("n", c_i64), ("draw_stride", c_i64), ("stream_id", c_u32), ("w_row_len", c_u32), ("w_taps", c_u32), ("reserved", c_u32)]
 
 
+class AdamSegment(ctypes.Structure):
+    _fields_ = [("param", c_void_p), ("grad", c_void_p), ("exp_avg", c_void_p), ("exp_avg_sq", c_void_p), ("n", c_i64)]
+
+
 class ConvDesc(ctypes.Structure):
     _fields_ = [("batch", c_i32), ("cin", c_i32), ("h", c_i32), ("w", c_i32), ("cout", c_i32), ("kh", c_i32),
                 ("kw", c_i32), ("stride_h", c_i32), ("stride_w", c_i32), ("pad_h", c_i32), ("pad_w", c_i32),
@@ -39,6 +43,8 @@ _SIGNATURES = {
     "bbb_reparam_partials": (c_i64, [ctypes.POINTER(Segment), c_int]),
     "bbb_reparam_kl_bwd": (c_int, [ctypes.POINTER(Segment), c_int, c_int, c_float, c_float, c_u64, c_u32, c_u32,
                                    c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), c_void_p]),
+    "bbb_adam_step": (c_int, [ctypes.POINTER(AdamSegment), c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                            c_i64, c_void_p]),
     "bbb_eps_dump": (c_int, [c_void_p, c_i64, c_i64, c_u64, c_u32, c_u32, c_void_p]),
     "bbb_conv2d_fwd": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "bbb_lrt_conv2d_fwd": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -1,0 +1,134 @@
+"""Training extension on the MI355X: multi-tensor Adam vs torch.optim.Adam, and the reference's
+train_model batch loop (main_bayesian.py:36-62) -- autograd through the HIP kernels + FusedAdam -- against the CPU port
+of the reference (oracle/ref_port_torch.train_steps) with the noise replayed from torch's CPU generator.
+Run with -m gpu."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import ref_port_torch as P
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import layers  # noqa: F401
+    from bbb_hip import ops, rng, ensemble, zoo, train
+    return dict(ops=ops, rng=rng, ens=ensemble, zoo=zoo, train=train)
+
+
+def test_fused_adam_matches_torch_adam(env):
+    """Same parameters, same gradients, 6 steps: parameters and both moments agree with torch.optim.Adam to 2 ulp-ish
+    (rtol 2e-6 + a few ulp of the tensor scale where terms cancel); state dicts are interchangeable."""
+    torch.manual_seed(0)
+    shapes = [(64, 3, 11, 11), (64,), (10, 33), (1,), (1025,), (7, 5, 3)]
+    a = [torch.randn(s, device="cuda").requires_grad_(True) for s in shapes]
+    b = [t.detach().clone().requires_grad_(True) for t in a]
+    fa = env["train"].FusedAdam(a, lr=3e-3, betas=(0.9, 0.999), eps=1e-8)
+    ta = torch.optim.Adam(b, lr=3e-3, betas=(0.9, 0.999), eps=1e-8)
+    for it in range(6):
+        for x, y in zip(a, b):
+            g = torch.randn_like(x) * (10.0 ** (it - 3))
+            x.grad, y.grad = g.clone(), g.clone()
+        fa.step()
+        ta.step()
+    for x, y in zip(a, b):
+        np.testing.assert_allclose(x.detach().cpu().numpy(), y.detach().cpu().numpy(), rtol=2e-6, atol=1e-8)   # atol: a few ulp of the lr-sized update
+        for key in ("exp_avg", "exp_avg_sq"):       # fused multiply-add contraction may differ: 1-2 ulp of the tensor's scale
+            want = ta.state[y][key].cpu().numpy()
+            np.testing.assert_allclose(fa.state[x][key].cpu().numpy(), want, rtol=2e-6, atol=4e-7 * float(np.abs(want).max()))
+    ta2 = torch.optim.Adam(a, lr=3e-3)
+    ta2.load_state_dict(fa.state_dict())            # interchangeable state
+    assert int(ta2.state[a[0]]["step"]) == 6
+
+
+def _cpu_eps(shape):
+    return torch.empty(tuple(shape)).normal_(0, 1)
+
+
+@pytest.mark.parametrize("net_type,layer_type", [("lenet", "bbb"), ("lenet", "lrt")])
+def test_training_loop_matches_reference_port(env, net_type, layer_type):
+    """3 iterations of train_model's loop, num_ens = 2, eps replayed in the reference's draw order.  Step-1 gradients
+    (rtol 3e-4 of each tensor's scale), per-step losses (rtol 1e-4) and the parameters after 3 Adam steps (an Adam update
+    is +-lr per element, so a gradient whose sign is inside rounding noise may differ by 2*lr: at most 0.5 % of the
+    elements may differ by more than 1e-5)."""
+    B, E, lr, beta, train_size, ncls = 8, 2, 1e-3, 0.1, 1000.0, 10
+    torch.manual_seed(42)
+    params = P.init_params(net_type, 1, ncls, P.CONFIG_PRIORS)
+    batches = [(torch.rand(B, 1, 32, 32), torch.randint(0, ncls, (B,))) for _ in range(3)]
+    net = env["zoo"].getModel(net_type, 1, ncls, P.CONFIG_PRIORS, layer_type, "softplus")
+    net.load_state_dict({f"{n}.{k}": v.clone() for n, p in params.items() if not n.startswith("_") for k, v in p.items()})
+    net = net.cuda().train()
+    for m in net.modules():
+        if hasattr(m, "eps_source"):
+            m.eps_source = _cpu_eps
+    opt = env["train"].FusedAdam(net.parameters(), lr=lr)
+    names = [n for n, _ in net.named_parameters()]
+    torch.manual_seed(7)
+    losses, first_grads = [], None
+    for x, y in batches:                                   # the reference's own loop shape (main_bayesian.py:40-58)
+        opt.zero_grad()
+        outs, kl = [], 0.0
+        for j in range(E):
+            net_out, _kl = net(x.cuda())
+            kl = kl + _kl
+            outs.append(F.log_softmax(net_out, dim=1))
+        kl = kl / E
+        log_outputs = torch.logsumexp(torch.stack(outs, 2), 2) - np.log(E)
+        loss = env["train"].elbo(log_outputs, y.cuda(), kl, beta, train_size)
+        loss.backward()
+        if first_grads is None:
+            first_grads = {n: p.grad.detach().cpu().clone() for n, p in net.named_parameters()}
+        opt.step()
+        losses.append(loss.item())
+    # reference side: same seeds, CPU autograd + torch.optim.Adam
+    ref = {n: {k: v.clone() for k, v in p.items()} if isinstance(p, dict) else p for n, p in params.items()}
+    torch.manual_seed(7)
+    probe = {n: {k: v.clone().requires_grad_(True) for k, v in p.items()} if isinstance(p, dict) else p for n, p in params.items()}
+    # step-1 gradients of the port (consumes the same eps as the first iteration)
+    x0, y0 = batches[0]
+    outputs = torch.zeros(B, ncls, E)
+    kl = 0.0
+    for j in range(E):
+        o, k = P.forward(net_type, probe, x0, layer_type, "softplus")
+        kl = kl + k
+        outputs[:, :, j] = F.log_softmax(o, dim=1)
+    (F.nll_loss(P.logmeanexp(outputs, 2), y0, reduction="mean") * train_size + beta * kl / E).backward()
+    for n in names:
+        lname, k = n.split(".")
+        want = probe[lname][k].grad
+        got = first_grads[n]
+        scale = float(want.abs().max())
+        assert float((got - want).abs().max()) <= 3e-4 * scale + 1e-7, (n, float((got - want).abs().max()), scale)
+    torch.manual_seed(7)
+    ref_losses = P.train_steps(net_type, ref, batches, ncls, E, lr, beta, train_size, layer_type, "softplus")
+    np.testing.assert_allclose(losses, ref_losses, rtol=1e-4)
+    tot = bad = 0
+    for n, p in net.named_parameters():
+        lname, k = n.split(".")
+        d = (p.detach().cpu() - ref[lname][k].detach()).abs()
+        assert float(d.max()) <= 2 * 3 * lr + 1e-6               # never further apart than every step going the other way
+        tot += d.numel()
+        bad += int((d > 1e-5).sum())
+    assert bad <= 0.005 * tot, (bad, tot)
+
+
+def test_train_step_helper_learns_and_counts_calls(env):
+    """train.train_step (Philox noise, batched draws): loss goes down on a fixed batch; the noise call counter advances
+    by num_ens per step."""
+    torch.manual_seed(1)
+    net = env["zoo"].BBBLeNet(10, 1, P.CONFIG_PRIORS, "bbb", "softplus").cuda()
+    env["rng"].assign_stream_ids(net)
+    env["rng"].manual_seed(5, call=0)
+    opt = env["train"].FusedAdam(net.parameters(), lr=1e-3)
+    x = torch.rand(64, 1, 32, 32, device="cuda")
+    y = torch.randint(0, 10, (64,), device="cuda")
+    losses = []
+    for it in range(25):
+        loss, lo, kl = env["train"].train_step(net, opt, x, y, 2, 1e-7, 64.0)
+        losses.append(loss.item())
+    assert np.isfinite(losses).all() and losses[-1] < losses[0]
+    assert env["rng"].get_state()[1] == 2 * 25
+    assert lo.shape == (64, 10) and float(lo.exp().sum(1).sub(1).abs().max()) < 1e-3

@@ -306,6 +306,59 @@ def test_ensemble_combine_over_gloo(tmp_path, world, E):
         assert p.returncode == 0 and f"RANK_OK {r}" in out, err[-3000:]
 
 
+_DP_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+import torch, torch.distributed as dist
+import ref_port_torch as P
+from bbb_hip import train
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % os.environ["MASTER_PORT"], rank=rank, world_size=world)
+# data-parallel step on the CPU port: every rank differentiates the ELBO of ITS shard, gradients are averaged with
+# train.allreduce_gradients (several buckets forced), and must equal the single-process gradient of the full batch
+torch.manual_seed(3)
+params = P.init_params("lenet", 1, 10, P.CONFIG_PRIORS)
+leaves = [p[k] for n, p in params.items() if not n.startswith("_") for k in ("W_mu", "W_rho", "bias_mu", "bias_rho")]
+for t in leaves: t.requires_grad_(True)
+Bs = 4
+x = torch.rand(world * Bs, 1, 32, 32); y = torch.randint(0, 10, (world * Bs,))
+def loss_of(xb, yb):
+    logits, kl = P.forward("lenet", params, xb, "bbb", "softplus", sample=False)     # deterministic forward: same on all ranks
+    return train.elbo(torch.log_softmax(logits, 1), yb, kl, 0.1, 1000.0)
+loss_of(x, y).backward()
+full = [t.grad.clone() for t in leaves]
+for t in leaves: t.grad = None
+loss_of(x[rank * Bs:(rank + 1) * Bs], y[rank * Bs:(rank + 1) * Bs]).backward()
+n = train.allreduce_gradients(leaves, dist.group.WORLD, bucket_bytes=64 * 1024)
+assert n >= 3, n                                      # LeNet's 247 KB of gradients in 64 KB buckets
+for g, t in zip(full, leaves):
+    assert torch.allclose(t.grad, g, rtol=2e-4, atol=1e-6 * float(g.abs().max())), float((t.grad - g).abs().max())
+dist.destroy_process_group()
+print("RANK_OK", rank)
+'''
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_data_parallel_gradient_allreduce_over_gloo(tmp_path, world):
+    """N1 (training extension), multi-GPU leg: shard the batch over ranks, average gradients with ONE all_reduce per
+    bucket -> the gradient of the full-batch ELBO (mean-reduced NLL * train_size + beta * KL)."""
+    script = tmp_path / "dp_worker.py"
+    script.write_text(_DP_WORKER)
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), PKG, os.path.join(ROOT, "oracle")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for r, p in enumerate(procs):
+        out, err = p.communicate(timeout=180)
+        assert p.returncode == 0 and f"RANK_OK {r}" in out, err[-3000:]
+
+
 @pytest.mark.reference
 def test_reference_driver_imports_unchanged_through_the_launcher():
     """N4: run_reference.prepare() makes the UNMODIFIED main_bayesian importable on today's torch / numpy without
