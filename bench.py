@@ -133,9 +133,9 @@ def reparam_probe(net, dev, n_params):
         del mu, rho, dst
     gbs = byts / t_model / 1e9
     return {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
-            "traffic": 104.2e6 if abs(byts - 104445408) < 1 else None,
+            "traffic": 102.2e6 if abs(byts - 104445408) < 1 else None,
             "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 wide-load correction) + WRITE_SIZE, separate passes: "
-                              "profiles/r01_pmc_hbm_traffic.txt (17.1 MB + 87.1 MB per launch)",
+                              "profiles/r01_pmc_FETCH_SIZE.txt, r01_pmc_WRITE_SIZE.txt (17.1 MB + 85.1 MB per launch)",
             "kernel": "reparam_kl_fwd_kernel + kl_finish_kernel, 12 tensors x 10 draws in one launch",
             "bytes_per_launch": byts, "avg_us": round(t_model * 1e6, 2),
             "note": "(8 + 4E) B per weight element; the 17 MB of (mu,rho) and 87 MB of w are Infinity-Cache resident here",
@@ -154,8 +154,14 @@ def gemm_roofline(g, timer_steps, dtype):
     peak = PEAK_BF16_MFMA_TFLOPS if dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
     kern = ("pconv_bf16_kernel (v_mfma_f32_32x32x16_bf16, batch-innermost, LDS transpose reads)" if dtype == "bf16" else
             "pconv_gemm_kernel (fp32 v_mfma_f32_32x32x2_f32, batch-innermost, in-bounds taps only)")
+    # HBM bytes per launch from the PMC passes of the metric workload (fp32 only; recorded, not re-measured per run)
+    traffic = 88.5e6 if (dtype != "bf16" and abs(g["work"] / timer_steps - 70812958720.0) < 1.0) else None
     return {"bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
-            "traffic": None, "kernel": kern + ", all conv/linear launches of a step",
+            "traffic": traffic,
+            "traffic_source": ("rocprofv3 --pmc FETCH_SIZE (x2, gfx950 wide-load correction) + WRITE_SIZE, separate passes "
+                               "(profiles/r01_pmc_FETCH_SIZE.txt, r01_pmc_WRITE_SIZE.txt): 326.3 MB read + 205.0 MB written per step "
+                               "over the 6 conv/linear launches; algorithmic bytes 197 MB + 210 MB") if traffic else None,
+            "kernel": kern + ", all conv/linear launches of a step",
             "launches": g["n"], "avg_us": round(1e3 * g["ms"] / g["n"], 2),
             "flop_per_step": g["work"] / timer_steps, "im2col_flop_per_step": g["work_im2col"] / timer_steps,
             "timed_by": "HIP events around every launch, %d eager single-stream steps of the same workload right after "
@@ -236,7 +242,9 @@ def main():
                 launch_note = "hipGraph capture failed (%s: %s); eager launches" % (type(exc).__name__, str(exc)[:120])
                 torch.cuda.synchronize(dev)
         if not use_graph:
-            step = lambda: ensemble.mc_forward(net, x, total_ens, group=group, streams=max(2, args.streams), precision=precision)
+            # explicit --no-graph: exactly the requested stream count (profiling runs); capture failure: two draw streams
+            eager_streams = args.streams if args.no_graph else max(2, args.streams)
+            step = lambda: ensemble.mc_forward(net, x, total_ens, group=group, streams=eager_streams, precision=precision)
         for _ in range(args.warmup):
             step()
         barrier()
@@ -315,7 +323,7 @@ def main():
                        "global_batch": BATCH, "num_ens_total": total_ens,
                        "parallelism": f"mc-ensemble x{world}" if world > 1 else "single",
                        "launch": ("hipGraph replay, %d step(s) in flight x %d draw streams" % (max(1, args.pipeline), args.streams))
-                       if use_graph else (launch_note or ("eager, %d streams" % max(2, args.streams)))},
+                       if use_graph else (launch_note or ("eager, %d streams" % (args.streams if args.no_graph else max(2, args.streams))))},
         }
         if timers is not None:
             agg = timers.summary()

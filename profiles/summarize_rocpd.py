@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Per-kernel summary (calls, total, average, share) from a rocprofv3 rocpd sqlite database.
-usage: summarize_rocpd.py results.db [--skip-first N]   (the same numbers as `rocprofv3 --stats`, as text)"""
+usage: summarize_rocpd.py results.db [--after-spin N [--steps K]]   (the same numbers as `rocprofv3 --stats`, as text)
+--after-spin N: only the kernels between the N-th at::cuda::spin_kernel (1-based) and the next one (or the end) --
+bench.py parks the GPU behind such a kernel before its HIP-event-bracketed eager pass, so this isolates exactly the
+launches the JSON's roofline block was timed on."""
 import re
 import sqlite3
 import sys
@@ -18,6 +21,20 @@ def main():
     rows = c.execute("select name, start, end, grid_x, grid_y, grid_z, workgroup_x from kernels order by start").fetchall() \
         if "grid_x" in [r[1] for r in c.execute("pragma table_info(kernels)")] else \
         [(r[0], r[1], r[2], 0, 0, 0, 0) for r in c.execute("select name, start, end from kernels order by start")]
+    if "--after-spin" in sys.argv:
+        n = int(sys.argv[sys.argv.index("--after-spin") + 1])
+        spins = [i for i, r in enumerate(rows) if "spin_kernel" in r[0]]
+        lo = spins[n - 1] + 1
+        hi = spins[n] if n < len(spins) else len(rows)
+        if "--steps" in sys.argv:        # a step ends with its mc_tail kernel
+            want, seen = int(sys.argv[sys.argv.index("--steps") + 1]), 0
+            for i in range(lo, hi):
+                if "mc_tail" in rows[i][0]:
+                    seen += 1
+                    if seen == want:
+                        hi = i + 1
+                        break
+        rows = rows[lo:hi]
     agg = {}
     for name, s, e, gx, gy, gz, wx in rows:
         a = agg.setdefault(short(name), [0, 0, 1 << 62, 0])
