@@ -50,21 +50,29 @@ __device__ __forceinline__ uint16_t f2bf(float v) {              // round to nea
 // Workgroup = KG k-groups x (WN x WM) waves; every wave owns a 64-channel x 64-image block of D (2 x 2 MFMA tiles, so
 // each LDS operand read feeds two MFMAs: the LDS pipe, not the matrix pipe, is what this kernel saturates first).
 //   (WN, WM) = (2, 2): 128 channels x 128 images    (1, 4): 64 x 256    (1, 2): 64 x 128, two waves
-template <bool OUT_F32, int WN, int WM, int KG>
-__global__ __launch_bounds__(64 * WN * WM * KG) void pconv_bf16_kernel(const PConvArgs p) {
-    constexpr int GT = 64 * WN * WM;                              // threads per k-group
+// WS = wave-specialised: the GT MFMA waves only read LDS and issue MFMAs; 4 extra staging waves (one per SIMD) only do
+// table lookups, buffer loads and ds_writes, one tile ahead into the other of TWO LDS stages with the tile after that in
+// flight in their registers; one barrier per tile.  (s_memtime of the unspecialised kernel: 800 cycles issuing loads +
+// 520 in ds_writes + 290 in barriers per iteration against 512 of MFMA, all serial inside the workgroup.)
+template <bool OUT_F32, int WN, int WM, int KG, bool WS>
+__global__ __launch_bounds__(64 * WN * WM * KG + (WS ? 256 : 0)) void pconv_bf16_kernel(const PConvArgs p) {
+    static_assert(!WS || KG == 1, "wave specialisation replaces the k-groups");
+    constexpr int GT = 64 * WN * WM;                              // MFMA threads per k-group
+    constexpr int LT = WS ? 256 : GT;                             // threads that stage one tile
+    constexpr int NSTG = WS ? 2 : 1;                              // LDS stages per k-group
     constexpr int BN = 64 * WN, BM = 64 * WM;
     constexpr int LDXB = BM + 32;                                 // image row pitch: = 64 B mod 256 for BM = 128, 256
-    constexpr int WPASS = BN * 8 / GT, WROWS = GT / 8;            // weight tile: 8 lanes x 16 B per 128-byte row
-    constexpr int XL = BM / 8, XROWS = GT / XL, XPASS = BK / XROWS;   // image tile: XL lanes x 16 B per row
+    constexpr int WPASS = BN * 8 / LT, WROWS = LT / 8;            // weight tile: 8 lanes x 16 B per 128-byte row
+    constexpr int XL = BM / 8, XROWS = LT / XL, XPASS = BK / XROWS;   // image tile: XL lanes x 16 B per row
     constexpr int KCHG = KCH * KG;
-    constexpr int kStage = BK * LDXB + BN * LDWB;                 // elements per k-group stage
+    constexpr int kStage = BK * LDXB + BN * LDWB;                 // elements per stage
     // dynamic LDS only (a static array in front would shift the 16-byte alignment of the carve)
     extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
-    const int kg = __builtin_amdgcn_readfirstlane((int)threadIdx.x / GT);
-    uint16_t* Xs = smem + kg * kStage;
+    const bool producer = WS && __builtin_amdgcn_readfirstlane((int)threadIdx.x >= GT ? 1 : 0) != 0;
+    const int kg = WS ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x / GT);
+    uint16_t* Xs = smem + kg * kStage;                            // stage 0 of this group (stage s: + s * kStage)
     uint16_t* Ws = Xs + BK * LDXB;
-    int32_t* kt_all = reinterpret_cast<int32_t*>(smem + KG * kStage);      // [2][KCHG] image-row offsets per k
+    int32_t* kt_all = reinterpret_cast<int32_t*>(smem + KG * NSTG * kStage);   // [2][KCHG] image-row offsets per k
     int32_t* kw_all = kt_all + 2 * KCHG;                                   // [2][KCHG] weight-column offsets per k
 
     const int bid = blockIdx.x;
@@ -96,7 +104,8 @@ __global__ __launch_bounds__(64 * WN * WM * KG) void pconv_bf16_kernel(const PCo
     const int K = p.wtap ? p.Cin * nr * nq : p.K;                 // contraction length of this pixel
     const int niter = (K + BK * KG - 1) / (BK * KG);              // every group runs the same number of iterations
 
-    const int tid = (int)threadIdx.x - kg * GT;                   // thread within its k-group
+    const int tid = (int)threadIdx.x - kg * GT;                   // thread within its k-group (MFMA role)
+    const int ltid = WS ? (int)threadIdx.x - GT : tid;            // thread within the staging team
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = (wave / WM) * 64, wm = (wave % WM) * 64;
@@ -111,17 +120,17 @@ __global__ __launch_bounds__(64 * WN * WM * KG) void pconv_bf16_kernel(const PCo
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(xb), 0, (int)x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(wb), 0, (int)w_bytes, 0x00020000);
 
-    const int wr = tid >> 3, wseg = (tid & 7) * 8;
+    const int wr = ltid >> 3, wseg = (ltid & 7) * 8;
     const uint32_t wbase = (uint32_t)(n0 + wr) * (uint32_t)Kp * 2u;
     const uint32_t wstep = (uint32_t)WROWS * (uint32_t)Kp * 2u;
-    const int xkr = tid / XL, xb8 = (tid % XL) * 8;
+    const int xkr = ltid / XL, xb8 = (ltid % XL) * 8;
     const uint32_t xcol = (uint32_t)(b0 + xb8) * 2u;
 
     // k -> (weight column offset, image row offset), float-reciprocal division + fix-up (exact below 2^24)
     const float inv_khkw = 1.0f / (float)p.khkw, inv_kw = 1.0f / (float)p.kw;
     const float inv_cin = 1.0f / (float)p.Cin, inv_nq = nq > 0 ? 1.0f / (float)nq : 0.0f;
     auto fill_chunk = [&](int chunk) {
-        for (int i = (int)threadIdx.x; i < KCHG; i += GT * KG) {
+        for (int i = WS ? ltid : (int)threadIdx.x; i < KCHG; i += WS ? LT : GT * KG) {
             const int k = chunk * KCHG + i;
             uint32_t xo = kXInv, wo = kWInv;
             if (p.wtap) {
@@ -172,11 +181,13 @@ __global__ __launch_bounds__(64 * WN * WM * KG) void pconv_bf16_kernel(const PCo
 #pragma unroll
         for (int ps = 0; ps < WPASS; ++ps) wreg[ps] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, wo + (uint32_t)ps * wstep, 0, 0));
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](int stage) {
+        uint16_t* Xd = Xs + stage * kStage;
+        uint16_t* Wd = Ws + stage * kStage;
 #pragma unroll
-        for (int ps = 0; ps < WPASS; ++ps) *reinterpret_cast<u32x4*>(&Ws[(wr + ps * WROWS) * LDWB + wseg]) = wreg[ps];
+        for (int ps = 0; ps < WPASS; ++ps) *reinterpret_cast<u32x4*>(&Wd[(wr + ps * WROWS) * LDWB + wseg]) = wreg[ps];
 #pragma unroll
-        for (int ps = 0; ps < XPASS; ++ps) *reinterpret_cast<u32x4*>(&Xs[(xkr + ps * XROWS) * LDXB + xb8]) = xreg[ps];
+        for (int ps = 0; ps < XPASS; ++ps) *reinterpret_cast<u32x4*>(&Xd[(xkr + ps * XROWS) * LDXB + xb8]) = xreg[ps];
     };
 
     f32x16 acc[2][2];
@@ -194,7 +205,9 @@ __global__ __launch_bounds__(64 * WN * WM * KG) void pconv_bf16_kernel(const PCo
     const int tr_off = ((8 * (tg >> 1) + (tt >> 2)) * LDXB + wm + 16 * (tg & 1) + 4 * (tt & 3));
     typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 
-    auto mma_tile = [&]() {
+    auto mma_tile = [&](int stage) {
+        const uint16_t* Xs = smem + (kg * NSTG + stage) * kStage;
+        const uint16_t* Ws = Xs + BK * LDXB;
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
             bf16x8 b[2], a[2];
@@ -222,13 +235,48 @@ __global__ __launch_bounds__(64 * WN * WM * KG) void pconv_bf16_kernel(const PCo
 #else
 #define TS() do { } while (0)
 #endif
-    {
+    if constexpr (WS) {
+        if (producer) {
+            // ---- staging waves: tile t+1 -> stage (t+1)&1 while the MFMA waves are on stage t&1; tile t+2 in flight ----
+            if (niter > 0) fill_chunk(0);
+            __syncthreads();                                       // P0: table chunk 0 visible to all staging waves
+            if (niter > 0) {
+                load_tile(0);
+                if (KCHG < K) fill_chunk(1);
+                store_tile(0);
+            }
+            __syncthreads();                                       // P1: stage 0 = tile 0, table chunk 1 visible
+            if (niter > 1) load_tile(1);
+            for (int t = 0; t < niter; ++t) {
+                if (t + 1 < niter) {
+                    store_tile((t + 1) & 1);                       // registers hold tile t+1, issued one iteration ago
+                    if (t + 2 < niter) load_tile(t + 2);
+                }
+                // decode chunk c+1 during the first tile of chunk c (c >= 1): its buffer was last read two barriers
+                // ago (load_tile(c*TPC - 1) at iteration c*TPC - 3) and is first read TPC - 2 barriers from now
+                if ((t % TPC) == 0 && t / TPC >= 1 && (t / TPC + 1) * KCHG < K) fill_chunk(t / TPC + 1);
+                __syncthreads();
+            }
+            return;
+        }
+        TS();
+        __syncthreads();                                           // P0
+        __syncthreads();                                           // P1
+        TS();
+        for (int t = 0; t < niter; ++t) {
+            TS();
+            mma_tile(t & 1);
+            TS();
+            __syncthreads();
+            TS(); TS(); TS();
+        }
+    } else {
         TS();
         fill_chunk(0);
         __syncthreads();
         load_tile(0);
         if (KCHG < K) fill_chunk(1);
-        store_tile();
+        store_tile(0);
         __syncthreads();
         TS();
         for (int t = 0; t < niter; ++t) {
@@ -236,11 +284,11 @@ __global__ __launch_bounds__(64 * WN * WM * KG) void pconv_bf16_kernel(const PCo
             if (more) load_tile(t + 1);
             if ((t % TPC) == 1 && t / TPC >= 1 && (t / TPC + 1) * KCHG < K) fill_chunk(t / TPC + 1);
             TS();
-            mma_tile();
+            mma_tile(0);
             TS();
             __syncthreads();
             TS();
-            if (more) store_tile();
+            if (more) store_tile(0);
             TS();
             __syncthreads();
             TS();
@@ -340,29 +388,38 @@ __global__ __launch_bounds__(64 * WN * WM * KG) void pconv_bf16_kernel(const PCo
 #endif
 }
 
-template <bool OUT_F32, int WN, int WM, int KG>
+template <bool OUT_F32, int WN, int WM, int KG, bool WS>
 int launch_cfg(const PConvArgs& a, int64_t blocks, hipStream_t st) {
-    constexpr int kSmem = KG * (BK * (64 * WM + 32) + 64 * WN * LDWB) * 2 + 4 * KCH * KG * 4;
+    constexpr int kStageB = (BK * (64 * WM + 32) + 64 * WN * LDWB) * 2;
+    constexpr int kSmem = KG * (WS ? 2 : 1) * kStageB + 4 * KCH * KG * 4;
     constexpr int kRed = (KG - 1) * 64 * (64 * WN * WM) * 4;
-    static_assert(kRed <= KG * (BK * (64 * WM + 32) + 64 * WN * LDWB) * 2, "reduction buffer must fit in the stage memory");
+    static_assert(kRed <= KG * kStageB, "reduction buffer must fit in the stage memory");
     static_assert(kSmem <= 160 * 1024, "LDS");
-    static_assert(WN * WM * 64 * 72 * 2 <= (BK * (64 * WM + 32) + 64 * WN * LDWB) * 2, "epilogue staging must fit in one stage");
+    static_assert(WN * WM * 64 * 72 * 2 <= kStageB, "epilogue staging must fit in one stage");
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(&pconv_bf16_kernel<OUT_F32, WN, WM, KG>),
+        hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(&pconv_bf16_kernel<OUT_F32, WN, WM, KG, WS>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, kSmem);
         if (er != hipSuccess) return (int)er;
         attr_done = true;
     }
-    hipLaunchKernelGGL((pconv_bf16_kernel<OUT_F32, WN, WM, KG>), dim3((unsigned)blocks), dim3(64 * WN * WM * KG), kSmem, st, a);
+    hipLaunchKernelGGL((pconv_bf16_kernel<OUT_F32, WN, WM, KG, WS>), dim3((unsigned)blocks),
+                       dim3(64 * WN * WM * KG + (WS ? 256 : 0)), kSmem, st, a);
     return (int)hipGetLastError();
 }
 
 template <bool OUT_F32>
-int launch_shape(const PConvArgs& a, int shape, int kgs, int64_t blocks, hipStream_t st) {
-    if (shape == 22) return kgs == 2 ? launch_cfg<OUT_F32, 2, 2, 2>(a, blocks, st) : launch_cfg<OUT_F32, 2, 2, 1>(a, blocks, st);
-    if (shape == 14) return kgs == 2 ? launch_cfg<OUT_F32, 1, 4, 2>(a, blocks, st) : launch_cfg<OUT_F32, 1, 4, 1>(a, blocks, st);
-    return kgs == 2 ? launch_cfg<OUT_F32, 1, 2, 2>(a, blocks, st) : launch_cfg<OUT_F32, 1, 2, 1>(a, blocks, st);
+int launch_shape(const PConvArgs& a, int shape, int kgs, bool ws, int64_t blocks, hipStream_t st) {
+    if (shape == 22) {
+        if (ws) return launch_cfg<OUT_F32, 2, 2, 1, true>(a, blocks, st);
+        return kgs == 2 ? launch_cfg<OUT_F32, 2, 2, 2, false>(a, blocks, st) : launch_cfg<OUT_F32, 2, 2, 1, false>(a, blocks, st);
+    }
+    if (shape == 14) {
+        if (ws) return launch_cfg<OUT_F32, 1, 4, 1, true>(a, blocks, st);
+        return kgs == 2 ? launch_cfg<OUT_F32, 1, 4, 2, false>(a, blocks, st) : launch_cfg<OUT_F32, 1, 4, 1, false>(a, blocks, st);
+    }
+    if (ws) return launch_cfg<OUT_F32, 1, 2, 1, true>(a, blocks, st);
+    return kgs == 2 ? launch_cfg<OUT_F32, 1, 2, 2, false>(a, blocks, st) : launch_cfg<OUT_F32, 1, 2, 1, false>(a, blocks, st);
 }
 
 // maxpool over [planes][H][W][B] bf16, 8 images per thread (bf16 order = fp32 order of the widened values: exact)
@@ -487,8 +544,14 @@ extern "C" int bbb_conv2d_chwn_bf16_fwd(const bbb_conv_desc_t* d, const void* x,
 #ifdef BBB_TIMESTAMPS
     { const char* tv = getenv("BBB_TS"); a.ts = tv ? (long long*)strtoull(tv, nullptr, 0) : nullptr; }
 #endif
+    // wave specialisation pays when few workgroups are resident per CU (nothing else hides the staging phases); measured
+    // on AlexNet bs=512 E=10: conv3 31.7 -> 23.2 us, conv4 46.5 -> 33.3, conv5 18.2 -> 16.8, but conv1 / conv2 (1280+
+    // workgroups, or the 64x256 shape whose two stages leave one workgroup per CU) 20-30 % slower
+    bool ws = shape == 22 && items <= 1024;
+    if (ws) kgs = 1;
+    if (const char* f = getenv("BBB_BF16_WS")) { ws = atoi(f) != 0; if (ws) kgs = 1; }
     hipStream_t st = (hipStream_t)stream;
-    return out_f32 ? launch_shape<true>(a, shape, kgs, blocks, st) : launch_shape<false>(a, shape, kgs, blocks, st);
+    return out_f32 ? launch_shape<true>(a, shape, kgs, ws, blocks, st) : launch_shape<false>(a, shape, kgs, ws, blocks, st);
 }
 
 extern "C" int bbb_maxpool_chwn_bf16(const void* x, void* y, int64_t planes, int h, int w, int batch, int k, int s, void* stream) {
