@@ -191,13 +191,20 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # test hooks (single-GPU rehearsal of the N > 1 code path): BBB_BENCH_DEVICE pins every rank to one device,
+    # BBB_BENCH_BACKEND=gloo replaces RCCL.  Never set by the driver.
+    dev_index = int(os.environ.get("BBB_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("BBB_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     group = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
         group = dist.group.WORLD
 
     from bbb_hip import ensemble, rng, zoo, _lib
