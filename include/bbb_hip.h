@@ -179,6 +179,16 @@ int bbb_lrt_conv2d_chwn_fwd(const bbb_conv_desc_t* d, const float* x, const floa
 int bbb_maxpool_chwn(const float* x, float* y, int64_t planes, int h, int w, int batch, int k, int s, void* stream);
 
 /*
+ * E noise draws from ONE pair of LRT moments, batch-innermost: y[e] = act(act_mu + sqrt(act_var) * eps[e]) with eps exactly
+ * as bbb_lrt_conv2d_chwn_fwd would have drawn it for draw e (layers/BBB_LRT/BBBConv.py:78-81).  For an LRT layer whose input
+ * is the same for every draw (the first layer of a model) this replaces E identical pairs of contractions by one.
+ *   act_mu, act_var: [channels][pixels][batch] (the act_mu_out / act_var_out of a draws = 1, sample = 0 launch)
+ *   y: [draws][channels][pixels][batch]
+ */
+int bbb_lrt_sample_chwn(const float* act_mu, const float* act_var, float* y, int draws, int channels, int pixels, int batch,
+                        int act, uint64_t seed, uint32_t call0, uint32_t stream_id, const uint32_t* call_dev, void* stream);
+
+/*
  * BF16 storage variants of the batch-innermost path (BASELINE.json configs[1]: "BBB layers, bf16"); fp32 accumulation,
  * fp32 bias and fp32 epilogue (bias + activation), one rounding (nearest-even) when a value is stored as bf16.
  *   x: [draws|1][cin][h][w][B] bf16   (B % 8 == 0, 16-byte aligned, draw strides multiples of 8 elements)

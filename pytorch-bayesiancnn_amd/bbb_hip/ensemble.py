@@ -287,14 +287,23 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
                     if not is_conv:
                         shp = (mod.out_features, mod.in_features, 1, 1)
                         w_mu, w_var = w_mu.reshape(shp), w_var.reshape(shp)
-                    if h5.shape[0] == 1 and Es > 1:
-                        h5 = h5.expand(Es, *h5.shape[1:])
+                    shared_in = h5.shape[0] == 1 and Es > 1
                     fl = conv_flops(B, h5.shape[1], h5.shape[2], h5.shape[3], w_mu.shape[0], w_mu.shape[2], w_mu.shape[3],
-                                    *geom, Es, 2) if timers is not None else None
-                    y = _run(timers, "lrt_gemm", fl,
-                             lambda: ops.lrt_conv2d_chwn_forward(h5, w_mu, w_var, mod.bias_mu if mod.use_bias else None, b_var,
-                                                                 seed, call0 + e0, mod._stream_base + 2, *geom, sample=True,
-                                                                 act=act)[0])
+                                    *geom, 1 if shared_in else Es, 2) if timers is not None else None
+                    if shared_in:
+                        # same input AND same (mu, sigma^2) weights for every draw: the two contractions run once, the E
+                        # draws differ only in the epilogue noise (bitwise the same result as E full launches)
+                        _, am, av = _run(timers, "lrt_gemm", fl,
+                                         lambda: ops.lrt_conv2d_chwn_forward(h5, w_mu, w_var, mod.bias_mu if mod.use_bias else None,
+                                                                             b_var, seed, call0 + e0, mod._stream_base + 2, *geom,
+                                                                             sample=False, want_moments=True, act=None))
+                        y = _run(timers, "lrt_sample", None,
+                                 lambda: ops.lrt_sample_chwn(am, av, Es, seed, call0 + e0, mod._stream_base + 2, act=act))
+                    else:
+                        y = _run(timers, "lrt_gemm", fl,
+                                 lambda: ops.lrt_conv2d_chwn_forward(h5, w_mu, w_var, mod.bias_mu if mod.use_bias else None, b_var,
+                                                                     seed, call0 + e0, mod._stream_base + 2, *geom, sample=True,
+                                                                     act=act)[0])
                 h = y
                 if act is not None:
                     i += 1

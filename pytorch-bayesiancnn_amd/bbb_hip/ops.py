@@ -17,7 +17,8 @@ _scratch = {}
 
 
 def _partials(device, n):
-    key = (device.index, "kl")
+    # one scratch buffer per (device, stream): launches on different streams (graph lanes, a second model) may overlap
+    key = (device.index, "kl", cur_stream(device))
     buf = _scratch.get(key)
     if buf is None or buf.numel() < n:
         buf = torch.empty(max(n, 4096), dtype=torch.float64, device=device)
@@ -237,6 +238,20 @@ def lrt_conv2d_chwn_forward(x, w_mu, w_var, b_mu, b_var, seed, call0, stream_id,
                                                  rng.call_dev_ptr(x.device), cur_stream(x.device)),
               "bbb_lrt_conv2d_chwn_fwd")
     return y, am, av
+
+
+def lrt_sample_chwn(act_mu, act_var, draws, seed, call0, stream_id, act=None):
+    """E draws y[e] = act(act_mu + sqrt(act_var) * eps[e]) from one pair of LRT moments [1|-, C, Ho, Wo, B] ->
+    [E, C, Ho, Wo, B]; eps as the LRT GEMM epilogue would draw it for draw e."""
+    require_device(act_mu, act_var)
+    act_mu, act_var = act_mu.contiguous(), act_var.contiguous()
+    C, Ho, Wo, B = act_mu.shape[-4:]
+    y = torch.empty((draws, C, Ho, Wo, B), dtype=torch.float32, device=act_mu.device)
+    with torch.cuda.device(act_mu.device):
+        check(_lib.lib().bbb_lrt_sample_chwn(act_mu.data_ptr(), act_var.data_ptr(), y.data_ptr(), draws, C, Ho * Wo, B,
+                                             {None: 0, "relu": 1, "softplus": 2}[act], seed, call0 & 0xFFFFFFFF, stream_id,
+                                             rng.call_dev_ptr(act_mu.device), cur_stream(act_mu.device)), "bbb_lrt_sample_chwn")
+    return y
 
 
 def maxpool_chwn(x, k, s):

@@ -170,6 +170,39 @@ __global__ __launch_bounds__(256) void transpose2d_kernel(const float* __restric
     }
 }
 
+// y[e] = act(act_mu + sqrt(act_var) * eps[e]) for E draws of ONE pair of LRT moments (batch-innermost layout).  Used when the
+// input of an LRT layer is shared by all draws (the first layer): the two contractions run once, only the noise differs.
+// eps element index = the canonical NCHW index ((b*C + n)*HW + pix) of draw e's output, as in the GEMM epilogue; one
+// thread takes 4 consecutive pixels (one Philox call) when HW % 4 == 0, one pixel otherwise.
+template <int PPT>
+__global__ __launch_bounds__(256) void lrt_sample_chwn_kernel(const float* __restrict__ mu, const float* __restrict__ var,
+                                                              float* __restrict__ y, int E, int C, int HW, int B, int act,
+                                                              uint32_t k0, uint32_t k1, uint32_t call0, uint32_t stream_id,
+                                                              const uint32_t* __restrict__ call_dev) {
+    const int64_t HWq = HW / PPT;
+    const int64_t total = (int64_t)E * C * HWq * B;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int b = (int)(i % B);
+    int64_t t = i / B;
+    const int q = (int)(t % HWq);
+    t /= HWq;
+    const int n = (int)(t % C);
+    const int e = (int)(t / C);
+    const uint32_t call = call0 + (call_dev ? *call_dev : 0u) + (uint32_t)e;
+    const uint64_t idx0 = (uint64_t)(((int64_t)b * C + n) * HW + (int64_t)q * PPT);
+    float z4[4];
+    bbb::normal4(idx0 >> 2, stream_id, call, k0, k1, z4);
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int64_t o = ((int64_t)n * HW + (int64_t)q * PPT + j) * B + b;          // offset inside one draw's slab
+        const int c = PPT == 4 ? j : (int)(idx0 & 3);
+        const float z = c == 0 ? z4[0] : c == 1 ? z4[1] : c == 2 ? z4[2] : z4[3];
+        const float v = mu[o] + __builtin_amdgcn_sqrtf(var[o]) * z;
+        y[(int64_t)e * C * HW * B + o] = bbb::apply_act(v, act);
+    }
+}
+
 }  // namespace
 
 extern "C" int bbb_mc_tail_cb(const float* logits, int draws, int batch, int classes, int mean_over, float* lse_out,
@@ -222,4 +255,25 @@ extern "C" int bbb_abi_version(void) { return BBB_ABI_VERSION; }
 
 extern "C" const char* bbb_build_info(void) {
     return "libbbb_hip gfx950 (CDNA4) fp32-MFMA; built " __DATE__ " " __TIME__;
+}
+
+extern "C" int bbb_lrt_sample_chwn(const float* act_mu, const float* act_var, float* y, int draws, int channels, int pixels,
+                                   int batch, int act, uint64_t seed, uint32_t call0, uint32_t stream_id,
+                                   const uint32_t* call_dev, void* stream) {
+    if (act_mu == nullptr || act_var == nullptr || y == nullptr || draws <= 0 || channels <= 0 || pixels <= 0 || batch <= 0 ||
+        act < 0 || act > 2)
+        return BBB_EINVAL;
+    if ((((uintptr_t)act_mu | (uintptr_t)act_var | (uintptr_t)y) & 3u) != 0) return BBB_EALIGN;
+    const bool quad = pixels % 4 == 0;
+    const int64_t total = (int64_t)draws * channels * (quad ? pixels / 4 : pixels) * batch;
+    const int64_t blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffffLL) return BBB_ESHAPE;
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    if (quad)
+        hipLaunchKernelGGL(lrt_sample_chwn_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, act_mu, act_var, y,
+                           draws, channels, pixels, batch, act, k0, k1, call0, stream_id, call_dev);
+    else
+        hipLaunchKernelGGL(lrt_sample_chwn_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, act_mu, act_var, y,
+                           draws, channels, pixels, batch, act, k0, k1, call0, stream_id, call_dev);
+    return (int)hipGetLastError();
 }

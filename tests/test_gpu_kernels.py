@@ -353,3 +353,22 @@ def test_conv_backward_helpers_vs_autograd(ops, case):
     np.testing.assert_allclose(wa.grad.cpu().numpy(), wd.grad.float().cpu().numpy(), rtol=2e-4, atol=2e-4)
     want_gb = gy.sum(dim=(1, 3, 4))
     np.testing.assert_allclose(ba.grad.cpu().numpy(), (want_gb.sum(0, keepdim=True) if shared else want_gb).cpu().numpy(), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("B,Cin,H,W,Cout,k,s,p", [(16, 3, 32, 32, 64, 11, 4, 5), (8, 2, 7, 5, 10, 3, 1, 1), (12, 4, 6, 6, 5, 3, 2, 0)])
+def test_lrt_shared_input_dedup_is_bitwise_the_full_launch(ops, B, Cin, H, W, Cout, k, s, p):
+    """First LRT layer of an ensemble: x and (mu, sigma^2) are the same for all draws, so the moments are computed once
+    and bbb_lrt_sample_chwn draws the E outputs -- must equal E full LRT launches bit for bit (pixels % 4 == 0 and != 0)."""
+    torch.manual_seed(B + Cout)
+    E, seed, call0, sid = 5, 321, 9, 6
+    x = torch.rand(1, Cin, H, W, B, device="cuda")
+    w_mu = torch.randn(Cout, Cin, k, k, device="cuda") * 0.2
+    w_var = torch.rand(Cout, Cin, k, k, device="cuda") * 0.01
+    b_mu, b_var = torch.randn(Cout, device="cuda"), torch.rand(Cout, device="cuda") * 0.01
+    full, _, _ = ops.lrt_conv2d_chwn_forward(x.expand(E, -1, -1, -1, -1).contiguous(), w_mu, w_var, b_mu, b_var, seed, call0, sid,
+                                             s, p, 1, sample=True, act="softplus")
+    _, am, av = ops.lrt_conv2d_chwn_forward(x, w_mu, w_var, b_mu, b_var, seed, call0, sid, s, p, 1, sample=False,
+                                            want_moments=True, act=None)
+    got = ops.lrt_sample_chwn(am, av, E, seed, call0, sid, act="softplus")
+    assert got.shape == full.shape
+    assert torch.equal(got, full)
