@@ -1,10 +1,10 @@
 """Tensor-level entry points over the C ABI + their autograd wiring.
 
 Forward math is entirely in the HIP kernels.  Backward (training extension): the parameter pass
-has its own fused HIP kernel (eps regenerated from the counter, never stored); conv / linear weight gradients and
-stride-1 input gradients run on the SAME fp32-MFMA implicit-GEMM kernel as the forward (wgrad = the axis-swapped
-convolution, dgrad = the flipped-weight convolution); only the input gradient of strided / dilated layers still goes
-through ATen's convolution_backward.  Activations, pooling and the loss tail use torch autograd in this mode.
+has its own fused HIP kernel (eps regenerated from the counter, never stored); conv / linear weight gradients and input
+gradients run on the SAME fp32-MFMA implicit-GEMM kernel as the forward (wgrad = the axis-swapped convolution, dgrad = the
+flipped-weight convolution of the stride-upsampled output gradient) -- no ATen / MIOpen / rocBLAS convolution or GEMM
+anywhere.  Activations, pooling and the loss tail use torch autograd (element-wise ops) in this mode.
 """
 import ctypes
 
@@ -506,16 +506,30 @@ class _KLOnly(torch.autograd.Function):
 
 
 def conv2d_input_grad(gy, w, x_shape, stride, padding, dilation):
-    """d loss / d x of y = conv2d(x, w) on the same fp32-MFMA kernel: for stride 1 / dilation 1 it is a convolution of
-    gy with the spatially flipped, channel-transposed weights and padding k-1-p.  gy [E,B,Cout,Ho,Wo], w [E|1,Cout,Cin,kh,kw].
-    Returns None when the geometry is not covered (strided / dilated layers: caller falls back)."""
+    """d loss / d x of y = conv2d(x, w) on the same fp32-MFMA kernel: a stride-1 convolution of gy -- zero-upsampled by the
+    layer's stride -- with the spatially flipped, channel-transposed weights, the layer's dilation and padding
+    d*(k-1) - p; rows / columns of x that no output touched get zero.  gy [E,B,Cout,Ho,Wo], w [E|1,Cout,Cin,kh,kw].
+    (Stride s multiplies s*s - 1 inserted zeros: fine for the rare strided layer that is not a model's first layer -- a
+    first layer needs no input gradient at all.)"""
     (sh, sw), (ph, pw), (dh, dw) = _pair(stride), _pair(padding), _pair(dilation)
     kh, kw = w.shape[3], w.shape[4]
-    if (sh, sw, dh, dw) != (1, 1, 1, 1) or ph > kh - 1 or pw > kw - 1:
-        return None
+    H, W = x_shape[-2], x_shape[-1]
+    E, B, Cout, Ho, Wo = gy.shape
+    # upsampled extent, extended so that the stride-1 transposed convolution yields exactly H x W: input rows past
+    # (Ho-1)*s + d*(k-1) - p still receive gradient from the last outputs only if they exist, i.e. zeros are appended
+    Uh, Uw = H + 2 * ph - dh * (kh - 1), W + 2 * pw - dw * (kw - 1)
+    if (sh, sw) != (1, 1) or (Uh, Uw) != (Ho, Wo):
+        up = gy.new_zeros((E, B, Cout, Uh, Uw))
+        up[:, :, :, :(Ho - 1) * sh + 1:sh, :(Wo - 1) * sw + 1:sw] = gy
+        gy = up
+    qh, qw = dh * (kh - 1) - ph, dw * (kw - 1) - pw                      # padding of the transposed convolution
     w_t = w.flip(3, 4).transpose(1, 2).contiguous()                     # [E|1, Cin, Cout, kh, kw]
-    gx = conv2d_forward(gy, w_t, None, 1, (kh - 1 - ph, kw - 1 - pw), 1)
-    return gx if tuple(gx.shape[1:]) == tuple(x_shape[1:]) else None
+    gx = conv2d_forward(gy, w_t, None, 1, (max(qh, 0), max(qw, 0)), (dh, dw))
+    if qh < 0 or qw < 0:                                                 # padding larger than the kernel reach: crop
+        gx = gx[:, :, :, max(-qh, 0):gx.shape[3] - max(-qh, 0), max(-qw, 0):gx.shape[4] - max(-qw, 0)]
+    if gx.shape[3] != H or gx.shape[4] != W:
+        raise _lib.BBBHipError("conv2d_input_grad: geometry mismatch")
+    return gx.contiguous()
 
 
 def conv2d_weight_grad(gy, x, w_shape, stride, padding, dilation):
@@ -551,8 +565,8 @@ def conv2d_weight_grad(gy, x, w_shape, stride, padding, dilation):
 
 
 class _Conv2d(torch.autograd.Function):
-    """y = conv2d(x, w, bias) batched over draws.  Backward runs on the same HIP GEMM (dgrad as a flipped-weight conv,
-    wgrad as the axis-swapped conv); only strided / dilated dgrad falls back to ATen's convolution_backward."""
+    """y = conv2d(x, w, bias) batched over draws.  Backward runs on the same HIP GEMM (dgrad as a flipped-weight conv of the
+    stride-upsampled gradient, wgrad as the axis-swapped conv)."""
 
     @staticmethod
     def forward(ctx, x, w, bias, stride, padding, dilation):
@@ -576,13 +590,6 @@ class _Conv2d(torch.autograd.Function):
             gw = conv2d_weight_grad(gy, x, tuple(w.shape), stride, padding, dilation)
         if ctx.needs_input_grad[0]:
             gx = conv2d_input_grad(gy, w, (E,) + tuple(x.shape[1:]), stride, padding, dilation)
-            if gx is None:                                               # strided / dilated layer: ATen stop-gap
-                gx = torch.empty((E,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-                for e in range(E):
-                    xe = x[e if x.shape[0] > 1 else 0]
-                    we = w[e if w.shape[0] > 1 else 0]
-                    gx[e] = torch.ops.aten.convolution_backward(gy[e], xe, we, None, list(stride), list(padding),
-                                                                list(dilation), False, [0, 0], 1, [True, False, False])[0]
             if x.shape[0] == 1 and E > 1:
                 gx = gx.sum(0, keepdim=True)
         return gx, gw, gb, None, None, None
@@ -615,13 +622,6 @@ class _LrtConv2d(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             g1 = conv2d_input_grad(gy, wm5, tuple(x.shape), *geom)
             g2 = conv2d_input_grad(gv, wv5, tuple(x.shape), *geom)
-            if g1 is None or g2 is None:                                 # strided / dilated layer: ATen stop-gap
-                st, pd, dl = list(_pair(geom[0])), list(_pair(geom[1])), list(_pair(geom[2]))
-                E, B = x.shape[0], x.shape[1]
-                x4 = x.reshape((E * B,) + tuple(x.shape[2:]))
-                f = lambda g, xx, ww: torch.ops.aten.convolution_backward(
-                    g.reshape((E * B,) + tuple(g.shape[2:])), xx, ww, None, st, pd, dl, False, [0, 0], 1, [True, False, False])[0]
-                g1, g2 = f(gy, x4, w_mu).reshape_as(x), f(gv, x4 * x4, w_var).reshape_as(x)
             gx = g1 + g2 * 2.0 * x
         gbm = gy.sum(dim=(0, 1, 3, 4)) if ctx.has_bias else None
         gbv = gv.sum(dim=(0, 1, 3, 4)) if ctx.has_bias else None

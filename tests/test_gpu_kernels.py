@@ -319,11 +319,13 @@ def test_to_batch_innermost(ops, shape):
 @pytest.mark.parametrize("case", [
     # B, Cin, H, W, Cout, kh, kw, stride, pad, dil, E, w_shared
     (6, 5, 9, 8, 7, 3, 3, 1, 1, 1, 2, False),
-    (4, 3, 12, 12, 6, 5, 5, 2, 2, 1, 1, False),      # strided: wgrad via dilation = stride (with cropping), dgrad -> ATen
+    (4, 3, 12, 12, 6, 5, 5, 2, 2, 1, 1, False),      # strided: wgrad via dilation = stride (with cropping), dgrad via upsampling
     (5, 4, 10, 9, 3, 3, 2, 3, 1, 1, 2, False),       # stride 3, (H + 2p - k) % s != 0
     (8, 16, 4, 4, 12, 3, 3, 1, 1, 1, 3, True),       # weights shared by the draws (LRT-style): grads summed over draws
     (4, 6, 7, 7, 5, 3, 3, 1, 0, 2, 1, False),        # dilated
     (16, 40, 1, 1, 10, 1, 1, 1, 0, 1, 2, False),     # linear as 1x1
+    (4, 3, 11, 9, 5, 3, 3, 2, 3, 1, 2, False),       # padding larger than the kernel reach (p > k - 1), strided
+    (4, 4, 13, 13, 6, 3, 3, 2, 1, 2, 1, False),      # strided AND dilated
 ])
 def test_conv_backward_helpers_vs_autograd(ops, case):
     B, Cin, H, W, Cout, kh, kw, s, p, d, E, shared = case
@@ -339,11 +341,8 @@ def test_conv_backward_helpers_vs_autograd(ops, case):
     loss.backward()
     gw = ops.conv2d_weight_grad(gy, x, tuple(w.shape), s, p, d)
     np.testing.assert_allclose(gw.cpu().numpy(), wd.grad.float().cpu().numpy(), rtol=2e-4, atol=2e-4)
-    gx = ops.conv2d_input_grad(gy, w, tuple(x.shape), s, p, d)
-    if s == 1 and d == 1:
-        np.testing.assert_allclose(gx.cpu().numpy(), xd.grad.float().cpu().numpy(), rtol=2e-4, atol=2e-4)
-    else:
-        assert gx is None                             # not covered: the autograd Function falls back to ATen
+    gx = ops.conv2d_input_grad(gy, w, tuple(x.shape), s, p, d)       # strided: zero-upsampled gy; dilated: dilated flipped kernel
+    np.testing.assert_allclose(gx.cpu().numpy(), xd.grad.float().cpu().numpy(), rtol=2e-4, atol=2e-4)
     # through the autograd Function (bias included)
     xa = x.clone().requires_grad_(True)
     wa = w.clone().requires_grad_(True)
