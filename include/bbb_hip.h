@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define BBB_ABI_VERSION 2
+#define BBB_ABI_VERSION 3
 #define BBB_MAX_SEGMENTS 16
 
 #define BBB_EINVAL (-1)   /* bad argument (null pointer, non-positive size, too many segments) */
@@ -91,12 +91,13 @@ int64_t bbb_reparam_partials(const bbb_segment_t* segs, int nseg);
  * eps is regenerated from (seed, call0 + e, stream_id), never stored.  In each segment `w` holds the
  * incoming gradient gw [draws][n] (may be NULL = 0), `sigma` is unused, `eps` optional external noise.
  * grad_mu / grad_rho are arrays of nseg device pointers given on the host.  gkl: device float
- * (d loss / d kl), NULL = 0.
+ * (d loss / d kl), NULL = 0.  call_dev: as in bbb_reparam_kl_fwd (a captured training step regenerates the forward's noise).
  */
 int bbb_reparam_kl_bwd(const bbb_segment_t* segs, int nseg, int draws,
                        float prior_mu, float prior_sigma,
                        uint64_t seed, uint32_t call0, uint32_t flags,
-                       const float* gkl, float* const* grad_mu, float* const* grad_rho, void* stream);
+                       const float* gkl, float* const* grad_mu, float* const* grad_rho,
+                       const uint32_t* call_dev, void* stream);
 
 /* One parameter tensor of an Adam step: all four arrays hold n fp32 elements on the device. */
 typedef struct bbb_adam_segment {
@@ -112,10 +113,12 @@ typedef struct bbb_adam_segment {
  * tensors in one launch, torch.optim.Adam semantics (amsgrad off, no weight decay), operation order as torch's:
  *   m += (g - m)(1 - beta1);  v = v*beta2 + (1 - beta2) g^2;  p -= lr/(1 - beta1^step) * m / (sqrt(v)/sqrt(1 - beta2^step) + eps)
  * `step` is the 1-based count of this update.  Hyper-parameters are doubles: derived scalars (1 - beta, the bias
- * corrections) are formed in double and rounded to fp32 once, as torch does.
+ * corrections) are formed in double and rounded to fp32 once, as torch does.  step_dev (optional): DEVICE float holding the
+ * step count (torch's capturable-Adam convention); when given it overrides `step` and the bias corrections are computed on
+ * the device, so a captured hipGraph advances correctly on every replay.
  */
 int bbb_adam_step(const bbb_adam_segment_t* segs, int nseg, double lr, double beta1, double beta2, double eps,
-                  int64_t step, void* stream);
+                  int64_t step, const float* step_dev, void* stream);
 
 /* Test entry: materialise n elements of a noise stream starting at element `start`. */
 int bbb_eps_dump(float* out, int64_t n, int64_t start, uint64_t seed, uint32_t call, uint32_t stream_id, void* stream);

@@ -42,9 +42,9 @@ _SIGNATURES = {
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "bbb_reparam_partials": (c_i64, [ctypes.POINTER(Segment), c_int]),
     "bbb_reparam_kl_bwd": (c_int, [ctypes.POINTER(Segment), c_int, c_int, c_float, c_float, c_u64, c_u32, c_u32,
-                                   c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), c_void_p]),
+                                   c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), c_void_p, c_void_p]),
     "bbb_adam_step": (c_int, [ctypes.POINTER(AdamSegment), c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
-                            c_i64, c_void_p]),
+                            c_i64, c_void_p, c_void_p]),
     "bbb_eps_dump": (c_int, [c_void_p, c_i64, c_i64, c_u64, c_u32, c_u32, c_void_p]),
     "bbb_conv2d_fwd": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "bbb_lrt_conv2d_fwd": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -87,8 +87,8 @@ def lib():
             fn = getattr(h, name)          # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if h.bbb_abi_version() != 2:
-            raise BBBHipError(f"ABI mismatch: library reports {h.bbb_abi_version()}, binding expects 2")
+        if h.bbb_abi_version() != 3:
+            raise BBBHipError(f"ABI mismatch: library reports {h.bbb_abi_version()}, binding expects 3")
         _lib = h
     return _lib
 

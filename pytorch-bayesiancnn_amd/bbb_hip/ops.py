@@ -92,7 +92,7 @@ def reparam_kl_backward(mus, rhos, gws, gkl, prior_mu, prior_sigma, stream_ids, 
     flags = _lib.KL_TEXTBOOK if textbook_kl else 0
     with torch.cuda.device(dev):
         rc = _lib.lib().bbb_reparam_kl_bwd(segs, len(mus), draws, float(prior_mu), float(prior_sigma), seed,
-                                           call0 & 0xFFFFFFFF, flags, ptr(gkl), pm, pr, cur_stream(dev))
+                                           call0 & 0xFFFFFFFF, flags, ptr(gkl), pm, pr, rng.call_dev_ptr(dev), cur_stream(dev))
     check(rc, "bbb_reparam_kl_bwd")
     return gmu, grho
 
@@ -505,6 +505,35 @@ class _KLOnly(torch.autograd.Function):
         return tuple(out)
 
 
+def conv2d_splitk(x, w, bias, stride=1, padding=0, dilation=1):
+    """conv2d_forward for the training path, where launches are small (one draw, a few hundred images): when the GEMM
+    would occupy fewer than ~512 workgroups, the input channels are split into S chunks that run as extra "draws" of one
+    launch and are summed afterwards in a fixed order (deterministic).  Same result up to fp32 summation order -- which is
+    why the inference paths, whose loop / batched forms must agree bit for bit, never come through here."""
+    (sh, sw), (ph, pw), (dh, dw) = _pair(stride), _pair(padding), _pair(dilation)
+    Ex, B, Cin, H, W = x.shape
+    Ew, Cout, _, kh, kw = w.shape
+    E = max(Ex, Ew)
+    ho = (H + 2 * ph - dh * (kh - 1) - 1) // sh + 1
+    wo = (W + 2 * pw - dw * (kw - 1) - 1) // sw + 1
+    tiles = E * -(-B * ho * wo // 64) * -(-Cout // 64)
+    S = 1
+    while tiles * S < 512 and Cin % (2 * S) == 0 and (Cin // (2 * S)) * kh * kw >= 64:
+        S *= 2
+    if S == 1:
+        return conv2d_forward(x, w, bias, stride, padding, dilation)
+    c = Cin // S
+    xs = x.reshape(Ex, B, S, c, H, W).permute(0, 2, 1, 3, 4, 5)                      # [Ex, S, B, c, H, W]
+    ws = w.reshape(Ew, Cout, S, c, kh, kw).permute(0, 2, 1, 3, 4, 5)                 # [Ew, S, Cout, c, kh, kw]
+    xs = xs.expand(E, S, B, c, H, W).reshape(E * S, B, c, H, W)
+    ws = ws.expand(E, S, Cout, c, kh, kw).reshape(E * S, Cout, c, kh, kw)
+    y = conv2d_forward(xs, ws, None, stride, padding, dilation)                      # [E*S, B, Cout, ho, wo]
+    y = y.reshape(E, S, B, Cout, ho, wo).sum(1)
+    if bias is not None:
+        y = y + bias.reshape(bias.shape[0], 1, Cout, 1, 1)
+    return y
+
+
 def conv2d_input_grad(gy, w, x_shape, stride, padding, dilation):
     """d loss / d x of y = conv2d(x, w) on the same fp32-MFMA kernel: a stride-1 convolution of gy -- zero-upsampled by the
     layer's stride -- with the spatially flipped, channel-transposed weights, the layer's dilation and padding
@@ -524,7 +553,7 @@ def conv2d_input_grad(gy, w, x_shape, stride, padding, dilation):
         gy = up
     qh, qw = dh * (kh - 1) - ph, dw * (kw - 1) - pw                      # padding of the transposed convolution
     w_t = w.flip(3, 4).transpose(1, 2).contiguous()                     # [E|1, Cin, Cout, kh, kw]
-    gx = conv2d_forward(gy, w_t, None, 1, (max(qh, 0), max(qw, 0)), (dh, dw))
+    gx = conv2d_splitk(gy, w_t, None, 1, (max(qh, 0), max(qw, 0)), (dh, dw))
     if qh < 0 or qw < 0:                                                 # padding larger than the kernel reach: crop
         gx = gx[:, :, :, max(-qh, 0):gx.shape[3] - max(-qh, 0), max(-qw, 0):gx.shape[4] - max(-qw, 0)]
     if gx.shape[3] != H or gx.shape[4] != W:
@@ -570,7 +599,7 @@ class _Conv2d(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, bias, stride, padding, dilation):
-        y = conv2d_forward(x, w, bias, stride, padding, dilation)
+        y = conv2d_splitk(x, w, bias, stride, padding, dilation)
         ctx.save_for_backward(x, w)
         ctx.geom = (_pair(stride), _pair(padding), _pair(dilation), bias is not None)
         return y
@@ -649,6 +678,11 @@ def kl_only(mus, rhos, prior_mu, prior_sigma, want_sigma=False, sigma_squared=Fa
 
 
 def conv2d(x, w, bias, stride=1, padding=0, dilation=1):
+    """Differentiable conv2d batched over draws.  Without autograd (inference through the drop-in layers) this is the
+    plain kernel launch, whose results the batched ensemble path reproduces bit for bit; with autograd the split-K
+    variant may be used (training launches are small)."""
+    if not (torch.is_grad_enabled() and (x.requires_grad or w.requires_grad or (bias is not None and bias.requires_grad))):
+        return conv2d_forward(x, w, bias, stride, padding, dilation)
     return _Conv2d.apply(x, w, bias, stride, padding, dilation)
 
 

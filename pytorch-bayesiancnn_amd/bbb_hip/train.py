@@ -15,12 +15,14 @@ from ._lib import AdamSegment, check, cur_stream
 class FusedAdam(torch.optim.Optimizer):
     """torch.optim.Adam(params, lr, betas, eps) semantics (amsgrad off, no weight decay) with the update of up to 16
     parameter tensors per HIP launch (`bbb_adam_step`).  State layout matches torch's ('step', 'exp_avg', 'exp_avg_sq'),
-    so state_dicts are interchangeable with torch.optim.Adam."""
+    so state_dicts are interchangeable with torch.optim.Adam.
+    capturable=True keeps 'step' on the device (torch's capturable convention) and lets the kernel derive the bias
+    corrections from it, so the step can be part of a captured hipGraph (GraphedTrainStep)."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, capturable=False):
         if not 0.0 <= lr or not 0.0 <= eps or not (0.0 <= betas[0] < 1.0 and 0.0 <= betas[1] < 1.0):
             raise ValueError("invalid Adam hyper-parameters")
-        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps))
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, capturable=bool(capturable)))
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -30,6 +32,7 @@ class FusedAdam(torch.optim.Optimizer):
                 loss = closure()
         L = _lib.lib()
         for group in self.param_groups:
+            cap = group.get("capturable", False)
             by_step = {}
             for p in group["params"]:
                 if p.grad is None:
@@ -39,11 +42,19 @@ class FusedAdam(torch.optim.Optimizer):
                     raise _lib.BBBHipError("FusedAdam needs contiguous parameters and gradients")
                 st = self.state[p]
                 if len(st) == 0:
-                    st["step"] = torch.tensor(0.0)
+                    st["step"] = torch.zeros((), dtype=torch.float32, device=p.device) if cap else torch.tensor(0.0)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["step"] += 1
-                by_step.setdefault(int(st["step"].item()), []).append((p, st))
+                if cap:
+                    by_step.setdefault(0, []).append((p, st))
+                else:
+                    st["step"] += 1
+                    by_step.setdefault(int(st["step"].item()), []).append((p, st))
+            if cap and by_step:
+                steps = [st["step"] for _, st in by_step[0]]
+                if any(not t.is_cuda for t in steps):
+                    raise _lib.BBBHipError("capturable FusedAdam needs its 'step' state on the device")
+                torch._foreach_add_(steps, 1.0)              # one launch; all tensors of a group step together
             for step, items in by_step.items():
                 for s0 in range(0, len(items), _lib.MAX_SEGMENTS):
                     part = items[s0:s0 + _lib.MAX_SEGMENTS]
@@ -55,7 +66,8 @@ class FusedAdam(torch.optim.Optimizer):
                     dev = part[0][0].device
                     with torch.cuda.device(dev):
                         check(L.bbb_adam_step(segs, len(part), float(group["lr"]), float(group["betas"][0]),
-                                              float(group["betas"][1]), float(group["eps"]), step, cur_stream(dev)),
+                                              float(group["betas"][1]), float(group["eps"]), step,
+                                              part[0][1]["step"].data_ptr() if cap else 0, cur_stream(dev)),
                               "bbb_adam_step")
         return loss
 
@@ -105,3 +117,56 @@ def train_step(net, optimizer, x, target, num_ens, beta, train_size, dp_group=No
         allreduce_gradients([p for g in optimizer.param_groups for p in g["params"]], dp_group)
     optimizer.step()
     return loss.detach(), log_outputs.detach(), kl.detach()
+
+
+class GraphedTrainStep:
+    """train_step captured as ONE hipGraph: Monte-Carlo forward with autograd, ELBO, backward, noise-counter increment
+    and the Adam update replay as a single graph launch (the eager step is host-bound: ~40 kernel launches plus autograd
+    bookkeeping per iteration).  Fresh noise per replay through the same device-side call counter as GraphedMC (the
+    backward kernel reads it too, so it regenerates the forward's eps); the Adam step count lives on the device.
+    Fixed shapes: copy each batch into `self.x` / `self.target` (or pass them to step()).  beta and train_size are
+    constants of the captured graph.  `warmup` real training iterations run eagerly on the capture stream first.
+    The optimizer must be FusedAdam(capturable=True) (or another capturable optimizer)."""
+
+    def __init__(self, net, optimizer, x, target, num_ens, beta, train_size, warmup=3):
+        from . import rng
+        _lib.require_device(x)
+        self.net, self.opt, self.num_ens = net, optimizer, int(num_ens)
+        self.beta, self.train_size = float(beta), float(train_size)
+        self.x, self.target = x.clone(), target.clone()
+        dev = x.device
+        self.counter = torch.zeros((1,), dtype=torch.int32, device=dev)
+        self.seed, self.call0 = rng.next_calls(0)
+        self.stream = torch.cuda.Stream(device=dev)
+        self.stream.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(self.stream), rng.device_call_offset(self.counter):
+            for _ in range(max(1, int(warmup))):
+                self.opt.zero_grad(set_to_none=True)
+                self._body()
+                rng.next_calls(self.num_ens)
+        torch.cuda.current_stream(dev).wait_stream(self.stream)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        self.opt.zero_grad(set_to_none=True)
+        with rng.device_call_offset(self.counter), torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="thread_local"):
+            self.loss, self.log_outputs, self.kl = self._body()
+        self.replays = 0
+
+    def _body(self):
+        log_outputs, kl = ensemble._local_lse(self.net, self.x, self.num_ens, self.seed, self.call0, self.num_ens)
+        loss = elbo(log_outputs, self.target, kl, self.beta, self.train_size)      # kl of one forward = kl / num_ens of the sum
+        loss.backward()
+        self.counter.add_(self.num_ens)              # after backward: it regenerates eps from the same counter value
+        self.opt.step()
+        return loss.detach(), log_outputs.detach(), kl.detach()
+
+    def step(self, x=None, target=None):
+        from . import rng
+        if x is not None:
+            self.x.copy_(x, non_blocking=True)
+        if target is not None:
+            self.target.copy_(target, non_blocking=True)
+        self.graph.replay()
+        self.replays += 1
+        rng.next_calls(self.num_ens)                 # keep the host-side noise counter in step with the device's
+        return self.loss, self.log_outputs, self.kl

@@ -22,10 +22,24 @@ struct AdamArgs {
     int32_t chunk_begin[BBB_MAX_SEGMENTS + 1];
     int32_t nseg;
     float step_size, beta1, beta2, omb1, omb2, eps, sqrt_bc2;
+    double lr_d, beta1_d, beta2_d;
+    const float* step_dev;
 };
 
 __global__ __launch_bounds__(kThreads) void adam_step_kernel(const AdamArgs a) {
     const int chunk = blockIdx.x;
+    float step_size = a.step_size, sqrt_bc2 = a.sqrt_bc2;
+    if (a.step_dev != nullptr) {       // captured graph: the step count lives on the device; one thread derives the scalars
+        __shared__ float sc[2];
+        if (threadIdx.x == 0) {
+            const double t = (double)*a.step_dev;
+            sc[0] = (float)(a.lr_d / (1.0 - pow(a.beta1_d, t)));
+            sc[1] = (float)sqrt(1.0 - pow(a.beta2_d, t));
+        }
+        __syncthreads();
+        step_size = sc[0];
+        sqrt_bc2 = sc[1];
+    }
     int s = 0;
     while (s + 1 < a.nseg && chunk >= a.chunk_begin[s + 1]) ++s;
     const bbb_adam_segment_t sg = a.seg[s];
@@ -51,8 +65,8 @@ __global__ __launch_bounds__(kThreads) void adam_step_kernel(const AdamArgs a) {
     for (int j = 0; j < 4; ++j) {
         m[j] = m[j] + (g[j] - m[j]) * a.omb1;
         v[j] = v[j] * a.beta2 + a.omb2 * g[j] * g[j];
-        const float denom = __fdiv_rn(__fsqrt_rn(v[j]), a.sqrt_bc2) + a.eps;
-        p[j] = p[j] - a.step_size * (m[j] / denom);
+        const float denom = __fdiv_rn(__fsqrt_rn(v[j]), sqrt_bc2) + a.eps;
+        p[j] = p[j] - step_size * (m[j] / denom);
     }
     if (vec) {
         f32x4 p4, m4, v4;
@@ -69,8 +83,10 @@ __global__ __launch_bounds__(kThreads) void adam_step_kernel(const AdamArgs a) {
 }  // namespace
 
 extern "C" int bbb_adam_step(const bbb_adam_segment_t* segs, int nseg, double lr, double beta1, double beta2, double eps,
-                             int64_t step, void* stream) {
-    if (segs == nullptr || nseg <= 0 || nseg > BBB_MAX_SEGMENTS || step <= 0) return BBB_EINVAL;
+                             int64_t step, const float* step_dev, void* stream) {
+    if (segs == nullptr || nseg <= 0 || nseg > BBB_MAX_SEGMENTS || (step <= 0 && step_dev == nullptr)) return BBB_EINVAL;
+    if (((uintptr_t)step_dev & 3u) != 0) return BBB_EALIGN;
+    if (step <= 0) step = 1;
     if (!(lr >= 0.0) || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0) || !(eps >= 0.0)) return BBB_EINVAL;
     AdamArgs a = {};
     int chunks = 0;
@@ -94,6 +110,7 @@ extern "C" int bbb_adam_step(const bbb_adam_segment_t* segs, int nseg, double lr
     a.sqrt_bc2 = (float)sqrt(bc2);
     a.beta1 = (float)beta1; a.beta2 = (float)beta2; a.omb1 = (float)(1.0 - beta1); a.omb2 = (float)(1.0 - beta2);
     a.eps = (float)eps;
+    a.lr_d = lr; a.beta1_d = beta1; a.beta2_d = beta2; a.step_dev = step_dev;
     hipLaunchKernelGGL(adam_step_kernel, dim3(chunks), dim3(kThreads), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }

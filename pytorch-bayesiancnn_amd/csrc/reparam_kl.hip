@@ -251,7 +251,7 @@ __global__ __launch_bounds__(kThreads) void reparam_kl_bwd_kernel(const ReparamA
 #pragma unroll
                     for (int j = 0; j < 4; ++j) z[j] = j < cnt ? sg.eps[o + j] : 0.0f;
                 } else {
-                    bbb::normal4(g, sg.stream_id, a.call0 + (uint32_t)e, a.k0, a.k1, z);
+                    bbb::normal4(g, sg.stream_id, a.call0 + (a.call_dev ? *a.call_dev : 0u) + (uint32_t)e, a.k0, a.k1, z);
                 }
                 if (aligned && cnt == 4) {
                     const f32x4 g4 = *reinterpret_cast<const f32x4*>(sg.w + o);
@@ -374,7 +374,7 @@ extern "C" int bbb_reparam_kl_fwd(const bbb_segment_t* segs, int nseg, int draws
 
 extern "C" int bbb_reparam_kl_bwd(const bbb_segment_t* segs, int nseg, int draws, float prior_mu, float prior_sigma,
                                   uint64_t seed, uint32_t call0, uint32_t flags, const float* gkl,
-                                  float* const* grad_mu, float* const* grad_rho, void* stream) {
+                                  float* const* grad_mu, float* const* grad_rho, const uint32_t* call_dev, void* stream) {
     ReparamArgs a = {};
     const int chunks = fill_args(a, segs, nseg, draws, true);
     if (chunks < 0) return chunks;
@@ -392,6 +392,7 @@ extern "C" int bbb_reparam_kl_bwd(const bbb_segment_t* segs, int nseg, int draws
     a.call0 = call0;
     a.flags = flags;
     a.gkl = gkl;
+    a.call_dev = call_dev;
     hipLaunchKernelGGL(reparam_kl_bwd_kernel, dim3(chunks), dim3(kThreads), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }

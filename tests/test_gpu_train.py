@@ -132,3 +132,40 @@ def test_train_step_helper_learns_and_counts_calls(env):
     assert np.isfinite(losses).all() and losses[-1] < losses[0]
     assert env["rng"].get_state()[1] == 2 * 25
     assert lo.shape == (64, 10) and float(lo.exp().sum(1).sub(1).abs().max()) < 1e-3
+
+
+@pytest.mark.parametrize("layer_type", ["bbb", "lrt"])
+def test_graphed_train_step_equals_eager_steps(env, layer_type):
+    """GraphedTrainStep (forward + backward + noise counter + Adam in one hipGraph, step count and call counter on the
+    device) reproduces the eager train_step sequence: same noise calls, same losses, same parameters."""
+    T = env["train"]
+    B, E, lr, beta, n = 32, 2, 1e-3, 0.1, 1000.0
+    torch.manual_seed(3)
+    x = torch.rand(B, 1, 32, 32, device="cuda")
+    y = torch.randint(0, 10, (B,), device="cuda")
+
+    def fresh():
+        torch.manual_seed(11)
+        net = env["zoo"].BBBLeNet(10, 1, P.CONFIG_PRIORS, layer_type, "softplus").cuda()
+        env["rng"].assign_stream_ids(net)
+        env["rng"].manual_seed(77, call=0)
+        return net
+
+    net_e = fresh()
+    opt_e = T.FusedAdam(net_e.parameters(), lr=lr)
+    eager_losses = [T.train_step(net_e, opt_e, x, y, E, beta, n)[0].item() for _ in range(6)]
+    net_g = fresh()
+    opt_g = T.FusedAdam(net_g.parameters(), lr=lr, capturable=True)
+    g = T.GraphedTrainStep(net_g, opt_g, x, y, E, beta, n, warmup=3)          # 3 real iterations, then capture
+    graph_losses = []
+    for _ in range(3):
+        loss, lo, kl = g.step()
+        graph_losses.append(loss.item())
+    np.testing.assert_allclose(graph_losses, eager_losses[3:], rtol=1e-5)
+    for (na, a), (nb, b) in zip(net_e.named_parameters(), net_g.named_parameters()):
+        np.testing.assert_allclose(b.detach().cpu().numpy(), a.detach().cpu().numpy(), rtol=1e-5, atol=1e-7, err_msg=na)
+    assert env["rng"].get_state()[1] == 6 * E
+    assert float(opt_g.state[next(iter(net_g.parameters()))]["step"].item()) == 6.0
+    # a new batch through the static buffers
+    loss2, _, _ = g.step(torch.rand_like(x), y)
+    assert np.isfinite(loss2.item())
