@@ -16,11 +16,15 @@ N > 1 (weak scaling): every rank runs num_ens=10 draws of the same 512-image bat
 sharded over the GPUs (draw j is noise call call0 + j on whichever rank owns it) -- and the ranks combine
 their log-sum-exp blocks and KL sums with ONE all_gather over RCCL per step.  value = B * 10 * N / step time.
 
-Prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
+Prints ONE JSON line on rank 0 (contract in the task description) with these extra objects:
   roofline      the dominant kernel (fp32-MFMA implicit-GEMM conv): algorithmic FLOP / HIP-event time vs the
-                157.3 TFLOP/s fp32 matrix peak; plus roofline_reparam for the fused reparam+KL pass vs HBM.
+                157.3 TFLOP/s fp32 matrix peak (+ its HBM traffic from the PMC passes in profiles/);
+                roofline_reparam: the fused reparam+KL pass vs HBM.
   cpu_baseline  the oracle's torch-CPU port of the reference MC step (oracle/ref_port_torch.py, bit-identical
                 to the upstream nn.Modules under the same seed) timed on this host's cores, rank 0, N=1 only.
+  one_step_in_flight   the same workload with a single graph lane (step latency instead of throughput).
+  bf16          secondary measurement of the same workload under the bf16 storage model (BASELINE.json configs[1]
+                precision; `--dtype bf16` makes it the reported value instead).  Never the default headline.
 """
 import argparse
 import json
