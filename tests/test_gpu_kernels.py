@@ -371,3 +371,20 @@ def test_lrt_shared_input_dedup_is_bitwise_the_full_launch(ops, B, Cin, H, W, Co
     got = ops.lrt_sample_chwn(am, av, E, seed, call0, sid, act="softplus")
     assert got.shape == full.shape
     assert torch.equal(got, full)
+
+
+@pytest.mark.parametrize("B,Cin,H,W,Cout,k,s,p,E,shared_w", [(256, 384, 2, 2, 256, 3, 1, 1, 1, False), (32, 64, 4, 4, 192, 5, 1, 2, 2, True),
+                                                             (16, 24, 6, 6, 10, 3, 2, 1, 1, False)])
+def test_conv2d_splitk_matches_the_single_launch(ops, B, Cin, H, W, Cout, k, s, p, E, shared_w):
+    """Training-path split-K (input channels as extra draws of one launch, fixed-order sum) = the plain launch up to fp32
+    summation order; falls through to the plain launch when the channels cannot be split."""
+    torch.manual_seed(Cin + B)
+    x = torch.randn(E, B, Cin, H, W, device="cuda")
+    w = torch.randn(1 if shared_w else E, Cout, Cin, k, k, device="cuda") * 0.1
+    b = torch.randn(w.shape[0], Cout, device="cuda")
+    want = ops.conv2d_forward(x, w, b, s, p, 1)
+    got = ops.conv2d_splitk(x, w, b, s, p, 1)
+    assert got.shape == want.shape
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) <= 2e-5 * scale
+    assert torch.equal(ops.conv2d_splitk(x, w, b, s, p, 1), got)            # deterministic
