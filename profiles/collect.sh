@@ -29,4 +29,14 @@ for C in FETCH_SIZE WRITE_SIZE; do
   { echo "# rocprofv3 --kernel-trace --pmc $C -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timers --no-bf16-extra --no-graph --streams 1   (KB per launch; gfx950: FETCH_SIZE counts 1/2 of wide coalesced reads)"
     python $R/profiles/summarize_pmc.py $(find /tmp/pm -name '*.db' | head -1); } > "$OUT/${TAG}_pmc_${C}.txt" 2>&1
 done
+EAGER16="python $R/bench.py --dtype bf16 --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timers --no-graph --streams 1"
+rm -rf /tmp/pm && mkdir -p /tmp/pm
+{ echo "# rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_WAIT_INST_ANY -- (fp32 eager step, then the bf16 eager step)"
+  for CMD in "$EAGER" "$EAGER16"; do
+    rm -rf /tmp/pm/* 
+    rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_WAIT_INST_ANY -d /tmp/pm -o pm -- $CMD > /tmp/pm_log.txt 2>&1
+    echo "## $CMD" | sed "s#$R/##"
+    python $R/profiles/summarize_pmc.py $(find /tmp/pm -name '*.db' | head -1) pconv
+    python $R/profiles/summarize_pmc.py $(find /tmp/pm -name '*.db' | head -1) reparam_kl_fwd
+  done; } > "$OUT/${TAG}_pmc_sq_mfma.txt" 2>&1
 ls -la "$OUT" | tail -5

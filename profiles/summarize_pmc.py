@@ -32,6 +32,14 @@ def main():
         print(key)
         for cn, (s, n) in sorted(cs.items()):
             print(f"    {cn:32s} avg {s / n:16.1f}   (n={n})")
+        avg = {cn: s / n for cn, (s, n) in cs.items()}
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in avg and "GRBM_GUI_ACTIVE" in avg and avg["GRBM_GUI_ACTIVE"] > 0:
+            # MFMA_BUSY is summed over the 1024 SIMDs (256 CUs x 4); GRBM_GUI_ACTIVE is summed over the 8 XCDs, so /8 = the
+            # shader-clock cycles the launch took
+            cyc = avg["GRBM_GUI_ACTIVE"] / 8.0
+            util = avg["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024.0)
+            clk = cyc / avg["_dur_ns"]
+            print(f"    -> matrix-pipe utilisation {100 * util:5.1f} % of the launch's cycles  (clock {clk:.2f} GHz over the launch)")
 
 
 if __name__ == "__main__":
