@@ -557,6 +557,8 @@ class GraphedMC:
         self.world = 1 if group is None else torch.distributed.get_world_size(group)
         rank = 0 if group is None else torch.distributed.get_rank(group)
         self.lo, self.hi = draw_range(self.num_ens, rank, self.world)
+        import os as _os
+        self._force_combine = group is not None and _os.environ.get("BBB_FORCE_COMBINE") == "1"   # test hook: N > 1 code path at world 1
         dev = x.device
         self.stride = int(lanes) * self.num_ens
         self.start = int(lane) * self.num_ens
@@ -584,8 +586,8 @@ class GraphedMC:
     def _step_body(self, streams):
         n_loc = self.hi - self.lo
         lse, kl1 = _local_lse(self.net, self.x, n_loc, self.seed, self.call0 + self.lo,
-                              self.num_ens if self.world == 1 else 0, streams=streams, precision=self.precision)
-        if self.world == 1:
+                              self.num_ens if (self.world == 1 and not self._force_combine) else 0, streams=streams, precision=self.precision)
+        if self.world == 1 and not self._force_combine:
             kl = kl1 * float(self.num_ens) if self.kl_mode == "sum" else kl1 * 1.0
         else:
             kl = kl1 * float(n_loc)
@@ -599,7 +601,7 @@ class GraphedMC:
                 self.graph.replay()
             self.replays += 1
             rng.next_calls(self.num_ens)             # keep the host-side counter in step with the device's
-            if self.world == 1:
+            if self.world == 1 and not self._force_combine:
                 return self.lse, self.kl_local
             with torch.no_grad():
                 return combine_ranks(self.lse, self.kl_local, self.num_ens, self.group, self.kl_mode, shape=self.shape)
