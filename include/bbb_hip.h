@@ -192,6 +192,14 @@ int bbb_lrt_sample_chwn(const float* act_mu, const float* act_var, float* y, int
                         int act, uint64_t seed, uint32_t call0, uint32_t stream_id, const uint32_t* call_dev, void* stream);
 
 /*
+ * The LRT sampling step alone, reference layout: y = act_mu + sqrt(act_var) * eps over `draws` contiguous slabs of n
+ * elements (layers/BBB_LRT/BBBConv.py:78-81), eps = element i of noise stream (seed, call0 + e, stream_id) -- the same
+ * numbers bbb_lrt_conv2d_fwd draws.  Used by the training path, which computes the two moments with split-K launches.
+ */
+int bbb_lrt_sample_nchw(const float* act_mu, const float* act_var, float* y, int64_t n, int draws, uint64_t seed,
+                        uint32_t call0, uint32_t stream_id, const uint32_t* call_dev, void* stream);
+
+/*
  * BF16 storage variants of the batch-innermost path (BASELINE.json configs[1]: "BBB layers, bf16"); fp32 accumulation,
  * fp32 bias and fp32 epilogue (bias + activation), one rounding (nearest-even) when a value is stored as bf16.
  *   x: [draws|1][cin][h][w][B] bf16   (B % 8 == 0, 16-byte aligned, draw strides multiples of 8 elements)

@@ -54,6 +54,7 @@ _SIGNATURES = {
                                         c_void_p, c_void_p, c_void_p, c_u64, c_u32, c_u32, c_int, c_void_p, c_void_p]),
     "bbb_lrt_sample_chwn": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_u64, c_u32, c_u32, c_void_p,
                                   c_void_p]),
+    "bbb_lrt_sample_nchw": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_u64, c_u32, c_u32, c_void_p, c_void_p]),
     "bbb_maxpool_chwn": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "bbb_conv2d_chwn_bf16_fwd": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_u32, c_void_p]),
     "bbb_maxpool_chwn_bf16": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_void_p]),

@@ -534,6 +534,32 @@ def conv2d_splitk(x, w, bias, stride=1, padding=0, dilation=1):
     return y
 
 
+def _small_launch(x, w, stride, padding, dilation):
+    """True when a conv of x [E,B,Cin,H,W] with w [*,Cout,Cin,kh,kw] would occupy fewer than 512 64x64 output tiles and its
+    channels can be split (the conv2d_splitk criterion)."""
+    (sh, sw), (ph, pw), (dh, dw) = _pair(stride), _pair(padding), _pair(dilation)
+    E, B, Cin, H, W = x.shape
+    Cout, kh, kw = w.shape[1], w.shape[3], w.shape[4]
+    ho = (H + 2 * ph - dh * (kh - 1) - 1) // sh + 1
+    wo = (W + 2 * pw - dw * (kw - 1) - 1) // sw + 1
+    tiles = E * -(-B * ho * wo // 64) * -(-Cout // 64)
+    return tiles < 512 and Cin % 2 == 0 and (Cin // 2) * kh * kw >= 64
+
+
+def lrt_sample_nchw(act_mu, act_var, seed, call0, stream_id):
+    """y = act_mu + sqrt(act_var) * eps for [E, ...] moments; eps = the LRT kernels' noise stream (draw e = call0 + e)."""
+    require_device(act_mu, act_var)
+    act_mu, act_var = act_mu.contiguous(), act_var.contiguous()
+    E = act_mu.shape[0]
+    n = act_mu.numel() // E
+    y = torch.empty_like(act_mu)
+    with torch.cuda.device(act_mu.device):
+        check(_lib.lib().bbb_lrt_sample_nchw(act_mu.data_ptr(), act_var.data_ptr(), y.data_ptr(), n, E, seed, call0 & 0xFFFFFFFF,
+                                             stream_id, rng.call_dev_ptr(act_mu.device), cur_stream(act_mu.device)),
+              "bbb_lrt_sample_nchw")
+    return y
+
+
 def conv2d_input_grad(gy, w, x_shape, stride, padding, dilation):
     """d loss / d x of y = conv2d(x, w) on the same fp32-MFMA kernel: a stride-1 convolution of gy -- zero-upsampled by the
     layer's stride -- with the spatially flipped, channel-transposed weights, the layer's dilation and padding
@@ -627,9 +653,21 @@ class _Conv2d(torch.autograd.Function):
 class _LrtConv2d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w_mu, w_var, b_mu, b_var, cfg):
-        y, am, av = lrt_conv2d_forward(x, w_mu, w_var, b_mu, b_var, cfg["seed"], cfg["call0"], cfg["stream_id"],
-                                       cfg["stride"], cfg["padding"], cfg["dilation"], sample=cfg["sample"],
-                                       eps=cfg.get("eps"), want_moments=True)
+        geom = (cfg["stride"], cfg["padding"], cfg["dilation"])
+        if _small_launch(x, w_mu.unsqueeze(0), *geom):
+            # training-sized launch: the fused kernel would run a few dozen workgroups with long k loops; compute the two
+            # moments with split-K launches and sample separately (same noise stream, same result up to summation order)
+            am = conv2d_splitk(x, w_mu.unsqueeze(0), None if b_mu is None else b_mu.unsqueeze(0), *geom)
+            av = conv2d_splitk(x * x, w_var.unsqueeze(0), None if b_var is None else b_var.unsqueeze(0), *geom) + 1e-16
+            if not cfg["sample"]:
+                y = am
+            elif cfg.get("eps") is not None:
+                y = am + av.sqrt() * cfg["eps"].reshape(am.shape)
+            else:
+                y = lrt_sample_nchw(am, av, cfg["seed"], cfg["call0"], cfg["stream_id"])
+        else:
+            y, am, av = lrt_conv2d_forward(x, w_mu, w_var, b_mu, b_var, cfg["seed"], cfg["call0"], cfg["stream_id"], *geom,
+                                           sample=cfg["sample"], eps=cfg.get("eps"), want_moments=True)
         ctx.cfg = cfg
         ctx.save_for_backward(x, w_mu, w_var, y, am, av)
         ctx.has_bias = b_mu is not None
@@ -689,4 +727,8 @@ def conv2d(x, w, bias, stride=1, padding=0, dilation=1):
 def lrt_conv2d(x, w_mu, w_var, b_mu, b_var, seed, call0, stream_id, stride=1, padding=0, dilation=1, sample=True, eps=None):
     cfg = dict(seed=seed, call0=call0, stream_id=stream_id, stride=stride, padding=padding, dilation=dilation,
                sample=sample, eps=eps)
+    needs_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, w_mu, w_var, b_mu, b_var))
+    if not needs_grad:          # inference through the drop-in layers: the fused kernel, bitwise what the ensemble path runs
+        return lrt_conv2d_forward(x, w_mu, w_var, b_mu, b_var, seed, call0, stream_id, stride, padding, dilation,
+                                  sample=sample, eps=eps)[0]
     return _LrtConv2d.apply(x, w_mu, w_var, b_mu, b_var, cfg)

@@ -203,6 +203,24 @@ __global__ __launch_bounds__(256) void lrt_sample_chwn_kernel(const float* __res
     }
 }
 
+// y = act_mu + sqrt(act_var) * eps over `draws` contiguous NCHW slabs of n elements each (element i of draw e uses noise
+// element i of call call0 + e): the LRT sampling step on its own, for callers that computed the two moments separately.
+__global__ __launch_bounds__(256) void lrt_sample_nchw_kernel(const float* __restrict__ mu, const float* __restrict__ var,
+                                                              float* __restrict__ y, int64_t n, int draws, uint32_t k0, uint32_t k1,
+                                                              uint32_t call0, uint32_t stream_id, const uint32_t* __restrict__ call_dev) {
+    const int64_t groups = (n + 3) >> 2;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= groups * draws) return;
+    const int e = (int)(i / groups);
+    const int64_t g = i - (int64_t)e * groups;
+    float z[4];
+    bbb::normal4((uint64_t)g, stream_id, call0 + (call_dev ? *call_dev : 0u) + (uint32_t)e, k0, k1, z);
+    const int64_t base = (int64_t)e * n + g * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (g * 4 + j < n) y[base + j] = mu[base + j] + __builtin_amdgcn_sqrtf(var[base + j]) * z[j];
+}
+
 }  // namespace
 
 extern "C" int bbb_mc_tail_cb(const float* logits, int draws, int batch, int classes, int mean_over, float* lse_out,
@@ -275,5 +293,17 @@ extern "C" int bbb_lrt_sample_chwn(const float* act_mu, const float* act_var, fl
     else
         hipLaunchKernelGGL(lrt_sample_chwn_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, act_mu, act_var, y,
                            draws, channels, pixels, batch, act, k0, k1, call0, stream_id, call_dev);
+    return (int)hipGetLastError();
+}
+
+extern "C" int bbb_lrt_sample_nchw(const float* act_mu, const float* act_var, float* y, int64_t n, int draws, uint64_t seed,
+                                   uint32_t call0, uint32_t stream_id, const uint32_t* call_dev, void* stream) {
+    if (act_mu == nullptr || act_var == nullptr || y == nullptr || n <= 0 || draws <= 0) return BBB_EINVAL;
+    if ((((uintptr_t)act_mu | (uintptr_t)act_var | (uintptr_t)y) & 3u) != 0) return BBB_EALIGN;
+    const int64_t total = ((n + 3) >> 2) * draws;
+    const int64_t blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffffLL) return BBB_ESHAPE;
+    hipLaunchKernelGGL(lrt_sample_nchw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, act_mu, act_var, y, n, draws,
+                       (uint32_t)seed, (uint32_t)(seed >> 32), call0, stream_id, call_dev);
     return (int)hipGetLastError();
 }
