@@ -112,6 +112,7 @@ def test_training_loop_matches_reference_port(env, net_type, layer_type):
         assert float(d.max()) <= 2 * 3 * lr + 1e-6               # never further apart than every step going the other way
         tot += d.numel()
         bad += int((d > 1e-5).sum())
+    print("params differing by > 1e-5:", bad, "of", tot)
     assert bad <= 0.005 * tot, (bad, tot)
 
 
