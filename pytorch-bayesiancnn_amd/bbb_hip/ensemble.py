@@ -552,7 +552,9 @@ class GraphedMC:
     def __init__(self, net, x, num_ens, streams=1, kl_mode="sum", lane=0, lanes=1, stream=None, seed_call=None, group=None,
                  precision="fp32"):
         _lib.require_device(x)
-        self.net, self.x, self.num_ens, self.group, self.kl_mode = net, x, int(num_ens), group, kl_mode
+        # a lane of a pipeline gets its OWN input buffer: several steps are in flight, so the next batch must not be
+        # written into memory an earlier step is still reading
+        self.net, self.x, self.num_ens, self.group, self.kl_mode = net, (x.clone() if int(lanes) > 1 else x), int(num_ens), group, kl_mode
         self.precision = precision
         self.world = 1 if group is None else torch.distributed.get_world_size(group)
         rank = 0 if group is None else torch.distributed.get_rank(group)
@@ -594,9 +596,15 @@ class GraphedMC:
         self.counter.add_(self.stride)               # part of the graph: next replay of this lane
         return lse, kl
 
-    def step(self):
+    def step(self, x=None):
+        """Replay the step; `x` (optional) is copied into this lane's input buffer first, on the lane's stream."""
+        producer = torch.cuda.current_stream(self.x.device) if (x is not None and self.own_stream) else None
         ctx = torch.cuda.stream(self.stream) if self.own_stream else _null_ctx()
         with ctx:
+            if x is not None:
+                if producer is not None:
+                    self.stream.wait_stream(producer)              # whoever produced x on the caller's stream
+                self.x.copy_(x, non_blocking=True)
             if self.graph is not None:
                 self.graph.replay()
             self.replays += 1
@@ -633,10 +641,12 @@ class GraphedPipeline:
         self.i = 0
         self.dev = x.device
 
-    def step(self):
+    def step(self, x=None):
+        """Enqueue the next step on the next lane.  Pass the batch as `x` (copied into that lane's own buffer); without it
+        the lane re-uses the batch it already holds."""
         lane = self.lanes[self.i % len(self.lanes)]
         self.i += 1
-        return lane.step()
+        return lane.step(x)
 
     def sync(self):
         for lane in self.lanes:

@@ -396,3 +396,39 @@ def test_uncertainty_per_batch_and_per_image(env):
     assert e2.max() > 1e-9 and np.isfinite(a2).all() and (a2 > -1e-7).all()
     # softmax identity: epistemic + aleatoric = p_bar - p_bar^2 per class, so the class sums stay below 1
     assert 0 < (e1 + a1).sum() < 1 and 0 < (e2 + a2).sum() < 1
+
+
+def test_pipeline_lanes_own_their_input_buffers(env):
+    """GraphedPipeline with a NEW batch every step: each lane copies the batch into its own buffer, so three steps in
+    flight never read a batch that a later step is overwriting; results equal the eager per-batch steps bit for bit."""
+    torch.manual_seed(8)
+    net = env["zoo"].BBBLeNet(10, 1, P.CONFIG_PRIORS, "bbb", "softplus").cuda()
+    env["rng"].assign_stream_ids(net)
+    batches = [torch.rand(64, 1, 32, 32, device="cuda") for _ in range(7)]
+    E = 4
+    with torch.no_grad():
+        env["rng"].manual_seed(99, call=0)
+        want = [env["ens"].mc_forward(net, b, E)[0].clone() for b in batches]
+        env["rng"].manual_seed(99, call=0)
+        pipe = env["ens"].GraphedPipeline(net, batches[0], E, depth=3)
+        outs = []
+        for b in batches:
+            lo, _ = pipe.step(b)
+            outs.append(lo)                      # lane buffer: read it before the lane is replayed again (3 steps later)
+            if len(outs) >= 3:
+                pipe.sync()
+        pipe.sync()
+        torch.cuda.synchronize()
+    # each lane's output buffer holds its LAST step: compare the last three batches, and all of them through a re-run
+    for k in range(1, 4):
+        assert torch.equal(outs[-k], want[-k])
+    env["rng"].manual_seed(99, call=0)
+    with torch.no_grad():
+        pipe2 = env["ens"].GraphedPipeline(net, batches[0], E, depth=3)
+        got = []
+        for b in batches:
+            lo, _ = pipe2.step(b)
+            pipe2.sync()
+            got.append(lo.clone())
+    for g, w in zip(got, want):
+        assert torch.equal(g, w)
