@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define BBB_ABI_VERSION 3
+#define BBB_ABI_VERSION 4
 #define BBB_MAX_SEGMENTS 16
 
 #define BBB_EINVAL (-1)   /* bad argument (null pointer, non-positive size, too many segments) */
@@ -68,12 +68,15 @@ typedef struct bbb_segment {
  * kl_loss() (metrics.py:27-29 via layers/BBB/BBBConv.py:79-83), plus the Python sum over layers
  * (layers/misc.py:20-23).
  *   segs        host array of nseg descriptors (copied into the kernel arguments)
- *   kl_partials device scratch, at least bbb_reparam_partials(segs, nseg) doubles
+ *   kl_partials device scratch, at least bbb_reparam_partials(segs, nseg) doubles, 8-byte aligned.  Element 0 is a
+ *               "blocks finished" ticket: it must be ZERO before the first launch that uses the buffer; every launch
+ *               leaves it zero again.  One scratch buffer per stream (launches that may overlap must not share one).
  *   kl_out      device float: sum over all segments of the KL term (NULL = no KL)
  *   kl_out64    optional device double with the same sum (NULL = skip)
  *   call_dev    optional DEVICE uint32 added to call0 when the kernel runs (NULL = 0).  This is what lets a
  *               captured hipGraph draw fresh noise on every replay: the graph also contains the increment.
- * KL does not depend on eps; the sum is reduced in a fixed order in fp64 (bitwise reproducible).
+ * KL does not depend on eps; the sum is reduced in a fixed order in fp64 (bitwise reproducible): blocks publish fp64
+ * partials and the block that finishes last adds them up in index order -- one launch, no separate finish kernel.
  */
 int bbb_reparam_kl_fwd(const bbb_segment_t* segs, int nseg, int draws,
                        float prior_mu, float prior_sigma,
@@ -81,7 +84,7 @@ int bbb_reparam_kl_fwd(const bbb_segment_t* segs, int nseg, int draws,
                        double* kl_partials, float* kl_out, double* kl_out64,
                        const uint32_t* call_dev, void* stream);
 
-/* Number of doubles of scratch bbb_reparam_kl_fwd needs for these segments (host-only helper). */
+/* Number of doubles of scratch bbb_reparam_kl_fwd needs for these segments, ticket slot included (host-only helper). */
 int64_t bbb_reparam_partials(const bbb_segment_t* segs, int nseg);
 
 /*

@@ -72,12 +72,14 @@ def _kl(mu_q, sig_q, mu_p, sig_p):
     return 0.5 * (2 * torch.log(sig_p / sig_q) - 1 + (sig_q / sig_p).pow(2) + ((mu_p - mu_q) / sig_p).pow(2)).sum()
 
 
-def _bbb_layer(h, p, conv_args, sample):
+def _bbb_layer(h, p, conv_args, sample, eps=None):
+    """eps: None = the reference's own source (torch's default CPU generator, W first then bias); or a callable
+    (kind, shape) -> tensor that replays another noise stream (the device's Philox stream in the parity tests)."""
     if sample:
-        W_eps = torch.empty(p["W_mu"].size()).normal_(0, 1)
+        W_eps = torch.empty(p["W_mu"].size()).normal_(0, 1) if eps is None else eps("W", tuple(p["W_mu"].shape))
         W_sigma = torch.log1p(torch.exp(p["W_rho"]))
         weight = p["W_mu"] + W_eps * W_sigma
-        bias_eps = torch.empty(p["bias_mu"].size()).normal_(0, 1)
+        bias_eps = torch.empty(p["bias_mu"].size()).normal_(0, 1) if eps is None else eps("bias", tuple(p["bias_mu"].shape))
         bias_sigma = torch.log1p(torch.exp(p["bias_rho"]))
         bias = p["bias_mu"] + bias_eps * bias_sigma
     else:
@@ -91,7 +93,7 @@ def _bbb_layer(h, p, conv_args, sample):
     return y, W_sigma, bias_sigma
 
 
-def _lrt_layer(h, p, conv_args, sample):
+def _lrt_layer(h, p, conv_args, sample, eps=None):
     W_sigma = torch.log1p(torch.exp(p["W_rho"]))
     bias_sigma = torch.log1p(torch.exp(p["bias_rho"]))
     bias_var = bias_sigma ** 2
@@ -103,13 +105,14 @@ def _lrt_layer(h, p, conv_args, sample):
         act_var = 1e-16 + F.linear(h ** 2, W_sigma ** 2, bias_var)
     act_std = torch.sqrt(act_var)
     if sample:
-        eps = torch.empty(act_mu.size()).normal_(0, 1)
-        return act_mu + act_std * eps, W_sigma, bias_sigma
+        e = torch.empty(act_mu.size()).normal_(0, 1) if eps is None else eps("act", tuple(act_mu.shape))
+        return act_mu + act_std * e, W_sigma, bias_sigma
     return act_mu, W_sigma, bias_sigma
 
 
-def forward(net_type, params, x, layer_type="bbb", activation="softplus", sample=True):
-    """One stochastic forward of the whole model -> (logits, kl)."""
+def forward(net_type, params, x, layer_type="bbb", activation="softplus", sample=True, eps_fn=None):
+    """One stochastic forward of the whole model -> (logits, kl).  eps_fn(layer_name, kind, shape) -> tensor replays an
+    external noise stream (kind in 'W', 'bias', 'act'); None = torch's CPU generator, as upstream."""
     act = F.softplus if activation == "softplus" else F.relu
     layer = _bbb_layer if layer_type == "bbb" else _lrt_layer
     h = x
@@ -123,7 +126,8 @@ def forward(net_type, params, x, layer_type="bbb", activation="softplus", sample
             h = h.view(-1, op[1])
         else:
             p = params[op[1]]
-            h, Ws, bs = layer(h, p, (op[4], op[5]) if op[0] == "conv" else None, sample)
+            eps = None if eps_fn is None else (lambda kind, shape, _n=op[1]: eps_fn(_n, kind, shape))
+            h, Ws, bs = layer(h, p, (op[4], op[5]) if op[0] == "conv" else None, sample, eps)
             sig.append((p, Ws, bs))
     kl = 0.0
     for p, Ws, bs in sig:  # layers/misc.py:20-23 + kl_loss of each layer

@@ -13,6 +13,7 @@ import torch  # noqa: F401  (must precede CDLL: shares torch's HIP runtime)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BBB_HIP_LIB") or os.path.join(_HERE, "libbbb_hip.so")   # env override: experiments only
 
+ABI_VERSION = 4
 MAX_SEGMENTS = 16
 SIGMA_SQUARED = 1
 KL_TEXTBOOK = 2
@@ -88,8 +89,8 @@ def lib():
             fn = getattr(h, name)          # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if h.bbb_abi_version() != 3:
-            raise BBBHipError(f"ABI mismatch: library reports {h.bbb_abi_version()}, binding expects 3")
+        if h.bbb_abi_version() != ABI_VERSION:
+            raise BBBHipError(f"ABI mismatch: library reports {h.bbb_abi_version()}, binding expects {ABI_VERSION}")
         _lib = h
     return _lib
 

@@ -26,6 +26,9 @@ except ImportError as e:  # pragma: no cover
     raise ImportError("bbb_hip.ensemble needs the sibling `layers` package on sys.path") from e
 
 
+stats = {"path": None}   # which layout the last mc_logits / mc_forward took: "chwn" (batch-innermost fast path) or "nchw"
+
+
 def draw_range(num_ens, rank, world):
     """Contiguous, balanced block of global draw indices for `rank`: [lo, hi)."""
     base, rem = divmod(num_ens, world)
@@ -367,6 +370,7 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
         out = logits_buf if (logits_buf is not None and all(pt.data_ptr() == logits_buf[b0:b1].data_ptr()
                                                             for pt, (b0, b1) in zip(parts, bounds))) \
             else torch.cat(parts, dim=0)
+    stats["path"] = "chwn"
     return out, kl                                               # logits stay batch-innermost: [E, C, B]
 
 
@@ -394,6 +398,7 @@ def mc_logits(net, x, draws, seed, call0, fuse_act=True, timers=None, eps=None, 
             return out[0].permute(0, 2, 1).contiguous(), out[1]      # API layout [E, B, C]
     if precision != "fp32":
         raise _lib.BBBHipError("this model / input does not fit the batch-innermost path, which is the only bf16 path")
+    stats["path"] = "nchw"
     layers = bayesian_layers(net)
     bbb = [l for l in layers if isinstance(l, _BBBLayer)]
     lrt = [l for l in layers if isinstance(l, _LRTLayer)]

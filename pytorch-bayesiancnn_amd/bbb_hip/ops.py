@@ -21,7 +21,8 @@ def _partials(device, n):
     key = (device.index, "kl", cur_stream(device))
     buf = _scratch.get(key)
     if buf is None or buf.numel() < n:
-        buf = torch.empty(max(n, 4096), dtype=torch.float64, device=device)
+        # element 0 is the kernel's "blocks finished" ticket: zero once, the kernel leaves it zero after every launch
+        buf = torch.zeros(max(n, 4096), dtype=torch.float64, device=device)
         _scratch[key] = buf
     return buf
 

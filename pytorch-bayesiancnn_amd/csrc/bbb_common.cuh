@@ -9,11 +9,14 @@ namespace bbb {
 constexpr int kWave = 64;
 
 // Philox4x32-10 (Random123).  One call yields four 32-bit words = noise for four consecutive
-// elements.  The 32x32->64 products lower to v_mad_u64_u32 / v_mul_hi_u32.
+// elements.  The 32x32->64 products lower to v_mad_u64_u32.
+#ifndef BBB_PHILOX_ROUNDS
+#define BBB_PHILOX_ROUNDS 10     // the noise contract (include/bbb_hip.h); other values exist for timing experiments only
+#endif
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                               uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < BBB_PHILOX_ROUNDS; ++r) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
         const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;

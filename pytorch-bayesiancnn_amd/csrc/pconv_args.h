@@ -1,4 +1,4 @@
-// Kernel-argument block shared by the pixel-major GEMM variants (pconv_gemm.hip, pconv_dma.hip, pconv_bf16.hip).
+// Kernel-argument block shared by the pixel-major GEMM variants (pconv_gemm.hip, pconv_bf16.hip).
 #pragma once
 #include <stdint.h>
 
@@ -15,15 +15,9 @@ struct PConvArgs {
     int64_t x_ds, w_ds, b_ds, y_ds;
     int32_t B, Cin, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, Ho, Wo;
     int32_t K, Kp, khkw, act, sample;   // Kp: bf16 weight row pitch (pconv_bf16.hip)
-    int32_t Mtiles, nbt, Ntiles, G, per_xcd, stagger;
-#ifdef BBB_TIMESTAMPS
-    long long* ts;
-#endif
+    int32_t Mtiles, nbt, Ntiles, G, per_xcd;
     uint32_t k0, k1, call0, stream_id;
     int32_t wtap;        // bf16: weight rows are tap-major ((r, q, ci) order)
     uint32_t x_inv;      // byte offset that marks an invalid image row: x_inv + any column offset is out of range and does not wrap
     const uint32_t* call_dev;
 };
-
-// pconv_dma.hip: LDS-DMA pipelined variant; returns -1000 when it does not apply.
-int bbb_pconv_dma_launch(const void* args, int lrt, int bm, int64_t blocks, void* stream);

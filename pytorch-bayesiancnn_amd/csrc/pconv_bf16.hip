@@ -23,7 +23,6 @@
 // 32-lane group land on disjoint banks), weight rows 144 B (conflict-free for the 16-byte reads).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 
 #include "../../include/bbb_hip.h"
 #include "bbb_common.cuh"
@@ -172,10 +171,6 @@ __global__ __launch_bounds__(64 * WN * WM * KG + (WS ? 256 : 0)) void pconv_bf16
         uint32_t xo[XPASS];
 #pragma unroll
         for (int ps = 0; ps < XPASS; ++ps) xo[ps] = (uint32_t)kt_all[buf * KCHG + kb + xkr + ps * XROWS] + xcol;
-#ifdef BBB_BF16_PROBE
-        if (p.stagger & 1) { for (int ps = 0; ps < XPASS; ++ps) xo[ps] = kOOB; }
-        if (p.stagger & 2) wo = 0x7FFFFF00u;
-#endif
 #pragma unroll
         for (int ps = 0; ps < XPASS; ++ps) xreg[ps] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xo[ps], 0, 0));
 #pragma unroll
@@ -227,14 +222,6 @@ __global__ __launch_bounds__(64 * WN * WM * KG + (WS ? 256 : 0)) void pconv_bf16
         }
     };
 
-#ifdef BBB_TIMESTAMPS   // debugging aid: s_memtime stamps of wave 0 of two workgroups
-    __shared__ long long tsbuf[120];
-    const bool tson = p.ts && (bid == 8 * 3 || bid == 8 * 20) && threadIdx.x == 0;
-    int tsi = 0;
-#define TS() do { if (tson && tsi < 120) tsbuf[tsi++] = (long long)__builtin_readcyclecounter(); } while (0)
-#else
-#define TS() do { } while (0)
-#endif
     if constexpr (WS) {
         if (producer) {
             // ---- staging waves: tile t+1 -> stage (t+1)&1 while the MFMA waves are on stage t&1; tile t+2 in flight ----
@@ -259,39 +246,27 @@ __global__ __launch_bounds__(64 * WN * WM * KG + (WS ? 256 : 0)) void pconv_bf16
             }
             return;
         }
-        TS();
         __syncthreads();                                           // P0
         __syncthreads();                                           // P1
-        TS();
         for (int t = 0; t < niter; ++t) {
-            TS();
             mma_tile(t & 1);
-            TS();
             __syncthreads();
-            TS(); TS(); TS();
         }
     } else {
-        TS();
         fill_chunk(0);
         __syncthreads();
         load_tile(0);
         if (KCHG < K) fill_chunk(1);
         store_tile(0);
         __syncthreads();
-        TS();
         for (int t = 0; t < niter; ++t) {
             const bool more = (t + 1) < niter;
             if (more) load_tile(t + 1);
             if ((t % TPC) == 1 && t / TPC >= 1 && (t / TPC + 1) * KCHG < K) fill_chunk(t / TPC + 1);
-            TS();
             mma_tile(0);
-            TS();
             __syncthreads();
-            TS();
             if (more) store_tile(0);
-            TS();
             __syncthreads();
-            TS();
         }
     }
 
@@ -382,10 +357,6 @@ __global__ __launch_bounds__(64 * WN * WM * KG + (WS ? 256 : 0)) void pconv_bf16
             __builtin_amdgcn_raw_buffer_store_b128(q, yrs, off, 0, 0);
         }
     }
-#ifdef BBB_TIMESTAMPS
-    TS();
-    if (tson) { long long* o = p.ts + (bid == 8 * 3 ? 0 : 128); o[127] = tsi; for (int i = 0; i < tsi && i < 127; ++i) o[i] = tsbuf[i]; }
-#endif
 }
 
 template <bool OUT_F32, int WN, int WM, int KG, bool WS>
@@ -520,7 +491,6 @@ extern "C" int bbb_conv2d_chwn_bf16_fwd(const bbb_conv_desc_t* d, const void* x,
     const double c14 = 288.0 * waste(a.Cout, 64) * waste(a.B, 256);
     const double c12 = 320.0 * waste(a.Cout, 64) * waste(a.B, 128);
     int shape = (c22 <= c14 && c22 <= c12) ? 22 : (c14 <= c12 ? 14 : 12);
-    if (const char* f = getenv("BBB_BF16_SHAPE")) { const int v = atoi(f); if (v == 22 || v == 14 || v == 12) shape = v; }
     const int bn = shape == 22 ? 128 : 64, bm = shape == 14 ? 256 : 128;
     a.Ntiles = (a.Cout + bn - 1) / bn;
     a.G = a.Ntiles * d->draws;
@@ -537,19 +507,11 @@ extern "C" int bbb_conv2d_chwn_bf16_fwd(const bbb_conv_desc_t* d, const void* x,
     // fill the chip with workgroups and the k loop is long: then per-tile latency, not LDS throughput, sets the pace
     const int t64 = (int)((K + BK - 1) / BK);
     int kgs = (items < 512 && t64 >= 8) ? 2 : 1;
-    if (const char* f = getenv("BBB_BF16_KG")) { const int v = atoi(f); if (v == 1 || v == 2) kgs = v; }
-#ifdef BBB_BF16_PROBE
-    if (const char* f = getenv("BBB_BF16_PROBE")) a.stagger = atoi(f);
-#endif
-#ifdef BBB_TIMESTAMPS
-    { const char* tv = getenv("BBB_TS"); a.ts = tv ? (long long*)strtoull(tv, nullptr, 0) : nullptr; }
-#endif
     // wave specialisation pays when few workgroups are resident per CU (nothing else hides the staging phases); measured
     // on AlexNet bs=512 E=10: conv3 31.7 -> 23.2 us, conv4 46.5 -> 33.3, conv5 18.2 -> 16.8, but conv1 / conv2 (1280+
     // workgroups, or the 64x256 shape whose two stages leave one workgroup per CU) 20-30 % slower
     bool ws = shape == 22 && items <= 1024;
     if (ws) kgs = 1;
-    if (const char* f = getenv("BBB_BF16_WS")) { ws = atoi(f) != 0; if (ws) kgs = 1; }
     hipStream_t st = (hipStream_t)stream;
     return out_f32 ? launch_shape<true>(a, shape, kgs, ws, blocks, st) : launch_shape<false>(a, shape, kgs, ws, blocks, st);
 }

@@ -21,7 +21,6 @@
 // indexed by the canonical NCHW element index (identical stream to the NCHW kernel and the oracle).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 
 #include "../../include/bbb_hip.h"
 #include "bbb_common.cuh"
@@ -200,15 +199,6 @@ __global__ __launch_bounds__(kThreads) void pconv_gemm_kernel(const PConvArgs p)
 
     const int lrow = lane & 31, lk = lane >> 5;
 
-#ifdef BBB_TIMESTAMPS   // debugging aid: s_memtime stamps of wave 0 of two workgroups (see profiles/r01_notes.md)
-    __shared__ long long tsbuf[112];
-    const bool tson = p.ts && (bid == 8 * 40 || bid == 8 * 100) && tid == 0;
-    int tsi = 0;
-#define TS() do { if (tson && tsi < 112) tsbuf[tsi++] = (long long)__builtin_readcyclecounter(); } while (0)
-#else
-#define TS() do { } while (0)
-#endif
-    TS();
     auto mma_tile = [&](bool more) {
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
@@ -235,10 +225,6 @@ __global__ __launch_bounds__(kThreads) void pconv_gemm_kernel(const PConvArgs p)
         }
     };
 
-    {   // de-phase the co-resident workgroups of a CU (experiment: BBB_STAGGER = units of 64 cycles per slot)
-        const int slot = (bid >> 8) & 3;
-        for (int i = 0; i < slot * p.stagger; ++i) __builtin_amdgcn_s_sleep(1);
-    }
     if (ntiles > 0) {
         fill_chunk(0);
         __syncthreads();
@@ -246,10 +232,8 @@ __global__ __launch_bounds__(kThreads) void pconv_gemm_kernel(const PConvArgs p)
         if (KCH < Keff) fill_chunk(1);
         store_tile(0, wregA, xregA);
         __syncthreads();
-        TS();
         for (int t = 0; t < ntiles; ++t) {
             const bool more = (t + 1) < ntiles;
-            TS();
             if (more) {
                 if (ILV) load_addr(t + 1);                            // loads themselves are issued inside mma_tile()
                 else     load_tile(t + 1, wregA, xregA);              // all loads up front (large launches)
@@ -257,21 +241,13 @@ __global__ __launch_bounds__(kThreads) void pconv_gemm_kernel(const PConvArgs p)
             // decode chunk c+1 early in chunk c (c >= 1; chunk 1 is decoded in the prologue): its buffer was last
             // read by load_tile(TPC*c - 1), several barriers ago
             if ((t % TPC) == 1 && t / TPC >= 1 && (t / TPC + 1) * KCH < Keff) fill_chunk(t / TPC + 1);
-            TS();
             mma_tile(more);
-            TS();
             __syncthreads();                                          // every wave is done reading the LDS stage
-            TS();
             if (more) store_tile(0, wregA, xregA);
-            TS();
             __syncthreads();
         }
     }
 
-    TS();
-#ifdef BBB_TIMESTAMPS
-    if (tson) { long long* o = p.ts + (bid == 8 * 40 ? 0 : 128); for (int i = 0; i < tsi; ++i) o[i] = tsbuf[i]; }
-#endif
     // ---- epilogue: rows = channels, lanes = images; bias via buffer loads, stores via buffer stores
     //      (out-of-range channel / image lanes get an out-of-range offset: no branches, no per-element waits) ----
     const int HoWo = p.Ho * p.Wo;
@@ -390,15 +366,10 @@ int launch(PConvArgs& a, int draws, hipStream_t st) {
     const int64_t pixels = (int64_t)a.Ho * a.Wo;
     // tile choice: 128 images per workgroup (two accumulator chains per wave) unless that leaves fewer than 3
     // workgroups per CU, then 64.  A 256-image tile (64x64 per wave) exists but measured 5-10 % slower on every
-    // AlexNet layer (3 instead of 4 workgroups per CU); it is kept for BBB_FORCE_BM experiments only.
+    // AlexNet layer (3 instead of 4 workgroups per CU); the launcher never selects it.
     // LRT stages two weight tiles and keeps two accumulator sets: 64-wide only.
     const int64_t nb128 = pixels * ((a.B + 127) / 128) * a.G;
     int bm = (LRT || nb128 < 768) ? 64 : 128;
-    if (const char* f = getenv("BBB_FORCE_BM")) { if (!LRT) bm = atoi(f); }
-    { const char* sv = getenv("BBB_STAGGER"); a.stagger = sv ? atoi(sv) : 0; }
-#ifdef BBB_TIMESTAMPS
-    { const char* tv = getenv("BBB_TS"); a.ts = tv ? (long long*)strtoull(tv, nullptr, 0) : nullptr; }
-#endif
     a.nbt = (a.B + bm - 1) / bm;
     const int64_t mt = pixels * a.nbt;
     if (mt > 0x7fffffffLL) return BBB_ESHAPE;
@@ -408,23 +379,9 @@ int launch(PConvArgs& a, int draws, hipStream_t st) {
     const int64_t blocks = 8 * per;
     if (blocks > 0x7fffffffLL) return BBB_ESHAPE;
     a.per_xcd = (int32_t)per;
-    {   // BBB_PCONV=dma selects the LDS-DMA pipelined variant (pconv_dma.hip: 3-stage ring, 2 workgroups per CU).  It
-        // measured 20-30 % SLOWER than this register-staged kernel at 4 workgroups per CU on every AlexNet layer, so it
-        // is opt-in, kept for comparison on other shapes.
-        const char* v = getenv("BBB_PCONV");
-        if (v && v[0] == 'd' && bm != 256) {
-            const int rc = bbb_pconv_dma_launch(&a, LRT ? 1 : 0, bm, blocks, st);
-            if (rc != -1000) return rc;
-        }
-    }
-    bool ilv = items <= 1536;      // <= 1.5 rounds of 4 workgroups x 256 CUs: latency-bound launch
-    if (const char* f = getenv("BBB_ILV")) ilv = atoi(f) != 0;
+    const bool ilv = items <= 1536;      // <= 1.5 rounds of 4 workgroups x 256 CUs: latency-bound launch
     const dim3 grid((unsigned)blocks), block(kThreads);
     if constexpr (!LRT) {
-        if (bm == 256) {
-            hipLaunchKernelGGL((pconv_gemm_kernel<256, false, false>), grid, block, 0, st, a);
-            return (int)hipGetLastError();
-        }
         if (bm == 128) {
             if (ilv) hipLaunchKernelGGL((pconv_gemm_kernel<128, false, true>), grid, block, 0, st, a);
             else     hipLaunchKernelGGL((pconv_gemm_kernel<128, false, false>), grid, block, 0, st, a);

@@ -31,7 +31,10 @@ struct ReparamArgs {
     int32_t draws;
     float prior_mu, prior_sigma;
     uint32_t k0, k1, call0, flags;
-    double* partials;
+    double* partials;      // [chunks] per-block KL partials (device scratch + 1: element 0 of the scratch is the ticket)
+    unsigned int* ticket;  // blocks-finished counter, zero between launches (the last block resets it)
+    float* out32;          // KL sum (fp32) or NULL
+    double* out64;         // KL sum (fp64) or NULL
     const float* gkl;
     const uint32_t* call_dev;
 };
@@ -57,6 +60,14 @@ __device__ __forceinline__ float kl_term(float mu, float sigma, float mu0, float
     return 0.5f * t;
 }
 
+// w = mu + eps*sigma with the reference's two roundings (layers/BBB/BBBConv.py:65: a multiply, then an add) -- contraction
+// into one FMA is switched off for this expression only.
+__device__ __forceinline__ float mul_then_add(float mu, float z, float sigma) {
+#pragma clang fp contract(off)
+    const float p = z * sigma;
+    return mu + p;
+}
+
 __device__ __forceinline__ uint16_t bf16_bits(float v) { return __builtin_bit_cast(uint16_t, (__bf16)v); }
 
 __device__ __forceinline__ int find_segment(const ReparamArgs& a, int chunk) {
@@ -65,12 +76,132 @@ __device__ __forceinline__ int find_segment(const ReparamArgs& a, int chunk) {
     return s;
 }
 
+// Block-level KL reduction with the grid-level finish fused in: every block publishes its fp64 partial, takes a ticket,
+// and the block that draws the last ticket sums ALL partials in a fixed strided order (thread t adds partials t, t+256, ...,
+// then an LDS tree) -- the result does not depend on which block happens to be last, so it is bitwise reproducible, and
+// it is the same order the separate finish kernel of round 1 used.  Partials cross XCDs (the L2s are not coherent with
+// each other): they are written and read with agent-scope atomics (write-through / cache-bypassing) around fences.
+__device__ __forceinline__ void block_kl_finish(const ReparamArgs& a, double kl_acc, double* sm /* [kThreads] */, int* flag) {
+    const int tid = threadIdx.x;
+    kl_acc = bbb::wave_sum(kl_acc);
+    const int lane = tid & (bbb::kWave - 1), wv = tid / bbb::kWave;
+    if (lane == 0) sm[wv] = kl_acc;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < kThreads / bbb::kWave; ++i) t += sm[i];
+        __hip_atomic_store(a.partials + blockIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        const unsigned int ticket = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        *flag = (ticket == gridDim.x - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (*flag == 0) return;
+    __threadfence();
+    double t = 0.0;
+    for (int i = tid; i < (int)gridDim.x; i += kThreads)
+        t += __hip_atomic_load(a.partials + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();                       // sm[0..3] (wave partials) have been consumed by thread 0
+    sm[tid] = t;
+    __syncthreads();
+    for (int s = kThreads / 2; s > 0; s >>= 1) {
+        if (tid < s) sm[tid] += sm[tid + s];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        if (a.out32) *a.out32 = (float)sm[0];
+        if (a.out64) *a.out64 = sm[0];
+        __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    }
+}
+
+// The hot instantiation: on-chip noise, dense fp32 outputs, every base pointer 16-byte aligned and draw strides multiples
+// of 4 (checked by the launcher).  Straight-line draw loop: no loads, no waits -- a thread's (mu, rho) vectors are loaded
+// once, sigma and the KL term are computed once, and every draw is one Philox call, two Box-Muller pairs, four
+// mul+add and one 16-byte store (a thread may have all of its draws' stores in flight at once).  The tail of a tensor
+// (n % 4 != 0) still LOADS a full 16-byte vector -- the aligned granule contains valid bytes, so it cannot fault -- and
+// stores its 1..3 elements one by one.  GPT = 16-byte groups per thread (1 at model size, 4 for tensors beyond ~16M
+// elements); NT = non-temporal stores of w (streaming sizes: the GEMM will not find w in cache anyway).
+template <int GPT, bool NT>
+__global__ __launch_bounds__(kThreads) void reparam_kl_fast_kernel(const ReparamArgs a) {
+    __shared__ double sm[kThreads];
+    __shared__ int last_flag;
+    const int chunk = blockIdx.x;
+    const int s = find_segment(a, chunk);
+    const bbb_segment_t sg = a.seg[s];
+    const int64_t base = (int64_t)(chunk - a.chunk_begin[s]) * (kChunk * GPT);
+    const float mu0 = a.prior_mu, sig0 = a.prior_sigma;
+    const bool textbook = (a.flags & BBB_KL_TEXTBOOK) != 0;
+    const bool sq = (a.flags & BBB_SIGMA_SQUARED) != 0;
+    const bool want_kl = a.partials != nullptr;
+    const uint32_t call0 = a.call0 + (a.call_dev ? *a.call_dev : 0u);
+    const float l2s0 = __builtin_amdgcn_logf(sig0), is0 = 1.0f / sig0;
+
+    f32x4 m4[GPT], r4[GPT];
+    int cnt[GPT];
+#pragma unroll
+    for (int it = 0; it < GPT; ++it) {
+        const int64_t i0 = base + ((int64_t)it * kThreads + threadIdx.x) * 4;
+        const int64_t left = sg.n - i0;
+        cnt[it] = left >= 4 ? 4 : (left > 0 ? (int)left : 0);
+        if (cnt[it] > 0) {
+            m4[it] = *reinterpret_cast<const f32x4*>(sg.mu + i0);
+            r4[it] = *reinterpret_cast<const f32x4*>(sg.rho + i0);
+        } else {
+            m4[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            r4[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    double kl_acc = 0.0;
+#pragma unroll
+    for (int it = 0; it < GPT; ++it) {
+        if (cnt[it] == 0) continue;
+        const int64_t i0 = base + ((int64_t)it * kThreads + threadIdx.x) * 4;
+        const uint64_t g = (uint64_t)i0 >> 2;
+        const int c = cnt[it];
+        f32x4 sig;
+        float klf = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            sig[j] = bbb::softplus_ref(r4[it][j]);
+            if (want_kl && j < c) klf += kl_term(m4[it][j], sig[j], mu0, sig0, l2s0, is0, textbook);
+        }
+        kl_acc += (double)klf;
+        if (sg.sigma != nullptr) {
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = sq ? sig[j] * sig[j] : sig[j];
+            if (c == 4) *reinterpret_cast<f32x4*>(sg.sigma + i0) = o;
+            else for (int j = 0; j < c; ++j) sg.sigma[i0 + j] = o[j];
+        }
+        if (sg.w != nullptr) {
+            float* wp = sg.w + i0;
+            for (int e = 0; e < a.draws; ++e, wp += sg.draw_stride) {
+                float z[4];
+                bbb::normal4(g, sg.stream_id, call0 + (uint32_t)e, a.k0, a.k1, z);
+                f32x4 w4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w4[j] = mul_then_add(m4[it][j], z[j], sig[j]);
+                if (c == 4) {
+                    if (NT) __builtin_nontemporal_store(w4, reinterpret_cast<f32x4*>(wp));
+                    else    *reinterpret_cast<f32x4*>(wp) = w4;   // plain store: the GEMM re-reads w from L2 / Infinity Cache
+                } else {
+                    for (int j = 0; j < c; ++j) wp[j] = w4[j];
+                }
+            }
+        }
+    }
+    if (want_kl) block_kl_finish(a, kl_acc, sm, &last_flag);
+}
+
 // GPT = groups of 4 elements per thread.  1 for model-sized launches (enough blocks as it is); 4 for very large
 // tensors, where 4x fewer, longer blocks with all their loads issued up front stream HBM better.
 template <int GPT>
 __global__ __launch_bounds__(kThreads) void reparam_kl_fwd_kernel(const ReparamArgs a) {
     constexpr int kGroupsPerThread = GPT;
-    __shared__ double wave_part[kThreads / bbb::kWave];
+    __shared__ double sm[kThreads];
+    __shared__ int last_flag;
     const int chunk = blockIdx.x;
     const int s = find_segment(a, chunk);
     const bbb_segment_t sg = a.seg[s];
@@ -125,7 +256,7 @@ __global__ __launch_bounds__(kThreads) void reparam_kl_fwd_kernel(const ReparamA
         // bf16 weight rows (w_row_len != 0): destination of each of the 4 elements inside one draw's matrix -- rows of rl
         // elements at a pitch rounded up to 8, optionally transposed to tap-major order; the element that ends a row also
         // zeroes the row's pad.  Independent of the draw, so computed once.
-        int64_t bf_dst[4] = {0, 0, 0, 0}, bf_rl = 0, bf_pitch = 0, bf_pad_row = -1;
+        int64_t bf_dst[4] = {0, 0, 0, 0}, bf_rl = 0, bf_pitch = 0, bf_pad_row[4] = {-1, -1, -1, -1};
         bool bf_vec = false;
         if (sg.w != nullptr && sg.w_row_len != 0) {
             bf_rl = sg.w_row_len;
@@ -138,7 +269,7 @@ __global__ __launch_bounds__(kThreads) void reparam_kl_fwd_kernel(const ReparamA
             for (int j = 0; j < 4; ++j) {
                 const uint32_t ci = col / taps, tp = col - ci * taps;            // taps == 1: ci = col, tp = 0
                 bf_dst[j] = row * bf_pitch + (int64_t)(tp * cin + ci);
-                if (j < cnt && col == (uint32_t)bf_rl - 1 && bf_pitch != bf_rl) bf_pad_row = row;
+                if (j < cnt && col == (uint32_t)bf_rl - 1 && bf_pitch != bf_rl) bf_pad_row[j] = row;   // every row that ends here
                 if (++col == (uint32_t)bf_rl) { col = 0; ++row; }
             }
             bf_vec = taps == 1 && cnt == 4 && bf_dst[3] == bf_dst[0] + 3 && ((bf_rl & 3) == 0) &&
@@ -159,55 +290,29 @@ __global__ __launch_bounds__(kThreads) void reparam_kl_fwd_kernel(const ReparamA
                     // bf16 weights for the bf16 GEMM (destinations computed once, above the draw loop)
                     uint16_t* wb = reinterpret_cast<uint16_t*>(sg.w) + (int64_t)e * sg.draw_stride;
                     if (bf_vec) {
-                        uint32_t lo = (uint32_t)bf16_bits(mu[0] + z[0] * sigma[0]) | ((uint32_t)bf16_bits(mu[1] + z[1] * sigma[1]) << 16);
-                        uint32_t hi = (uint32_t)bf16_bits(mu[2] + z[2] * sigma[2]) | ((uint32_t)bf16_bits(mu[3] + z[3] * sigma[3]) << 16);
+                        uint32_t lo = (uint32_t)bf16_bits(mul_then_add(mu[0], z[0], sigma[0])) | ((uint32_t)bf16_bits(mul_then_add(mu[1], z[1], sigma[1])) << 16);
+                        uint32_t hi = (uint32_t)bf16_bits(mul_then_add(mu[2], z[2], sigma[2])) | ((uint32_t)bf16_bits(mul_then_add(mu[3], z[3], sigma[3])) << 16);
                         *reinterpret_cast<uint2*>(wb + bf_dst[0]) = make_uint2(lo, hi);
                     } else {
-                        for (int j = 0; j < cnt; ++j) wb[bf_dst[j]] = bf16_bits(mu[j] + z[j] * sigma[j]);
+                        for (int j = 0; j < cnt; ++j) wb[bf_dst[j]] = bf16_bits(mul_then_add(mu[j], z[j], sigma[j]));
                     }
-                    if (bf_pad_row >= 0)
-                        for (int64_t c = bf_rl; c < bf_pitch; ++c) wb[bf_pad_row * bf_pitch + c] = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (bf_pad_row[j] >= 0)
+                            for (int64_t c = bf_rl; c < bf_pitch; ++c) wb[bf_pad_row[j] * bf_pitch + c] = 0;
                 } else if (aligned && cnt == 4) {
                     f32x4 w4;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) w4[j] = mu[j] + z[j] * sigma[j];   // mul then add, like the reference
+                    for (int j = 0; j < 4; ++j) w4[j] = mul_then_add(mu[j], z[j], sigma[j]);
                     *reinterpret_cast<f32x4*>(sg.w + o) = w4;   // plain store: the GEMM re-reads w from L2 / Infinity Cache
                 } else {
-                    for (int j = 0; j < cnt; ++j) sg.w[o + j] = mu[j] + z[j] * sigma[j];
+                    for (int j = 0; j < cnt; ++j) sg.w[o + j] = mul_then_add(mu[j], z[j], sigma[j]);
                 }
             }
         }
     }
 
-    if (want_kl) {
-        kl_acc = bbb::wave_sum(kl_acc);
-        const int lane = threadIdx.x & (bbb::kWave - 1), wv = threadIdx.x / bbb::kWave;
-        if (lane == 0) wave_part[wv] = kl_acc;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double t = 0.0;
-#pragma unroll
-            for (int i = 0; i < kThreads / bbb::kWave; ++i) t += wave_part[i];
-            a.partials[blockIdx.x] = t;
-        }
-    }
-}
-
-// Deterministic second stage: fixed strided order, fp64.
-__global__ __launch_bounds__(kThreads) void kl_finish_kernel(const double* partials, int n, float* out32, double* out64) {
-    __shared__ double sm[kThreads];
-    double t = 0.0;
-    for (int i = threadIdx.x; i < n; i += kThreads) t += partials[i];
-    sm[threadIdx.x] = t;
-    __syncthreads();
-    for (int s = kThreads / 2; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        if (out32) *out32 = (float)sm[0];
-        if (out64) *out64 = sm[0];
-    }
+    if (want_kl) block_kl_finish(a, kl_acc, sm, &last_flag);
 }
 
 __global__ __launch_bounds__(kThreads) void reparam_kl_bwd_kernel(const ReparamArgs a) {
@@ -336,7 +441,18 @@ extern "C" int64_t bbb_reparam_partials(const bbb_segment_t* segs, int nseg) {
     if (segs == nullptr || nseg <= 0 || nseg > BBB_MAX_SEGMENTS) return BBB_EINVAL;
     int64_t chunks = 0;
     for (int s = 0; s < nseg; ++s) chunks += (segs[s].n + kChunk - 1) / kChunk;
-    return chunks;
+    return chunks + 1;      // + the ticket slot (element 0 of the scratch)
+}
+
+// The fast kernel applies when every segment is a dense fp32, Philox-sampled tensor whose pointers are 16-byte aligned.
+static bool fast_path_ok(const bbb_segment_t* segs, int nseg) {
+    for (int s = 0; s < nseg; ++s) {
+        const bbb_segment_t& g = segs[s];
+        if (g.eps != nullptr || g.w_row_len != 0) return false;
+        if ((((uintptr_t)g.mu | (uintptr_t)g.rho | (uintptr_t)g.w | (uintptr_t)g.sigma) & 15u) != 0) return false;
+        if (g.w != nullptr && (g.draw_stride & 3) != 0) return false;
+    }
+    return true;
 }
 
 extern "C" int bbb_reparam_kl_fwd(const bbb_segment_t* segs, int nseg, int draws, float prior_mu, float prior_sigma,
@@ -346,11 +462,12 @@ extern "C" int bbb_reparam_kl_fwd(const bbb_segment_t* segs, int nseg, int draws
     int64_t total = 0;
     if (segs != nullptr && nseg > 0 && nseg <= BBB_MAX_SEGMENTS)
         for (int s = 0; s < nseg; ++s) total += segs[s].n;
-    const int gpt = total > (int64_t)kChunk * 16384 ? 4 : 1;       // > 16M elements: longer blocks
+    const bool big = total > (int64_t)kChunk * 16384;               // > 16M elements: longer blocks, streaming stores
+    const int gpt = big ? 4 : 1;
     const int chunks = fill_args(a, segs, nseg, draws, false, gpt);
     if (chunks < 0) return chunks;
     const bool want_kl = (kl_out != nullptr) || (kl_out64 != nullptr);
-    if (want_kl && kl_partials == nullptr) return BBB_EINVAL;
+    if (want_kl && (kl_partials == nullptr || ((uintptr_t)kl_partials & 7u) != 0)) return BBB_EINVAL;
     if (!(prior_sigma > 0.0f)) return BBB_EINVAL;
     a.prior_mu = prior_mu;
     a.prior_sigma = prior_sigma;
@@ -358,18 +475,25 @@ extern "C" int bbb_reparam_kl_fwd(const bbb_segment_t* segs, int nseg, int draws
     a.k1 = (uint32_t)(seed >> 32);
     a.call0 = call0;
     a.flags = flags;
-    a.partials = want_kl ? kl_partials : nullptr;
+    a.partials = want_kl ? kl_partials + 1 : nullptr;
+    a.ticket = want_kl ? reinterpret_cast<unsigned int*>(kl_partials) : nullptr;
+    a.out32 = kl_out;
+    a.out64 = kl_out64;
     a.call_dev = call_dev;
     hipStream_t st = (hipStream_t)stream;
-    if (gpt == 4) hipLaunchKernelGGL(reparam_kl_fwd_kernel<4>, dim3(chunks), dim3(kThreads), 0, st, a);
-    else          hipLaunchKernelGGL(reparam_kl_fwd_kernel<1>, dim3(chunks), dim3(kThreads), 0, st, a);
-    hipError_t err = hipGetLastError();
-    if (err != hipSuccess) return (int)err;
-    if (want_kl) {
-        hipLaunchKernelGGL(kl_finish_kernel, dim3(1), dim3(kThreads), 0, st, (const double*)kl_partials, chunks, kl_out, kl_out64);
-        err = hipGetLastError();
+    const dim3 grid(chunks), block(kThreads);
+#ifdef BBB_FORCE_GENERIC_REPARAM     // timing experiments: the general kernel on inputs the fast one would take
+    if (false) {
+#else
+    if (fast_path_ok(segs, nseg)) {
+#endif
+        if (big) hipLaunchKernelGGL((reparam_kl_fast_kernel<4, true>), grid, block, 0, st, a);
+        else     hipLaunchKernelGGL((reparam_kl_fast_kernel<1, false>), grid, block, 0, st, a);
+    } else {
+        if (big) hipLaunchKernelGGL(reparam_kl_fwd_kernel<4>, grid, block, 0, st, a);
+        else     hipLaunchKernelGGL(reparam_kl_fwd_kernel<1>, grid, block, 0, st, a);
     }
-    return (int)err;
+    return (int)hipGetLastError();
 }
 
 extern "C" int bbb_reparam_kl_bwd(const bbb_segment_t* segs, int nseg, int draws, float prior_mu, float prior_sigma,

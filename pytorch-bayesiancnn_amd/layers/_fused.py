@@ -12,11 +12,12 @@ from bbb_hip import rng
 
 
 class _Scope:
-    __slots__ = ("kl", "pushed")
+    __slots__ = ("kl", "pushed", "layers")
 
     def __init__(self):
         self.kl = None
         self.pushed = False
+        self.layers = ()
 
 
 def enter(wrapper):
@@ -27,8 +28,18 @@ def enter(wrapper):
     if not layers:
         return None
     sc = _Scope()
+    sc.layers = layers
     seed, call = rng.push_forward_scope()
     sc.pushed = True
+    try:
+        _presample(sc, layers, seed, call)
+    except BaseException:
+        leave(sc)                        # an aborted enter must not leave the noise scope pushed
+        raise
+    return sc
+
+
+def _presample(sc, layers, seed, call):
     dev_ok = all(l.W_mu.is_cuda for l in layers)
     replay = any(l.eps_source is not None for l in layers)
     if dev_ok and not replay:
@@ -50,9 +61,11 @@ def enter(wrapper):
                 l._kl = None
             kl = k2 if kl is None else kl + k2
         sc.kl = kl
-    return sc
 
 
 def leave(scope):
     if scope is not None and scope.pushed:
+        scope.pushed = False
         rng.pop_forward_scope()
+        for l in scope.layers:           # a forward that aborted midway must not hand stale samples to the next one
+            l._presampled = None

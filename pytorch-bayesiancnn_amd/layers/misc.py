@@ -19,9 +19,10 @@ class ModuleWrapper(nn.Module):
 
     def forward(self, x):
         from . import _fused
-        scope = _fused.enter(self)          # one noise call index (and, when possible, ONE fused reparam+KL
-        try:                                # launch) for every Bayesian layer below this wrapper
-            for child in self.children():
+        scope = None
+        try:
+            scope = _fused.enter(self)      # one noise call index (and, when possible, ONE fused reparam+KL
+            for child in self.children():   # launch) for every Bayesian layer below this wrapper
                 x = child(x)
             if scope is not None and scope.kl is not None:
                 return x, scope.kl          # KL of all layers, already reduced on the device

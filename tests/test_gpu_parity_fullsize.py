@@ -1,0 +1,225 @@
+"""The benchmarked path vs the CPU oracle at BASELINE.json's FULL sizes (run with -m gpu).
+
+What runs on the device is exactly what bench.py times: `ensemble.mc_logits` / `mc_forward` / `GraphedMC` on the
+batch-innermost path (pixel-major GEMM that skips padding taps, fused bias + activation epilogue, pooled layers,
+`mc_tail_cb`).  The oracle is fed the device's own noise stream: `bbb_numpy.normal_eps(seed, call0 + draw, stream id)`
+for every W / bias (BBB) or activation (LRT) tensor, so logits are compared draw by draw -- no statistics involved.
+
+  * `bbb_numpy.model_forward`  : numpy, float64 accumulation -> the "true" value of the reference's arithmetic
+  * `ref_port_torch.forward`   : the reference's own ATen ops on the CPU (fp32, mkldnn) -> the reference's result,
+                                 including ITS accumulation error
+
+Tolerances (stated per test, as a fraction of max|logit| of the config): the device's fp32 fmaf chain (K <= 3456 per
+layer, 6-8 layers deep) is held to a small multiple of the distance between the reference's own fp32 result and the
+float64 value -- i.e. the device may not be a worse approximation of the exact arithmetic than the reference's CPU path
+by more than that factor.  KL: 2e-6 relative (fp64 tree vs the reference's fp32 sum).  Each test prints the measured
+errors so that the bound can be audited against the log.
+
+Reference lines: main_bayesian.py:73-80 (the step), layers/BBB/BBBConv.py:61-83, layers/BBB_LRT/BBBConv.py:62-87,
+layers/misc.py:16-35, utils.py:14-22.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import bbb_numpy as O
+import ref_port_torch as P
+
+pytestmark = pytest.mark.gpu
+
+KIND = {"W": 0, "bias": 1, "act": 2}
+
+
+@pytest.fixture(scope="module")
+def env():
+    import layers  # noqa: F401
+    from bbb_hip import ops, rng, ensemble, zoo
+    return dict(ops=ops, rng=rng, ens=ensemble, zoo=zoo)
+
+
+def build(env, net_type, lt, ncls, cin=3, seed=0):
+    torch.manual_seed(seed)
+    net = env["zoo"].getModel(net_type, cin, ncls, P.CONFIG_PRIORS, lt, "softplus").cuda()
+    env["rng"].assign_stream_ids(net)
+    names = [n for n, m in net.named_children() if hasattr(m, "W_mu")]
+    params = {"_prior_mu": 0, "_prior_sigma": 0.1}
+    sid = {}
+    for n in names:
+        m = getattr(net, n)
+        params[n] = {k: getattr(m, k).detach().cpu() for k in ("W_mu", "W_rho", "bias_mu", "bias_rho")}
+        sid[n] = m._stream_base
+    return net, params, sid
+
+
+def np_params(params):
+    return {k: ({kk: vv.numpy() for kk, vv in v.items()} if isinstance(v, dict) else v) for k, v in params.items()}
+
+
+def eps_numpy(seed, call, sid):
+    def fn(name, kind, shape):
+        return O.normal_eps(seed, call, sid[name] + KIND[kind], int(np.prod(shape))).reshape(shape)
+    return fn
+
+
+def eps_torch(seed, call, sid):
+    f = eps_numpy(seed, call, sid)
+    return lambda name, kind, shape: torch.from_numpy(f(name, kind, shape))
+
+
+def report(tag, **kw):
+    print("[parity] " + tag + ": " + ", ".join(f"{k}={v:.3e}" if isinstance(v, float) else f"{k}={v}" for k, v in kw.items()))
+
+
+def assert_fast_path(env):
+    assert env["ens"].stats["path"] == "chwn", "the batch-innermost (benchmarked) path did not run"
+
+
+# --------------------------------------------------------------------------------------------------------------------
+def test_metric_config_alexnet10_bbb_bs512_ens10_vs_oracle(env):
+    """BASELINE metric config.  Logits of draws 0 and 9 vs the float64 oracle and vs the reference's fp32 CPU ops; the whole
+    step (10 draws -> log_softmax -> logmeanexp, KL summed over calls) vs ref_port_torch.mc_step's arithmetic with replayed
+    noise; the hipGraph replay the bench times returns the eager step's bits."""
+    net, params, sid = build(env, "alexnet", "bbb", 10)
+    x = torch.rand(512, 3, 32, 32)
+    xd = x.cuda()
+    E, seed, call0 = 10, 4242, 17
+    with torch.no_grad():
+        logits, kl = env["ens"].mc_logits(net, xd, E, seed, call0)
+        assert_fast_path(env)
+        env["rng"].manual_seed(seed, call=call0)
+        lo, klsum = env["ens"].mc_forward(net, xd, E)
+        assert_fast_path(env)
+        env["rng"].manual_seed(seed, call=call0)
+        g = env["ens"].GraphedMC(net, xd, E)
+        lo_g, kl_g = g.step()
+        torch.cuda.synchronize()
+        assert torch.equal(lo_g, lo) and kl_g.item() == klsum.item()
+    logits = logits.cpu().numpy()
+    npp = np_params(params)
+    ls_ref = []
+    kl_ref = 0.0
+    worst_dev = worst_ref = 0.0
+    for j in range(E):
+        lt, klt = P.forward("alexnet", params, x, "bbb", "softplus", eps_fn=eps_torch(seed, call0 + j, sid))
+        ls_ref.append(F.log_softmax(lt, dim=1))
+        kl_ref += float(klt)
+        scale = float(lt.abs().max())
+        if j in (0, E - 1):
+            l64, kl64 = O.model_forward("alexnet", npp, x.numpy(), "bbb", "softplus", eps_numpy(seed, call0 + j, sid))
+            e_dev = float(np.abs(logits[j] - l64).max()) / scale
+            e_ref = float(np.abs(lt.numpy() - l64).max()) / scale
+            worst_dev, worst_ref = max(worst_dev, e_dev), max(worst_ref, e_ref)
+            assert abs(kl.item() - kl64) <= 2e-6 * kl64
+        # every draw against the reference's own fp32 result
+        assert float(np.abs(logits[j] - lt.numpy()).max()) <= 2e-5 * scale, j
+    report("metric alexnet10 bbb bs512", scale=scale, dev_vs_f64=worst_dev, cpu_ref_vs_f64=worst_ref)
+    assert worst_dev <= max(4.0 * worst_ref, 4e-6)          # not a worse approximation of the exact result than the CPU path (x4)
+    want = P.logmeanexp(torch.stack(ls_ref, dim=2), 2).numpy()
+    got = lo.cpu().numpy()
+    report("metric step", lse_abs_err=float(np.abs(got - want).max()), kl_rel=abs(klsum.item() - kl_ref) / kl_ref)
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-5 * scale)    # log-probabilities inherit the logits' absolute error
+    assert abs(klsum.item() - kl_ref) <= 5e-6 * kl_ref                 # the reference adds 12 fp32 partial sums per call
+
+
+def test_config1_3conv3fc_bs256_bf16_vs_oracle(env):
+    """configs[1]: Bayesian3Conv3FC, BBB layers, bf16 storage, batch 256.  The reference has no bf16 mode; the oracle is the same
+    algorithm with this project's rounding points (bbb_numpy.model_forward_bf16).  Bound: 2e-2 of max|logit|; the
+    fp32 path on the same draw is compared too (1e-5)."""
+    net, params, sid = build(env, "3conv3fc", "bbb", 10)
+    x = torch.rand(256, 3, 32, 32)
+    xd = x.cuda()
+    E, seed, call0 = 2, 99, 3
+    with torch.no_grad():
+        l16, kl16 = env["ens"].mc_logits(net, xd, E, seed, call0, precision="bf16")
+        assert_fast_path(env)
+        l32, kl32 = env["ens"].mc_logits(net, xd, E, seed, call0)
+        assert_fast_path(env)
+    assert kl16.item() == kl32.item()
+    npp = np_params(params)
+    for j in range(E):
+        want16, klw = O.model_forward_bf16("3conv3fc", npp, x.numpy(), "softplus", eps_numpy(seed, call0 + j, sid))
+        want32, _ = O.model_forward("3conv3fc", npp, x.numpy(), "bbb", "softplus", eps_numpy(seed, call0 + j, sid))
+        scale = float(np.abs(want32).max())
+        e16 = float(np.abs(l16[j].cpu().numpy() - want16).max()) / scale
+        e32 = float(np.abs(l32[j].cpu().numpy() - want32).max()) / scale
+        report(f"cfg1 3conv3fc bs256 draw {j}", scale=scale, bf16_vs_bf16_oracle=e16, fp32_vs_f64=e32,
+               bf16_model_vs_fp32_model=float(np.abs(want16 - want32).max()) / scale)
+        assert e16 <= 2e-2
+        assert e32 <= 1e-5
+        assert abs(kl16.item() - klw) <= 2e-6 * klw
+
+
+def test_config2_alexnet100_lrt_bs512_vs_oracle(env):
+    """configs[2]: BayesianAlexNet CIFAR-100, BBB_LRT layers, batch 512: act_mu + sqrt(act_var) * eps with eps replayed by
+    canonical NCHW element index of each layer's output."""
+    net, params, sid = build(env, "alexnet", "lrt", 100)
+    x = torch.rand(512, 3, 32, 32)
+    xd = x.cuda()
+    E, seed, call0 = 2, 31337, 8
+    with torch.no_grad():
+        logits, kl = env["ens"].mc_logits(net, xd, E, seed, call0)
+        assert_fast_path(env)
+        env["rng"].manual_seed(seed, call=call0)
+        lo, klsum = env["ens"].mc_forward(net, xd, E)
+    npp = np_params(params)
+    ls = []
+    for j in range(E):
+        l64, kl64 = O.model_forward("alexnet", npp, x.numpy(), "lrt", "softplus", eps_numpy(seed, call0 + j, sid))
+        lt, _ = P.forward("alexnet", params, x, "lrt", "softplus", eps_fn=eps_torch(seed, call0 + j, sid))
+        scale = float(np.abs(l64).max())
+        e_dev = float(np.abs(logits[j].cpu().numpy() - l64).max()) / scale
+        e_ref = float(np.abs(lt.numpy() - l64).max()) / scale
+        report(f"cfg2 alexnet100 lrt bs512 draw {j}", scale=scale, dev_vs_f64=e_dev, cpu_ref_vs_f64=e_ref)
+        assert e_dev <= max(4.0 * e_ref, 1e-5)
+        assert abs(kl.item() - kl64) <= 2e-6 * kl64
+        ls.append(O.log_softmax(l64, axis=1))
+    want = O.logmeanexp(np.stack(ls, axis=2), axis=2)
+    np.testing.assert_allclose(lo.cpu().numpy(), want, rtol=0, atol=3e-5 * scale)
+    assert abs(klsum.item() - E * kl64) <= 2e-6 * E * kl64
+
+
+def test_config3_alexnet10_ens25_vs_oracle(env):
+    """configs[3] on one device: num_ens = 25.  All 25 draws against the reference's CPU ops with replayed noise, then the
+    25-way logmeanexp and the KL sum."""
+    net, params, sid = build(env, "alexnet", "bbb", 10, seed=1)
+    x = torch.rand(512, 3, 32, 32)
+    xd = x.cuda()
+    E, seed, call0 = 25, 2025, 100
+    with torch.no_grad():
+        logits, kl = env["ens"].mc_logits(net, xd, E, seed, call0)
+        assert_fast_path(env)
+        env["rng"].manual_seed(seed, call=call0)
+        lo, klsum = env["ens"].mc_forward(net, xd, E)
+    logits = logits.cpu().numpy()
+    ls, klr, worst = [], 0.0, 0.0
+    for j in range(E):
+        lt, klt = P.forward("alexnet", params, x, "bbb", "softplus", eps_fn=eps_torch(seed, call0 + j, sid))
+        scale = float(lt.abs().max())
+        worst = max(worst, float(np.abs(logits[j] - lt.numpy()).max()) / scale)
+        ls.append(F.log_softmax(lt, dim=1))
+        klr += float(klt)
+    report("cfg3 alexnet10 E=25", dev_vs_cpu_ref=worst)
+    assert worst <= 2e-5
+    want = P.logmeanexp(torch.stack(ls, dim=2), 2).numpy()
+    np.testing.assert_allclose(lo.cpu().numpy(), want, rtol=0, atol=2e-5 * scale)
+    assert abs(klsum.item() - klr) <= 5e-6 * klr
+
+
+def test_config4_alexnet_224_bs64_vs_oracle(env):
+    """configs[4] shape (3x224x224, the MFMA-bound regime), 64 images of the 512-per-GPU shard: one draw vs the reference's CPU
+    ops, including the view(-1, 128) flatten quirk ([B,128,7,7] -> [B*49,128], layers/misc.py:35)."""
+    net, params, sid = build(env, "alexnet", "bbb", 10, seed=2)
+    x = torch.rand(64, 3, 224, 224)
+    xd = x.cuda()
+    seed, call0 = 5, 0
+    with torch.no_grad():
+        logits, kl = env["ens"].mc_logits(net, xd, 1, seed, call0)
+        assert_fast_path(env)
+    lt, klt = P.forward("alexnet", params, x, "bbb", "softplus", eps_fn=eps_torch(seed, call0, sid))
+    assert tuple(logits.shape) == (1, 64 * 49, 10) and tuple(lt.shape) == (64 * 49, 10)
+    scale = float(lt.abs().max())
+    err = float(np.abs(logits[0].cpu().numpy() - lt.numpy()).max()) / scale
+    report("cfg4 alexnet 224 bs64", scale=scale, dev_vs_cpu_ref=err)
+    assert err <= 2e-5
+    assert abs(kl.item() - float(klt)) <= 5e-6 * float(klt)
