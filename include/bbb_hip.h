@@ -15,9 +15,11 @@
  * Noise contract (replaces torch.empty(shape).normal_(0,1) on the CPU generator,
  * layers/BBB/BBBConv.py:63,68; layers/BBB_LRT/BBBConv.py:78): element i of noise stream
  * (seed, call, stream_id) is output (i & 3) of
- *     Philox4x32-10(counter = {lo32(i >> 2), i >> 34, stream_id, call}, key = {lo32(seed), hi32(seed)})
- * pushed through Box-Muller pairs (x0,x1)->(z0,z1), (x2,x3)->(z2,z3) with
- *     u1 = ((xa >> 8) + 1) * 2^-24,  u2 = (xb >> 8) * 2^-24,  z = sqrt(-2 ln u1) * {cos,sin}(2 pi u2).
+ *     Philox4x32-7(counter = {lo32(i >> 2), i >> 34, stream_id, call}, key = {lo32(seed), hi32(seed)})
+ * (Random123; 7 rounds = its published BigCrush-passing minimum) pushed through Box-Muller pairs
+ * (x0,x1)->(z0,z1), (x2,x3)->(z2,z3) with 23-bit mantissas
+ *     u1 = 1 - (xa >> 9) * 2^-23 in (0,1],  u2 = (xb >> 9) * 2^-23 in [0,1),  z = sqrt(-2 ln u1) * {cos,sin}(2 pi u2).
+ * (ABI <= 3 used Philox4x32-10 and 24-bit uniforms; the stream definition is part of the ABI version.)
  * Monte-Carlo draw j of an ensemble uses call = call0 + j, so a batched E-draw launch and E
  * single-draw launches produce the same numbers, and any GPU can materialise any draw.
  */
@@ -68,15 +70,16 @@ typedef struct bbb_segment {
  * kl_loss() (metrics.py:27-29 via layers/BBB/BBBConv.py:79-83), plus the Python sum over layers
  * (layers/misc.py:20-23).
  *   segs        host array of nseg descriptors (copied into the kernel arguments)
- *   kl_partials device scratch, at least bbb_reparam_partials(segs, nseg) doubles, 8-byte aligned.  Element 0 is a
- *               "blocks finished" ticket: it must be ZERO before the first launch that uses the buffer; every launch
- *               leaves it zero again.  One scratch buffer per stream (launches that may overlap must not share one).
+ *   kl_partials device scratch, at least bbb_reparam_partials(segs, nseg) doubles, 8-byte aligned, FILLED WITH 0xFF
+ *               BYTES before the first launch that uses it ("not published yet"); every launch leaves the slots it
+ *               used in that state again.  One scratch buffer per stream (launches that may overlap must not share one).
  *   kl_out      device float: sum over all segments of the KL term (NULL = no KL)
  *   kl_out64    optional device double with the same sum (NULL = skip)
  *   call_dev    optional DEVICE uint32 added to call0 when the kernel runs (NULL = 0).  This is what lets a
  *               captured hipGraph draw fresh noise on every replay: the graph also contains the increment.
- * KL does not depend on eps; the sum is reduced in a fixed order in fp64 (bitwise reproducible): blocks publish fp64
- * partials and the block that finishes last adds them up in index order -- one launch, no separate finish kernel.
+ * KL does not depend on eps; the sum is reduced in a fixed order in fp64 (bitwise reproducible): every 1024-element
+ * chunk publishes an fp64 partial before its draws start and one extra block of the same launch adds them up in index
+ * order -- one launch, no separate finish kernel, the reduction hidden behind the sampling work.
  */
 int bbb_reparam_kl_fwd(const bbb_segment_t* segs, int nseg, int draws,
                        float prior_mu, float prior_sigma,
@@ -84,7 +87,7 @@ int bbb_reparam_kl_fwd(const bbb_segment_t* segs, int nseg, int draws,
                        double* kl_partials, float* kl_out, double* kl_out64,
                        const uint32_t* call_dev, void* stream);
 
-/* Number of doubles of scratch bbb_reparam_kl_fwd needs for these segments, ticket slot included (host-only helper). */
+/* Number of doubles of scratch bbb_reparam_kl_fwd needs for these segments, host-only helper. */
 int64_t bbb_reparam_partials(const bbb_segment_t* segs, int nseg);
 
 /*

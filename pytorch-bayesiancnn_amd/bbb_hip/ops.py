@@ -21,8 +21,8 @@ def _partials(device, n):
     key = (device.index, "kl", cur_stream(device))
     buf = _scratch.get(key)
     if buf is None or buf.numel() < n:
-        # element 0 is the kernel's "blocks finished" ticket: zero once, the kernel leaves it zero after every launch
-        buf = torch.zeros(max(n, 4096), dtype=torch.float64, device=device)
+        # every slot starts as "not published yet" (0xFF bytes); each launch re-arms the slots it consumed
+        buf = torch.full((max(n, 4096),), -1, dtype=torch.int64, device=device).view(torch.float64)
         _scratch[key] = buf
     return buf
 

@@ -1,10 +1,12 @@
 // Fused reparameterisation + KL for Bayes-by-Backprop layers on gfx950 (MI355X).
 //
 // One pass over (mu, rho) of up to 16 parameter tensors and E Monte-Carlo draws:
-//   sigma = log1p(exp(rho));  w[e] = mu + sigma * eps[e]  (eps from on-chip Philox4x32-10);
+//   sigma = log1p(exp(rho));  w[e] = mu + sigma * eps[e]  (eps from on-chip Philox4x32-7);
 //   KL term of the reference's call order (prior as "q", posterior as "p"), reduced per thread in
-//   fp64 -> wave shuffles -> LDS -> one partial per block; a second tiny kernel sums the partials in
-//   a fixed order.  HBM traffic per element: 8 B read + 4 B written per draw; eps and KL cost none.
+//   fp64 -> wave shuffles -> LDS -> one partial per 1024-element chunk, published BEFORE the block starts its draws;
+//   one extra block of the same launch waits for all partials and adds them in index order (bitwise reproducible),
+//   hidden behind the other blocks' draw loops.  HBM traffic per element: 8 B read + 4 B written per draw; eps and
+//   KL cost none.
 // Replaces layers/BBB/BBBConv.py:63-70,79-83, layers/BBB/BBBLinear.py:56-63,72-76,
 // layers/BBB_LRT/BBBConv.py:64-69,83-87, layers/BBB_LRT/BBBLinear.py:58-63,75-79, metrics.py:27-29,
 // layers/misc.py:20-23 of the reference.
@@ -18,9 +20,14 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kChunk = kThreads * 4;                         // elements per (block, group slot): 4 per thread
+// A KL partial slot that has not been published yet holds this bit pattern (an all-ones NaN; the scratch is filled with
+// 0xFF bytes once by the host, and every launch re-arms the slots it consumed).
+constexpr unsigned long long kUnpublished = 0xFFFFFFFFFFFFFFFFull;
+constexpr int kSpinBudget = 1 << 20;                         // bounded wait (~0.1 s): a lost partial gives NaN, never a hang
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+typedef bbb::bbb_f32x4 f32x4;
+using bbb::bbb_f32x2;
+using bbb::bbb_f32x4;
 
 struct ReparamArgs {
     bbb_segment_t seg[BBB_MAX_SEGMENTS];
@@ -31,10 +38,13 @@ struct ReparamArgs {
     int32_t draws;
     float prior_mu, prior_sigma;
     uint32_t k0, k1, call0, flags;
-    double* partials;      // [chunks] per-block KL partials (device scratch + 1: element 0 of the scratch is the ticket)
-    unsigned int* ticket;  // blocks-finished counter, zero between launches (the last block resets it)
+    unsigned long long* partials;   // [chunks] per-chunk KL partials (fp64 bits); kUnpublished between launches
     float* out32;          // KL sum (fp32) or NULL
     double* out64;         // KL sum (fp64) or NULL
+    int32_t n_chunks;      // publishers = partials to add up
+    int32_t sum_block;     // index of the block that only sums the partials (-1: no KL wanted)
+    int32_t n_small;       // leading blocks that own ONE draw of one of the last chunks (see the launcher); 0 = none
+    int32_t small_chunk0;  // first chunk handled by small blocks
     const float* gkl;
     const uint32_t* call_dev;
 };
@@ -60,13 +70,39 @@ __device__ __forceinline__ float kl_term(float mu, float sigma, float mu0, float
     return 0.5f * t;
 }
 
-// w = mu + eps*sigma with the reference's two roundings (layers/BBB/BBBConv.py:65: a multiply, then an add) -- contraction
-// into one FMA is switched off for this expression only.
-__device__ __forceinline__ float mul_then_add(float mu, float z, float sigma) {
-#pragma clang fp contract(off)
-    const float p = z * sigma;
-    return mu + p;
+// kl_term on four elements with packed math (same operations per element, same bits); returns the terms, unsummed.
+__device__ __forceinline__ bbb_f32x4 kl_term4(bbb_f32x4 mu, bbb_f32x4 sigma, float mu0, float sig0, float l2s0, float is0, bool textbook) {
+    using bbb::pk_fma;
+    using bbb::pk_splat;
+    bbb_f32x4 out;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const bbb_f32x2 m = bbb_f32x2{mu[2 * h], mu[2 * h + 1]};
+        const bbb_f32x2 sg = bbb_f32x2{sigma[2 * h], sigma[2 * h + 1]};
+        const bbb_f32x2 l2 = bbb_f32x2{__builtin_amdgcn_logf(sg.x), __builtin_amdgcn_logf(sg.y)} - pk_splat(l2s0);
+        bbb_f32x2 t;
+        if (!textbook) {
+            const bbb_f32x2 r = bbb_f32x2{__builtin_amdgcn_rcpf(sg.x), __builtin_amdgcn_rcpf(sg.y)};
+            const bbb_f32x2 is = pk_fma(pk_fma(-sg, r, pk_splat(1.0f)), r, r);          // rcp_newton
+            const bbb_f32x2 a = pk_splat(sig0) * is;
+            const bbb_f32x2 b = (m - pk_splat(mu0)) * is;
+            t = pk_fma(pk_splat(1.3862943611198906f), l2, pk_splat(-1.0f)) + a * a + b * b;
+        } else {
+            const bbb_f32x2 a = sg * pk_splat(is0);
+            const bbb_f32x2 b = (pk_splat(mu0) - m) * pk_splat(is0);
+            t = pk_fma(pk_splat(-1.3862943611198906f), l2, pk_splat(-1.0f)) + a * a + b * b;
+        }
+        t = t * pk_splat(0.5f);
+        out[2 * h] = t.x;
+        out[2 * h + 1] = t.y;
+    }
+    return out;
 }
+
+// w = mu + eps*sigma as ONE fused multiply-add in every kernel of this file (so the result does not depend on which
+// kernel variant a launch takes).  The reference rounds twice (layers/BBB/BBBConv.py:65: a multiply, then an add); the
+// FMA is within half an ulp of that, three orders of magnitude below the 2e-5 the hardware sin/cos/log leave in eps.
+__device__ __forceinline__ float sample_w(float mu, float z, float sigma) { return fmaf(z, sigma, mu); }
 
 __device__ __forceinline__ uint16_t bf16_bits(float v) { return __builtin_bit_cast(uint16_t, (__bf16)v); }
 
@@ -76,12 +112,14 @@ __device__ __forceinline__ int find_segment(const ReparamArgs& a, int chunk) {
     return s;
 }
 
-// Block-level KL reduction with the grid-level finish fused in: every block publishes its fp64 partial, takes a ticket,
-// and the block that draws the last ticket sums ALL partials in a fixed strided order (thread t adds partials t, t+256, ...,
-// then an LDS tree) -- the result does not depend on which block happens to be last, so it is bitwise reproducible, and
-// it is the same order the separate finish kernel of round 1 used.  Partials cross XCDs (the L2s are not coherent with
-// each other): they are written and read with agent-scope atomics (write-through / cache-bypassing) around fences.
-__device__ __forceinline__ void block_kl_finish(const ReparamArgs& a, double kl_acc, double* sm /* [kThreads] */, int* flag) {
+// KL across blocks without a second launch, without fences and without counters.  Every chunk's owner reduces its terms
+// (fp64: thread -> wave shuffles -> LDS) and lane 0 PUBLISHES the partial with ONE 8-byte write-through (agent-scope,
+// `sc1`) store into the chunk's slot -- a data-tagged granule: the slot holds kUnpublished until then, and an aligned
+// 8-byte store is observed whole.  No drain, no ticket: the publisher does not wait for anything.  (Round-2 history,
+// measured at model size: a release fence per block = `buffer_wbl2` of the whole dirty L2 -> 155 us; store + drain + ONE
+// atomic counter -> 33 us, the counter word taking ~88 increments/us; 64 striped counters -> 14 us fixed; this -> see
+// profiles/r02_notes.md.)
+__device__ __forceinline__ void publish_partial(const ReparamArgs& a, int chunk, double kl_acc, double* sm /* [kThreads] */) {
     const int tid = threadIdx.x;
     kl_acc = bbb::wave_sum(kl_acc);
     const int lane = tid & (bbb::kWave - 1), wv = tid / bbb::kWave;
@@ -91,18 +129,30 @@ __device__ __forceinline__ void block_kl_finish(const ReparamArgs& a, double kl_
         double t = 0.0;
 #pragma unroll
         for (int i = 0; i < kThreads / bbb::kWave; ++i) t += sm[i];
-        __hip_atomic_store(a.partials + blockIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence();
-        const unsigned int ticket = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        *flag = (ticket == gridDim.x - 1) ? 1 : 0;
+        unsigned long long bits = __builtin_bit_cast(unsigned long long, t);
+        if (bits == kUnpublished) bits = 0x7FF8000000000000ull;      // a NaN partial stays a NaN, but never looks unpublished
+        __hip_atomic_store(a.partials + chunk, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __syncthreads();
-    if (*flag == 0) return;
-    __threadfence();
+}
+
+// The summing block (last block index of the launch, so every publisher has been dispatched before it): thread t waits
+// for, consumes and re-arms slots t, t+256, ... IN THAT ORDER, then an LDS tree -- the fixed summation order of round 1's
+// separate finish kernel, so the KL bits did not change and do not depend on timing.  Slots are read with agent-scope
+// (cache-bypassing) loads, the counterpart of the publishers' write-through stores.
+__device__ __forceinline__ void sum_partials(const ReparamArgs& a, double* sm /* [kThreads] */) {
+    const int tid = threadIdx.x;
     double t = 0.0;
-    for (int i = tid; i < (int)gridDim.x; i += kThreads)
-        t += __hip_atomic_load(a.partials + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();                       // sm[0..3] (wave partials) have been consumed by thread 0
+    int budget = kSpinBudget;
+    for (int i = tid; i < a.n_chunks; i += kThreads) {
+        unsigned long long v = __hip_atomic_load(a.partials + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (v == kUnpublished && budget > 0) {
+            __builtin_amdgcn_s_sleep(4);
+            --budget;
+            v = __hip_atomic_load(a.partials + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        t += __builtin_bit_cast(double, v);                       // a slot that never arrived adds NaN
+        __hip_atomic_store(a.partials + i, kUnpublished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    }
     sm[tid] = t;
     __syncthreads();
     for (int s = kThreads / 2; s > 0; s >>= 1) {
@@ -112,87 +162,130 @@ __device__ __forceinline__ void block_kl_finish(const ReparamArgs& a, double kl_
     if (tid == 0) {
         if (a.out32) *a.out32 = (float)sm[0];
         if (a.out64) *a.out64 = sm[0];
-        __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
     }
 }
 
-// The hot instantiation: on-chip noise, dense fp32 outputs, every base pointer 16-byte aligned and draw strides multiples
-// of 4 (checked by the launcher).  Straight-line draw loop: no loads, no waits -- a thread's (mu, rho) vectors are loaded
-// once, sigma and the KL term are computed once, and every draw is one Philox call, two Box-Muller pairs, four
-// mul+add and one 16-byte store (a thread may have all of its draws' stores in flight at once).  The tail of a tensor
-// (n % 4 != 0) still LOADS a full 16-byte vector -- the aligned granule contains valid bytes, so it cannot fault -- and
-// stores its 1..3 elements one by one.  GPT = 16-byte groups per thread (1 at model size, 4 for tensors beyond ~16M
-// elements); NT = non-temporal stores of w (streaming sizes: the GEMM will not find w in cache anyway).
+// The hot instantiation: on-chip noise, dense fp32 outputs.  Straight-line draw loop: no loads, no waits -- a thread's (mu, rho) vectors are loaded
+// once, sigma and the KL term are computed once (and published), and every draw is one Philox call, two Box-Muller pairs,
+// four FMAs and one 16-byte store; a thread may have all of its draws' stores in flight at once.  The tail of an aligned tensor (n % 4 != 0) still LOADS a full
+// 16-byte vector -- the aligned granule contains valid bytes, so it cannot fault -- and stores its 1..3 elements one by one.
+// GPT = 16-byte groups per thread (1 at model size, 4 for tensors beyond ~16M elements); NT = non-temporal stores of w
+// (streaming sizes: the GEMM will not find w in cache anyway).
+// Block kinds (b = blockIdx.x): b == sum_block: sum_partials only.  b < n_small: ONE draw of one of the last chunks
+// (see the launcher: it evens out a launch that is slightly larger than one round of resident blocks).  Otherwise: a whole
+// chunk, all draws.
 template <int GPT, bool NT>
 __global__ __launch_bounds__(kThreads) void reparam_kl_fast_kernel(const ReparamArgs a) {
     __shared__ double sm[kThreads];
-    __shared__ int last_flag;
-    const int chunk = blockIdx.x;
+    const int b = blockIdx.x;
+    if (b == a.sum_block) { sum_partials(a, sm); return; }
+    int chunk, e_lo, e_hi;
+    if (b < a.n_small) {
+        const int q = b / a.draws;
+        chunk = a.small_chunk0 + q;
+        e_lo = b - q * a.draws;
+        e_hi = e_lo + 1;
+    } else {
+        chunk = b - a.n_small;
+        e_lo = 0;
+        e_hi = a.draws;
+    }
     const int s = find_segment(a, chunk);
     const bbb_segment_t sg = a.seg[s];
     const int64_t base = (int64_t)(chunk - a.chunk_begin[s]) * (kChunk * GPT);
     const float mu0 = a.prior_mu, sig0 = a.prior_sigma;
     const bool textbook = (a.flags & BBB_KL_TEXTBOOK) != 0;
     const bool sq = (a.flags & BBB_SIGMA_SQUARED) != 0;
-    const bool want_kl = a.partials != nullptr;
+    const bool first = e_lo == 0;                               // this block owns the chunk's KL partial and sigma output
+    // 16-byte accesses need aligned bases (and draw strides that keep them aligned); a tensor that does not qualify (a
+    // 10-element bias: draw stride 10) moves element by element -- decided per segment, uniform over the block
+    const bool ld_vec = ((((uintptr_t)sg.mu | (uintptr_t)sg.rho) & 15u) == 0);
+    const bool st_vec = (((uintptr_t)sg.w & 15u) == 0) && ((sg.draw_stride & 3) == 0);
+    const bool sg_vec = (((uintptr_t)sg.sigma & 15u) == 0);
+    const bool want_kl = a.partials != nullptr && first;
     const uint32_t call0 = a.call0 + (a.call_dev ? *a.call_dev : 0u);
     const float l2s0 = __builtin_amdgcn_logf(sig0), is0 = 1.0f / sig0;
 
-    f32x4 m4[GPT], r4[GPT];
+    f32x4 m4[GPT], sig[GPT], r4[GPT];
     int cnt[GPT];
 #pragma unroll
-    for (int it = 0; it < GPT; ++it) {
+    for (int it = 0; it < GPT; ++it) {                          // all loads first
         const int64_t i0 = base + ((int64_t)it * kThreads + threadIdx.x) * 4;
         const int64_t left = sg.n - i0;
-        cnt[it] = left >= 4 ? 4 : (left > 0 ? (int)left : 0);
-        if (cnt[it] > 0) {
+        const int c = left >= 4 ? 4 : (left > 0 ? (int)left : 0);
+        cnt[it] = c;
+        r4[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        m4[it] = r4[it];
+        if (c > 0 && ld_vec) {
             m4[it] = *reinterpret_cast<const f32x4*>(sg.mu + i0);
             r4[it] = *reinterpret_cast<const f32x4*>(sg.rho + i0);
-        } else {
-            m4[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-            r4[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        } else if (c > 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j < c) { m4[it][j] = sg.mu[i0 + j]; r4[it][j] = sg.rho[i0 + j]; }
         }
+    }
+    // The first draw's noise does not depend on (mu, rho): generate it while the loads are in flight (the blocks of a launch
+    // start together, so without this every wave of the chip sits in the same load-latency hole at the same time).
+    float z0[4] = {0.f, 0.f, 0.f, 0.f};
+    if (GPT == 1 && sg.w != nullptr && cnt[0] > 0) {
+        const uint64_t g = (uint64_t)(base + (int64_t)threadIdx.x * 4) >> 2;
+        bbb::normal4(g, sg.stream_id, call0 + (uint32_t)e_lo, a.k0, a.k1, z0);
+        __builtin_amdgcn_sched_barrier(0);                      // keep it ahead of the first use of the loaded vectors
     }
     double kl_acc = 0.0;
 #pragma unroll
     for (int it = 0; it < GPT; ++it) {
-        if (cnt[it] == 0) continue;
         const int64_t i0 = base + ((int64_t)it * kThreads + threadIdx.x) * 4;
-        const uint64_t g = (uint64_t)i0 >> 2;
         const int c = cnt[it];
-        f32x4 sig;
         float klf = 0.0f;
+        sig[it] = bbb::softplus_ref4(r4[it]);
+        if (want_kl) {
+            const f32x4 kt = kl_term4(m4[it], sig[it], mu0, sig0, l2s0, is0, textbook);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            sig[j] = bbb::softplus_ref(r4[it][j]);
-            if (want_kl && j < c) klf += kl_term(m4[it][j], sig[j], mu0, sig0, l2s0, is0, textbook);
+            for (int j = 0; j < 4; ++j)
+                if (j < c) klf += kt[j];
         }
         kl_acc += (double)klf;
-        if (sg.sigma != nullptr) {
+        if (first && c > 0 && sg.sigma != nullptr) {
             f32x4 o;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = sq ? sig[j] * sig[j] : sig[j];
-            if (c == 4) *reinterpret_cast<f32x4*>(sg.sigma + i0) = o;
+            for (int j = 0; j < 4; ++j) o[j] = sq ? sig[it][j] * sig[it][j] : sig[it][j];
+            if (c == 4 && sg_vec) *reinterpret_cast<f32x4*>(sg.sigma + i0) = o;
             else for (int j = 0; j < c; ++j) sg.sigma[i0 + j] = o[j];
         }
-        if (sg.w != nullptr) {
-            float* wp = sg.w + i0;
-            for (int e = 0; e < a.draws; ++e, wp += sg.draw_stride) {
-                float z[4];
-                bbb::normal4(g, sg.stream_id, call0 + (uint32_t)e, a.k0, a.k1, z);
-                f32x4 w4;
+    }
+    if (a.partials != nullptr && first) publish_partial(a, chunk, kl_acc, sm);     // block-uniform condition
+    if (sg.w == nullptr) return;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) w4[j] = mul_then_add(m4[it][j], z[j], sig[j]);
-                if (c == 4) {
-                    if (NT) __builtin_nontemporal_store(w4, reinterpret_cast<f32x4*>(wp));
-                    else    *reinterpret_cast<f32x4*>(wp) = w4;   // plain store: the GEMM re-reads w from L2 / Infinity Cache
-                } else {
-                    for (int j = 0; j < c; ++j) wp[j] = w4[j];
-                }
+    for (int it = 0; it < GPT; ++it) {
+        const int c = cnt[it];
+        if (c == 0) continue;
+        const int64_t i0 = base + ((int64_t)it * kThreads + threadIdx.x) * 4;
+        const uint64_t g = (uint64_t)i0 >> 2;
+        float* wp = sg.w + i0 + (int64_t)e_lo * sg.draw_stride;
+        float z[4];
+        if (GPT == 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) z[j] = z0[j];
+        } else {
+            bbb::normal4(g, sg.stream_id, call0 + (uint32_t)e_lo, a.k0, a.k1, z);
+        }
+        for (int e = e_lo;;) {                                   // noise for draw e+1 is generated at the end of iteration e
+            f32x4 w4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w4[j] = sample_w(m4[it][j], z[j], sig[it][j]);
+            if (c == 4 && st_vec) {
+                if (NT) __builtin_nontemporal_store(w4, reinterpret_cast<f32x4*>(wp));
+                else    *reinterpret_cast<f32x4*>(wp) = w4;
+            } else {
+                for (int j = 0; j < c; ++j) wp[j] = w4[j];
             }
+            if (++e >= e_hi) break;
+            wp += sg.draw_stride;
+            bbb::normal4(g, sg.stream_id, call0 + (uint32_t)e, a.k0, a.k1, z);
         }
     }
-    if (want_kl) block_kl_finish(a, kl_acc, sm, &last_flag);
 }
 
 // GPT = groups of 4 elements per thread.  1 for model-sized launches (enough blocks as it is); 4 for very large
@@ -201,7 +294,7 @@ template <int GPT>
 __global__ __launch_bounds__(kThreads) void reparam_kl_fwd_kernel(const ReparamArgs a) {
     constexpr int kGroupsPerThread = GPT;
     __shared__ double sm[kThreads];
-    __shared__ int last_flag;
+    if ((int)blockIdx.x == a.sum_block) { sum_partials(a, sm); return; }
     const int chunk = blockIdx.x;
     const int s = find_segment(a, chunk);
     const bbb_segment_t sg = a.seg[s];
@@ -290,11 +383,11 @@ __global__ __launch_bounds__(kThreads) void reparam_kl_fwd_kernel(const ReparamA
                     // bf16 weights for the bf16 GEMM (destinations computed once, above the draw loop)
                     uint16_t* wb = reinterpret_cast<uint16_t*>(sg.w) + (int64_t)e * sg.draw_stride;
                     if (bf_vec) {
-                        uint32_t lo = (uint32_t)bf16_bits(mul_then_add(mu[0], z[0], sigma[0])) | ((uint32_t)bf16_bits(mul_then_add(mu[1], z[1], sigma[1])) << 16);
-                        uint32_t hi = (uint32_t)bf16_bits(mul_then_add(mu[2], z[2], sigma[2])) | ((uint32_t)bf16_bits(mul_then_add(mu[3], z[3], sigma[3])) << 16);
+                        uint32_t lo = (uint32_t)bf16_bits(sample_w(mu[0], z[0], sigma[0])) | ((uint32_t)bf16_bits(sample_w(mu[1], z[1], sigma[1])) << 16);
+                        uint32_t hi = (uint32_t)bf16_bits(sample_w(mu[2], z[2], sigma[2])) | ((uint32_t)bf16_bits(sample_w(mu[3], z[3], sigma[3])) << 16);
                         *reinterpret_cast<uint2*>(wb + bf_dst[0]) = make_uint2(lo, hi);
                     } else {
-                        for (int j = 0; j < cnt; ++j) wb[bf_dst[j]] = bf16_bits(mul_then_add(mu[j], z[j], sigma[j]));
+                        for (int j = 0; j < cnt; ++j) wb[bf_dst[j]] = bf16_bits(sample_w(mu[j], z[j], sigma[j]));
                     }
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
@@ -303,16 +396,16 @@ __global__ __launch_bounds__(kThreads) void reparam_kl_fwd_kernel(const ReparamA
                 } else if (aligned && cnt == 4) {
                     f32x4 w4;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) w4[j] = mul_then_add(mu[j], z[j], sigma[j]);
+                    for (int j = 0; j < 4; ++j) w4[j] = sample_w(mu[j], z[j], sigma[j]);
                     *reinterpret_cast<f32x4*>(sg.w + o) = w4;   // plain store: the GEMM re-reads w from L2 / Infinity Cache
                 } else {
-                    for (int j = 0; j < cnt; ++j) sg.w[o + j] = mul_then_add(mu[j], z[j], sigma[j]);
+                    for (int j = 0; j < cnt; ++j) sg.w[o + j] = sample_w(mu[j], z[j], sigma[j]);
                 }
             }
         }
     }
 
-    if (want_kl) block_kl_finish(a, kl_acc, sm, &last_flag);
+    if (want_kl) publish_partial(a, chunk, kl_acc, sm);
 }
 
 __global__ __launch_bounds__(kThreads) void reparam_kl_bwd_kernel(const ReparamArgs a) {
@@ -441,18 +534,27 @@ extern "C" int64_t bbb_reparam_partials(const bbb_segment_t* segs, int nseg) {
     if (segs == nullptr || nseg <= 0 || nseg > BBB_MAX_SEGMENTS) return BBB_EINVAL;
     int64_t chunks = 0;
     for (int s = 0; s < nseg; ++s) chunks += (segs[s].n + kChunk - 1) / kChunk;
-    return chunks + 1;      // + the ticket slot (element 0 of the scratch)
+    return chunks;
 }
 
-// The fast kernel applies when every segment is a dense fp32, Philox-sampled tensor whose pointers are 16-byte aligned.
+// The fast kernel applies when every segment is a dense fp32, Philox-sampled tensor (alignment is handled per segment).
 static bool fast_path_ok(const bbb_segment_t* segs, int nseg) {
-    for (int s = 0; s < nseg; ++s) {
-        const bbb_segment_t& g = segs[s];
-        if (g.eps != nullptr || g.w_row_len != 0) return false;
-        if ((((uintptr_t)g.mu | (uintptr_t)g.rho | (uintptr_t)g.w | (uintptr_t)g.sigma) & 15u) != 0) return false;
-        if (g.w != nullptr && (g.draw_stride & 3) != 0) return false;
-    }
+    for (int s = 0; s < nseg; ++s)
+        if (segs[s].eps != nullptr || segs[s].w_row_len != 0) return false;
     return true;
+}
+
+// 256-thread blocks the current device keeps resident at once: 8 per CU (<= 64 VGPRs, 2 KB LDS; 32 waves per CU).
+static int resident_blocks() {
+    static int cached[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 2048;
+    if (cached[dev] == 0) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        cached[dev] = cus * 8;
+    }
+    return cached[dev];
 }
 
 extern "C" int bbb_reparam_kl_fwd(const bbb_segment_t* segs, int nseg, int draws, float prior_mu, float prior_sigma,
@@ -475,21 +577,42 @@ extern "C" int bbb_reparam_kl_fwd(const bbb_segment_t* segs, int nseg, int draws
     a.k1 = (uint32_t)(seed >> 32);
     a.call0 = call0;
     a.flags = flags;
-    a.partials = want_kl ? kl_partials + 1 : nullptr;
-    a.ticket = want_kl ? reinterpret_cast<unsigned int*>(kl_partials) : nullptr;
+    a.partials = want_kl ? reinterpret_cast<unsigned long long*>(kl_partials) : nullptr;
     a.out32 = kl_out;
     a.out64 = kl_out64;
     a.call_dev = call_dev;
+    a.n_chunks = chunks;
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid(chunks), block(kThreads);
+    const dim3 block(kThreads);
 #ifdef BBB_FORCE_GENERIC_REPARAM     // timing experiments: the general kernel on inputs the fast one would take
-    if (false) {
+    const bool fast = false;
 #else
-    if (fast_path_ok(segs, nseg)) {
+    const bool fast = fast_path_ok(segs, nseg);
 #endif
-        if (big) hipLaunchKernelGGL((reparam_kl_fast_kernel<4, true>), grid, block, 0, st, a);
-        else     hipLaunchKernelGGL((reparam_kl_fast_kernel<1, false>), grid, block, 0, st, a);
+    if (fast) {
+        // A launch a little larger than one round of resident blocks (the model-sized case: 2137 chunks on 2048 slots) would
+        // run its excess blocks alone at the end, one wave per SIMD, for a whole 10-draw block time.  Instead the LAST
+        // `excess` chunks are cut into one block per draw and put FIRST in the grid: they finish early, the whole-chunk
+        // blocks behind them fill the freed slots, and the launch ends with every SIMD still sharing work.  (The block of
+        // draw 0 owns the chunk's KL partial and sigma output; partial indices = chunk indices, so the KL sum is unchanged.)
+        const int slots = resident_blocks();
+        int excess = 0;
+        if (gpt == 1 && draws > 1 && chunks > slots && chunks <= 3 * slots) excess = chunks % slots;
+        a.n_small = excess * draws;
+        a.small_chunk0 = chunks - excess;
+        const int blocks = a.n_small + (chunks - excess);
+        a.sum_block = want_kl ? blocks : -1;
+        const dim3 grid(blocks + (want_kl ? 1 : 0));
+        // Store flavour of w (measured, AlexNet's 12 tensors, us per launch, plain / non-temporal): E=4 14.6 / 12.2, E=10
+        // 21.7 / 19.2, E=25 40.0 / 42.5 -- with plain stores the launch ends with up to 32 MB of dirty L2 lines to write back
+        // at the kernel boundary; streaming them out as they are produced wins until the launch is long enough to hide that.
+        const bool nt = big || draws <= 16;
+        if (big)     hipLaunchKernelGGL((reparam_kl_fast_kernel<4, true>), grid, block, 0, st, a);
+        else if (nt) hipLaunchKernelGGL((reparam_kl_fast_kernel<1, true>), grid, block, 0, st, a);
+        else         hipLaunchKernelGGL((reparam_kl_fast_kernel<1, false>), grid, block, 0, st, a);
     } else {
+        a.sum_block = want_kl ? chunks : -1;
+        const dim3 grid(chunks + (want_kl ? 1 : 0));
         if (big) hipLaunchKernelGGL(reparam_kl_fwd_kernel<4>, grid, block, 0, st, a);
         else     hipLaunchKernelGGL(reparam_kl_fwd_kernel<1>, grid, block, 0, st, a);
     }

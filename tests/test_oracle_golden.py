@@ -143,14 +143,31 @@ def test_port_mc_step(golden):
 
 
 def test_philox_known_answers():
-    """Random123 kat_vectors for philox4x32-10."""
-    def run(c, k):
-        r = O.philox4x32_10(*[np.array([v], dtype=np.uint32) for v in c], k[0], k[1])
+    """Random123 kat_vectors (`philox4x32 7 ...` and `philox4x32 10 ...` lines) for the round count the noise contract
+    uses (7) and for Random123's default (10)."""
+    def run(c, k, rounds):
+        r = O.philox4x32(*[np.array([v], dtype=np.uint32) for v in c], k[0], k[1], rounds=rounds)
         return [int(v[0]) for v in r]
-    assert run([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
-    assert run([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
-    assert run([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
-        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    pi_c, pi_k = [0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]
+    assert O.PHILOX_ROUNDS == 7
+    assert run([0, 0, 0, 0], [0, 0], 7) == [0x5f6fb709, 0x0d893f64, 0x4f121f81, 0x4f730a48]
+    assert run([0xffffffff] * 4, [0xffffffff] * 2, 7) == [0x5207ddc2, 0x45165e59, 0x4d8ee751, 0x8c52f662]
+    assert run(pi_c, pi_k, 7) == [0x4dfccaba, 0x190a87f0, 0xc47362ba, 0xb6b5242a]
+    assert run([0, 0, 0, 0], [0, 0], 10) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert run([0xffffffff] * 4, [0xffffffff] * 2, 10) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert run(pi_c, pi_k, 10) == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_box_muller_definition():
+    """The uniform construction of the noise contract: 23-bit mantissas, u1 in (0, 1], u2 in [0, 1)."""
+    xa = np.array([0, 0xFFFFFFFF, 0x80000000, 0x000001FF], dtype=np.uint32)
+    xb = np.array([0, 0, 0x40000000, 0xFFFFFFFF], dtype=np.uint32)
+    z0, z1 = O.box_muller(xa, xb)
+    assert z0[0] == 0 and z1[0] == 0                                  # u1 = 1 -> radius 0
+    np.testing.assert_allclose(z0[1], np.sqrt(-2 * np.log(2.0 ** -23)), rtol=1e-6)   # smallest u1, angle 0: 5.65 sigma
+    np.testing.assert_allclose(z1[2], np.sqrt(-2 * np.log(0.5)), rtol=1e-6)          # u1 = 1/2, quarter turn
+    assert abs(z0[2]) < 1e-6
+    assert z0[3] == 0 and z1[3] == 0                                  # the low 9 bits of a word are not used
 
 
 def test_eps_stream_moments_and_windows():
