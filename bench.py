@@ -12,23 +12,28 @@ layers' own reset_parameters with config_bayesian.priors, x ~ U[0,1).
 Launch structure: each step is one captured hipGraph (a device-side call counter inside it advances the Philox
 noise on every replay) and `--pipeline` (default 3) independent steps are in flight on separate HIP streams.
 
-N > 1 (weak scaling): every rank runs num_ens=10 draws of the same 512-image batch -- a 10*N-draw ensemble
-sharded over the GPUs (draw j is noise call call0 + j on whichever rank owns it) -- and the ranks combine
-their log-sum-exp blocks and KL sums with ONE all_gather over RCCL per step.  value = B * 10 * N / step time.
+N > 1 is STRONG scaling of the metric's workload: the same 512 images x 10 draws, cut into (draw x batch-slice) work
+units dealt evenly over the ranks (ensemble.shard_plan; 8 ranks: 40 quarter-batch units, 5 each), every rank sampling
+only the weight sets its units touch, ONE all_gather of [B*C + 1] floats per step over RCCL.  value = 512 * 10 / step
+time.  (`weak_scaling`: a short secondary run with 10 draws PER rank, reported next to it.)
 
 Prints ONE JSON line on rank 0 (contract in the task description) with these extra objects:
-  roofline      the dominant kernel (fp32-MFMA implicit-GEMM conv): algorithmic FLOP / HIP-event time vs the
-                157.3 TFLOP/s fp32 matrix peak (+ its HBM traffic from the PMC passes in profiles/);
-                roofline_reparam: the fused reparam+KL pass vs HBM.
-  cpu_baseline  the oracle's torch-CPU port of the reference MC step (oracle/ref_port_torch.py, bit-identical
-                to the upstream nn.Modules under the same seed) timed on this host's cores, rank 0, N=1 only.
-  one_step_in_flight   the same workload with a single graph lane (step latency instead of throughput).
-  bf16          secondary measurement of the same workload under the bf16 storage model (BASELINE.json configs[1]
-                precision; `--dtype bf16` makes it the reported value instead).  Never the default headline.
+  roofline          the dominant kernel (fp32-MFMA implicit-GEMM conv): algorithmic FLOP / HIP-event time vs the 157.3 TFLOP/s
+                    fp32 matrix peak; `traffic` = HBM bytes per step from the committed rocprofv3 PMC passes, parsed from
+                    profiles/ at run time (null when the files are absent).
+  roofline_reparam  the fused reparam+KL pass vs HBM (8 TB/s).
+  cpu_baseline      the reference's CPU nn.Module path timed on this host's cores (rank 0, N=1 only): the unmodified upstream
+                    modules when /root/reference exists (kind "reference"), else the oracle's bit-identical torch-CPU port
+                    (kind "port"); no_grad and autograd-enabled variants, median and p10/p90.
+  one_step_in_flight / stats / dropin_loop / configs   single-lane latency, block-time statistics, the unmodified-loop
+                    shape through the drop-in layers, and BASELINE.json's other configurations -- each with its own roofline.
 """
 import argparse
 import json
 import os
+import re
+import statistics
+import subprocess
 import sys
 import time
 
@@ -39,10 +44,23 @@ sys.dont_write_bytecode = True
 import torch  # noqa: E402
 
 PRIORS = {"prior_mu": 0, "prior_sigma": 0.1, "posterior_mu_initial": (0, 0.1), "posterior_rho_initial": (-5, 0.1)}
-BATCH, NUM_ENS, CLASSES = 512, 10, 10
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense v_mfma_f32_32x32x16_bf16 peak (same guide)
 PEAK_HBM_GBS = 8000.0             # HBM3E spec (6.3 TB/s achievable)
+
+# BASELINE.json: metric config + configs[1..4] (configs[0] is the reference's CPU-only plumbing case)
+CONFIGS = {
+    "metric": dict(net="alexnet", classes=10, lt="bbb", B=512, E=10, hw=32, precision="fp32",
+                   what="BayesianAlexNet 3x32x32 -> 10, layer_type=bbb, softplus, bs=512, num_ens=10"),
+    "configs[1]": dict(net="3conv3fc", classes=10, lt="bbb", B=256, E=1, hw=32, precision="bf16",
+                       what="Bayesian3Conv3FC CIFAR-10, BBB layers, bf16 storage, batch 256, num_ens=1"),
+    "configs[2]": dict(net="alexnet", classes=100, lt="lrt", B=512, E=1, hw=32, precision="fp32",
+                       what="BayesianAlexNet CIFAR-100, BBB_LRT layers, batch 512, num_ens=1"),
+    "configs[3]": dict(net="alexnet", classes=10, lt="bbb", B=512, E=25, hw=32, precision="fp32",
+                       what="BayesianAlexNet CIFAR-10, num_ens=25 (the 8-GPU ensemble of configs[3], all 25 draws on this GPU)"),
+    "configs[4]": dict(net="alexnet", classes=10, lt="bbb", B=512, E=1, hw=224, precision="fp32",
+                       what="BayesianAlexNet 3x224x224, 512 images = one GPU's shard of the batch-4096 data-parallel run"),
+}
 
 
 def usable_cpus():
@@ -57,51 +75,174 @@ def usable_cpus():
     return n
 
 
-def cpu_baseline(budget_s=16.0):
-    """Reference CPU path (oracle port: same ATen ops / order as the upstream modules), bounded sample."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import ref_port_torch as P
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    try:
+        out = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=5).stdout
+        m = re.search(r"Model name:\s*(.+)", out)
+        return m.group(1).strip() if m else None
+    except Exception:
+        return None
+
+
+def pctl(xs, q):
+    xs = sorted(xs)
+    if not xs:
+        return None
+    i = q * (len(xs) - 1)
+    lo, hi = int(i), min(int(i) + 1, len(xs) - 1)
+    return xs[lo] + (xs[hi] - xs[lo]) * (i - lo)
+
+
+def cpu_baseline(budget_s=20.0):
+    """The reference's CPU nn.Module path on the metric config (bs=512, num_ens=10, bbb, fp32), a bounded sample."""
+    cfg = CONFIGS["metric"]
+    B, E, C = cfg["B"], cfg["E"], cfg["classes"]
     avail = usable_cpus()
+    ref_dir = "/root/reference"
     torch.manual_seed(0)
-    params = P.init_params("alexnet", 3, CLASSES, P.CONFIG_PRIORS)
-    x = torch.rand(BATCH, 3, 32, 32)
+    x = torch.rand(B, 3, 32, 32)
+    if os.path.isdir(os.path.join(ref_dir, "layers")):
+        # the UNMODIFIED upstream modules (build container only: the GPU box has no checkout)
+        kind = "reference"
+        saved_path, saved_mods = list(sys.path), {k: v for k, v in sys.modules.items() if k == "layers" or k.startswith("layers.")}
+        for k in list(saved_mods):
+            del sys.modules[k]
+        sys.path.insert(0, ref_dir)
+        try:
+            from models.BayesianModels.BayesianAlexNet import BBBAlexNet as RefAlexNet
+            import utils as ref_utils
+            import torch.nn.functional as F
+            net = RefAlexNet(C, 3, PRIORS, "bbb", "softplus")
 
-    def run(nthreads, budget):
+            def step():                                   # main_bayesian.py:73-80
+                outputs = torch.zeros(B, C, E)
+                kl = 0.0
+                for j in range(E):
+                    net_out, _kl = net(x)
+                    kl += _kl
+                    outputs[:, :, j] = F.log_softmax(net_out, dim=1).data
+                return ref_utils.logmeanexp(outputs, dim=2), kl
+            src = "unmodified upstream modules imported from /root/reference (models.BayesianModels.BayesianAlexNet, utils.logmeanexp)"
+        finally:
+            sys.path[:] = saved_path
+            for k in [k for k in sys.modules if k == "layers" or k.startswith("layers.")]:
+                del sys.modules[k]
+            sys.modules.update(saved_mods)
+    else:
+        kind = "port"
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import ref_port_torch as P
+        params = P.init_params("alexnet", 3, C, P.CONFIG_PRIORS)
+
+        def step():
+            return P.mc_step("alexnet", params, x, C, E, "bbb", "softplus")
+        src = "oracle/ref_port_torch.mc_step (same ATen ops / draw order as the upstream modules, bit-identical under a seed)"
+
+    def run(nthreads, budget, grad):
         torch.set_num_threads(nthreads)
-        with torch.no_grad():
-            P.mc_step("alexnet", params, x, CLASSES, 1, "bbb", "softplus")      # warm-up (1 draw)
-            t0 = time.perf_counter()
-            n = 0
+        times = []
+        ctx = torch.enable_grad() if grad else torch.no_grad()
+        with ctx:
+            step()                                        # warm-up
+            t_all = time.perf_counter()
             while True:
-                P.mc_step("alexnet", params, x, CLASSES, NUM_ENS, "bbb", "softplus")
-                n += 1
-                el = time.perf_counter() - t0
-                if (n >= 3 and el > budget) or n >= 100 or el > 4 * budget:
+                t0 = time.perf_counter()
+                step()
+                times.append(time.perf_counter() - t0)
+                el = time.perf_counter() - t_all
+                if (len(times) >= 3 and el > budget) or len(times) >= 100 or el > 4 * budget:
                     break
-        return BATCH * NUM_ENS * n / el, n, el
+        return times
 
-    # mkldnn does not always scale to every core of the cgroup: time all cores and half of them, report the best
+    # mkldnn does not always scale to every core of the cgroup: time all cores and half of them, keep the faster
     best = None
     for nt in sorted({avail, max(1, avail // 2)}, reverse=True):
-        v, n, el = run(nt, budget_s / 2)
-        if best is None or v > best[0]:
-            best = (v, n, el, nt)
-    v, n, el, nt = best
-    return {"value": round(v, 1), "unit": "samples/s", "cores": nt, "kind": "port",
-            "sample": f"{n} full MC steps (bs={BATCH}, num_ens={NUM_ENS}, fp32, no_grad) of oracle/ref_port_torch.mc_step "
-                      f"in {el:.1f}s after a warm-up; {avail} CPUs usable (cgroup quota / affinity) of "
-                      f"{os.cpu_count()} logical, best of {{all, half}} thread counts"}
+        ts = run(nt, budget_s * 0.3, False)
+        med = statistics.median(ts)
+        if best is None or med < best[0]:
+            best = (med, ts, nt)
+    med, ts, nt = best
+    tg = run(nt, budget_s * 0.25, True)                   # validate_model does not disable autograd (main_bayesian.py:65-86)
+    torch.set_num_threads(avail)
+    n = B * E
+    return {"value": round(n / med, 1), "unit": "samples/s", "cores": nt, "kind": kind,
+            "p10": round(n / pctl(ts, 0.9), 1), "p90": round(n / pctl(ts, 0.1), 1), "steps_timed": len(ts),
+            "autograd_enabled": {"value": round(n / statistics.median(tg), 1), "p10": round(n / pctl(tg, 0.9), 1),
+                                 "p90": round(n / pctl(tg, 0.1), 1), "steps_timed": len(tg)},
+            "cpu_model": cpu_model_name(), "torch_num_threads": nt, "usable_cpus": avail, "logical_cpus": os.cpu_count(),
+            "sample": f"{len(ts)} full MC steps (bs={B}, num_ens={E}, fp32, no_grad; median) + {len(tg)} with autograd enabled, "
+                      f"after a warm-up each; {src}; {avail} CPUs usable (cgroup quota / affinity), best of {{all, half}} thread counts"}
 
 
-def reparam_probe(net, dev, n_params):
+def profile_traffic(kind):
+    """HBM bytes per launch-group from the committed PMC summaries (profiles/r02_pmc_FETCH_SIZE.txt / _WRITE_SIZE.txt, written
+    by profiles/collect.sh): (read_bytes, written_bytes, source) or None.  FETCH_SIZE x2 = the gfx950 wide-load correction."""
+    out = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        path = os.path.join(ROOT, "profiles", f"r02_pmc_{c}.txt")
+        if not os.path.exists(path):
+            return None
+        kb = None
+        for line in open(path):
+            m = re.match(r"\s*STEP_TOTAL\s+%s\s+(\S+)\s+KB_per_step=([0-9.]+)" % kind, line)
+            if m:
+                kb = float(m.group(2))
+        if kb is None:
+            return None
+        out[c] = kb * 1024.0
+    rd = 2.0 * out["FETCH_SIZE"]
+    return rd, out["WRITE_SIZE"], "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 wide-load correction) + WRITE_SIZE, separate passes: " \
+        "profiles/r02_pmc_FETCH_SIZE.txt, profiles/r02_pmc_WRITE_SIZE.txt (STEP_TOTAL %s rows)" % kind
+
+
+def build_net(cfg, dev):
+    from bbb_hip import rng, zoo
+    torch.manual_seed(0)
+    net = zoo.getModel(cfg["net"], 3, cfg["classes"], PRIORS, cfg["lt"], "softplus").to(dev)
+    rng.assign_stream_ids(net)
+    x = torch.rand(cfg["B"], 3, cfg["hw"], cfg["hw"]).to(dev)
+    return net, x
+
+
+def gemm_roofline(agg, timer_steps, precision, metric_cfg):
+    """Dominant kernel of the step: all conv / linear launches.  FLOPs counted = in-bounds taps only (what the fp32 kernel
+    multiplies; the bf16 kernel also multiplies the zero taps of first layers, which is not counted as useful work)."""
+    g = agg.get("conv_gemm") or agg.get("lrt_gemm")
+    if not g:
+        return None
+    if "conv_gemm" in agg and "lrt_gemm" in agg:
+        g = {k: agg["conv_gemm"][k] + agg["lrt_gemm"][k] for k in ("ms", "n", "work", "work_im2col")}
+    tf = g["work"] / (g["ms"] * 1e-3) / 1e12
+    peak = PEAK_BF16_MFMA_TFLOPS if precision == "bf16" else PEAK_F32_MFMA_TFLOPS
+    kern = ("pconv_bf16_kernel (v_mfma_f32_32x32x16_bf16, batch-innermost, LDS transpose reads)" if precision == "bf16" else
+            "pconv_gemm_kernel (fp32 v_mfma_f32_32x32x2_f32, batch-innermost, in-bounds taps only)")
+    r = {"bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
+         "traffic": None, "kernel": kern + ", all conv/linear launches of a step",
+         "launches": g["n"], "avg_us": round(1e3 * g["ms"] / g["n"], 2),
+         "flop_per_step": g["work"] / timer_steps, "im2col_flop_per_step": g["work_im2col"] / timer_steps,
+         "timed_by": "HIP events around every launch, %d eager single-stream steps of the same workload" % timer_steps}
+    if metric_cfg:
+        tr = profile_traffic("pconv_gemm")
+        if tr:
+            r["traffic"] = round(tr[0] + tr[1], 1)
+            r["traffic_read_written"] = [round(tr[0], 1), round(tr[1], 1)]
+            r["traffic_source"] = tr[2] + "; bytes per step over the 6 conv/linear launches"
+    return r
+
+
+def reparam_probe(net, dev, n_params, E):
     """Fused reparam+KL pass timed on its own: 20 back-to-back launches inside one hipGraph (no host gaps), HIP events
-    around the replay.  (a) the model's 12 tensors, E=10 - what the step runs, Infinity-Cache resident; (b) one
-    2^26-element tensor (0.8-1.6 GB of traffic, far beyond the 256 MB cache) for a genuine HBM figure."""
-    import torch
+    around the replay, median of 7 replays.  (a) the model's 12 tensors, E draws - what the step runs, Infinity-Cache
+    resident; (b) one 2^26-element tensor (0.8-3.2 GB of traffic, far beyond the 256 MB cache) for a genuine HBM figure."""
     from bbb_hip import ensemble, ops
-    layers_ = ensemble.bayesian_layers(net)
     mus, rhos, ids = [], [], []
-    for l in layers_:
+    for l in ensemble.bayesian_layers(net):
         m, r, i = l._param_lists()
         mus += m
         rhos += r
@@ -117,59 +258,155 @@ def reparam_probe(net, dev, n_params):
                 fn()
         g.replay()
         torch.cuda.synchronize(dev)
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        g.replay()
-        e.record()
-        torch.cuda.synchronize(dev)
-        return s.elapsed_time(e) * 1e-3 / reps
+        ts = []
+        for _ in range(7):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            g.replay()
+            e.record()
+            torch.cuda.synchronize(dev)
+            ts.append(s.elapsed_time(e) * 1e-3 / reps)
+        return statistics.median(ts), min(ts), max(ts)
 
     with torch.no_grad():
-        t_model = timed(lambda: ops.reparam_kl_forward(mus, rhos, 0, 0.1, ids, 1, 0, draws=NUM_ENS), 20)
-        byts = (8 + 4 * NUM_ENS) * n_params
+        t_model, t_lo, t_hi = timed(lambda: ops.reparam_kl_forward(mus, rhos, 0, 0.1, ids, 1, 0, draws=E), 20)
+        byts = (8 + 4 * E) * n_params
         big = 1 << 26
         mu = torch.randn(big, device=dev) * 0.1
         rho = torch.randn(big, device=dev) * 0.1 - 5
-        t1 = timed(lambda: ops.reparam_kl_forward([mu], [rho], 0, 0.1, [0], 1, 0, draws=1), 3)
-        t4 = timed(lambda: ops.reparam_kl_forward([mu], [rho], 0, 0.1, [0], 1, 0, draws=4), 3)
+        t1 = timed(lambda: ops.reparam_kl_forward([mu], [rho], 0, 0.1, [0], 1, 0, draws=1), 3)[0]
+        t10 = timed(lambda: ops.reparam_kl_forward([mu], [rho], 0, 0.1, [0], 1, 0, draws=10), 2)[0]
         dst = torch.empty_like(mu)
-        tc = timed(lambda: dst.copy_(mu), 3)
+        tc = timed(lambda: dst.copy_(mu), 3)[0]
         del mu, rho, dst
     gbs = byts / t_model / 1e9
-    return {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
-            "traffic": 102.2e6 if abs(byts - 104445408) < 1 else None,
-            "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 wide-load correction) + WRITE_SIZE, separate passes: "
-                              "profiles/r01_pmc_FETCH_SIZE.txt, r01_pmc_WRITE_SIZE.txt (17.1 MB + 85.1 MB per launch)",
-            "kernel": "reparam_kl_fwd_kernel + kl_finish_kernel, 12 tensors x 10 draws in one launch",
-            "bytes_per_launch": byts, "avg_us": round(t_model * 1e6, 2),
-            "note": "(8 + 4E) B per weight element; the 17 MB of (mu,rho) and 87 MB of w are Infinity-Cache resident here",
-            "hbm_resident_probe": {
-                "elements": big,
-                "E1_GBps": round(12 * big / t1 / 1e9, 1), "E4_GBps": round(24 * big / t4 / 1e9, 1),
-                "device_copy_GBps": round(8 * big / tc / 1e9, 1),
-                "note": "single 2^26-element tensor, (8+4E) B/element; device_copy = torch copy_ of the same tensor (8 B/element), "
-                        "the achievable streaming rate on this box"}}
+    r = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+         "traffic": None,
+         "kernel": "reparam_kl_fast_kernel: 12 tensors x %d draws + the KL sum in ONE launch (Philox4x32-7, packed softplus/KL)" % E,
+         "bytes_per_launch": byts, "avg_us": round(t_model * 1e6, 2), "min_us": round(t_lo * 1e6, 2), "max_us": round(t_hi * 1e6, 2),
+         "note": "(8 + 4E) B per weight element; median of 7 graph replays of 20 back-to-back launches; the 17 MB of (mu,rho) and "
+                 "87 MB of w are Infinity-Cache resident at this size, and the pass is VALU-bound (profiles/r02_notes.md)",
+         "hbm_resident_probe": {
+             "elements": big,
+             "E1_GBps": round(12 * big / t1 / 1e9, 1), "E10_GBps": round(48 * big / t10 / 1e9, 1),
+             "device_copy_GBps": round(8 * big / tc / 1e9, 1),
+             "note": "single 2^26-element tensor, (8+4E) B/element; device_copy = torch copy_ of the same tensor (8 B/element), "
+                     "the achievable streaming rate on this box"}}
+    tr = profile_traffic("reparam")
+    if tr and E == 10:
+        r["traffic"] = round(tr[0] + tr[1], 1)
+        r["traffic_read_written"] = [round(tr[0], 1), round(tr[1], 1)]
+        r["traffic_source"] = tr[2]
+    return r
 
 
-def gemm_roofline(g, timer_steps, dtype):
-    """Dominant kernel of the step: all conv / linear launches.  FLOPs counted = in-bounds taps only (what the fp32 kernel
-    multiplies; the bf16 kernel also multiplies the zero taps, which is not counted as useful work)."""
-    tf = g["work"] / (g["ms"] * 1e-3) / 1e12
-    peak = PEAK_BF16_MFMA_TFLOPS if dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
-    kern = ("pconv_bf16_kernel (v_mfma_f32_32x32x16_bf16, batch-innermost, LDS transpose reads)" if dtype == "bf16" else
-            "pconv_gemm_kernel (fp32 v_mfma_f32_32x32x2_f32, batch-innermost, in-bounds taps only)")
-    # HBM bytes per launch from the PMC passes of the metric workload (fp32 only; recorded, not re-measured per run)
-    traffic = 88.5e6 if (dtype != "bf16" and abs(g["work"] / timer_steps - 70812958720.0) < 1.0) else None
-    return {"bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
-            "traffic": traffic,
-            "traffic_source": ("rocprofv3 --pmc FETCH_SIZE (x2, gfx950 wide-load correction) + WRITE_SIZE, separate passes "
-                               "(profiles/r01_pmc_FETCH_SIZE.txt, r01_pmc_WRITE_SIZE.txt): 326.3 MB read + 205.0 MB written per step "
-                               "over the 6 conv/linear launches; algorithmic bytes 197 MB + 210 MB") if traffic else None,
-            "kernel": kern + ", all conv/linear launches of a step",
-            "launches": g["n"], "avg_us": round(1e3 * g["ms"] / g["n"], 2),
-            "flop_per_step": g["work"] / timer_steps, "im2col_flop_per_step": g["work_im2col"] / timer_steps,
-            "timed_by": "HIP events around every launch, %d eager single-stream steps of the same workload right after "
-                        "the timed region" % timer_steps}
+def run_config(cfg, steps, warmup, pipeline, dev, group=None, world=1, want_roofline=True, stat_blocks=0, timer_steps=5,
+               total_ens=None):
+    """Throughput of one configuration: hipGraph lanes, K timed steps between device syncs (max over ranks) -> dict."""
+    from bbb_hip import ensemble
+    net, x = build_net(cfg, dev)
+    E = cfg["E"] if total_ens is None else total_ens
+    prec = cfg["precision"]
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier(group=group)
+        torch.cuda.synchronize(dev)
+
+    out = {}
+    with torch.no_grad():
+        if pipeline > 1:
+            gstep = ensemble.GraphedPipeline(net, x, E, depth=pipeline, group=group, precision=prec)
+        else:
+            gstep = ensemble.GraphedMC(net, x, E, group=group, precision=prec)
+        step = gstep.step
+        step()
+        torch.cuda.synchronize(dev)
+        for _ in range(warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            lo, kl = step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        lo, kl = lo.clone(), kl.clone()
+        assert torch.isfinite(lo).all() and torch.isfinite(kl).all()
+        if world > 1:
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=group)
+            elapsed = t.item()
+        rows = lo.shape[0]
+        out["ms_per_step"] = round(1e3 * elapsed / steps, 4)
+        out["value"] = round(cfg["B"] * E / (elapsed / steps), 1)
+        out["rows_out"] = rows
+        if stat_blocks and world == 1:
+            # block statistics: `stat_blocks` blocks of `steps` steps, each between device syncs
+            vals = []
+            for _ in range(stat_blocks):
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                for _ in range(steps):
+                    step()
+                torch.cuda.synchronize(dev)
+                vals.append(cfg["B"] * E * steps / (time.perf_counter() - t1))
+            out["stats"] = {"blocks": stat_blocks, "steps_per_block": steps, "median": round(statistics.median(vals), 1),
+                            "p10": round(pctl(vals, 0.1), 1), "p90": round(pctl(vals, 0.9), 1), "unit": "samples/s"}
+        if world == 1 and pipeline > 1:
+            g1 = ensemble.GraphedMC(net, x, E, precision=prec)
+            for _ in range(5):
+                g1.step()
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                g1.step()
+            torch.cuda.synchronize(dev)
+            dt = (time.perf_counter() - t1) / steps
+            out["one_step_in_flight"] = {"value": round(cfg["B"] * E / dt, 1), "ms_per_step": round(1e3 * dt, 4),
+                                         "note": "one hipGraph lane: step i+1 starts only after step i has drained (step latency)"}
+        if want_roofline and world == 1:
+            timers = ensemble.Timers()
+            # park the GPU behind a ~40 ms spin kernel so that every launch below is already queued when its turn comes:
+            # the event brackets then hold kernel time only, not host launch latency
+            torch.cuda._sleep(int(1.0e8))
+            for _ in range(timer_steps):
+                ensemble.mc_forward(net, x, E, timers=timers, precision=prec)
+            torch.cuda.synchronize(dev)
+            out["roofline"] = gemm_roofline(timers.summary(), timer_steps, prec, cfg is CONFIGS["metric"])
+    return out, net, x
+
+
+def dropin_loop(dev, steps):
+    """What an unmodified validate_model gets (main_bayesian.py:73-80): a Python loop of net(x) through the drop-in `layers`
+    (NCHW kernels, one draw per call, torch log_softmax / logmeanexp), eager launches."""
+    import torch.nn.functional as F
+    cfg = CONFIGS["metric"]
+    net, x = build_net(cfg, dev)
+    B, C, E = cfg["B"], cfg["classes"], cfg["E"]
+
+    def step():
+        outputs = torch.zeros(B, C, E, device=dev)
+        kl = 0.0
+        for j in range(E):
+            net_out, _kl = net(x)
+            kl = kl + _kl
+            outputs[:, :, j] = F.log_softmax(net_out, dim=1)
+        m = outputs.max(dim=2, keepdim=True).values
+        return (m + torch.log(torch.mean(torch.exp(outputs - m), dim=2, keepdim=True))).squeeze(2), kl
+
+    with torch.no_grad():
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / steps
+    return {"value": round(B * E / dt, 1), "unit": "samples/s", "ms_per_step": round(1e3 * dt, 4),
+            "note": "for j in range(10): net(x) through the drop-in layers (reference layout, conv_gemm_kernel, eager launches, "
+                    "one fused reparam+KL launch per forward) + torch log_softmax / logmeanexp: the path an unmodified "
+                    "validate_model takes; the headline uses the batched ensemble entry point instead"}
 
 
 def main():
@@ -178,23 +415,17 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--layer-type", default="bbb", choices=["bbb", "lrt"])
-    ap.add_argument("--no-kernel-timers", action="store_true")
-    ap.add_argument("--streams", type=int, default=1, help="independent sub-ensembles on separate HIP streams")
-    ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
+    ap.add_argument("--no-extras", action="store_true", help="headline measurement only (profiling runs)")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches on one stream (profiling runs: rocprofv3 --pmc per launch)")
     ap.add_argument("--pipeline", type=int, default=3, help="independent MC steps in flight (hipGraph lanes on separate streams)")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
-                    help="f32: the reference's arithmetic on the exact fp32 matrix cores (headline).  bf16: sampled weights and "
-                         "hidden activations stored as bf16, fp32 accumulate (BASELINE.json configs[1] precision)")
-    ap.add_argument("--no-bf16-extra", action="store_true", help="skip the secondary bf16 measurement of the default run")
+    ap.add_argument("--config", default="metric", choices=list(CONFIGS), help="which BASELINE configuration is the reported value")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
     # test hooks (single-GPU rehearsal of the N > 1 code path): BBB_BENCH_DEVICE pins every rank to one device,
     # BBB_BENCH_BACKEND=gloo replaces RCCL.  Never set by the driver.
     dev_index = int(os.environ.get("BBB_BENCH_DEVICE", local_rank))
@@ -211,150 +442,93 @@ def main():
             dist.init_process_group(backend)
         group = dist.group.WORLD
 
-    from bbb_hip import ensemble, rng, zoo, _lib
+    from bbb_hip import ensemble, _lib
     _lib.lib()   # fail loudly here if the HIP library is missing
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.no_extras:
         cpu = cpu_baseline()
 
-    torch.manual_seed(0)
-    net = zoo.BBBAlexNet(CLASSES, 3, PRIORS, args.layer_type, "softplus").to(dev)
-    rng.assign_stream_ids(net)
-    x = torch.rand(BATCH, 3, 32, 32).to(dev)
-    total_ens = NUM_ENS * world
+    cfg = CONFIGS[args.config]
+    if args.no_graph:
+        # profiling mode: the step launched eagerly on one stream, nothing else
+        net, x = build_net(cfg, dev)
+        with torch.no_grad():
+            for _ in range(args.warmup):
+                ensemble.mc_forward(net, x, cfg["E"], group=group, precision=cfg["precision"])
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                ensemble.mc_forward(net, x, cfg["E"], group=group, precision=cfg["precision"])
+            torch.cuda.synchronize(dev)
+            dt = (time.perf_counter() - t0) / args.steps
+        if rank == 0:
+            print(json.dumps({"metric": "eager single-stream step (profiling mode)", "value": round(cfg["B"] * cfg["E"] / dt, 1),
+                              "unit": "samples/s", "ms_per_step": round(1e3 * dt, 4), "n_gpus": world, "steps": args.steps,
+                              "warmup": args.warmup}), flush=True)
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+
+    extras = rank == 0 and world == 1 and not args.no_extras
+    head, net, x = run_config(cfg, args.steps, args.warmup, args.pipeline, dev, group, world, want_roofline=True,
+                              stat_blocks=5 if extras else 0, timer_steps=min(args.steps, 10))
     n_params = sum(p.numel() for n, p in net.named_parameters() if n.endswith("_mu"))
 
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier(group=group)
-        torch.cuda.synchronize(dev)
-
-    use_graph = not args.no_graph
-    precision = "bf16" if args.dtype == "bf16" else "fp32"
-    if precision == "bf16" and args.layer_type != "bbb":
-        raise SystemExit("--dtype bf16 covers BBB layers only")
-    with torch.no_grad():
-        launch_note = None
-        if use_graph:
-            # the whole step (E draws x all layers + tail) is one captured hipGraph; a device-side call counter inside the
-            # graph gives every replay fresh Philox noise (no cached outputs)
-            try:
-                if args.pipeline > 1:
-                    gstep = ensemble.GraphedPipeline(net, x, total_ens, depth=args.pipeline, streams=args.streams, group=group,
-                                                     precision=precision)
-                else:
-                    gstep = ensemble.GraphedMC(net, x, total_ens, streams=args.streams, group=group, precision=precision)
-                step = gstep.step
-                step()                    # first replay (+ first collective when N > 1) inside the guarded region
-                torch.cuda.synchronize(dev)
-            except Exception as exc:      # launch-mode fallback only (same kernels, launched eagerly); reported in the JSON
-                use_graph = False
-                launch_note = "hipGraph capture failed (%s: %s); eager launches" % (type(exc).__name__, str(exc)[:120])
-                torch.cuda.synchronize(dev)
-        if not use_graph:
-            # explicit --no-graph: exactly the requested stream count (profiling runs); capture failure: two draw streams
-            eager_streams = args.streams if args.no_graph else max(2, args.streams)
-            step = lambda: ensemble.mc_forward(net, x, total_ens, group=group, streams=eager_streams, precision=precision)
-        for _ in range(args.warmup):
-            step()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            lo, kl = step()
-        barrier()
-        elapsed = time.perf_counter() - t0
-        lo, kl = lo.clone(), kl.clone()
-        # transparency: the same step with ONE step in flight (single graph lane), same process, same data
-        serial = None
-        if use_graph and args.pipeline > 1 and world == 1:
-            g1 = ensemble.GraphedMC(net, x, total_ens, streams=args.streams, precision=precision)
-            for _ in range(5):
-                g1.step()
-            torch.cuda.synchronize(dev)
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                g1.step()
-            torch.cuda.synchronize(dev)
-            dt = (time.perf_counter() - t1) / args.steps
-            serial = {"value": round(BATCH * total_ens / dt, 1), "ms_per_step": round(1e3 * dt, 4),
-                      "note": "one hipGraph lane: step i+1 starts only after step i has drained (step latency)"}
-        # per-kernel HIP-event brackets: the same step launched eagerly on one stream (events cannot sit inside a graph)
-        timers = None
-        if not args.no_kernel_timers:
-            timers = ensemble.Timers()
-            timer_steps = min(args.steps, 10)
-            # park the GPU behind a ~40 ms spin kernel so that every launch below is already queued when its turn comes:
-            # the event brackets then hold kernel time only, not host launch latency
-            torch.cuda._sleep(int(1.0e8))
-            for _ in range(timer_steps):
-                ensemble.mc_forward(net, x, total_ens, group=group, timers=timers, precision=precision)
-            torch.cuda.synchronize(dev)
-        # secondary measurement: the same workload under the bf16 storage model (never the headline value)
-        bf16_extra = None
-        if precision == "fp32" and args.layer_type == "bbb" and use_graph and not args.no_bf16_extra:
-            try:
-                gb = ensemble.GraphedPipeline(net, x, total_ens, depth=max(1, args.pipeline), streams=args.streams, group=group,
-                                              precision="bf16")
-                for _ in range(max(3, args.warmup)):
-                    gb.step()
-                barrier()
-                tb = time.perf_counter()
-                for _ in range(args.steps):
-                    gb.step()
-                barrier()
-                tb = time.perf_counter() - tb
-                tmb = ensemble.Timers()
-                torch.cuda._sleep(int(1.0e8))
-                for _ in range(5):
-                    ensemble.mc_forward(net, x, total_ens, group=group, timers=tmb, precision="bf16")
-                torch.cuda.synchronize(dev)
-                bf16_extra = (tb, tmb.summary())
-            except Exception as exc:
-                bf16_extra = "bf16 measurement failed: %s: %s" % (type(exc).__name__, str(exc)[:160])
-
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=group)
-        elapsed = t.item()
-    assert torch.isfinite(lo).all() and torch.isfinite(kl).all()
+    weak = None
+    if world > 1 and not args.no_extras:
+        w, _, _ = run_config(cfg, max(5, args.steps // 2), 3, args.pipeline, dev, group, world, want_roofline=False,
+                             total_ens=cfg["E"] * world)
+        weak = {"value": w["value"], "unit": "samples/s", "ms_per_step": w["ms_per_step"], "num_ens_total": cfg["E"] * world,
+                "note": "weak scaling, secondary: %d draws per GPU (a %d-draw ensemble of the same 512 images)" % (cfg["E"], cfg["E"] * world)}
 
     if rank == 0:
-        ms = 1e3 * elapsed / args.steps
+        S, lo, hi = ensemble.shard_plan(net, x, cfg["E"], 0, world, True, cfg["precision"])
         out = {
             "metric": "MC-forward samples/sec, BayesianAlexNet CIFAR-10 bs=512 num_ens=10",
-            "value": round(BATCH * total_ens / (elapsed / args.steps), 1),
-            "unit": "samples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"BayesianAlexNet 3x32x32 -> {CLASSES} classes, layer_type={args.layer_type}, "
-                                   f"softplus, bs={BATCH}, num_ens={NUM_ENS} per GPU ({total_ens} draws total), "
-                                   "forward only (main_bayesian.py:73-80)",
-                       "global_batch": BATCH, "num_ens_total": total_ens,
-                       "parallelism": f"mc-ensemble x{world}" if world > 1 else "single",
-                       "launch": ("hipGraph replay, %d step(s) in flight x %d draw streams" % (max(1, args.pipeline), args.streams))
-                       if use_graph else (launch_note or ("eager, %d streams" % (args.streams if args.no_graph else max(2, args.streams))))},
+            "value": head["value"], "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "bf16" if cfg["precision"] == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": cfg["what"] + ", forward only (main_bayesian.py:73-80)",
+                       "global_batch": cfg["B"], "num_ens_total": cfg["E"],
+                       "parallelism": ("mc-ensemble work units: %d batch slices per draw, %d (draw x slice) units of %d images, "
+                                       "<= %d per GPU, one all_gather per step" % (S, cfg["E"] * S, cfg["B"] // S, hi - lo))
+                       if world > 1 else "single",
+                       "launch": "hipGraph replay, %d step(s) in flight" % max(1, args.pipeline)},
         }
-        if timers is not None:
-            agg = timers.summary()
-            g = agg.get("conv_gemm") or agg.get("lrt_gemm")
-            if g:
-                out["roofline"] = gemm_roofline(g, timer_steps, args.dtype)
-            if args.layer_type == "bbb":
-                out["roofline_reparam"] = reparam_probe(net, dev, n_params)
-        if serial is not None:
-            out["one_step_in_flight"] = serial
-        if isinstance(bf16_extra, tuple):
-            tb, aggb = bf16_extra
-            out["bf16"] = {"value": round(BATCH * total_ens / (tb / args.steps), 1), "unit": "samples/s",
-                           "ms_per_step": round(1e3 * tb / args.steps, 4),
-                           "note": "same workload, launch structure and noise streams with sampled weights + hidden activations "
-                                   "stored as bf16 (fp32 accumulate / bias / activation / KL); parity: tests/test_gpu_bf16.py; "
-                                   "not the headline value",
-                           "roofline": gemm_roofline(aggb["conv_gemm"], 5, "bf16") if "conv_gemm" in aggb else None}
-        elif bf16_extra is not None:
-            out["bf16"] = {"error": bf16_extra}
+        if args.config != "metric":
+            out["metric"] = "MC-forward samples/sec, " + cfg["what"]
+        if head.get("roofline"):
+            out["roofline"] = head["roofline"]
+        for k in ("stats", "one_step_in_flight"):
+            if k in head:
+                out[k] = head[k]
+        if weak is not None:
+            out["weak_scaling"] = weak
+        if extras:
+            if cfg["lt"] == "bbb":
+                out["roofline_reparam"] = reparam_probe(net, dev, n_params, cfg["E"])
+            del net, x
+            try:
+                out["dropin_loop"] = dropin_loop(dev, max(5, args.steps // 5))
+            except Exception as exc:
+                out["dropin_loop"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:160])}
+            others = {}
+            for name, c in CONFIGS.items():
+                if name == args.config:
+                    continue
+                try:
+                    r, n2, x2 = run_config(c, max(10, args.steps // 2), 5, args.pipeline, dev, want_roofline=True, timer_steps=3)
+                    del n2, x2
+                    r["workload"] = c["what"]
+                    r["dtype"] = "bf16" if c["precision"] == "bf16" else "f32"
+                    r["unit"] = "samples/s"
+                    others[name] = r
+                except Exception as exc:
+                    others[name] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:160])}
+                torch.cuda.empty_cache()
+            out["configs"] = others
         if cpu is not None:
             out["cpu_baseline"] = cpu
             out["speedup_vs_cpu"] = round(out["value"] / cpu["value"], 1)

@@ -140,6 +140,17 @@ typedef struct bbb_conv_desc {
     int64_t w_draw_stride; /* elements between draws of w (0 = shared weights) */
     int64_t b_draw_stride; /* elements between draws of bias (0 = shared) */
     int32_t act;          /* fused epilogue: 0 none, 1 ReLU, 2 Softplus(beta=1, threshold=20) */
+    /* Work units for ensemble sharding (batch-innermost entry points only; all zero = every slab is a whole draw).
+     * With unit_div = S > 1 the `draws` slabs of a launch are UNITS u = unit_off + e of the draw-major grid
+     * (Monte-Carlo draw, batch slice): draw = u / S, slice = u % S, `batch` = images per slice.  Slab e then reads
+     * weight / bias set (u / S) - (unit_off / S) ... i.e. (unit_off % S + e) / S relative to the first set passed in,
+     * writes output slab e, and reads input slab e -- or, with x_unit_mod = S (a layer whose input is the same for every
+     * draw), input slab u % S of an [S][cin][h][w][batch] tensor.  unit_off is passed already reduced modulo S. */
+    int32_t unit_div;
+    int32_t unit_off;
+    int32_t x_unit_mod;
+    int32_t b_offset;     /* LRT noise only: global index of local image 0 (batch-parallel shards), added to the image index
+                             that keys the activation noise; a unit's slice adds slice * batch on top */
     int32_t reserved;
 } bbb_conv_desc_t;
 
@@ -241,6 +252,12 @@ int bbb_mc_tail(const float* logits, int draws, int batch, int classes, int mean
 /* bbb_mc_tail for logits stored batch-innermost, [draws][C][B] (output of the batched ensemble path); lse_out is [B][C]. */
 int bbb_mc_tail_cb(const float* logits, int draws, int batch, int classes, int mean_over,
                    float* lse_out, void* stream);
+
+/* The same for a rank's WORK UNITS (bbb_conv_desc_t: unit u = unit_off + e is draw u / slices, batch slice u % slices):
+ * logits [units][C][batch_slice] -> lse_out [slices * batch_slice][C]; image b of slice s gets the log-sum-exp over the local
+ * units of that slice, -inf where the rank holds none (the ranks' blocks are then combined by one more log-sum-exp). */
+int bbb_mc_tail_units(const float* logits, int units, int slices, int unit_off, int batch_slice, int classes, int mean_over,
+                      float* lse_out, void* stream);
 
 /*
  * Uncertainty decomposition over `draws` stochastic forwards (uncertainty_estimation.py:37-58 per image, :61-102 per

@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Per-kernel averages of rocprofv3 --pmc counters from a rocpd sqlite database.
-usage: summarize_pmc.py results.db [name-substring]"""
+usage: summarize_pmc.py results.db [name-substring] [--steps N]
+With --steps N (the number of MC steps the profiled command ran, warm-up included) the summary ends with STEP_TOTAL rows:
+a counter summed over ALL launches of a kernel family ("pconv_gemm", "reparam") divided by N = per-step totals, which
+bench.py parses (FETCH_SIZE / WRITE_SIZE are in KB)."""
 import re
 import sqlite3
 import sys
@@ -13,12 +16,24 @@ def short(name):
 
 
 def main():
-    c = sqlite3.connect(sys.argv[1])
-    filt = sys.argv[2] if len(sys.argv) > 2 else ""
+    args = sys.argv[1:]
+    steps = None
+    if "--steps" in args:
+        i = args.index("--steps")
+        steps = int(args[i + 1])
+        del args[i:i + 2]
+    c = sqlite3.connect(args[0])
+    filt = args[1] if len(args) > 1 else ""
     rows = c.execute("select kernel_name, grid_size_x, grid_size_y, grid_size_z, workgroup_size_x, dispatch_id, counter_name, "
                      "value, duration from counters_collection").fetchall()
     per = {}
+    fam = {}
     for n, gx, gy, gz, wx, did, cn, v, dur in rows:
+        for f in ("pconv_gemm", "pconv_bf16", "reparam", "maxpool", "mc_tail"):
+            if f in n:
+                t = fam.setdefault((f, cn), [0.0, 0])
+                t[0] += v
+                t[1] += 1
         if filt and filt not in n:
             continue
         key = (short(n), gx // max(wx, 1), gy, gz)
@@ -40,6 +55,11 @@ def main():
             util = avg["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024.0)
             clk = cyc / avg["_dur_ns"]
             print(f"    -> matrix-pipe utilisation {100 * util:5.1f} % of the launch's cycles  (clock {clk:.2f} GHz over the launch)")
+
+
+    if steps:
+        for (f, cn), (tot, cnt) in sorted(fam.items()):
+            print(f"STEP_TOTAL {f} {cn} KB_per_step={tot / steps:.1f} launches_per_step={cnt / steps:.2f}")
 
 
 if __name__ == "__main__":

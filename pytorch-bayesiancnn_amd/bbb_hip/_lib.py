@@ -35,7 +35,8 @@ class ConvDesc(ctypes.Structure):
     _fields_ = [("batch", c_i32), ("cin", c_i32), ("h", c_i32), ("w", c_i32), ("cout", c_i32), ("kh", c_i32),
                 ("kw", c_i32), ("stride_h", c_i32), ("stride_w", c_i32), ("pad_h", c_i32), ("pad_w", c_i32),
                 ("dil_h", c_i32), ("dil_w", c_i32), ("draws", c_i32), ("x_draw_stride", c_i64),
-                ("w_draw_stride", c_i64), ("b_draw_stride", c_i64), ("act", c_i32), ("reserved", c_i32)]
+                ("w_draw_stride", c_i64), ("b_draw_stride", c_i64), ("act", c_i32),
+                ("unit_div", c_i32), ("unit_off", c_i32), ("x_unit_mod", c_i32), ("b_offset", c_i32), ("reserved", c_i32)]
 
 
 _SIGNATURES = {
@@ -62,6 +63,7 @@ _SIGNATURES = {
     "bbb_nchw_to_chwn_bf16": (c_int, [c_void_p, c_void_p, c_int, c_i64, c_void_p]),
     "bbb_mc_tail": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "bbb_mc_tail_cb": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "bbb_mc_tail_units": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "bbb_uncertainty": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "bbb_transpose2d": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_void_p]),
     "bbb_abi_version": (c_int, []),

@@ -6,9 +6,12 @@ Reference semantics (main_bayesian.py:43-53 train, :73-80 validate):
 Here the E draws run as ONE pass: one fused reparam+KL launch materialises the E weight sets of every
 layer (draw j uses noise call index call0 + j, so the result equals the Python loop over `net(x)`), each
 conv / linear is one launch batched over draws, and one tail kernel does log_softmax + log-sum-exp over
-draws.  Multi-GPU: contiguous blocks of draws per rank (parameters replicated, no weight traffic), local
-log-sum-exp, ONE all_gather of [B*C + 1] floats (the lse block + the KL sum) over RCCL, then a log-sum-exp
-over ranks in rank order -- every rank ends with the same bits.
+draws.  Multi-GPU (strong scaling): the work grid (draw j) x (batch slice s) is enumerated
+draw-major, u = j*S + s, and dealt out in contiguous equal ranges; parameters are replicated and the noise is keyed by
+(seed, call = draw, stream, element), so a rank materialises exactly the weight sets its units touch -- no weight
+traffic.  Each rank reduces its units to a [B, C] log-sum-exp block (-inf where it holds no unit of a slice), and ONE
+all_gather of [B*C + 1] floats (the block + its share of the KL sum) over RCCL is followed by a log-sum-exp over ranks
+in rank order -- every rank ends with the same bits.
 """
 import math
 
@@ -36,8 +39,72 @@ def draw_range(num_ens, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def plan_slices(num_ens, world, batch, multiple=4, min_slice=64):
+    """Batch slices per draw (S) for `world` ranks: the smallest S in {1, 2, 4, 8, 16} whose busiest rank processes
+    (within 5 %) the fewest images -- E=10 on 8 ranks: S=1 -> 2 draws x 512 = 1024 images on the busiest rank, S=4 -> 5 units
+    x 128 = 640 = a perfect split.  Slices must keep `multiple` images alignment (4 fp32, 8 bf16) and at least `min_slice`
+    images (smaller GEMM tiles waste the matrix cores)."""
+    best = None
+    for S in (1, 2, 4, 8, 16):
+        if batch % S or (batch // S) % multiple or (S > 1 and batch // S < min_slice):
+            continue
+        cost = -(-num_ens * S // world) * (batch // S)
+        if best is None or cost < 0.95 * best[0]:
+            best = (cost, S)
+    return 1 if best is None else best[1]
+
+
+def unit_range(num_ens, slices, rank, world):
+    """This rank's contiguous range [lo, hi) of the draw-major unit enumeration u = draw * slices + slice."""
+    return draw_range(num_ens * slices, rank, world)
+
+
 def bayesian_layers(net):
     return [m for m in net.modules() if isinstance(m, (_BBBLayer, _LRTLayer))]
+
+
+def flat_children(net):
+    """The model as the flat list of modules ModuleWrapper.forward runs: nn.Sequential and plain ModuleWrapper
+    containers (no forward of their own, like the reference's models) are expanded recursively.  Returns None if a
+    Bayesian layer sits inside any other kind of module -- the batched paths cannot see through an arbitrary forward."""
+    from layers.misc import ModuleWrapper
+    out = []
+
+    def walk(mod):
+        for child in mod.children():
+            plain_wrapper = isinstance(child, ModuleWrapper) and type(child).forward is ModuleWrapper.forward \
+                and not isinstance(child, (_BBBLayer, _LRTLayer))
+            if isinstance(child, nn.Sequential) or plain_wrapper:
+                walk(child)
+            else:
+                out.append(child)
+
+    walk(net)
+    direct = {id(m) for m in out if isinstance(m, (_BBBLayer, _LRTLayer))}
+    if direct != {id(m) for m in bayesian_layers(net)}:
+        return None
+    return out
+
+
+def output_rows(net, x_shape):
+    """Rows of the model's output for an input of shape x_shape (B, except where FlattenLayer cuts a larger feature map into
+    several rows per image: the reference's view(-1, num_features), layers/misc.py:35)."""
+    B, C, H, W = x_shape
+    rows = B
+    for m in flat_children(net) or []:
+        if isinstance(m, (_BBBConv, _LRTConv)):
+            (sh, sw), (ph, pw), (dh, dw) = ops._pair(m.stride), ops._pair(m.padding), ops._pair(m.dilation)
+            kh, kw = m.kernel_size
+            H = (H + 2 * ph - dh * (kh - 1) - 1) // sh + 1
+            W = (W + 2 * pw - dw * (kw - 1) - 1) // sw + 1
+            C = m.out_channels
+        elif isinstance(m, nn.MaxPool2d):
+            k, st = m.kernel_size, m.stride
+            H, W = (H - k) // st + 1, (W - k) // st + 1
+        elif isinstance(m, FlattenLayer):
+            rows = rows * C * H * W // m.num_features
+            C, H, W = m.num_features, 1, 1
+    return rows
 
 
 class Timers:
@@ -197,7 +264,10 @@ def _chwn_ok(net, x):
         return False
     if x.dim() != 4 or x.shape[0] % 4 != 0:
         return False
-    for m in net.children():
+    mods = flat_children(net)
+    if mods is None:
+        return False
+    for m in mods:
         if isinstance(m, (_BBBLayer, _LRTLayer, FlattenLayer, nn.ReLU)):
             continue
         if isinstance(m, nn.Softplus) and m.beta == 1 and m.threshold == 20:
@@ -222,24 +292,43 @@ def _check_precision(precision, net, x, fast_path_allowed):
                                "4-d input with B % 8 == 0, BBB layers + ReLU/Softplus/MaxPool2d/FlattenLayer)")
 
 
-def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precision="fp32"):
+def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precision="fp32", units=None):
     """Inference path of mc_logits in the batch-innermost layout ([E, C, H, W, B]): pixel-major GEMMs that
-    skip padding taps, activation fused into the GEMM epilogue, pooling on contiguous image vectors."""
+    skip padding taps, activation fused into the GEMM epilogue, pooling on contiguous image vectors.
+    units = (S, lo, hi): instead of `draws` whole draws starting at call0, run the work units lo..hi-1 of the draw-major
+    (draw, batch slice) grid with S slices per draw (call0 = the call index of draw 0); returns logits [hi-lo, C, B/S]."""
     layers = bayesian_layers(net)
     bbb = [l for l in layers if isinstance(l, _BBBLayer)]
     lrt = [l for l in layers if isinstance(l, _LRTLayer)]
     kl, sampled, variances = None, {}, {}
     bf16 = precision == "bf16"
-    if bf16 and (lrt or x.shape[0] % 8 != 0):
+    E, B = draws, x.shape[0]
+    ukw = {}
+    if units is not None and units[0] > 1:
+        S, lo, hi = units
+        if B % S or (B // S) % (8 if bf16 else 4):
+            raise _lib.BBBHipError("work units: batch slices must hold a multiple of 4 (bf16: 8) images")
+        E, B = hi - lo, B // S
+        j_lo = lo // S
+        n_draws = (hi - 1) // S - j_lo + 1                     # weight sets this rank needs
+        call0 = call0 + j_lo
+        ukw = dict(units=(S, lo % S), n_units=E)
+        streams = 1
+    else:
+        S, n_draws = 1, draws
+    if bf16 and (lrt or B % 8 != 0):
         raise _lib.BBBHipError("the bf16 path covers BBB (non-LRT) layers and batch sizes that are multiples of 8")
     if bbb:
-        sampled, kl = _sample_all_bf16(bbb, draws, seed, call0, timers) if bf16 else _sample_all(bbb, draws, seed, call0, timers)
+        sampled, kl = _sample_all_bf16(bbb, n_draws, seed, call0, timers) if bf16 else _sample_all(bbb, n_draws, seed, call0, timers)
     if lrt:
         variances, k2 = _variances_all(lrt, timers)
         kl = k2 if kl is None else kl + k2
-    E, B = draws, x.shape[0]
-    xt = (ops.to_batch_innermost_bf16(x) if bf16 else ops.to_batch_innermost(x)).unsqueeze(0)   # [1, C, H, W, B], shared
-    children = list(net.children())
+    to_cb = ops.to_batch_innermost_bf16 if bf16 else ops.to_batch_innermost
+    if S > 1:                                                   # [S, C, H, W, B/S]: one batch-innermost block per slice
+        xt = torch.stack([to_cb(x[s * B:(s + 1) * B]) for s in range(S)])
+    else:
+        xt = to_cb(x).unsqueeze(0)                              # [1, C, H, W, B], shared by all draws
+    children = flat_children(net)
     last_bayes = max((i for i, m in enumerate(children) if isinstance(m, (_BBBLayer, _LRTLayer))), default=-1)
     tail_is_last = last_bayes == len(children) - 1
     n_out = getattr(children[last_bayes], "out_features", None) if tail_is_last else None
@@ -248,9 +337,10 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
     def run(e0, e1):
         """Layers for draws [e0, e1) on the current stream -> logits [e1-e0, C, B] (or None: fall back)."""
         nonlocal logits_buf
-        B = x.shape[0]
+        B = xt.shape[-1]
         Es = e1 - e0
         h = xt
+        per_slice = bool(ukw)          # work units: until the first Bayesian layer, h is one block per batch slice
         i = 0
         while i < len(children):
             mod = children[i]
@@ -262,10 +352,13 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
                 h5 = h if is_conv else h.reshape(h.shape[0], mod.in_features, 1, 1, -1)
                 if h5.dim() != 5 or h5.shape[-1] != B:
                     return None                                  # flatten quirk etc.: caller falls back
+                ukw2 = dict(ukw, x_per_slice=per_slice) if ukw else {}
+                per_slice = False
                 if isinstance(mod, _BBBLayer) and bf16:
                     w, b = sampled[mod]
-                    w = w[e0:e1]
-                    b = None if b is None else b[e0:e1]
+                    if not ukw:
+                        w = w[e0:e1]
+                        b = None if b is None else b[e0:e1]
                     ckk = (mod.in_channels, *mod.kernel_size) if is_conv else (mod.in_features, 1, 1)
                     fl = conv_flops(B, h5.shape[1], h5.shape[2], h5.shape[3], w.shape[1], ckk[1], ckk[2], *geom, Es) \
                         if timers is not None else None
@@ -273,24 +366,26 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
                     dst = logits_buf[e0:e1] if is_logits else None
                     y = _run(timers, "conv_gemm", fl,
                              lambda: ops.conv2d_chwn_bf16_forward(h5, w, b, ckk, *geom, act=act, out_f32=(i == last_bayes and tail_is_last),
-                                                                  out=dst, tap_major=is_conv and ops.bf16_tap_major(tuple(mod.W_mu.shape))))
+                                                                  out=dst, tap_major=is_conv and ops.bf16_tap_major(tuple(mod.W_mu.shape)),
+                                                                  **ukw2))
                 elif isinstance(mod, _BBBLayer):
                     w, b = sampled[mod]
-                    w = w[e0:e1]
-                    b = None if b is None else b[e0:e1]
+                    if not ukw:
+                        w = w[e0:e1]
+                        b = None if b is None else b[e0:e1]
                     if not is_conv:
-                        w = w.reshape(Es, mod.out_features, mod.in_features, 1, 1)
+                        w = w.reshape(w.shape[0], mod.out_features, mod.in_features, 1, 1)
                     fl = conv_flops(B, h5.shape[1], h5.shape[2], h5.shape[3], w.shape[1], w.shape[3], w.shape[4], *geom, Es) \
                         if timers is not None else None
                     dst = logits_buf[e0:e1] if (logits_buf is not None and i == last_bayes and not is_conv) else None
-                    y = _run(timers, "conv_gemm", fl, lambda: ops.conv2d_chwn_forward(h5, w, b, *geom, act=act, out=dst))
+                    y = _run(timers, "conv_gemm", fl, lambda: ops.conv2d_chwn_forward(h5, w, b, *geom, act=act, out=dst, **ukw2))
                 else:
                     w_var, b_var = variances[mod]
                     w_mu = mod.W_mu
                     if not is_conv:
                         shp = (mod.out_features, mod.in_features, 1, 1)
                         w_mu, w_var = w_mu.reshape(shp), w_var.reshape(shp)
-                    shared_in = h5.shape[0] == 1 and Es > 1
+                    shared_in = h5.shape[0] == 1 and Es > 1 and not ukw
                     fl = conv_flops(B, h5.shape[1], h5.shape[2], h5.shape[3], w_mu.shape[0], w_mu.shape[2], w_mu.shape[3],
                                     *geom, 1 if shared_in else Es, 2) if timers is not None else None
                     if shared_in:
@@ -306,7 +401,7 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
                         y = _run(timers, "lrt_gemm", fl,
                                  lambda: ops.lrt_conv2d_chwn_forward(h5, w_mu, w_var, mod.bias_mu if mod.use_bias else None, b_var,
                                                                      seed, call0 + e0, mod._stream_base + 2, *geom, sample=True,
-                                                                     act=act)[0])
+                                                                     act=act, **ukw2)[0])
                 h = y
                 if act is not None:
                     i += 1
@@ -384,6 +479,25 @@ def _side_streams(device, n):
     return _stream_pool[key]
 
 
+def _loop_logits(net, x, draws, seed, call0, eps=None):
+    """The reference's own loop, `for j in range(E): net(x)` under call indices call0 + j, for models the batched paths
+    cannot flatten (a Bayesian layer inside a module with its own forward): same numbers, E times the launches."""
+    if eps is not None:
+        raise _lib.BBBHipError("external eps needs a model made of direct-child / Sequential-nested Bayesian layers")
+    stats["path"] = "loop"
+    saved = dict(rng._state)
+    try:
+        rng.manual_seed(seed, call=call0)
+        outs, kl = [], None
+        for _ in range(draws):
+            y, k = net(x)
+            outs.append(y)
+            kl = k
+    finally:
+        rng._state.update(saved)
+    return torch.stack(outs), kl
+
+
 def mc_logits(net, x, draws, seed, call0, fuse_act=True, timers=None, eps=None, layout="auto", streams=1, precision="fp32"):
     """E stochastic forwards of `net` on the same batch x -> (logits [E, B', C], kl of ONE forward).
 
@@ -398,6 +512,8 @@ def mc_logits(net, x, draws, seed, call0, fuse_act=True, timers=None, eps=None, 
             return out[0].permute(0, 2, 1).contiguous(), out[1]      # API layout [E, B, C]
     if precision != "fp32":
         raise _lib.BBBHipError("this model / input does not fit the batch-innermost path, which is the only bf16 path")
+    if flat_children(net) is None:
+        return _loop_logits(net, x, draws, seed, call0, eps)
     stats["path"] = "nchw"
     layers = bayesian_layers(net)
     bbb = [l for l in layers if isinstance(l, _BBBLayer)]
@@ -412,7 +528,7 @@ def mc_logits(net, x, draws, seed, call0, fuse_act=True, timers=None, eps=None, 
         kl = k2 if kl is None else kl + k2
     E = draws
     h = x.unsqueeze(0)                      # [1, B, ...] shared by all draws until a Bayesian layer splits it
-    children = list(net.children())
+    children = flat_children(net)
     i = 0
     while i < len(children):
         mod = children[i]
@@ -474,10 +590,17 @@ def mc_logits(net, x, draws, seed, call0, fuse_act=True, timers=None, eps=None, 
     return h, kl
 
 
-def _local_lse(net, x, draws, seed, call0, mean_over, fuse_act=True, timers=None, streams=1, precision="fp32"):
-    """(log-sum-exp over `draws` local draws of the per-draw log_softmax [B, C], kl of one forward), staying in the
-    batch-innermost layout end to end when the fast path applies."""
+def _local_lse(net, x, draws, seed, call0, mean_over, fuse_act=True, timers=None, streams=1, precision="fp32", units=None):
+    """(log-sum-exp over the local draws of the per-draw log_softmax [B, C], kl of one forward), staying in the
+    batch-innermost layout end to end when the fast path applies.  units = (S, lo, hi): the local work is the unit range
+    lo..hi-1 instead of `draws` whole draws (call0 = call index of draw 0); rows of slices without a local unit are -inf."""
     _check_precision(precision, net, x, fuse_act)
+    if units is not None and units[0] > 1:
+        out = _mc_logits_chwn(net, x, draws, seed, call0, timers, 1, precision, units=units)
+        if out is None:
+            raise _lib.BBBHipError("work units need the batch-innermost path (checked by units_ok before planning)")
+        lse = _run(timers, "mc_tail", 0, lambda: ops.mc_tail_units(out[0], units[0], units[1], mean_over=mean_over))
+        return lse, out[1]
     if fuse_act and _chwn_ok(net, x):
         out = _mc_logits_chwn(net, x, draws, seed, call0, timers, streams, precision)
         if out is not None:
@@ -494,38 +617,61 @@ def _local_lse(net, x, draws, seed, call0, mean_over, fuse_act=True, timers=None
     return lse, kl1
 
 
+def units_ok(net, x, fuse_act=True):
+    """Work-unit sharding runs on the batch-innermost path only, and needs the flatten (if any) to keep one row per image."""
+    return bool(fuse_act) and _chwn_ok(net, x) and output_rows(net, tuple(x.shape)) == x.shape[0]
+
+
+def shard_plan(net, x, num_ens, rank, world, fuse_act=True, precision="fp32"):
+    """How this rank's share of one MC step is cut: -> (S, lo, hi).  S = 1: lo..hi are whole draws (the fallback when the
+    fast path does not apply).  Every rank computes the same S from the same shapes."""
+    S = 1
+    if world > 1 and units_ok(net, x, fuse_act):
+        S = plan_slices(num_ens, world, x.shape[0], multiple=8 if precision == "bf16" else 4)
+    lo, hi = unit_range(num_ens, S, rank, world)
+    return S, lo, hi
+
+
 def mc_forward(net, x, num_ens, group=None, fuse_act=True, timers=None, kl_mode="sum", streams=1, precision="fp32"):
     """One Monte-Carlo step: -> (log_outputs [B, C], kl).
 
     kl_mode "sum": kl summed over the num_ens calls as validate_model does (main_bayesian.py:76-77);
             "mean": divided by num_ens as train_model does (main_bayesian.py:51).
-    With a process group, rank r runs draws draw_range(num_ens, r, world) and the ranks combine through one
-    all_gather; every rank returns identical values."""
+    With a process group the (draw x batch-slice) work units are dealt out to the ranks (shard_plan) and the ranks combine
+    through one all_gather; every rank returns identical values, equal to the single-device result."""
     world = 1 if group is None else torch.distributed.get_world_size(group)
     rank = 0 if group is None else torch.distributed.get_rank(group)
+    rng.assign_stream_ids(net)                       # stream ids by module order: identical on every rank
     seed, call0 = rng.next_calls(num_ens)            # all ranks advance identically
-    lo, hi = draw_range(num_ens, rank, world)
+    S, lo, hi = shard_plan(net, x, num_ens, rank, world, fuse_act, precision)
     if hi > lo:
-        lse, kl1 = _local_lse(net, x, hi - lo, seed, call0 + lo, 0 if world > 1 else num_ens, fuse_act=fuse_act,
-                              timers=timers, streams=streams, precision=precision)
-        kl_local = kl1 * float(hi - lo)
-    else:                                            # more ranks than draws
+        if S > 1:
+            lse, kl1 = _local_lse(net, x, num_ens, seed, call0, 0, fuse_act=fuse_act, timers=timers, precision=precision,
+                                  units=(S, lo, hi))
+        else:
+            lse, kl1 = _local_lse(net, x, hi - lo, seed, call0 + lo, 0 if world > 1 else num_ens, fuse_act=fuse_act,
+                                  timers=timers, streams=streams, precision=precision)
+        kl_local = kl1 * (float(hi - lo) / S)
+    else:                                            # more ranks than work units
         lse, kl_local = None, None
     if world == 1:
         kl = kl_local if kl_mode == "sum" else kl_local / num_ens
         return lse, kl
-    return combine_ranks(lse, kl_local, num_ens, group, kl_mode)
+    shape = (output_rows(net, tuple(x.shape)), getattr(net, "num_classes", None)) if lse is None else None
+    return combine_ranks(lse, kl_local, num_ens, group, kl_mode, shape=shape, device=x.device)
 
 
-def combine_ranks(lse_local, kl_local, num_ens, group, kl_mode="sum", shape=None):
+def combine_ranks(lse_local, kl_local, num_ens, group, kl_mode="sum", shape=None, device=None):
     """All-gather [B*C + 1] floats per rank, then log-sum-exp over ranks in rank order.
-    lse_local: [B, C] log-sum-exp over this rank's draws (None if the rank had no draw)."""
+    lse_local: [B, C] log-sum-exp over this rank's work (rows of -inf where it held no unit of a batch slice; None if the
+    rank had no work at all -- then `shape` = (B, C) and `device` say what to contribute)."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
     if lse_local is None:
-        if shape is None:
-            raise _lib.BBBHipError("a rank without draws must be given the [B, C] shape")
-        dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        if shape is None or shape[1] is None:
+            raise _lib.BBBHipError("a rank without work must be given the [B, C] shape")
+        dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device())
+                                                 if torch.cuda.is_available() else torch.device("cpu"))
         lse_local = torch.full(shape, -float("inf"), device=dev)
         kl_local = torch.zeros((), device=dev)
     B, C = lse_local.shape
@@ -541,6 +687,28 @@ def combine_ranks(lse_local, kl_local, num_ens, group, kl_mode="sum", shape=None
     return log_outputs, kl
 
 
+def mc_forward_batch_parallel(net, x_local, num_ens, group=None, gather=False, fuse_act=True, precision="fp32", b_offset=None):
+    """Data-parallel inference (BASELINE.json configs[4]: 4096 x 3 x 224 x 224 over 8 GPUs, 512 images each): every rank runs
+    ALL num_ens draws on ITS images.  The weight noise is keyed by (seed, call, stream, element), so all ranks sample the
+    same weights without any communication, and the outputs are exactly the rows a single device would compute for these
+    images; KL is identical everywhere.  No collective unless gather=True (one all_gather of the [B_local', C] blocks).
+    LRT layers key their activation noise by the global image index: pass b_offset (default rank * B_local)."""
+    world = 1 if group is None else torch.distributed.get_world_size(group)
+    rank = 0 if group is None else torch.distributed.get_rank(group)
+    rng.assign_stream_ids(net)
+    if any(isinstance(l, _LRTLayer) for l in bayesian_layers(net)) and world > 1:
+        raise _lib.BBBHipError("batch-parallel LRT inference is not wired up (activation noise needs the global image index)")
+    seed, call0 = rng.next_calls(num_ens)
+    lse, kl1 = _local_lse(net, x_local, num_ens, seed, call0, num_ens, fuse_act=fuse_act, precision=precision)
+    kl = kl1 * float(num_ens)
+    if gather and world > 1:
+        import torch.distributed as dist
+        full = torch.empty((world * lse.shape[0], lse.shape[1]), dtype=lse.dtype, device=lse.device)
+        dist.all_gather_into_tensor(full, lse.contiguous(), group=group)
+        return full, kl
+    return lse, kl
+
+
 class GraphedMC:
     """One Monte-Carlo step captured as a hipGraph (launch-bound inner loop -> one graph launch per step).
 
@@ -550,8 +718,9 @@ class GraphedMC:
     used; the Python-side counter is advanced in step().
     `lane` / `lanes`: this graph is lane `lane` of `lanes` graphs replayed round-robin (GraphedPipeline): its counter
     starts at lane*num_ens and advances by lanes*num_ens.
-    With a process group the graph holds this rank's draws (draw_range) and the one all_gather per step is issued
-    eagerly after the replay, on the lane's stream (collectives stay outside the graph).
+    With a process group the graph holds this rank's work units (shard_plan: (draw x batch-slice) units, or whole draws when
+    the fast path does not apply) and the one all_gather per step is issued eagerly after the replay, on the lane's stream
+    (collectives stay outside the graph).
     step() returns (log_outputs [B, C], kl); with world == 1 these are buffers overwritten by the next replay."""
 
     def __init__(self, net, x, num_ens, streams=1, kl_mode="sum", lane=0, lanes=1, stream=None, seed_call=None, group=None,
@@ -563,7 +732,8 @@ class GraphedMC:
         self.precision = precision
         self.world = 1 if group is None else torch.distributed.get_world_size(group)
         rank = 0 if group is None else torch.distributed.get_rank(group)
-        self.lo, self.hi = draw_range(self.num_ens, rank, self.world)
+        rng.assign_stream_ids(net)
+        self.S, self.lo, self.hi = shard_plan(net, self.x, self.num_ens, rank, self.world, True, precision)
         import os as _os
         self._force_combine = group is not None and _os.environ.get("BBB_FORCE_COMBINE") == "1"   # test hook: N > 1 code path at world 1
         dev = x.device
@@ -587,17 +757,22 @@ class GraphedMC:
                 self.lse, self.kl_local = self._step_body(streams)
         else:
             self.graph = None                        # more ranks than draws: this rank only joins the collective
-        self.shape = (x.shape[0], getattr(net, "num_classes", None))
+        self.shape = (output_rows(net, tuple(x.shape)), getattr(net, "num_classes", None))
         self.replays = 0
 
     def _step_body(self, streams):
         n_loc = self.hi - self.lo
-        lse, kl1 = _local_lse(self.net, self.x, n_loc, self.seed, self.call0 + self.lo,
-                              self.num_ens if (self.world == 1 and not self._force_combine) else 0, streams=streams, precision=self.precision)
+        if self.S > 1:
+            lse, kl1 = _local_lse(self.net, self.x, self.num_ens, self.seed, self.call0, 0, precision=self.precision,
+                                  units=(self.S, self.lo, self.hi))
+        else:
+            lse, kl1 = _local_lse(self.net, self.x, n_loc, self.seed, self.call0 + self.lo,
+                                  self.num_ens if (self.world == 1 and not self._force_combine) else 0, streams=streams,
+                                  precision=self.precision)
         if self.world == 1 and not self._force_combine:
             kl = kl1 * float(self.num_ens) if self.kl_mode == "sum" else kl1 * 1.0
         else:
-            kl = kl1 * float(n_loc)
+            kl = kl1 * (float(n_loc) / self.S)
         self.counter.add_(self.stride)               # part of the graph: next replay of this lane
         return lse, kl
 
@@ -617,7 +792,8 @@ class GraphedMC:
             if self.world == 1 and not self._force_combine:
                 return self.lse, self.kl_local
             with torch.no_grad():
-                return combine_ranks(self.lse, self.kl_local, self.num_ens, self.group, self.kl_mode, shape=self.shape)
+                return combine_ranks(self.lse, self.kl_local, self.num_ens, self.group, self.kl_mode, shape=self.shape,
+                                     device=self.x.device)
 
 
 class _null_ctx:

@@ -183,6 +183,17 @@ def lrt_conv2d_forward(x, w_mu, w_var, b_mu, b_var, seed, call0, stream_id, stri
     return y, am, av
 
 
+def _apply_units(d, units, x_per_slice):
+    """units = (S, off) or None: the launch's slabs are work units u = off + e of the draw-major (draw, batch slice) grid
+    (see bbb_conv_desc_t).  x_per_slice: the input is an [S][...] per-slice tensor shared by all draws (first layer)."""
+    if units is None:
+        return
+    S, off = int(units[0]), int(units[1])
+    if S > 1:
+        d.unit_div, d.unit_off = S, off % S
+        d.x_unit_mod = S if x_per_slice else 0
+
+
 def _desc_chwn(x, w, stride, padding, dilation, draws, x_shared, w_shared, act):
     """x: [Ex, Cin, H, W, B]; w: [Ew, Cout, Cin, kh, kw]."""
     Ex, Cin, H, W, B = x.shape
@@ -191,16 +202,26 @@ def _desc_chwn(x, w, stride, padding, dilation, draws, x_shared, w_shared, act):
     return d, ho, wo
 
 
-def conv2d_chwn_forward(x, w, bias, stride=1, padding=0, dilation=1, act=None, out=None):
+def conv2d_chwn_forward(x, w, bias, stride=1, padding=0, dilation=1, act=None, out=None, units=None, n_units=None,
+                        x_per_slice=False):
     """Batch-innermost conv for the ensemble path.  x: [E|1, Cin, H, W, B] (B % 4 == 0); w: [E|1, Cout, Cin, kh, kw];
-    bias [E|1, Cout] or None -> y [E, Cout, Ho, Wo, B].  Padding taps are skipped, not multiplied."""
+    bias [E|1, Cout] or None -> y [E, Cout, Ho, Wo, B].  Padding taps are skipped, not multiplied.
+    Work units (ensemble sharding): units = (S, off), n_units = U output slabs; w / bias hold the weight sets of the draws
+    the units touch, x is [U, ...] or, for a layer whose input is the same for every draw, the per-slice [S, Cin, H, W, Bs]."""
     require_device(x, w, bias)
     x, w = x.contiguous(), w.contiguous()
     bias = None if bias is None else bias.contiguous()
-    E = max(x.shape[0], w.shape[0])
-    if x.shape[0] not in (1, E) or w.shape[0] not in (1, E):
-        raise _lib.BBBHipError("leading (draw) dims of x and w must be 1 or equal")
-    d, ho, wo = _desc_chwn(x, w, stride, padding, dilation, E, x.shape[0] == 1 and E > 1, w.shape[0] == 1 and E > 1, act)
+    if units is not None and units[0] > 1:
+        E = int(n_units)
+        if x.shape[0] != (units[0] if x_per_slice else E):
+            raise _lib.BBBHipError("work units: x must hold one slab per unit, or one per batch slice with x_per_slice")
+        d, ho, wo = _desc_chwn(x, w, stride, padding, dilation, E, False, False, act)
+        _apply_units(d, units, x_per_slice)
+    else:
+        E = max(x.shape[0], w.shape[0])
+        if x.shape[0] not in (1, E) or w.shape[0] not in (1, E):
+            raise _lib.BBBHipError("leading (draw) dims of x and w must be 1 or equal")
+        d, ho, wo = _desc_chwn(x, w, stride, padding, dilation, E, x.shape[0] == 1 and E > 1, w.shape[0] == 1 and E > 1, act)
     shape = (E, w.shape[1], ho, wo, x.shape[4])
     if out is None:
         y = torch.empty(shape, dtype=torch.float32, device=x.device)
@@ -215,15 +236,21 @@ def conv2d_chwn_forward(x, w, bias, stride=1, padding=0, dilation=1, act=None, o
 
 
 def lrt_conv2d_chwn_forward(x, w_mu, w_var, b_mu, b_var, seed, call0, stream_id, stride=1, padding=0, dilation=1,
-                            sample=True, eps=None, want_moments=False, act=None):
-    """LRT layer, batch-innermost.  x: [E, Cin, H, W, B] -> (y, act_mu|None, act_var|None) [E, Cout, Ho, Wo, B]."""
+                            sample=True, eps=None, want_moments=False, act=None, units=None, n_units=None, b_offset=0,
+                            x_per_slice=False):
+    """LRT layer, batch-innermost.  x: [E, Cin, H, W, B] -> (y, act_mu|None, act_var|None) [E, Cout, Ho, Wo, B].
+    Work units as in conv2d_chwn_forward (call0 = the call index of the first unit's draw; the noise of unit u is keyed by
+    its draw and by the GLOBAL image index slice*B + b).  b_offset: global index of local image 0 (batch-parallel shards)."""
     require_device(x, w_mu, w_var, b_mu, b_var, eps)
     x = x.contiguous()
     w_mu, w_var = w_mu.contiguous(), w_var.contiguous()
     b_mu = None if b_mu is None else b_mu.contiguous()
     b_var = None if b_var is None else b_var.contiguous()
-    E = x.shape[0]
+    E = x.shape[0] if (units is None or units[0] <= 1) else int(n_units)
     d, ho, wo = _desc_chwn(x, w_mu.unsqueeze(0), stride, padding, dilation, E, False, True, act)
+    if units is not None and units[0] > 1:
+        _apply_units(d, units, x_per_slice)
+    d.b_offset = int(b_offset)
     d.w_draw_stride = 0
     d.b_draw_stride = 0
     shape = (E, w_mu.shape[0], ho, wo, x.shape[4])
@@ -336,7 +363,7 @@ def to_batch_innermost_bf16(x):
 
 
 def conv2d_chwn_bf16_forward(x, w, bias, cin_khkw, stride=1, padding=0, dilation=1, act=None, out_f32=False, out=None,
-                             tap_major=False):
+                             tap_major=False, units=None, n_units=None, x_per_slice=False):
     """bf16 batch-innermost conv.  x: [E|1, Cin, H, W, B] bf16 (B % 8 == 0); w: [E|1, Cout, Kp] bf16 as written by
     sample_weights_bf16 (tap_major = its column order, see bf16_tap_major); cin_khkw = (Cin, kh, kw); bias [E|1, Cout]
     fp32 or None -> y [E, Cout, Ho, Wo, B] bf16 (fp32 when out_f32)."""
@@ -345,8 +372,9 @@ def conv2d_chwn_bf16_forward(x, w, bias, cin_khkw, stride=1, padding=0, dilation
     x, w = x.contiguous(), w.contiguous()
     bias = None if bias is None else bias.contiguous()
     cin, kh, kw = cin_khkw
-    E = max(x.shape[0], w.shape[0])
-    if x.shape[0] not in (1, E) or w.shape[0] not in (1, E):
+    sharded = units is not None and units[0] > 1
+    E = int(n_units) if sharded else max(x.shape[0], w.shape[0])
+    if not sharded and (x.shape[0] not in (1, E) or w.shape[0] not in (1, E)):
         raise _lib.BBBHipError("leading (draw) dims of x and w must be 1 or equal")
     Ex, Cin, H, W, B = x.shape
     if Cin != cin or w.shape[2] != bf16_row_pitch(cin * kh * kw):
@@ -356,10 +384,12 @@ def conv2d_chwn_bf16_forward(x, w, bias, cin_khkw, stride=1, padding=0, dilation
     d.batch, d.cin, d.h, d.w, d.cout, d.kh, d.kw = B, Cin, H, W, w.shape[1], kh, kw
     d.stride_h, d.stride_w, d.pad_h, d.pad_w, d.dil_h, d.dil_w = sh, sw, ph, pw, dh, dw
     d.draws = E
-    d.x_draw_stride = 0 if (Ex == 1 and E > 1) else Cin * H * W * B
-    d.w_draw_stride = 0 if (w.shape[0] == 1 and E > 1) else w.shape[1] * w.shape[2]
-    d.b_draw_stride = 0 if (bias is None or (bias.shape[0] == 1 and E > 1)) else w.shape[1]
+    d.x_draw_stride = 0 if (Ex == 1 and E > 1 and not sharded) else Cin * H * W * B
+    d.w_draw_stride = 0 if (w.shape[0] == 1 and E > 1 and not sharded) else w.shape[1] * w.shape[2]
+    d.b_draw_stride = 0 if (bias is None or (bias.shape[0] == 1 and E > 1 and not sharded)) else w.shape[1]
     d.act = {None: 0, "relu": 1, "softplus": 2}[act]
+    if sharded:
+        _apply_units(d, units, x_per_slice)
     ho = (H + 2 * ph - dh * (kh - 1) - 1) // sh + 1
     wo = (W + 2 * pw - dw * (kw - 1) - 1) // sw + 1
     shape = (E, w.shape[1], ho, wo, B)
@@ -402,6 +432,19 @@ def mc_tail_cb(logits, mean_over=0):
     with torch.cuda.device(logits.device):
         check(_lib.lib().bbb_mc_tail_cb(logits.data_ptr(), E, B, C, int(mean_over), out.data_ptr(), cur_stream(logits.device)),
               "bbb_mc_tail_cb")
+    return out
+
+
+def mc_tail_units(logits, slices, unit_off, mean_over=0):
+    """mc_tail_cb for a rank's work units: logits [U, C, Bs] (unit u = unit_off + e is draw u // slices, batch slice
+    u % slices) -> [slices * Bs, C]; -inf rows for slices the rank holds no unit of."""
+    require_device(logits)
+    logits = logits.contiguous()
+    U, C, Bs = logits.shape
+    out = torch.empty((int(slices) * Bs, C), dtype=torch.float32, device=logits.device)
+    with torch.cuda.device(logits.device):
+        check(_lib.lib().bbb_mc_tail_units(logits.data_ptr(), U, int(slices), int(unit_off) % int(slices), Bs, C, int(mean_over),
+                                           out.data_ptr(), cur_stream(logits.device)), "bbb_mc_tail_units")
     return out
 
 

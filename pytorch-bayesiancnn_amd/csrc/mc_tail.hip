@@ -64,31 +64,38 @@ constexpr int kCbThreads = 64;
 constexpr int kCbRows = 16;
 // blockDim = (64 images, ny <= 16): phase 1 spreads the draws over y (log-partition of each draw), phase 2 spreads the
 // classes over y (log-sum-exp over draws) -- the serial chain per thread is E*C/ny long instead of E*C.
-__global__ __launch_bounds__(kCbThreads * kCbRows) void mc_tail_cb_kernel(const float* __restrict__ logits, int E, int B, int C,
-                                                                          float sub, float* __restrict__ out) {
-    extern __shared__ float lz[];                       // [E][64]
+// Work units (ensemble sharding, include/bbb_hip.h): the E slabs are units u = off + e of the draw-major (draw, batch slice)
+// grid with S slices of Bs images; image b = s*Bs + bl reduces over the local units of ITS slice, e = e0, e0 + S, ...
+// (e0 = (s - off) mod S), and gets -inf when the rank holds none.  S = 1, off = 0 is the plain [E][C][B] case.
+__global__ __launch_bounds__(kCbThreads * kCbRows) void mc_tail_cb_kernel(const float* __restrict__ logits, int E, int Bs, int S,
+                                                                          int off, int C, float sub, float* __restrict__ out) {
+    extern __shared__ float lz[];                       // [ceil(E/S)][64]
     const int tx = threadIdx.x, ty = threadIdx.y, ny = blockDim.y;
+    const int B = Bs * S;
     const int b = blockIdx.x * kCbThreads + tx;
     const bool ok = b < B;
     const int bb = ok ? b : B - 1;
-    for (int e = ty; e < E; e += ny) {
-        const float* p = logits + (int64_t)e * C * B + bb;
+    const int sl = bb / Bs, bl = bb - sl * Bs;
+    const int e0 = (sl - off % S + S) % S;
+    const int ne = e0 < E ? (E - e0 + S - 1) / S : 0;
+    for (int k = ty; k < ne; k += ny) {
+        const float* p = logits + (int64_t)(e0 + k * S) * C * Bs + bl;
         float mx = -INFINITY;
-        for (int c = 0; c < C; ++c) mx = fmaxf(mx, p[(int64_t)c * B]);
+        for (int c = 0; c < C; ++c) mx = fmaxf(mx, p[(int64_t)c * Bs]);
         float se = 0.0f;
-        for (int c = 0; c < C; ++c) se += expf(p[(int64_t)c * B] - mx);
-        lz[e * kCbThreads + tx] = mx + logf(se);
+        for (int c = 0; c < C; ++c) se += expf(p[(int64_t)c * Bs] - mx);
+        lz[k * kCbThreads + tx] = mx + logf(se);
     }
     __syncthreads();
     for (int c = ty; c < C; c += ny) {
         float m = -INFINITY, s = 0.0f;
-        for (int e = 0; e < E; ++e) {
-            const float ls = logits[((int64_t)e * C + c) * B + bb] - lz[e * kCbThreads + tx];
+        for (int k = 0; k < ne; ++k) {
+            const float ls = logits[((int64_t)(e0 + k * S) * C + c) * Bs + bl] - lz[k * kCbThreads + tx];
             const float nm = fmaxf(m, ls);
             s = s * expf(m - nm) + expf(ls - nm);
             m = nm;
         }
-        if (ok) out[(int64_t)b * C + c] = m + logf(s) - sub;
+        if (ok) out[(int64_t)b * C + c] = ne > 0 ? m + logf(s) - sub : -INFINITY;
     }
 }
 
@@ -223,18 +230,28 @@ __global__ __launch_bounds__(256) void lrt_sample_nchw_kernel(const float* __res
 
 }  // namespace
 
-extern "C" int bbb_mc_tail_cb(const float* logits, int draws, int batch, int classes, int mean_over, float* lse_out,
-                              void* stream) {
-    if (logits == nullptr || lse_out == nullptr || draws <= 0 || batch <= 0 || classes <= 0 || mean_over < 0 || draws > 512)
+extern "C" int bbb_mc_tail_units(const float* logits, int units, int slices, int unit_off, int batch_slice, int classes,
+                                 int mean_over, float* lse_out, void* stream) {
+    if (logits == nullptr || lse_out == nullptr || units <= 0 || slices <= 0 || unit_off < 0 || batch_slice <= 0 || classes <= 0 ||
+        mean_over < 0 || units > 4096)
         return BBB_EINVAL;
     if ((((uintptr_t)logits | (uintptr_t)lse_out) & 3u) != 0) return BBB_EALIGN;
     const float sub = mean_over > 0 ? logf((float)mean_over) : 0.0f;
-    const int blocks = (batch + kCbThreads - 1) / kCbThreads;
-    const int mx = draws > classes ? draws : classes;
+    const int64_t batch = (int64_t)batch_slice * slices;
+    if (batch > 0x7fffffffLL) return BBB_ESHAPE;
+    const int blocks = (int)((batch + kCbThreads - 1) / kCbThreads);
+    const int per_slice = (units + slices - 1) / slices;            // local units an image reduces over, at most
+    const int mx = per_slice > classes ? per_slice : classes;
     const int ny = mx < kCbRows ? mx : kCbRows;
-    hipLaunchKernelGGL(mc_tail_cb_kernel, dim3(blocks), dim3(kCbThreads, ny), (size_t)draws * kCbThreads * sizeof(float),
-                       (hipStream_t)stream, logits, draws, batch, classes, sub, lse_out);
+    hipLaunchKernelGGL(mc_tail_cb_kernel, dim3(blocks), dim3(kCbThreads, ny), (size_t)per_slice * kCbThreads * sizeof(float),
+                       (hipStream_t)stream, logits, units, batch_slice, slices, unit_off, classes, sub, lse_out);
     return (int)hipGetLastError();
+}
+
+extern "C" int bbb_mc_tail_cb(const float* logits, int draws, int batch, int classes, int mean_over, float* lse_out,
+                              void* stream) {
+    if (draws > 512) return BBB_EINVAL;
+    return bbb_mc_tail_units(logits, draws, 1, 0, batch, classes, mean_over, lse_out, stream);
 }
 
 extern "C" int bbb_uncertainty(const float* logits, int draws, int batch, int classes, int normalized, float* pred,

@@ -20,4 +20,5 @@ struct PConvArgs {
     int32_t wtap;        // bf16: weight rows are tap-major ((r, q, ci) order)
     uint32_t x_inv;      // byte offset that marks an invalid image row: x_inv + any column offset is out of range and does not wrap
     const uint32_t* call_dev;
+    int32_t unit_div, unit_off, x_mod, b_off;   // work units (include/bbb_hip.h, bbb_conv_desc_t); unit_div <= 1: slab = draw
 };

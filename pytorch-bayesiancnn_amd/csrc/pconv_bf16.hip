@@ -82,6 +82,9 @@ __global__ __launch_bounds__(64 * WN * WM * KG + (WS ? 256 : 0)) void pconv_bf16
     const int g = (int)(item / p.Mtiles);
     const int j = (int)(item - (int64_t)g * p.Mtiles);
     const int e = g / p.Ntiles;
+    const int ue = p.unit_off + e;                                   // work units, as in pconv_gemm.hip
+    const int ew = p.unit_div > 1 ? ue / p.unit_div : e;
+    const int ex = p.x_mod > 0 ? ue % p.x_mod : e;
     const int n0 = (g - e * p.Ntiles) * BN;
     const int pix = j / p.nbt;
     const int b0 = (j - pix * p.nbt) * BM;
@@ -112,8 +115,8 @@ __global__ __launch_bounds__(64 * WN * WM * KG + (WS ? 256 : 0)) void pconv_bf16
     constexpr uint32_t kOOB = 0xFFFFFFF0u;
     constexpr uint32_t kWInv = 0x7FFFFFF0u;                       // + a row offset (< 2^31): out of range, no wrap
     const uint32_t kXInv = p.x_inv;
-    const uint16_t* xb = reinterpret_cast<const uint16_t*>(p.x) + (int64_t)e * p.x_ds;
-    const uint16_t* wb = reinterpret_cast<const uint16_t*>(p.w) + (int64_t)e * p.w_ds;
+    const uint16_t* xb = reinterpret_cast<const uint16_t*>(p.x) + (int64_t)ex * p.x_ds;
+    const uint16_t* wb = reinterpret_cast<const uint16_t*>(p.w) + (int64_t)ew * p.w_ds;
     const int64_t x_bytes = (int64_t)p.Cin * p.H * p.W * p.B * 2;
     const int64_t w_bytes = (int64_t)p.Cout * Kp * 2;
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(xb), 0, (int)x_bytes, 0x00020000);
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(64 * WN * WM * KG + (WS ? 256 : 0)) void pconv_bf16
     // ---- epilogue ----
     const int HoWo = p.Ho * p.Wo;
     const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.bias ? p.bias + (int64_t)e * p.b_ds : reinterpret_cast<const float*>(p.w)), 0, p.bias ? p.Cout * 4 : 0, 0x00020000);
+        const_cast<float*>(p.bias ? p.bias + (int64_t)ew * p.b_ds : reinterpret_cast<const float*>(p.w)), 0, p.bias ? p.Cout * 4 : 0, 0x00020000);
     constexpr int OSZ = OUT_F32 ? 4 : 2;
     char* yb = reinterpret_cast<char*>(p.y) + (int64_t)e * p.y_ds * OSZ;
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(yb, 0, (int)((int64_t)p.Cout * HoWo * p.B * OSZ), 0x00020000);
@@ -484,6 +487,10 @@ extern "C" int bbb_conv2d_chwn_bf16_fwd(const bbb_conv_desc_t* d, const void* x,
     a.y = reinterpret_cast<float*>(y);
     a.x_inv = x_inv;
     a.wtap = tap_major ? 1 : 0;
+    if (d->unit_div < 0 || d->unit_off < 0 || d->x_unit_mod < 0 || (d->unit_div > 1 && d->unit_off >= d->unit_div) ||
+        (d->x_unit_mod > 0 && d->x_unit_mod != d->unit_div))
+        return BBB_EINVAL;
+    a.unit_div = d->unit_div; a.unit_off = d->unit_div > 1 ? d->unit_off : 0; a.x_mod = d->x_unit_mod;
     // tile shape: LDS-pipe cycles per unit of useful work (see the kernel comment), including the waste of ragged
     // channel / image tiles: 128x128 -> 256, 64x256 -> 288, 64x128 (two waves) -> 320
     auto waste = [](int n, int t) { return (double)(((n + t - 1) / t) * t) / (double)n; };

@@ -72,6 +72,10 @@ __global__ __launch_bounds__(kThreads) void pconv_gemm_kernel(const PConvArgs p)
     const int g = (int)(item / p.Mtiles);
     const int j = (int)(item - (int64_t)g * p.Mtiles);
     const int e = g / p.Ntiles;
+    // work units (ensemble sharding): slab e is unit u = unit_off + e -> weight set u / S, input slab e (or u % S)
+    const int ue = p.unit_off + e;
+    const int ew = p.unit_div > 1 ? ue / p.unit_div : e;
+    const int ex = p.x_mod > 0 ? ue % p.x_mod : e;
     const int n0 = (g - e * p.Ntiles) * BN;
     const int pix = j / p.nbt;
     const int b0 = (j - pix * p.nbt) * BM;
@@ -104,11 +108,11 @@ __global__ __launch_bounds__(kThreads) void pconv_gemm_kernel(const PConvArgs p)
     const int64_t w_elems = (int64_t)p.Cout * p.K;
     const int64_t x_elems = (int64_t)p.Cin * p.H * p.W * p.B;
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.x + (int64_t)e * p.x_ds), 0, (int)(x_elems * 4), 0x00020000);
+        const_cast<float*>(p.x + (int64_t)ex * p.x_ds), 0, (int)(x_elems * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.w + (int64_t)e * p.w_ds), 0, (int)(w_elems * 4), 0x00020000);
+        const_cast<float*>(p.w + (int64_t)ew * p.w_ds), 0, (int)(w_elems * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t w2rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(LRT ? p.w2 + (int64_t)e * p.w_ds : p.w), 0, (int)(w_elems * 4), 0x00020000);
+        const_cast<float*>(LRT ? p.w2 + (int64_t)ew * p.w_ds : p.w), 0, (int)(w_elems * 4), 0x00020000);
 
     // loaders
     const int wkl = tid & 31, wnl = tid >> 5;            // weights: lane -> k, 8 channel rows per pass
@@ -252,7 +256,7 @@ __global__ __launch_bounds__(kThreads) void pconv_gemm_kernel(const PConvArgs p)
     //      (out-of-range channel / image lanes get an out-of-range offset: no branches, no per-element waits) ----
     const int HoWo = p.Ho * p.Wo;
     const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.bias ? p.bias + (int64_t)e * p.b_ds : p.w), 0, p.bias ? p.Cout * 4 : 0, 0x00020000);
+        const_cast<float*>(p.bias ? p.bias + (int64_t)ew * p.b_ds : p.w), 0, p.bias ? p.Cout * 4 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
         p.y + (int64_t)e * p.y_ds, 0, (int)((int64_t)p.Cout * HoWo * p.B * 4), 0x00020000);
     float bv[NT][16];
@@ -279,7 +283,8 @@ __global__ __launch_bounds__(kThreads) void pconv_gemm_kernel(const PConvArgs p)
                 }
         } else if (b_ok) {
             const int64_t ybase = (int64_t)e * p.y_ds + (int64_t)pix * p.B + b;
-            const float* __restrict__ b2g = p.bias2 ? p.bias2 + (int64_t)e * p.b_ds : nullptr;
+            const float* __restrict__ b2g = p.bias2 ? p.bias2 + (int64_t)ew * p.b_ds : nullptr;
+            const int bglob = b + p.b_off + (p.unit_div > 1 ? (ue % p.unit_div) * p.B : 0);      // image index that keys the noise
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
@@ -296,9 +301,9 @@ __global__ __launch_bounds__(kThreads) void pconv_gemm_kernel(const PConvArgs p)
                             if (p.eps_ext) {
                                 z = p.eps_ext[o];
                             } else {   // canonical NCHW element index of this draw's [B][Cout][Ho][Wo] slab
-                                const uint64_t idx = (uint64_t)(((int64_t)b * p.Cout + n) * HoWo + pix);
+                                const uint64_t idx = (uint64_t)(((int64_t)bglob * p.Cout + n) * HoWo + pix);
                                 float z4[4];
-                                bbb::normal4(idx >> 2, p.stream_id, p.call0 + (p.call_dev ? *p.call_dev : 0u) + (uint32_t)e, p.k0, p.k1, z4);
+                                bbb::normal4(idx >> 2, p.stream_id, p.call0 + (p.call_dev ? *p.call_dev : 0u) + (uint32_t)ew, p.k0, p.k1, z4);
                                 const int c = (int)(idx & 3);
                                 z = c == 0 ? z4[0] : c == 1 ? z4[1] : c == 2 ? z4[2] : z4[3];
                             }
@@ -356,6 +361,10 @@ int fill(const bbb_conv_desc_t* d, PConvArgs& a) {
     a.Ho = ho; a.Wo = wo; a.K = d->cin * d->kh * d->kw; a.khkw = d->kh * d->kw; a.act = d->act;
     a.x_ds = d->x_draw_stride; a.w_ds = d->w_draw_stride; a.b_ds = d->b_draw_stride;
     a.y_ds = (int64_t)d->cout * ho * wo * d->batch;
+    if (d->unit_div < 0 || d->unit_off < 0 || d->x_unit_mod < 0 || d->b_offset < 0) return BBB_EINVAL;
+    if (d->unit_div > 1 && d->unit_off >= d->unit_div) return BBB_EINVAL;          // passed reduced modulo S
+    if (d->x_unit_mod > 0 && d->x_unit_mod != d->unit_div) return BBB_EINVAL;
+    a.unit_div = d->unit_div; a.unit_off = d->unit_div > 1 ? d->unit_off : 0; a.x_mod = d->x_unit_mod; a.b_off = d->b_offset;
     return 0;
 }
 

@@ -11,27 +11,47 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("extra", [[], ["--dtype", "bf16", "--pipeline", "1"]])
-def test_bench_json_contract(extra):
+def _run(extra):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--no-cpu-baseline"] + extra,
-                       capture_output=True, text=True, timeout=600)
+                       capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout
-    j = json.loads(lines[0])
-    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-              "dtype", "data", "config", "roofline"):
-        assert k in j, k
-    assert j["n_gpus"] == 1 and j["steps"] == 4 and j["warmup"] == 2 and j["higher_is_better"] is True
-    assert j["unit"] == "samples/s" and j["scaling"] == "weak" and j["vs_baseline"] is None and j["data"] == "synthetic"
-    assert "workload" in j["config"] and "model" not in j["config"]
-    assert abs(j["value"] - 512 * 10 / (j["ms_per_step"] * 1e-3)) <= 1e-3 * j["value"]
-    r = j["roofline"]
+    return json.loads(lines[0])
+
+
+def _check_roofline(r, peak):
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
-    assert r["bound"] == "mfma" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0 < r["frac"] < 1
-    if not extra:
-        assert j["dtype"] == "f32" and r["peak"] == 157.3 and "roofline_reparam" in j and "bf16" in j
-        assert j["roofline_reparam"]["bound"] == "hbm"
-    else:
-        assert j["dtype"] == "bf16" and r["peak"] == 2500.0
+    assert r["bound"] == "mfma" and r["peak"] == peak and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0 < r["frac"] < 1
+
+
+def test_bench_json_contract_default():
+    j = _run([])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "roofline_reparam", "stats", "one_step_in_flight", "dropin_loop", "configs"):
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 4 and j["warmup"] == 2 and j["higher_is_better"] is True
+    assert j["unit"] == "samples/s" and j["scaling"] == "strong" and j["vs_baseline"] is None and j["data"] == "synthetic"
+    assert j["metric"] == "MC-forward samples/sec, BayesianAlexNet CIFAR-10 bs=512 num_ens=10" and j["dtype"] == "f32"
+    assert "workload" in j["config"] and "model" not in j["config"]
+    assert abs(j["value"] - 512 * 10 / (j["ms_per_step"] * 1e-3)) <= 1e-3 * j["value"]
+    _check_roofline(j["roofline"], 157.3)
+    rr = j["roofline_reparam"]
+    assert rr["bound"] == "hbm" and rr["peak"] == 8000.0 and abs(rr["frac"] - rr["achieved"] / rr["peak"]) < 1e-3
+    st = j["stats"]
+    assert st["p10"] <= st["median"] <= st["p90"]
+    assert "error" not in j["dropin_loop"] and j["dropin_loop"]["value"] > 0
+    # every other BASELINE configuration is measured, each with its own roofline
+    assert set(j["configs"]) == {"configs[1]", "configs[2]", "configs[3]", "configs[4]"}
+    for name, c in j["configs"].items():
+        assert "error" not in c, (name, c)
+        assert c["value"] > 0 and c["roofline"] is not None
+        _check_roofline(c["roofline"], 2500.0 if c["dtype"] == "bf16" else 157.3)
+    assert j["configs"]["configs[1]"]["dtype"] == "bf16" and j["configs"]["configs[4]"]["rows_out"] == 512 * 49
+
+
+def test_bench_json_contract_other_config_as_headline():
+    j = _run(["--config", "configs[1]", "--pipeline", "1", "--no-extras"])
+    assert j["dtype"] == "bf16" and j["n_gpus"] == 1 and "3Conv3FC" in j["metric"]
+    _check_roofline(j["roofline"], 2500.0)

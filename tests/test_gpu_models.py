@@ -331,7 +331,7 @@ def test_graphed_step_multirank_logic_simulated(env, monkeypatch):
     E, world = 5, 2
     captured = {}
 
-    def fake_combine(lse, kl_local, num_ens, group, kl_mode="sum", shape=None):
+    def fake_combine(lse, kl_local, num_ens, group, kl_mode="sum", shape=None, device=None):
         captured[group] = (lse.clone(), kl_local.clone())
         return lse, kl_local
 

@@ -306,6 +306,87 @@ def test_ensemble_combine_over_gloo(tmp_path, world, E):
         assert p.returncode == 0 and f"RANK_OK {r}" in out, err[-3000:]
 
 
+_UNIT_WORKER = r'''
+import os, sys, math
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+import numpy as np, torch, torch.distributed as dist
+import bbb_numpy as O
+from bbb_hip import ensemble
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % os.environ["MASTER_PORT"], rank=rank, world_size=world)
+E, B, C = int(sys.argv[3]), int(sys.argv[4]), 5
+S = ensemble.plan_slices(E, world, B)
+Bs = B // S
+rng = np.random.default_rng(0)
+logits = (rng.standard_normal((E, B, C)) * 3).astype(np.float32)          # what the E draws would produce for all B images
+lo, hi = ensemble.unit_range(E, S, rank, world)
+# what this rank's kernels produce: for every batch slice, the log-sum-exp over ITS units of that slice (-inf if none)
+lse = np.full((B, C), -np.inf, dtype=np.float64)
+for u in range(lo, hi):
+    j, s = divmod(u, S)
+    ls = O.log_softmax(logits[j, s * Bs:(s + 1) * Bs], axis=1).astype(np.float64)
+    lse[s * Bs:(s + 1) * Bs] = np.logaddexp(lse[s * Bs:(s + 1) * Bs], ls)
+if hi > lo:
+    lse_t, kl_local = torch.tensor(lse, dtype=torch.float32), torch.tensor(123.5 * (hi - lo) / S)
+else:
+    lse_t, kl_local = None, None
+out, kl = ensemble.combine_ranks(lse_t, kl_local, E, dist.group.WORLD, "sum", shape=(B, C))
+want = O.mc_log_outputs(logits)
+assert np.allclose(out.numpy(), want, rtol=1e-5, atol=2e-6), np.abs(out.numpy() - want).max()
+assert abs(kl.item() - 123.5 * E) < 1e-2, kl.item()
+g = [torch.empty_like(out) for _ in range(world)]
+dist.all_gather(g, out)
+assert all(torch.equal(g[0], t) for t in g)                                  # every rank holds the same bits
+# the deal is even: no rank holds more than ceil(E*S/world) units, and the union is the whole grid
+cnt = torch.tensor([hi - lo]); allc = [torch.zeros_like(cnt) for _ in range(world)]
+dist.all_gather(allc, cnt)
+assert sum(int(c) for c in allc) == E * S and max(int(c) for c in allc) == -(-E * S // world)
+dist.destroy_process_group()
+print("RANK_OK", rank, "S", S)
+'''
+
+
+@pytest.mark.parametrize("world,E,B,S_expected", [(2, 10, 512, 1), (3, 10, 512, 2), (4, 10, 512, 2), (8, 10, 512, 4),
+                                                  (8, 25, 512, 4), (8, 3, 256, 2)])
+def test_unit_sharded_ensemble_over_gloo(tmp_path, world, E, B, S_expected):
+    """SURVEY.md 8(e): (draw x batch-slice) work units dealt evenly over the ranks; ONE all_gather; the combined
+    log_outputs equal the single-device logmeanexp for E = 10 with half- and quarter-batch units (world 3/4 and 8)."""
+    from bbb_hip import ensemble
+    assert ensemble.plan_slices(E, world, B) == S_expected
+    script = tmp_path / "unit_worker.py"
+    script.write_text(_UNIT_WORKER)
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script), PKG, os.path.join(ROOT, "oracle"), str(E), str(B)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for r, p in enumerate(procs):
+        out, err = p.communicate(timeout=240)
+        assert p.returncode == 0 and f"RANK_OK {r}" in out, err[-3000:]
+
+
+def test_plan_slices_and_output_rows():
+    from bbb_hip import ensemble, zoo
+    assert ensemble.plan_slices(10, 1, 512) == 1
+    assert ensemble.plan_slices(10, 8, 512, multiple=8) == 4
+    assert ensemble.plan_slices(10, 8, 100) == 1                       # 100 images cannot be cut into aligned slices of >= 64
+    # busiest rank at E=10: 8 ranks -> 5 quarter-batch units = 640 images (a perfect 1/8), 4 ranks -> 5 half-batch units
+    for world, S, per in [(8, 4, 5), (4, 2, 5), (2, 1, 5)]:
+        counts = [hi - lo for lo, hi in (ensemble.unit_range(10, S, r, world) for r in range(world))]
+        assert max(counts) == per and sum(counts) == 10 * S
+    pri = {"prior_mu": 0, "prior_sigma": 0.1, "posterior_mu_initial": (0, 0.1), "posterior_rho_initial": (-5, 0.1)}
+    net = zoo.BBBAlexNet(10, 3, pri, "bbb", "softplus")
+    assert ensemble.output_rows(net, (512, 3, 32, 32)) == 512
+    assert ensemble.output_rows(net, (16, 3, 224, 224)) == 16 * 49      # the view(-1, 128) quirk, layers/misc.py:35
+    assert [type(m).__name__ for m in ensemble.flat_children(net)][:3] == ["BBBConv2d", "Softplus", "MaxPool2d"]
+
+
 _DP_WORKER = r'''
 import os, sys
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
