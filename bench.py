@@ -483,7 +483,8 @@ def main():
                 "note": "weak scaling, secondary: %d draws per GPU (a %d-draw ensemble of the same 512 images)" % (cfg["E"], cfg["E"] * world)}
 
     if rank == 0:
-        S, lo, hi = ensemble.shard_plan(net, x, cfg["E"], 0, world, True, cfg["precision"])
+        with torch.no_grad():
+            S, lo, hi = ensemble.shard_plan(net, x, cfg["E"], 0, world, True, cfg["precision"])
         out = {
             "metric": "MC-forward samples/sec, BayesianAlexNet CIFAR-10 bs=512 num_ens=10",
             "value": head["value"], "unit": "samples/s",

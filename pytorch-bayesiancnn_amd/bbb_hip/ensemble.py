@@ -733,7 +733,8 @@ class GraphedMC:
         self.world = 1 if group is None else torch.distributed.get_world_size(group)
         rank = 0 if group is None else torch.distributed.get_rank(group)
         rng.assign_stream_ids(net)
-        self.S, self.lo, self.hi = shard_plan(net, self.x, self.num_ens, rank, self.world, True, precision)
+        with torch.no_grad():                        # the captured step is inference: plan for the inference path
+            self.S, self.lo, self.hi = shard_plan(net, self.x, self.num_ens, rank, self.world, True, precision)
         import os as _os
         self._force_combine = group is not None and _os.environ.get("BBB_FORCE_COMBINE") == "1"   # test hook: N > 1 code path at world 1
         dev = x.device
