@@ -121,10 +121,12 @@ typedef struct bbb_adam_segment {
  * `step` is the 1-based count of this update.  Hyper-parameters are doubles: derived scalars (1 - beta, the bias
  * corrections) are formed in double and rounded to fp32 once, as torch does.  step_dev (optional): DEVICE float holding the
  * step count (torch's capturable-Adam convention); when given it overrides `step` and the bias corrections are computed on
- * the device, so a captured hipGraph advances correctly on every replay.
+ * the device, so a captured hipGraph advances correctly on every replay.  lr_dev (optional, only with step_dev): DEVICE
+ * float holding the learning rate, read at run time instead of `lr` -- a scheduler (the reference uses ReduceLROnPlateau,
+ * main_bayesian.py:118) can then change the rate of an already captured step.
  */
 int bbb_adam_step(const bbb_adam_segment_t* segs, int nseg, double lr, double beta1, double beta2, double eps,
-                  int64_t step, const float* step_dev, void* stream);
+                  int64_t step, const float* step_dev, const float* lr_dev, void* stream);
 
 /* Test entry: materialise n elements of a noise stream starting at element `start`. */
 int bbb_eps_dump(float* out, int64_t n, int64_t start, uint64_t seed, uint32_t call, uint32_t stream_id, void* stream);

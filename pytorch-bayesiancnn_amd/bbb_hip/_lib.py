@@ -46,7 +46,7 @@ _SIGNATURES = {
     "bbb_reparam_kl_bwd": (c_int, [ctypes.POINTER(Segment), c_int, c_int, c_float, c_float, c_u64, c_u32, c_u32,
                                    c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), c_void_p, c_void_p]),
     "bbb_adam_step": (c_int, [ctypes.POINTER(AdamSegment), c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
-                            c_i64, c_void_p, c_void_p]),
+                            c_i64, c_void_p, c_void_p, c_void_p]),
     "bbb_eps_dump": (c_int, [c_void_p, c_i64, c_i64, c_u64, c_u32, c_u32, c_void_p]),
     "bbb_conv2d_fwd": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "bbb_lrt_conv2d_fwd": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

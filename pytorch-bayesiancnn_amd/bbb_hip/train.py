@@ -17,12 +17,23 @@ class FusedAdam(torch.optim.Optimizer):
     parameter tensors per HIP launch (`bbb_adam_step`).  State layout matches torch's ('step', 'exp_avg', 'exp_avg_sq'),
     so state_dicts are interchangeable with torch.optim.Adam.
     capturable=True keeps 'step' on the device (torch's capturable convention) and lets the kernel derive the bias
-    corrections from it, so the step can be part of a captured hipGraph (GraphedTrainStep)."""
+    corrections from it, so the step can be part of a captured hipGraph (GraphedTrainStep).  The learning rate of a
+    capturable group also lives on the device (group['lr_dev']): `sync_lr()` copies group['lr'] there, which is how a
+    scheduler's change reaches a step that was captured earlier."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, capturable=False):
         if not 0.0 <= lr or not 0.0 <= eps or not (0.0 <= betas[0] < 1.0 and 0.0 <= betas[1] < 1.0):
             raise ValueError("invalid Adam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, capturable=bool(capturable)))
+
+    def sync_lr(self):
+        """Push every capturable group's current lr to its device scalar (call outside a graph capture, e.g. after
+        scheduler.step(); GraphedTrainStep.step does it before each replay)."""
+        for group in self.param_groups:
+            t = group.get("lr_dev")
+            if t is not None and group.get("_lr_pushed") != float(group["lr"]):
+                t.fill_(float(group["lr"]))
+                group["_lr_pushed"] = float(group["lr"])
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -50,11 +61,18 @@ class FusedAdam(torch.optim.Optimizer):
                 else:
                     st["step"] += 1
                     by_step.setdefault(int(st["step"].item()), []).append((p, st))
+            lr_dev = 0
             if cap and by_step:
                 steps = [st["step"] for _, st in by_step[0]]
                 if any(not t.is_cuda for t in steps):
                     raise _lib.BBBHipError("capturable FusedAdam needs its 'step' state on the device")
                 torch._foreach_add_(steps, 1.0)              # one launch; all tensors of a group step together
+                if group.get("lr_dev") is None:
+                    group["lr_dev"] = torch.full((), float(group["lr"]), dtype=torch.float32, device=steps[0].device)
+                    group["_lr_pushed"] = float(group["lr"])
+                elif not torch.cuda.is_current_stream_capturing():
+                    self.sync_lr()
+                lr_dev = group["lr_dev"].data_ptr()
             for step, items in by_step.items():
                 for s0 in range(0, len(items), _lib.MAX_SEGMENTS):
                     part = items[s0:s0 + _lib.MAX_SEGMENTS]
@@ -67,7 +85,7 @@ class FusedAdam(torch.optim.Optimizer):
                     with torch.cuda.device(dev):
                         check(L.bbb_adam_step(segs, len(part), float(group["lr"]), float(group["betas"][0]),
                                               float(group["betas"][1]), float(group["eps"]), step,
-                                              part[0][1]["step"].data_ptr() if cap else 0, cur_stream(dev)),
+                                              part[0][1]["step"].data_ptr() if cap else 0, lr_dev, cur_stream(dev)),
                               "bbb_adam_step")
         return loss
 
@@ -124,17 +142,21 @@ class GraphedTrainStep:
     and the Adam update replay as a single graph launch (the eager step is host-bound: ~40 kernel launches plus autograd
     bookkeeping per iteration).  Fresh noise per replay through the same device-side call counter as GraphedMC (the
     backward kernel reads it too, so it regenerates the forward's eps); the Adam step count lives on the device.
-    Fixed shapes: copy each batch into `self.x` / `self.target` (or pass them to step()).  beta and train_size are
-    constants of the captured graph.  `warmup` real training iterations run eagerly on the capture stream first.
-    The optimizer must be FusedAdam(capturable=True) (or another capturable optimizer)."""
+    Fixed shapes: copy each batch into `self.x` / `self.target` (or pass them to step()).  train_size is a constant of the
+    captured graph; the KL weight `beta` (a per-batch schedule in the reference: metrics.get_beta, main_bayesian.py:55) and
+    the learning rate (ReduceLROnPlateau, main_bayesian.py:118) are DEVICE scalars the graph reads at run time:
+    step(beta=...) sets the former, optimizer.param_groups[i]['lr'] is pushed before every replay.
+    `warmup` real training iterations run eagerly on the capture stream first.
+    The optimizer must be FusedAdam(capturable=True) (or another capturable optimizer that keeps lr on the device)."""
 
     def __init__(self, net, optimizer, x, target, num_ens, beta, train_size, warmup=3):
         from . import rng
         _lib.require_device(x)
         self.net, self.opt, self.num_ens = net, optimizer, int(num_ens)
-        self.beta, self.train_size = float(beta), float(train_size)
+        self.train_size = float(train_size)
         self.x, self.target = x.clone(), target.clone()
         dev = x.device
+        self.beta = torch.full((), float(beta), dtype=torch.float32, device=dev)
         self.counter = torch.zeros((1,), dtype=torch.int32, device=dev)
         self.seed, self.call0 = rng.next_calls(0)
         self.stream = torch.cuda.Stream(device=dev)
@@ -160,12 +182,16 @@ class GraphedTrainStep:
         self.opt.step()
         return loss.detach(), log_outputs.detach(), kl.detach()
 
-    def step(self, x=None, target=None):
+    def step(self, x=None, target=None, beta=None):
         from . import rng
         if x is not None:
             self.x.copy_(x, non_blocking=True)
         if target is not None:
             self.target.copy_(target, non_blocking=True)
+        if beta is not None:
+            self.beta.fill_(float(beta))
+        if hasattr(self.opt, "sync_lr"):
+            self.opt.sync_lr()
         self.graph.replay()
         self.replays += 1
         rng.next_calls(self.num_ens)                 # keep the host-side noise counter in step with the device's

@@ -24,6 +24,7 @@ struct AdamArgs {
     float step_size, beta1, beta2, omb1, omb2, eps, sqrt_bc2;
     double lr_d, beta1_d, beta2_d;
     const float* step_dev;
+    const float* lr_dev;       // optional DEVICE learning rate (captured graphs: schedulers change lr between replays)
 };
 
 __global__ __launch_bounds__(kThreads) void adam_step_kernel(const AdamArgs a) {
@@ -33,7 +34,8 @@ __global__ __launch_bounds__(kThreads) void adam_step_kernel(const AdamArgs a) {
         __shared__ float sc[2];
         if (threadIdx.x == 0) {
             const double t = (double)*a.step_dev;
-            sc[0] = (float)(a.lr_d / (1.0 - pow(a.beta1_d, t)));
+            const double lr = a.lr_dev != nullptr ? (double)*a.lr_dev : a.lr_d;
+            sc[0] = (float)(lr / (1.0 - pow(a.beta1_d, t)));
             sc[1] = (float)sqrt(1.0 - pow(a.beta2_d, t));
         }
         __syncthreads();
@@ -83,9 +85,10 @@ __global__ __launch_bounds__(kThreads) void adam_step_kernel(const AdamArgs a) {
 }  // namespace
 
 extern "C" int bbb_adam_step(const bbb_adam_segment_t* segs, int nseg, double lr, double beta1, double beta2, double eps,
-                             int64_t step, const float* step_dev, void* stream) {
+                             int64_t step, const float* step_dev, const float* lr_dev, void* stream) {
     if (segs == nullptr || nseg <= 0 || nseg > BBB_MAX_SEGMENTS || (step <= 0 && step_dev == nullptr)) return BBB_EINVAL;
-    if (((uintptr_t)step_dev & 3u) != 0) return BBB_EALIGN;
+    if (lr_dev != nullptr && step_dev == nullptr) return BBB_EINVAL;      // device-side lr goes with the device-side step count
+    if ((((uintptr_t)step_dev | (uintptr_t)lr_dev) & 3u) != 0) return BBB_EALIGN;
     if (step <= 0) step = 1;
     if (!(lr >= 0.0) || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0) || !(eps >= 0.0)) return BBB_EINVAL;
     AdamArgs a = {};
@@ -110,7 +113,7 @@ extern "C" int bbb_adam_step(const bbb_adam_segment_t* segs, int nseg, double lr
     a.sqrt_bc2 = (float)sqrt(bc2);
     a.beta1 = (float)beta1; a.beta2 = (float)beta2; a.omb1 = (float)(1.0 - beta1); a.omb2 = (float)(1.0 - beta2);
     a.eps = (float)eps;
-    a.lr_d = lr; a.beta1_d = beta1; a.beta2_d = beta2; a.step_dev = step_dev;
+    a.lr_d = lr; a.beta1_d = beta1; a.beta2_d = beta2; a.step_dev = step_dev; a.lr_dev = lr_dev;
     hipLaunchKernelGGL(adam_step_kernel, dim3(chunks), dim3(kThreads), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }

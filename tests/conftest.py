@@ -29,3 +29,9 @@ def pytest_collection_modifyitems(config, items):
 def golden():
     import numpy as np
     return {n: np.load(os.path.join(GOLDEN, n + ".npz")) for n in ("layers_small", "functions", "models", "uncertainty")}
+
+
+@pytest.fixture(scope="session")
+def golden_driver():
+    import numpy as np
+    return np.load(os.path.join(GOLDEN, "driver.npz"))

@@ -9,6 +9,8 @@ The reference has no golden vectors of its own, so parity 
 outputs of the reference modules themselves, executed on CPU in fp32 with fixed torch seeds:
   layers_small.npz  -- the four layer types on tiny shapes: params, input, replayed eps, output, KL
   functions.npz     -- metrics.calculate_kl / ELBO / get_beta, utils.logmeanexp on fixed inputs
+  driver.npz        -- the UNMODIFIED main_bayesian.train_model / validate_model (main_bayesian.py:33-86) run on a synthetic
+                       loader: initial state_dict, the batches, per-iteration ELBO values and the functions' return values
   models.npz        -- whole-model forwards (LeNet with full params; AlexNet / 3Conv3FC by seed +
                        parameter checksums + expected logits / KL), one MC-ensemble step, and the
                        3x224x224 AlexNet case whose logits come out as [B*49, classes].
@@ -240,10 +242,70 @@ def make_uncertainty():
     np.savez_compressed(os.path.join(HERE, "uncertainty.npz"), **out)
 
 
+def make_driver():
+    """Per-iteration numbers of the reference's own training / validation loop (not a restatement of it): main_bayesian is
+    imported unmodified (torchvision stubbed: it is not installed and the loop does not use it), its train_model and
+    validate_model run on CPU with the reference's layers.  The noise is the default CPU generator's stream after
+    torch.manual_seed(EPS_SEED): a consumer that draws torch.empty(shape).normal_(0, 1) in the layers' order (W, then bias,
+    layer by layer, forward by forward) replays it exactly."""
+    import types
+    for name in ("torchvision", "torchvision.transforms", "torchvision.datasets"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    sys.modules["torchvision"].datasets = sys.modules["torchvision.datasets"]
+    if not hasattr(np, "Inf"):
+        np.Inf = np.inf
+    import main_bayesian as mb
+    out = {}
+    EPS_SEED, NB, BS, E = 4321, 3, 8, 2
+    for lt in ("bbb", "lrt"):
+        torch.manual_seed(77)
+        net = mb.getModel("lenet", 1, 10, ref_cfg.priors, lt, "softplus")
+        for k, v in net.state_dict().items():      # same seed, same shapes: one copy serves both layer types
+            if lt == "bbb":
+                out[f"init.{k}"] = npy(v)
+            else:
+                assert np.array_equal(out[f"init.{k}"], npy(v))
+        g = torch.Generator().manual_seed(5)
+        batches = [(torch.rand(BS, 1, 32, 32, generator=g), torch.randint(0, 10, (BS,), generator=g)) for _ in range(NB)]
+        out[f"{lt}.x"] = np.stack([npy(b[0]) for b in batches])
+        out[f"{lt}.y"] = np.stack([npy(b[1]) for b in batches])
+        elbo = ref_metrics.ELBO(NB * BS)
+        seen = []
+
+        class Recording(torch.nn.Module):           # records what the unmodified loop passes to / gets from its criterion
+            def forward(self, inp, target, kl, beta):
+                v = elbo(inp, target, kl, beta)
+                nll = F.nll_loss(inp.detach().double(), target)       # the part of the ELBO that depends on the outputs
+                acc = (inp.detach().argmax(1) == target).double().mean()
+                seen.append((float(v.detach()), float(kl), float(beta), float(nll), float(acc)))
+                return v
+
+        opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+        torch.manual_seed(EPS_SEED)
+        tl, ta, tk = mb.train_model(net, opt, Recording(), batches, num_ens=E, beta_type="Blundell", epoch=0, num_epochs=1)
+        n_train = len(seen)
+        vl, va = mb.validate_model(net, Recording(), batches, num_ens=E, beta_type=0.1, epoch=0, num_epochs=1)
+        out[f"{lt}.train_iter"] = np.array(seen[:n_train], dtype=np.float64)        # [NB, (loss, kl, beta, nll, acc)]
+        out[f"{lt}.valid_iter"] = np.array(seen[n_train:], dtype=np.float64)
+        out[f"{lt}.train_ret"] = np.array([float(tl), float(ta), float(tk)], dtype=np.float64)
+        out[f"{lt}.valid_ret"] = np.array([float(vl), float(va)], dtype=np.float64)
+        for k, v in net.state_dict().items():      # parameters after the 3 Adam steps: moments + a 64-element window
+            a = npy(v).astype(np.float64).ravel()
+            out[f"{lt}.final.{k}"] = np.concatenate([[a.sum(), np.abs(a).sum(), (a * a).sum()], a[:64]])
+    out["meta"] = np.array([EPS_SEED, NB, BS, E], dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, "driver.npz"), **out)
+
+
 if __name__ == "__main__":
+    if "--driver-only" in sys.argv:
+        make_driver()
+        print("driver.npz", os.path.getsize(os.path.join(HERE, "driver.npz")), "bytes")
+        sys.exit(0)
+    make_driver()
     make_uncertainty()
     make_layers()
     make_functions()
     make_models()
-    for f in ("layers_small.npz", "functions.npz", "models.npz", "uncertainty.npz"):
+    for f in ("layers_small.npz", "functions.npz", "models.npz", "uncertainty.npz", "driver.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

@@ -469,3 +469,17 @@ print("OK")
 ''' % (PKG, PKG)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-3000:]
+
+
+def test_metrics_helpers_match_the_oracle():
+    """bbb_hip.metrics.get_beta / ELBO (host side, no device needed) against the oracle's restatement of metrics.py:12-46."""
+    import bbb_numpy as O
+    from bbb_hip import metrics as M
+    for bt in (0.25, "Blundell", "Standard", "Soenderby", None):
+        for i in range(5):
+            assert M.get_beta(i, 5, bt, 3, 20) == O.get_beta(i, 5, bt, 3, 20)
+    lo = torch.log_softmax(torch.randn(6, 4, generator=torch.Generator().manual_seed(0)), dim=1)
+    y = torch.tensor([0, 3, 1, 1, 2, 0])
+    v = M.ELBO(50)(lo, y, torch.tensor(7.0), 0.3).item()
+    assert abs(v - O.elbo(lo.numpy(), y.numpy(), 7.0, 0.3, 50)) < 1e-4
+    assert abs(M.acc(lo, lo.argmax(1)).item() - 1.0) < 1e-7

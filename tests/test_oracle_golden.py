@@ -239,3 +239,41 @@ def test_bf16_storage_model_is_a_small_perturbation_of_the_fp32_oracle():
     assert kl16 == kl
     assert np.abs(got - want).max() <= 2e-2 * np.abs(want).max()
     assert np.abs(got - want).max() > 0
+
+
+@pytest.mark.reference
+def test_port_times_like_the_live_reference():
+    """bench.py's cpu_baseline uses the port where /root/reference does not exist (the GPU box): besides producing the same
+    bits, the port must COST the same as the unmodified modules on the same cores.  One AlexNet draw at bs=256, interleaved
+    runs, minimum of 7 each, within 5 % (three attempts: shared build hosts are noisy)."""
+    import subprocess
+    code = r"""
+import sys, time; sys.dont_write_bytecode = True
+sys.path.insert(0, %r); sys.path.insert(0, "/root/reference")
+import torch
+import ref_port_torch as P
+from models.BayesianModels.BayesianAlexNet import BBBAlexNet
+torch.manual_seed(0)
+net = BBBAlexNet(10, 3, P.CONFIG_PRIORS, "bbb", "softplus")
+params = P.init_params("alexnet", 3, 10, P.CONFIG_PRIORS)
+x = torch.rand(256, 3, 32, 32)
+def t_ref():
+    t = time.perf_counter(); net(x); return time.perf_counter() - t
+def t_port():
+    t = time.perf_counter(); P.forward("alexnet", params, x, "bbb", "softplus"); return time.perf_counter() - t
+with torch.no_grad():
+    for _ in range(2): t_ref(); t_port()
+    best = None
+    for attempt in range(3):
+        a, b = [], []
+        for _ in range(7):
+            a.append(t_ref()); b.append(t_port())
+        r = min(b) / min(a)
+        best = r if best is None or abs(r - 1) < abs(best - 1) else best
+        if abs(r - 1) <= 0.05: break
+print("RATIO %%.4f" %% best)
+""" % os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ratio = float(r.stdout.split("RATIO")[1])
+    assert abs(ratio - 1.0) <= 0.05, f"port / reference time ratio {ratio}"
