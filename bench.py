@@ -377,8 +377,8 @@ def run_config(cfg, steps, warmup, pipeline, dev, group=None, world=1, want_roof
 
 
 def dropin_loop(dev, steps):
-    """What an unmodified validate_model gets (main_bayesian.py:73-80): a Python loop of net(x) through the drop-in `layers`
-    (NCHW kernels, one draw per call, torch log_softmax / logmeanexp), eager launches."""
+    """The loop of main_bayesian.py:73-80 as written upstream -- a Python loop of net(x) through the drop-in `layers`, torch
+    log_softmax / logmeanexp, eager launches -- with and without autograd."""
     import torch.nn.functional as F
     cfg = CONFIGS["metric"]
     net, x = build_net(cfg, dev)
@@ -394,19 +394,26 @@ def dropin_loop(dev, steps):
         m = outputs.max(dim=2, keepdim=True).values
         return (m + torch.log(torch.mean(torch.exp(outputs - m), dim=2, keepdim=True))).squeeze(2), kl
 
-    with torch.no_grad():
-        for _ in range(3):
-            step()
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
-        torch.cuda.synchronize(dev)
-        dt = (time.perf_counter() - t0) / steps
-    return {"value": round(B * E / dt, 1), "unit": "samples/s", "ms_per_step": round(1e3 * dt, 4),
-            "note": "for j in range(10): net(x) through the drop-in layers (reference layout, conv_gemm_kernel, eager launches, "
-                    "one fused reparam+KL launch per forward) + torch log_softmax / logmeanexp: the path an unmodified "
-                    "validate_model takes; the headline uses the batched ensemble entry point instead"}
+    def timed(ctx):
+        with ctx:
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            torch.cuda.synchronize(dev)
+            return (time.perf_counter() - t0) / steps
+
+    dt_ng = timed(torch.no_grad())
+    dt_ag = timed(torch.enable_grad())
+    return {"value": round(B * E / dt_ng, 1), "unit": "samples/s", "ms_per_step": round(1e3 * dt_ng, 4),
+            "autograd_enabled": {"value": round(B * E / dt_ag, 1), "ms_per_step": round(1e3 * dt_ag, 4),
+                                 "note": "what the UNMODIFIED validate_model gets: it does not disable autograd, so the forwards "
+                                         "run on the reference-layout kernels (conv_gemm_kernel) and record an autograd graph"},
+            "note": "for j in range(10): net(x) through the drop-in layers + torch log_softmax / logmeanexp, eager launches.  Under "
+                    "torch.no_grad() each net(x) runs on the batch-innermost inference kernels (one draw per call); the headline "
+                    "uses the batched ensemble entry point (all draws per launch, one hipGraph) instead"}
 
 
 def main():
@@ -502,6 +509,14 @@ def main():
             out["metric"] = "MC-forward samples/sec, " + cfg["what"]
         if head.get("roofline"):
             out["roofline"] = head["roofline"]
+            fps = head["roofline"].get("flop_per_step")
+            if fps and world == 1:
+                peak = head["roofline"]["peak"]
+                out["roofline"]["sustained_in_timed_region"] = {
+                    "achieved": round(fps / (head["ms_per_step"] * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
+                    "frac": round(fps / (head["ms_per_step"] * 1e-3) / 1e12 / peak, 4),
+                    "note": "the same FLOPs per step / ms_per_step of the timed region (%d steps in flight; includes every "
+                            "non-GEMM kernel of the step)" % max(1, args.pipeline)}
         for k in ("stats", "one_step_in_flight"):
             if k in head:
                 out[k] = head[k]

@@ -69,3 +69,33 @@ def leave(scope):
         rng.pop_forward_scope()
         for l in scope.layers:           # a forward that aborted midway must not hand stale samples to the next one
             l._presampled = None
+
+
+def fast_forward(wrapper, x):
+    """Whole-model inference forward on the batch-innermost path of bbb_hip.ensemble (pixel-major GEMMs that skip padding
+    taps, activation fused into the epilogue, HIP pooling): one draw, the same kernels -- hence the same bits -- as draw j
+    of a batched mc_forward under the same call index.  Applies when nothing needs autograd (torch.no_grad(), or frozen
+    parameters), the input is a CUDA [B, C, H, W] batch with B % 4 == 0, the model is made of modules that path knows, it
+    ends in a Bayesian linear layer, no layer replays external noise, and this is the outermost wrapper of the forward.
+    Returns (output, kl) or None (-> the reference-layout path below, which also serves training)."""
+    from ._base import BayesianLayer
+    if isinstance(wrapper, BayesianLayer) or rng._scope or not torch.is_tensor(x) or not x.is_cuda or x.dim() != 4:
+        return None
+    from bbb_hip import ensemble
+    mods = ensemble.flat_children(wrapper)
+    if not mods or not isinstance(mods[-1], BayesianLayer) or not hasattr(mods[-1], "out_features"):
+        return None
+    layers = [m for m in mods if isinstance(m, BayesianLayer)]
+    if any(l.eps_source is not None for l in layers) or not all(l.W_mu.is_cuda for l in layers):
+        return None
+    if not ensemble._chwn_ok(wrapper, x):
+        return None
+    seed, call = rng.next_calls(1)
+    out = ensemble._mc_logits_chwn(wrapper, x, 1, seed, call)
+    if out is None:
+        rng._state["call"] = call                # nothing was launched: give the call index back
+        return None
+    logits, kl = out                             # [1, C, B']
+    for l in layers:
+        l._kl = None
+    return logits[0].t().contiguous(), kl

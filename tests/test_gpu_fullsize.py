@@ -34,8 +34,12 @@ def test_metric_config_alexnet_bs512_ens10(env):
     with torch.no_grad():
         fast, kl_f = env["ens"].mc_logits(net, x, E, 99, 0)
         nchw, kl_n = env["ens"].mc_logits(net, x, E, 99, 0, fuse_act=False, layout="nchw")
+        from layers.misc import reference_layout
+        with reference_layout():
+            env["rng"].manual_seed(99, call=0)
+            loop = torch.stack([net(x)[0] for _ in range(3)])
         env["rng"].manual_seed(99, call=0)
-        loop = torch.stack([net(x)[0] for _ in range(3)])
+        assert torch.equal(torch.stack([net(x)[0] for _ in range(3)]), fast[:3])     # drop-in inference forward = fast path
         fast2, _ = env["ens"].mc_logits(net, x, E, 99, 0)
         other, _ = env["ens"].mc_logits(net, x, E, 100, 0)
         kl_layers = sum(m.kl_loss() for m in net.modules() if hasattr(m, "kl_loss"))
@@ -114,8 +118,10 @@ def test_config5_alexnet_224_flatten_quirk(env):
     x = torch.rand(8, 3, 224, 224, device="cuda")
     with torch.no_grad():
         batched, _ = env["ens"].mc_logits(net, x, 2, 21, 0, fuse_act=False)
-        env["rng"].manual_seed(21, call=0)
-        loop = torch.stack([net(x)[0] for _ in range(2)])
+        from layers.misc import reference_layout
+        with reference_layout():
+            env["rng"].manual_seed(21, call=0)
+            loop = torch.stack([net(x)[0] for _ in range(2)])
     assert batched.shape == (2, 8 * 49, 10)
     assert torch.equal(batched, loop)
     # the batch-innermost fast path handles the quirk too (one pass through the NCHW order at the flatten) and agrees

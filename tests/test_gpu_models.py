@@ -172,13 +172,18 @@ def test_batched_ensemble_equals_loop(env, net_type, lt, B, hw, cin):
     env["rng"].assign_stream_ids(net)
     x = torch.rand(B, cin, hw, hw, device="cuda")
     E = 5
+    from layers.misc import reference_layout
     with torch.no_grad():
-        env["rng"].manual_seed(1234, call=10)
-        loop = torch.stack([net(x)[0] for _ in range(E)])
-        kl_loop = net(x)[1]
+        with reference_layout():                        # the drop-in forward on the reference-layout (NCHW) kernels
+            env["rng"].manual_seed(1234, call=10)
+            loop = torch.stack([net(x)[0] for _ in range(E)])
+            kl_loop = net(x)[1]
         batched, kl = env["ens"].mc_logits(net, x, E, 1234, 10, fuse_act=False)
         fused, _ = env["ens"].mc_logits(net, x, E, 1234, 10, fuse_act=True)
+        env["rng"].manual_seed(1234, call=10)           # the drop-in inference forward proper: batch-innermost when B % 4 == 0
+        fast_loop = torch.stack([net(x)[0] for _ in range(E)])
     assert torch.equal(loop, batched)                   # same kernels, same k order, same noise calls
+    assert torch.equal(fast_loop, fused)                # net(x) under no_grad == draw j of the batched fast path, bitwise
     # batch-innermost path: hardware exp2/log2 softplus in the GEMM epilogue vs torch's softplus between layers
     scale = max(1.0, float(loop.abs().max()))
     np.testing.assert_allclose(fused.cpu().numpy(), loop.cpu().numpy(), rtol=5e-4, atol=2e-5 * scale)

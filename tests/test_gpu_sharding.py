@@ -140,9 +140,13 @@ def test_nested_sequential_model_is_flattened(env):
         nchw, _ = ens.mc_logits(net, x, 3, 5, 0, fuse_act=False, layout="nchw")
         fast, _ = ens.mc_logits(net, x, 3, 5, 0)
         assert ens.stats["path"] == "chwn"
+        from layers.misc import reference_layout
+        with reference_layout():
+            env["rng"].manual_seed(5, call=0)
+            loop = torch.stack([net(x)[0] for _ in range(3)])
         env["rng"].manual_seed(5, call=0)
-        loop = torch.stack([net(x)[0] for _ in range(3)])
-    assert torch.equal(nchw, loop)
+        fast_loop = torch.stack([net(x)[0] for _ in range(3)])
+    assert torch.equal(nchw, loop) and torch.equal(fast, fast_loop)
     assert not torch.equal(loop[0], loop[1])                       # three different weight draws
     np.testing.assert_allclose(fast.cpu().numpy(), loop.cpu().numpy(), rtol=5e-4, atol=1e-5)
 
