@@ -151,9 +151,10 @@ typedef struct bbb_conv_desc {
     int32_t unit_div;
     int32_t unit_off;
     int32_t x_unit_mod;
+    int32_t w_row_pitch;  /* fp32 batch-innermost entry only: elements between consecutive output-channel rows of w (0 = dense,
+                             cin*kh*kw).  Lets a launch contract over a K-slice of a wider matrix in place (split-K over draws). */
     int32_t b_offset;     /* LRT noise only: global index of local image 0 (batch-parallel shards), added to the image index
                              that keys the activation noise; a unit's slice adds slice * batch on top */
-    int32_t reserved;
 } bbb_conv_desc_t;
 
 /*
@@ -199,6 +200,17 @@ int bbb_lrt_conv2d_chwn_fwd(const bbb_conv_desc_t* d, const float* x, const floa
 /* nn.MaxPool2d(kernel_size=k, stride=s) (no padding, floor mode; models/BayesianModels/BayesianAlexNet.py:37)
  * on batch-innermost planes: x [planes][h][w][B] -> y [planes][(h-k)/s+1][(w-k)/s+1][B]. */
 int bbb_maxpool_chwn(const float* x, float* y, int64_t planes, int h, int w, int batch, int k, int s, void* stream);
+
+/*
+ * Training extension: backward of [fused activation -> nn.MaxPool2d(k, s)] on batch-innermost planes (k = 0: activation only).
+ *   y      [planes][h][w][B]   the layer's ACTIVATED output (what the forward GEMM stored)
+ *   g_out  [planes][hp][wp][B] gradient w.r.t. the pooled output (k = 0: same shape as y)
+ *   g_pre  [planes][h][w][B]   gradient w.r.t. the pre-activation: the first maximum of every window receives that window's
+ *                              gradient (torch's max_pool2d backward), times act'(.) recovered from y (Softplus: 1 - exp(-y)).
+ * Gather formulation: deterministic, handles overlapping windows (k > s).
+ */
+int bbb_pool_act_bwd_chwn(const float* g_out, const float* y, float* g_pre, int64_t planes, int h, int w, int batch,
+                          int k, int s, int act, void* stream);
 
 /*
  * E noise draws from ONE pair of LRT moments, batch-innermost: y[e] = act(act_mu + sqrt(act_var) * eps[e]) with eps exactly
@@ -271,6 +283,16 @@ int bbb_uncertainty(const float* logits, int draws, int batch, int classes, int 
 
 /* [rows][cols] -> [cols][rows] (e.g. an NCHW batch [B][C*H*W] into the batch-innermost [C*H*W][B] layout). */
 int bbb_transpose2d(const float* in, float* out, int64_t rows, int64_t cols, void* stream);
+
+/* Batched strided transpose: out[i1*out_b1 + i2*out_b2 + c*out_col + r] = in[i1*in_b1 + i2*in_b2 + r*in_row + c] for r < rows,
+ * c < cols, i1 < nb1, i2 < nb2 (nb1*nb2 <= 65535).  Training extension: operand layouts of the role-swapped weight gradient. */
+int bbb_transpose_batched(const float* in, float* out, int rows, int cols, int nb1, int nb2, int64_t in_b1, int64_t in_b2,
+                          int64_t in_row, int64_t out_b1, int64_t out_b2, int64_t out_col, void* stream);
+
+/* Training extension: im2col of an NCHW batch x [batch][cin][h][w] (geometry from d; draws / strides / act ignored) into
+ * out [ho*wo][batch][Jp], Jp = cin*kh*kw rounded up to 4 (pad columns zero): the K-major operand of the first layer's
+ * weight-gradient GEMM (see bbb_hip/ops.py: conv2d_chwn_weight_grad_shared_input). */
+int bbb_im2col_pbj(const float* x, float* out, const bbb_conv_desc_t* d, void* stream);
 
 /* Library / device introspection (host-only). */
 int bbb_abi_version(void);

@@ -36,7 +36,7 @@ class ConvDesc(ctypes.Structure):
                 ("kw", c_i32), ("stride_h", c_i32), ("stride_w", c_i32), ("pad_h", c_i32), ("pad_w", c_i32),
                 ("dil_h", c_i32), ("dil_w", c_i32), ("draws", c_i32), ("x_draw_stride", c_i64),
                 ("w_draw_stride", c_i64), ("b_draw_stride", c_i64), ("act", c_i32),
-                ("unit_div", c_i32), ("unit_off", c_i32), ("x_unit_mod", c_i32), ("b_offset", c_i32), ("reserved", c_i32)]
+                ("unit_div", c_i32), ("unit_off", c_i32), ("x_unit_mod", c_i32), ("w_row_pitch", c_i32), ("b_offset", c_i32)]
 
 
 _SIGNATURES = {
@@ -58,6 +58,7 @@ _SIGNATURES = {
                                   c_void_p]),
     "bbb_lrt_sample_nchw": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_u64, c_u32, c_u32, c_void_p, c_void_p]),
     "bbb_maxpool_chwn": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "bbb_pool_act_bwd_chwn": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "bbb_conv2d_chwn_bf16_fwd": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_u32, c_void_p]),
     "bbb_maxpool_chwn_bf16": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "bbb_nchw_to_chwn_bf16": (c_int, [c_void_p, c_void_p, c_int, c_i64, c_void_p]),
@@ -66,6 +67,8 @@ _SIGNATURES = {
     "bbb_mc_tail_units": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "bbb_uncertainty": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "bbb_transpose2d": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_void_p]),
+    "bbb_im2col_pbj": (c_int, [c_void_p, c_void_p, ctypes.POINTER(ConvDesc), c_void_p]),
+    "bbb_transpose_batched": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_void_p]),
     "bbb_abi_version": (c_int, []),
     "bbb_build_info": (ctypes.c_char_p, []),
 }

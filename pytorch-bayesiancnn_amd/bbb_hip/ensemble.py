@@ -29,6 +29,7 @@ except ImportError as e:  # pragma: no cover
     raise ImportError("bbb_hip.ensemble needs the sibling `layers` package on sys.path") from e
 
 
+fast_autograd = True      # False: training forwards take the reference-layout autograd path (tests compare the two)
 stats = {"path": None}   # which layout the last mc_logits / mc_forward took: "chwn" (batch-innermost fast path) or "nchw"
 
 
@@ -608,6 +609,15 @@ def _local_lse(net, x, draws, seed, call0, mean_over, fuse_act=True, timers=None
             return lse, out[1]
     if precision != "fp32":
         raise _lib.BBBHipError("this model / input does not fit the batch-innermost path, which is the only bf16 path")
+    if fuse_act and fast_autograd and torch.is_grad_enabled() and timers is None:
+        from . import fast_train
+        if fast_train.train_path_ok(net, x):
+            # training on the batch-innermost kernels: one autograd node for the whole batched forward
+            logits_cb, kl1 = fast_train.mc_logits_autograd(net, x, draws, seed, call0)
+            stats["path"] = "chwn-autograd"
+            lse = torch.logsumexp(F.log_softmax(logits_cb.permute(0, 2, 1), dim=2), dim=0) \
+                - (math.log(mean_over) if mean_over > 0 else 0.0)
+            return lse, kl1
     logits, kl1 = mc_logits(net, x, draws, seed, call0, fuse_act=fuse_act, timers=timers, layout="nchw")
     if torch.is_grad_enabled() and logits.requires_grad:
         # training extension: differentiable tail through torch ops

@@ -776,3 +776,155 @@ def lrt_conv2d(x, w_mu, w_var, b_mu, b_var, seed, call0, stream_id, stride=1, pa
         return lrt_conv2d_forward(x, w_mu, w_var, b_mu, b_var, seed, call0, stream_id, stride, padding, dilation,
                                   sample=sample, eps=eps)[0]
     return _LrtConv2d.apply(x, w_mu, w_var, b_mu, b_var, cfg)
+
+
+# ------------------------------------------------------------------------------------------------
+# batch-innermost backward helpers (training on the fast path, bbb_hip/fast_train.py)
+# ------------------------------------------------------------------------------------------------
+def pool_act_backward_chwn(g_out, y, k, s, act):
+    """Backward of [fused activation -> MaxPool2d(k, s)] (k = 0: activation only) on [..., H, W, B] planes: gradient w.r.t.
+    the layer's pre-activation from the gradient w.r.t. the (pooled) output and the ACTIVATED output y (bbb_pool_act_bwd_chwn)."""
+    require_device(g_out, y)
+    g_out, y = g_out.contiguous(), y.contiguous()
+    *lead, H, W, B = y.shape
+    planes = 1
+    for v in lead:
+        planes *= v
+    g_pre = torch.empty_like(y)
+    with torch.cuda.device(y.device):
+        check(_lib.lib().bbb_pool_act_bwd_chwn(g_out.data_ptr(), y.data_ptr(), g_pre.data_ptr(), planes, H, W, B, int(k), int(s),
+                                               ACT_CODE[act], cur_stream(y.device)), "bbb_pool_act_bwd_chwn")
+    return g_pre
+
+
+def conv2d_chwn_input_grad(g_pre, w, x_hw, padding, dilation):
+    """d loss / d x of a STRIDE-1 y = conv(x, w) in the batch-innermost layout, on the forward kernel itself: the convolution
+    of g_pre [E, Cout, Ho, Wo, B] with the spatially flipped, channel-transposed weights, padding d*(k-1) - p.
+    w [E, Cout, Cin, kh, kw] -> [E, Cin, H, W, B]."""
+    (ph, pw), (dh, dw) = _pair(padding), _pair(dilation)
+    kh, kw = w.shape[3], w.shape[4]
+    qh, qw = dh * (kh - 1) - ph, dw * (kw - 1) - pw
+    if qh < 0 or qw < 0:
+        raise _lib.BBBHipError("conv2d_chwn_input_grad: padding larger than the kernel reach")
+    w_t = w.flip(3, 4).transpose(1, 2).contiguous()                     # [E, Cin, Cout, kh, kw]
+    gx = conv2d_chwn_forward(g_pre, w_t, None, 1, (qh, qw), (dh, dw))
+    if gx.shape[2] != x_hw[0] or gx.shape[3] != x_hw[1]:
+        raise _lib.BBBHipError("conv2d_chwn_input_grad: geometry mismatch (stride-1 layers only)")
+    return gx
+
+
+def _transpose_batched(src, out, rows, cols, nb1, nb2, ib1, ib2, ir, ob1, ob2, oc):
+    nb = nb1 * nb2
+    if nb > 65535 or (rows + 31) // 32 > 65535:
+        return False
+    with torch.cuda.device(src.device):
+        check(_lib.lib().bbb_transpose_batched(src.data_ptr(), out.data_ptr(), rows, cols, nb1, nb2, ib1, ib2, ir, ob1, ob2, oc,
+                                               cur_stream(src.device)), "bbb_transpose_batched")
+    return True
+
+
+def chwn_to_bhwc(x):
+    """[E, C, H, W, B] -> [E, B, H, W, C] (the batch becomes the contraction channels, C the innermost axis)."""
+    E, C, H, W, B = x.shape
+    x = x.contiguous()
+    out = torch.empty((E, B, H, W, C), dtype=x.dtype, device=x.device)
+    HW = H * W
+    if not _transpose_batched(x, out, C, B, E, HW, C * HW * B, B, HW * B, B * HW * C, C, HW * C):
+        out = x.permute(0, 4, 2, 3, 1).contiguous()
+    return out
+
+
+def chwn_grad_as_weights(g):
+    """[E, Cout, Ho, Wo, B] -> [E, Cout, B, Ho, Wo] (the output gradient in the layout of a weight operand)."""
+    E, Co, Ho, Wo, B = g.shape
+    g = g.contiguous()
+    out = torch.empty((E, Co, B, Ho, Wo), dtype=g.dtype, device=g.device)
+    P_ = Ho * Wo
+    if not _transpose_batched(g, out, P_, B, E * Co, 1, P_ * B, 0, B, B * P_, 0, P_):
+        out = g.permute(0, 1, 4, 2, 3).contiguous()
+    return out
+
+
+def conv2d_chwn_weight_grad(g_pre, x, w_shape, stride, padding, dilation):
+    """d loss / d w in the batch-innermost layout, again on the forward kernel with the roles swapped: the batch becomes the
+    contraction channels, the layer's input channels the innermost ("image") axis, the output pixels the kernel taps:
+        gw[e][n][tap][ci] = sum_{b, opix} g_pre'[e][n][b][opix] * x'[e][b][ipix(tap, opix)][ci]
+    with x' = x as [E|1, B, H, W, Cin], g_pre' = g_pre as [E, Cout, B, Ho, Wo], stride <-> dilation swapped.  Padding taps
+    are skipped as in the forward.  Needs Cin % 4 == 0 (the innermost axis moves as 16-byte vectors); x may be shared by all
+    draws ([1, ...]).  A launch that would occupy fewer than 512 workgroups (one draw of a small model) splits the batch into
+    S chunks that run as extra draws and are summed in a fixed order.  g_pre [E, Cout, Ho, Wo, B], x [E|1, Cin, H, W, B] ->
+    [E, Cout, Cin, kh, kw]."""
+    (sh, sw), (ph, pw), (dh, dw) = _pair(stride), _pair(padding), _pair(dilation)
+    Ew, Cout, Cin, kh, kw = w_shape
+    if Cin % 4 != 0:
+        raise _lib.BBBHipError("conv2d_chwn_weight_grad needs Cin % 4 == 0")
+    E, B = g_pre.shape[0], g_pre.shape[4]
+    xr = chwn_to_bhwc(x)                                                # [E|1, B, H, W, Cin]
+    gr = chwn_grad_as_weights(g_pre)                                    # [E, Cout, B, Ho, Wo]
+    wgs = E * kh * kw * -(-Cout // 64) * -(-Cin // 64)
+    S = 1
+    while wgs * S < 512 and B % (2 * S) == 0 and B // (2 * S) >= 8:
+        S *= 2
+    if S > 1:
+        if xr.shape[0] == 1 and E > 1:
+            xr = xr.expand(E, *xr.shape[1:])
+        xr = xr.reshape(xr.shape[0] * S, B // S, *xr.shape[2:])
+        gr = gr.reshape(E, Cout, S, B // S, *gr.shape[3:]).permute(0, 2, 1, 3, 4, 5).reshape(E * S, Cout, B // S, *gr.shape[3:])
+    y = conv2d_chwn_forward(xr, gr, None, (dh, dw), (ph, pw), (sh, sw))  # [E*S, Cout, kh', kw', Cin], kh' >= kh
+    if S > 1:
+        y = y.reshape(E, S, *y.shape[1:]).sum(1)
+    return y[:, :, :kh, :kw, :].permute(0, 1, 4, 2, 3).contiguous()
+
+
+def conv2d_chwn_weight_grad_shared_input(g_pre, x_nchw, w_shape, stride, padding, dilation):
+    """Weight gradient of a layer whose INPUT is the same for every draw (a model's first layer; 3-channel images do not fit
+    the role-swapped launch, whose innermost axis would be Cin).  The draws stack into the row dimension instead:
+        GW[(e, n)][j] = sum_k G[(e, n)][k] * Xcol[k][j],   k = (output pixel, image), j = (ci, r, q)
+    -- g_pre's own memory IS the [E*Cout, K] matrix G, Xcol is the im2col of the shared input (built once: F.unfold + one
+    permute), and the product runs on the forward kernel as a 1x1 "convolution" with K as the contraction channels and j as
+    the innermost axis, K split into S slices that run as the launch's draws (w_row_pitch lets a slice of G's rows be read in
+    place) and are summed in a fixed order.  g_pre [E, Cout, Ho, Wo, B], x_nchw [B, Cin, H, W] -> [E, Cout, Cin, kh, kw]."""
+    E, Cout, Ho, Wo, B = g_pre.shape
+    _, _, Cin, kh, kw = w_shape
+    g_pre = g_pre.contiguous()
+    x_nchw = x_nchw.contiguous()
+    dd, ho, wo = _desc(x_nchw.unsqueeze(0), torch.empty((1, Cout, Cin, kh, kw), device="meta"), stride, padding, dilation, 1, False,
+                       False, None)
+    if (ho, wo) != (Ho, Wo) or x_nchw.shape[0] != B:
+        raise _lib.BBBHipError("conv2d_chwn_weight_grad_shared_input: geometry mismatch")
+    J, P_ = Cin * kh * kw, Ho * Wo
+    Jp = (J + 3) // 4 * 4
+    K = P_ * B
+    xk = torch.empty((P_, B, Jp), dtype=torch.float32, device=g_pre.device)
+    with torch.cuda.device(g_pre.device):
+        check(_lib.lib().bbb_im2col_pbj(x_nchw.data_ptr(), xk.data_ptr(), ctypes.byref(dd), cur_stream(g_pre.device)), "bbb_im2col_pbj")
+    M = E * Cout
+    wgs = -(-M // 64) * -(-Jp // 64)
+    S = 1
+    while wgs * S < 768 and K % (2 * S) == 0 and (K // (2 * S)) % 4 == 0 and K // (2 * S) >= 256:
+        S *= 2
+    Ks = K // S
+    d = ConvDesc()
+    d.batch, d.cin, d.h, d.w, d.cout, d.kh, d.kw = Jp, Ks, 1, 1, M, 1, 1
+    d.stride_h = d.stride_w = d.dil_h = d.dil_w = 1
+    d.pad_h = d.pad_w = 0
+    d.draws = S
+    d.x_draw_stride = Ks * Jp
+    d.w_draw_stride = Ks
+    d.b_draw_stride = 0
+    d.act = 0
+    # G's rows are K floats apart -- 128 KiB for 64 pixels x 512 images, a power of two: the 64 rows of a weight tile would all
+    # sit in the same memory channel (measured: the launch ran 10x slower).  One copy into rows of pitch K + 32 fixes that.
+    pitch = K + 32 if (K & (K - 1)) == 0 or K % 1024 == 0 else K
+    if pitch != K:
+        gp = torch.empty((M, pitch), dtype=torch.float32, device=g_pre.device)
+        gp[:, :K] = g_pre.view(M, K)
+    else:
+        gp = g_pre
+    d.w_row_pitch = pitch
+    y = torch.empty((S, M, Jp), dtype=torch.float32, device=g_pre.device)
+    with torch.cuda.device(g_pre.device):
+        check(_lib.lib().bbb_conv2d_chwn_fwd(ctypes.byref(d), xk.data_ptr(), gp.data_ptr(), 0, y.data_ptr(),
+                                             cur_stream(g_pre.device)), "bbb_conv2d_chwn_fwd")
+    gw = y.sum(0) if S > 1 else y[0]
+    return gw[:, :J].reshape(E, Cout, Cin, kh, kw)

@@ -177,6 +177,54 @@ __global__ __launch_bounds__(256) void transpose2d_kernel(const float* __restric
     }
 }
 
+// im2col of an NCHW batch into the operand of the first layer's weight-gradient GEMM (training extension):
+//   out[(p*B + b)*Jp + j] = x[b][ci][oh*s - pad + r*d][ow*s - pad + q*d]   (0 outside the image and for the pad columns j >= J)
+// with p = oh*Wo + ow and j = (ci*kh + r)*kw + q.  One thread per output element, j innermost (coalesced writes; the 6 MB
+// input stays in L2).
+__global__ __launch_bounds__(256) void im2col_pbj_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t total, int B,
+                                                         int Cin, int H, int W, int Wo, int kh, int kw, int sh, int sw, int ph,
+                                                         int pw, int dh, int dw, int J, int Jp) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int j = (int)(i % Jp);
+    int64_t t = i / Jp;
+    const int b = (int)(t % B);
+    const int p = (int)(t / B);
+    float v = 0.0f;
+    if (j < J) {
+        const int q = j % kw, r = (j / kw) % kh, ci = j / (kw * kh);
+        const int oh = p / Wo, ow = p - oh * Wo;
+        const int ih = oh * sh - ph + r * dh, iw = ow * sw - pw + q * dw;
+        if (ih >= 0 && ih < H && iw >= 0 && iw < W) v = x[(((int64_t)b * Cin + ci) * H + ih) * W + iw];
+    }
+    out[i] = v;
+}
+
+// Batched strided transpose (training extension: the operand permutations of the role-swapped weight-gradient launch):
+//   out[i1*ob1 + i2*ob2 + c*oc + r] = in[i1*ib1 + i2*ib2 + r*ir + c],  r < R, c < C, (i1, i2) < (nb1, nb2)
+// i.e. every batch entry is an [R][C] matrix with contiguous columns that lands as a [C][R] matrix with contiguous rows.
+__global__ __launch_bounds__(256) void transpose_batched_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int Cc,
+                                                                int nb2, int64_t ib1, int64_t ib2, int64_t ir, int64_t ob1,
+                                                                int64_t ob2, int64_t oc) {
+    __shared__ float tile[32][33];
+    const int i1 = blockIdx.z / nb2, i2 = blockIdx.z - i1 * nb2;
+    const float* src = in + i1 * ib1 + i2 * ib2;
+    float* dst = out + i1 * ob1 + i2 * ob2;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + i * 8, c = c0 + tx;
+        if (r < R && c < Cc) tile[ty + i * 8][tx] = src[(int64_t)r * ir + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + i * 8, r = r0 + tx;
+        if (r < R && c < Cc) dst[(int64_t)c * oc + r] = tile[tx][ty + i * 8];
+    }
+}
+
 // y[e] = act(act_mu + sqrt(act_var) * eps[e]) for E draws of ONE pair of LRT moments (batch-innermost layout).  Used when the
 // input of an LRT layer is shared by all draws (the first layer): the two contractions run once, only the noise differs.
 // eps element index = the canonical NCHW index ((b*C + n)*HW + pix) of draw e's output, as in the GEMM epilogue; one
@@ -322,5 +370,33 @@ extern "C" int bbb_lrt_sample_nchw(const float* act_mu, const float* act_var, fl
     if (blocks > 0x7fffffffLL) return BBB_ESHAPE;
     hipLaunchKernelGGL(lrt_sample_nchw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, act_mu, act_var, y, n, draws,
                        (uint32_t)seed, (uint32_t)(seed >> 32), call0, stream_id, call_dev);
+    return (int)hipGetLastError();
+}
+
+extern "C" int bbb_transpose_batched(const float* in, float* out, int rows, int cols, int nb1, int nb2, int64_t in_b1, int64_t in_b2,
+                                     int64_t in_row, int64_t out_b1, int64_t out_b2, int64_t out_col, void* stream) {
+    if (in == nullptr || out == nullptr || rows <= 0 || cols <= 0 || nb1 <= 0 || nb2 <= 0) return BBB_EINVAL;
+    if ((((uintptr_t)in | (uintptr_t)out) & 3u) != 0) return BBB_EALIGN;
+    const int64_t nb = (int64_t)nb1 * nb2, gy = (rows + 31) / 32;
+    if (nb > 65535 || gy > 65535) return BBB_ESHAPE;
+    hipLaunchKernelGGL(transpose_batched_kernel, dim3((cols + 31) / 32, (unsigned)gy, (unsigned)nb), dim3(256), 0, (hipStream_t)stream, in, out,
+                       rows, cols, nb2, in_b1, in_b2, in_row, out_b1, out_b2, out_col);
+    return (int)hipGetLastError();
+}
+
+extern "C" int bbb_im2col_pbj(const float* x, float* out, const bbb_conv_desc_t* d, void* stream) {
+    if (x == nullptr || out == nullptr || d == nullptr || d->batch <= 0 || d->cin <= 0 || d->h <= 0 || d->w <= 0 || d->kh <= 0 ||
+        d->kw <= 0 || d->stride_h <= 0 || d->stride_w <= 0 || d->pad_h < 0 || d->pad_w < 0 || d->dil_h <= 0 || d->dil_w <= 0)
+        return BBB_EINVAL;
+    if ((((uintptr_t)x | (uintptr_t)out) & 3u) != 0) return BBB_EALIGN;
+    const int ho = (d->h + 2 * d->pad_h - d->dil_h * (d->kh - 1) - 1) / d->stride_h + 1;
+    const int wo = (d->w + 2 * d->pad_w - d->dil_w * (d->kw - 1) - 1) / d->stride_w + 1;
+    if (ho <= 0 || wo <= 0) return BBB_ESHAPE;
+    const int J = d->cin * d->kh * d->kw, Jp = (J + 3) / 4 * 4;
+    const int64_t total = (int64_t)ho * wo * d->batch * Jp;
+    const int64_t blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffffLL) return BBB_ESHAPE;
+    hipLaunchKernelGGL(im2col_pbj_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, out, total, d->batch, d->cin,
+                       d->h, d->w, wo, d->kh, d->kw, d->stride_h, d->stride_w, d->pad_h, d->pad_w, d->dil_h, d->dil_w, J, Jp);
     return (int)hipGetLastError();
 }

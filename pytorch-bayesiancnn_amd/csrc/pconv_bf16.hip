@@ -488,7 +488,7 @@ extern "C" int bbb_conv2d_chwn_bf16_fwd(const bbb_conv_desc_t* d, const void* x,
     a.x_inv = x_inv;
     a.wtap = tap_major ? 1 : 0;
     if (d->unit_div < 0 || d->unit_off < 0 || d->x_unit_mod < 0 || (d->unit_div > 1 && d->unit_off >= d->unit_div) ||
-        (d->x_unit_mod > 0 && d->x_unit_mod != d->unit_div))
+        (d->x_unit_mod > 0 && d->x_unit_mod != d->unit_div) || d->w_row_pitch != 0)
         return BBB_EINVAL;
     a.unit_div = d->unit_div; a.unit_off = d->unit_div > 1 ? d->unit_off : 0; a.x_mod = d->x_unit_mod;
     // tile shape: LDS-pipe cycles per unit of useful work (see the kernel comment), including the waste of ragged

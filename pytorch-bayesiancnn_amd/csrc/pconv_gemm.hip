@@ -105,7 +105,7 @@ __global__ __launch_bounds__(kThreads) void pconv_gemm_kernel(const PConvArgs p)
     constexpr uint32_t kOOB = 0xFFFFFFF0u;
     constexpr uint32_t kWInv = 0x7FFFFFF0u;    // invalid weight k: slab bytes < 2^30, so row + kWInv is out of range
     const uint32_t kXInv = p.x_inv;            // invalid x row: + column bytes (< one row) neither wraps nor lands in range
-    const int64_t w_elems = (int64_t)p.Cout * p.K;
+    const int64_t w_elems = (int64_t)p.Cout * p.Kp;                  // Kp = weight row pitch (= K unless the caller passed one)
     const int64_t x_elems = (int64_t)p.Cin * p.H * p.W * p.B;
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.x + (int64_t)ex * p.x_ds), 0, (int)(x_elems * 4), 0x00020000);
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(kThreads) void pconv_gemm_kernel(const PConvArgs p)
     const uint32_t xcol = (uint32_t)(b0 + xb4) * 4u;                 // byte offset of this lane's 4 images in a row
     uint32_t wrow[8];                                                // byte offset of this lane's 8 channel rows
 #pragma unroll
-    for (int ps = 0; ps < 8; ++ps) wrow[ps] = (uint32_t)(n0 + wnl + ps * 8) * (uint32_t)p.K * 4u;
+    for (int ps = 0; ps < 8; ++ps) wrow[ps] = (uint32_t)(n0 + wnl + ps * 8) * (uint32_t)p.Kp * 4u;
 
     float wregA[WSETS][8];
     f32x4 xregA[XPASS];
@@ -339,6 +339,63 @@ __global__ __launch_bounds__(256) void maxpool_chwn_kernel(const float* __restri
     reinterpret_cast<f32x4*>(y)[i] = m;
 }
 
+// Backward of [activation -> MaxPool2d(k, s)] (or of the activation alone, k = 0) in the batch-innermost layout -- training
+// extension.  Gather form, one thread per (plane, h, w, 4 images) of the layer's activated output y:
+//   g_act(h, w) = sum over the pooling windows that contain (h, w) of g_out(window) if (h, w) is that window's FIRST maximum
+//                 in scan order (torch's max_pool2d backward routes the gradient to the first argmax), else 0;
+//   g_pre = g_act * act'(pre-activation), written from y alone: Softplus' = sigmoid(v) = 1 - exp(-y), ReLU' = [y > 0].
+// Overlapping windows (k > s: Bayesian3Conv3FC pools 3x3 / 2) make up to ceil(k/s)^2 windows per element; nothing is
+// scattered, so no atomics and a deterministic result.
+__global__ __launch_bounds__(256) void pool_act_bwd_chwn_kernel(const float* __restrict__ g_out, const float* __restrict__ y,
+                                                                float* __restrict__ g_pre, int64_t total4, int H, int W, int Hp,
+                                                                int Wp, int B4, int k, int s, int act) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total4) return;
+    const int b4 = (int)(i % B4);
+    int64_t t = i / B4;
+    const int w = (int)(t % W);
+    t /= W;
+    const int h = (int)(t % H);
+    const int64_t pl = t / H;
+    const f32x4* yp = reinterpret_cast<const f32x4*>(y) + pl * H * W * B4 + b4;
+    const f32x4 me = yp[((int64_t)h * W + w) * B4];
+    f32x4 g = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (k == 0) {
+        g = reinterpret_cast<const f32x4*>(g_out)[i];
+    } else {
+        const f32x4* gp = reinterpret_cast<const f32x4*>(g_out) + pl * Hp * Wp * B4 + b4;
+        // windows (ph, pw) with ph*s <= h < ph*s + k
+        const int ph_lo = h - k + 1 > 0 ? (h - k + 1 + s - 1) / s : 0, ph_hi = h / s < Hp - 1 ? h / s : Hp - 1;
+        const int pw_lo = w - k + 1 > 0 ? (w - k + 1 + s - 1) / s : 0, pw_hi = w / s < Wp - 1 ? w / s : Wp - 1;
+        for (int ph = ph_lo; ph <= ph_hi; ++ph)
+            for (int pw = pw_lo; pw <= pw_hi; ++pw) {
+                // am I the first maximum of this window?  (an earlier element >= me, or a later one > me, disqualifies)
+                bool first[4] = {true, true, true, true};
+                const int my = (h - ph * s) * k + (w - pw * s);
+                for (int a = 0; a < k; ++a)
+                    for (int c = 0; c < k; ++c) {
+                        const int idx = a * k + c;
+                        if (idx == my) continue;
+                        const f32x4 v = yp[((int64_t)(ph * s + a) * W + (pw * s + c)) * B4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) first[u] = first[u] && (idx < my ? v[u] < me[u] : v[u] <= me[u]);
+                    }
+                const f32x4 go = gp[((int64_t)ph * Wp + pw) * B4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) g[u] += first[u] ? go[u] : 0.0f;
+            }
+    }
+    f32x4 o;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        float d = 1.0f;
+        if (act == 1) d = me[u] > 0.0f ? 1.0f : 0.0f;
+        else if (act == 2) d = me[u] > 20.0f ? 1.0f : -expm1f(-me[u]);      // y = softplus(v) -> sigmoid(v) = 1 - exp(-y)
+        o[u] = g[u] * d;
+    }
+    reinterpret_cast<f32x4*>(g_pre)[i] = o;
+}
+
 int fill(const bbb_conv_desc_t* d, PConvArgs& a) {
     if (d == nullptr) return BBB_EINVAL;
     if (d->batch <= 0 || d->cin <= 0 || d->h <= 0 || d->w <= 0 || d->cout <= 0 || d->kh <= 0 || d->kw <= 0 ||
@@ -359,6 +416,9 @@ int fill(const bbb_conv_desc_t* d, PConvArgs& a) {
     a.B = d->batch; a.Cin = d->cin; a.H = d->h; a.W = d->w; a.Cout = d->cout; a.kh = d->kh; a.kw = d->kw;
     a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w; a.dh = d->dil_h; a.dw = d->dil_w;
     a.Ho = ho; a.Wo = wo; a.K = d->cin * d->kh * d->kw; a.khkw = d->kh * d->kw; a.act = d->act;
+    if (d->w_row_pitch < 0 || (d->w_row_pitch > 0 && d->w_row_pitch < a.K)) return BBB_EINVAL;
+    a.Kp = d->w_row_pitch > 0 ? d->w_row_pitch : a.K;
+    if (((int64_t)d->cout + 64) * a.Kp * 4 > 0x3FFFFFFFLL) return BBB_ESHAPE;
     a.x_ds = d->x_draw_stride; a.w_ds = d->w_draw_stride; a.b_ds = d->b_draw_stride;
     a.y_ds = (int64_t)d->cout * ho * wo * d->batch;
     if (d->unit_div < 0 || d->unit_off < 0 || d->x_unit_mod < 0 || d->b_offset < 0) return BBB_EINVAL;
@@ -447,5 +507,21 @@ extern "C" int bbb_maxpool_chwn(const float* x, float* y, int64_t planes, int h,
     if (blocks > 0x7fffffffLL) return BBB_ESHAPE;
     hipLaunchKernelGGL(maxpool_chwn_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, y, total4, h, w, ho, wo,
                        batch / 4, k, s);
+    return (int)hipGetLastError();
+}
+
+extern "C" int bbb_pool_act_bwd_chwn(const float* g_out, const float* y, float* g_pre, int64_t planes, int h, int w, int batch,
+                                     int k, int s, int act, void* stream) {
+    if (g_out == nullptr || y == nullptr || g_pre == nullptr || planes <= 0 || h <= 0 || w <= 0 || batch <= 0 || k < 0 ||
+        (k > 0 && s <= 0) || act < 0 || act > 2)
+        return BBB_EINVAL;
+    if (batch % 4 != 0 || (k > 0 && (h < k || w < k))) return BBB_ESHAPE;
+    if ((((uintptr_t)g_out | (uintptr_t)y | (uintptr_t)g_pre) & 15u) != 0) return BBB_EALIGN;
+    const int hp = k > 0 ? (h - k) / s + 1 : h, wp = k > 0 ? (w - k) / s + 1 : w;
+    const int64_t total4 = planes * h * w * (batch / 4);
+    const int64_t blocks = (total4 + 255) / 256;
+    if (blocks > 0x7fffffffLL) return BBB_ESHAPE;
+    hipLaunchKernelGGL(pool_act_bwd_chwn_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g_out, y, g_pre, total4, h, w,
+                       hp, wp, batch / 4, k, s, act);
     return (int)hipGetLastError();
 }

@@ -88,6 +88,16 @@ def fast_forward(wrapper, x):
     layers = [m for m in mods if isinstance(m, BayesianLayer)]
     if any(l.eps_source is not None for l in layers) or not all(l.W_mu.is_cuda for l in layers):
         return None
+    if torch.is_grad_enabled() and any(p.requires_grad for p in wrapper.parameters()):
+        # training / the reference's validate loop (which does not disable autograd): the same kernels behind ONE autograd node
+        from bbb_hip import fast_train
+        if not ensemble.fast_autograd or not fast_train.train_path_ok(wrapper, x):
+            return None
+        seed, call = rng.next_calls(1)
+        logits, kl = fast_train.mc_logits_autograd(wrapper, x, 1, seed, call)
+        for l in layers:
+            l._kl = None
+        return logits[0].t(), kl
     if not ensemble._chwn_ok(wrapper, x):
         return None
     seed, call = rng.next_calls(1)

@@ -1,0 +1,180 @@
+"""Training on the batch-innermost kernels (bbb_hip/fast_train.py): gradients against the reference-layout autograd path and
+against torch autograd in float64, the pooling / activation backward kernel, and a 3-iteration BayesianAlexNet training run
+against the CPU port of the reference's loop (main_bayesian.py:36-62) fed with the device's own Philox noise.  Run with -m gpu."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import bbb_numpy as O
+import ref_port_torch as P
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import layers  # noqa: F401
+    from bbb_hip import ops, rng, ensemble, zoo, train, fast_train
+    return dict(ops=ops, rng=rng, ens=ensemble, zoo=zoo, train=train, ft=fast_train)
+
+
+@pytest.mark.parametrize("k,s,act,H", [(2, 2, "softplus", 8), (3, 2, "relu", 9), (3, 2, "softplus", 7), (0, 1, "relu", 5),
+                                       (2, 2, None, 6), (0, 1, "softplus", 4)])
+def test_pool_act_backward_kernel_vs_torch(env, k, s, act, H):
+    g = torch.Generator(device="cuda").manual_seed(k * 10 + H)
+    planes, B = 6, 12
+    v = torch.randn(planes, H, H, B, device="cuda", generator=g) * 2
+    if act == "relu":
+        v[:, :2] = -v[:, :2].abs()                          # whole rows of exact zeros after ReLU: ties inside windows
+    vt = v.permute(3, 0, 1, 2).contiguous().double().requires_grad_(True)      # [B, planes, H, W] for torch
+    a = F.softplus(vt) if act == "softplus" else (F.relu(vt) if act == "relu" else vt)
+    out = F.max_pool2d(a, k, s) if k else a
+    go = torch.randn(out.shape, device="cuda", generator=g, dtype=torch.float64)
+    out.backward(go)
+    y = (F.softplus(v) if act == "softplus" else (F.relu(v) if act == "relu" else v)).contiguous()
+    g_out = go.float().permute(1, 2, 3, 0).contiguous()
+    got = env["ops"].pool_act_backward_chwn(g_out, y, k, s, act)
+    want = vt.grad.permute(1, 2, 3, 0).float()
+    np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("Cin,Cout,kk,pad,H", [(8, 12, 3, 1, 6), (64, 32, 5, 2, 4), (16, 10, 1, 0, 1)])
+def test_chwn_wgrad_dgrad_vs_torch_float64(env, Cin, Cout, kk, pad, H):
+    ops = env["ops"]
+    g = torch.Generator(device="cuda").manual_seed(Cin)
+    E, B = 2, 8
+    x = torch.randn(E, Cin, H, H, B, device="cuda", generator=g)
+    w = torch.randn(E, Cout, Cin, kk, kk, device="cuda", generator=g) * 0.2
+    gy = torch.randn(E, Cout, H + 2 * pad - kk + 1, H + 2 * pad - kk + 1, B, device="cuda", generator=g)
+    gw = ops.conv2d_chwn_weight_grad(gy, x, tuple(w.shape), 1, pad, 1)
+    gx = ops.conv2d_chwn_input_grad(gy, w, (H, H), pad, 1)
+    for e in range(E):
+        xt = x[e].permute(3, 0, 1, 2).double().requires_grad_(True)
+        wt = w[e].double().requires_grad_(True)
+        y = F.conv2d(xt, wt, None, 1, pad)
+        y.backward(gy[e].permute(3, 0, 1, 2).double())
+        np.testing.assert_allclose(gw[e].cpu().numpy(), wt.grad.float().cpu().numpy(), rtol=2e-4, atol=2e-4)
+        np.testing.assert_allclose(gx[e].cpu().numpy(), xt.grad.permute(1, 2, 3, 0).float().cpu().numpy(), rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("net_type,cin,B", [("alexnet", 3, 16), ("3conv3fc", 3, 8), ("alexnet", 3, 64)])
+def test_fast_autograd_matches_reference_layout_autograd(env, net_type, cin, B):
+    """Same noise, same loss: every parameter gradient of the fast path equals the reference-layout path's.
+    (BayesianLeNet's second conv has 6 input channels: not a multiple of 4, so it stays on the reference-layout path.)"""
+    ens = env["ens"]
+    torch.manual_seed(1)
+    net = env["zoo"].getModel(net_type, cin, 10, P.CONFIG_PRIORS, "bbb", "softplus").cuda()
+    env["rng"].assign_stream_ids(net)
+    x = torch.rand(B, cin, 32, 32, device="cuda")
+    y = torch.randint(0, 10, (B,), device="cuda")
+    E = 3
+    grads = {}
+    for fast in (True, False):
+        ens.fast_autograd = fast
+        try:
+            net.zero_grad(set_to_none=True)
+            env["rng"].manual_seed(5, call=7)
+            lo, kl = ens.mc_forward(net, x, E, kl_mode="mean")
+            assert ens.stats["path"] == ("chwn-autograd" if fast else "nchw")
+            loss = F.nll_loss(lo, y) * 100.0 + 1e-6 * kl
+            loss.backward()
+            grads[fast] = ({n: p.grad.detach().clone() for n, p in net.named_parameters()}, lo.detach().clone(), kl.item())
+        finally:
+            ens.fast_autograd = True
+    ga, loa, kla = grads[True]
+    gb, lob, klb = grads[False]
+    assert kla == klb
+    np.testing.assert_allclose(loa.cpu().numpy(), lob.cpu().numpy(), rtol=2e-5, atol=2e-4)    # fused hw softplus vs torch softplus
+    for n in ga:
+        scale = float(gb[n].abs().max()) + 1e-12
+        err = float((ga[n] - gb[n]).abs().max()) / scale
+        assert err <= 2e-3, (n, err)
+
+
+def test_lenet_is_not_eligible_and_falls_back(env):
+    torch.manual_seed(1)
+    net = env["zoo"].getModel("lenet", 1, 10, P.CONFIG_PRIORS, "bbb", "softplus").cuda()
+    x = torch.rand(8, 1, 32, 32, device="cuda")
+    assert not env["ft"].train_path_ok(net, x)
+    lo, kl = env["ens"].mc_forward(net, x, 2, kl_mode="mean")
+    assert env["ens"].stats["path"] == "nchw" and lo.requires_grad
+
+
+def test_dropin_forward_with_autograd_uses_the_fast_kernels(env):
+    ens = env["ens"]
+    torch.manual_seed(2)
+    net = env["zoo"].getModel("alexnet", 3, 10, P.CONFIG_PRIORS, "bbb", "softplus").cuda()
+    env["rng"].assign_stream_ids(net)
+    x = torch.rand(16, 3, 32, 32, device="cuda")
+    env["rng"].manual_seed(9, call=0)
+    out, kl = net(x)                                            # autograd enabled: what train_model / validate_model do
+    assert out.requires_grad and kl.requires_grad
+    with torch.no_grad():
+        env["rng"].manual_seed(9, call=0)
+        out2, kl2 = net(x)
+    assert torch.equal(out.detach(), out2) and kl.item() == kl2.item()
+    (out.sum() + 1e-6 * kl).backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+
+
+def test_alexnet_training_iterations_vs_cpu_port(env):
+    """3 iterations of the reference's batch loop (main_bayesian.py:40-58) on BayesianAlexNet, num_ens = 2: the GPU fast path
+    (train.train_step + FusedAdam) vs the CPU port with torch.optim.Adam, both consuming the SAME Philox noise."""
+    T = env["train"]
+    torch.manual_seed(3)
+    net = env["zoo"].getModel("alexnet", 3, 10, P.CONFIG_PRIORS, "bbb", "softplus").cuda()
+    env["rng"].assign_stream_ids(net)
+    names = [n for n, m in net.named_children() if hasattr(m, "W_mu")]
+    params = {"_prior_mu": 0, "_prior_sigma": 0.1}
+    sid = {}
+    for n in names:
+        m = getattr(net, n)
+        params[n] = {k: getattr(m, k).detach().cpu().clone() for k in ("W_mu", "W_rho", "bias_mu", "bias_rho")}
+        sid[n] = m._stream_base
+    g = torch.Generator().manual_seed(0)
+    B, E, NB = 16, 2, 3
+    batches = [(torch.rand(B, 3, 32, 32, generator=g), torch.randint(0, 10, (B,), generator=g)) for _ in range(NB)]
+    seed, call = 31, 0
+    env["rng"].manual_seed(seed, call=call)
+    opt = T.FusedAdam(net.parameters(), lr=1e-3)
+    losses = []
+    for xb, yb in batches:
+        loss, lo, kl = T.train_step(net, opt, xb.cuda(), yb.cuda(), E, 0.1, NB * B)
+        assert env["ens"].stats["path"] == "chwn-autograd"
+        losses.append(loss.item())
+    # CPU port, same noise calls: iteration i uses calls call + i*E + j
+    leaves = []
+    for n in names:
+        for k in ("W_mu", "W_rho", "bias_mu", "bias_rho"):
+            params[n][k].requires_grad_(True)
+            leaves.append(params[n][k])
+    copt = torch.optim.Adam(leaves, lr=1e-3)
+    KIND = {"W": 0, "bias": 1, "act": 2}
+    want = []
+    for i, (xb, yb) in enumerate(batches):
+        copt.zero_grad()
+        outs, klsum = [], 0.0
+        for j in range(E):
+            c = call + i * E + j
+            eps = lambda name, kind, shape, c=c: torch.from_numpy(
+                O.normal_eps(seed, c, sid[name] + KIND[kind], int(np.prod(shape))).reshape(shape))
+            lg, k = P.forward("alexnet", params, xb, "bbb", "softplus", eps_fn=eps)
+            outs.append(F.log_softmax(lg, dim=1))
+            klsum = klsum + k
+        lo = P.logmeanexp(torch.stack(outs, dim=2), 2)
+        loss = F.nll_loss(lo, yb) * (NB * B) + 0.1 * (klsum / E)
+        loss.backward()
+        copt.step()
+        want.append(loss.item())
+    print("[fast-train alexnet] losses gpu", losses, "cpu", want)
+    np.testing.assert_allclose(losses, want, rtol=2e-5)
+    for n in names:
+        m = getattr(net, n)
+        for k in ("W_mu", "W_rho", "bias_mu", "bias_rho"):
+            a, b = getattr(m, k).detach().cpu(), params[n][k].detach()
+            # after 3 Adam steps each element has moved by <= 3 * lr; the two runs may disagree where |g| ~ 1e-8 (sign flips)
+            assert float((a - b).abs().max()) <= 6.1e-3, (n, k)
+            assert float((a - b).abs().mean()) <= 2e-5, (n, k, float((a - b).abs().mean()))
