@@ -25,7 +25,7 @@ Prints ONE JSON line on rank 0 (contract in the task description) with these ext
   cpu_baseline      the reference's CPU nn.Module path timed on this host's cores (rank 0, N=1 only): the unmodified upstream
                     modules when /root/reference exists (kind "reference"), else the oracle's bit-identical torch-CPU port
                     (kind "port"); no_grad and autograd-enabled variants, median and p10/p90.
-  one_step_in_flight / stats / dropin_loop / configs   single-lane latency, block-time statistics, the unmodified-loop
+  one_step_in_flight / stats / dropin_loop / training_step / configs   single-lane latency, block-time statistics, the unmodified-loop
                     shape through the drop-in layers, and BASELINE.json's other configurations -- each with its own roofline.
 """
 import argparse
@@ -416,6 +416,28 @@ def dropin_loop(dev, steps):
                     "uses the batched ensemble entry point (all draws per launch, one hipGraph) instead"}
 
 
+def training_step(dev, steps):
+    """N1 (training extension), not the metric: one iteration of train_model's batch loop (main_bayesian.py:40-58) at the metric
+    shape -- 10 stochastic forwards of 512 images, KL, logmeanexp, ELBO, backward, Adam -- on the batch-innermost kernels with
+    ONE autograd node for the batched forward (bbb_hip/fast_train.py), eager launches."""
+    from bbb_hip import train, ensemble
+    cfg = CONFIGS["metric"]
+    net, x = build_net(cfg, dev)
+    y = torch.randint(0, cfg["classes"], (cfg["B"],), device=dev)
+    opt = train.FusedAdam(net.parameters(), lr=1e-3)
+    for _ in range(3):
+        train.train_step(net, opt, x, y, cfg["E"], 0.1, 50000.0)
+    path = ensemble.stats["path"]
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        train.train_step(net, opt, x, y, cfg["E"], 0.1, 50000.0)
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / steps
+    return {"ms_per_step": round(1e3 * dt, 4), "value": round(cfg["B"] * cfg["E"] / dt, 1), "unit": "samples/s (forward + backward + Adam)",
+            "path": path, "note": "BayesianAlexNet bs=512 num_ens=10, fp32; round 1 (reference-layout autograd path): 8.3 ms"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -530,6 +552,11 @@ def main():
                 out["dropin_loop"] = dropin_loop(dev, max(5, args.steps // 5))
             except Exception as exc:
                 out["dropin_loop"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:160])}
+            try:
+                out["training_step"] = training_step(dev, max(5, args.steps // 5))
+            except Exception as exc:
+                out["training_step"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:160])}
+            torch.cuda.empty_cache()
             others = {}
             for name, c in CONFIGS.items():
                 if name == args.config:

@@ -207,10 +207,12 @@ int bbb_maxpool_chwn(const float* x, float* y, int64_t planes, int h, int w, int
  *   g_out  [planes][hp][wp][B] gradient w.r.t. the pooled output (k = 0: same shape as y)
  *   g_pre  [planes][h][w][B]   gradient w.r.t. the pre-activation: the first maximum of every window receives that window's
  *                              gradient (torch's max_pool2d backward), times act'(.) recovered from y (Softplus: 1 - exp(-y)).
- * Gather formulation: deterministic, handles overlapping windows (k > s).
+ * Gather formulation: deterministic, handles overlapping windows (k > s).  out_plane_pitch (elements, multiple of 4; 0 = dense
+ * h*w*B): pitch between the planes of g_pre -- the first layer's gradient is written straight into the padded-row matrix its
+ * weight-gradient GEMM reads (rows of exactly 2^n bytes would all fall into one memory channel).
  */
 int bbb_pool_act_bwd_chwn(const float* g_out, const float* y, float* g_pre, int64_t planes, int h, int w, int batch,
-                          int k, int s, int act, void* stream);
+                          int k, int s, int act, int64_t out_plane_pitch, void* stream);
 
 /*
  * E noise draws from ONE pair of LRT moments, batch-innermost: y[e] = act(act_mu + sqrt(act_var) * eps[e]) with eps exactly
@@ -288,6 +290,10 @@ int bbb_transpose2d(const float* in, float* out, int64_t rows, int64_t cols, voi
  * c < cols, i1 < nb1, i2 < nb2 (nb1*nb2 <= 65535).  Training extension: operand layouts of the role-swapped weight gradient. */
 int bbb_transpose_batched(const float* in, float* out, int rows, int cols, int nb1, int nb2, int64_t in_b1, int64_t in_b2,
                           int64_t in_row, int64_t out_b1, int64_t out_b2, int64_t out_col, void* stream);
+
+/* Training extension: out [draws][cin][cout][kh*kw] = w [draws][cout][cin][kh*kw] with the taps reversed (spatial flip +
+ * channel transpose: the weights of the stride-1 input-gradient convolution). */
+int bbb_flip_transpose_w(const float* w, float* out, int64_t draws, int cout, int cin, int khkw, void* stream);
 
 /* Training extension: im2col of an NCHW batch x [batch][cin][h][w] (geometry from d; draws / strides / act ignored) into
  * out [ho*wo][batch][Jp], Jp = cin*kh*kw rounded up to 4 (pad columns zero): the K-major operand of the first layer's

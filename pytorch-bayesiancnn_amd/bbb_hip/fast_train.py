@@ -146,10 +146,11 @@ class _MCForward(torch.autograd.Function):
             if g is None:
                 break
             g = g.reshape(rec["out_shape"])
+            pad = rec["first"] and x_in.shape[1] % 4 != 0                # feeds conv2d_chwn_weight_grad_shared_input
             if rec["pool"] is not None:
-                g_pre = ops.pool_act_backward_chwn(g, y, rec["pool"][0], rec["pool"][1], act)
+                g_pre = ops.pool_act_backward_chwn(g, y, rec["pool"][0], rec["pool"][1], act, pad_planes=pad)
             elif act is not None:
-                g_pre = ops.pool_act_backward_chwn(g, y, 0, 1, act)
+                g_pre = ops.pool_act_backward_chwn(g, y, 0, 1, act, pad_planes=pad)
             else:
                 g_pre = g
             gws[2 * li + 1] = g_pre.sum(dim=(2, 3, 4))                    # bias gradient [E, Cout]

@@ -781,19 +781,32 @@ def lrt_conv2d(x, w_mu, w_var, b_mu, b_var, seed, call0, stream_id, stride=1, pa
 # ------------------------------------------------------------------------------------------------
 # batch-innermost backward helpers (training on the fast path, bbb_hip/fast_train.py)
 # ------------------------------------------------------------------------------------------------
-def pool_act_backward_chwn(g_out, y, k, s, act):
+def padded_plane_pitch(K):
+    """Row pitch for a [planes, K] matrix that a GEMM reads row-wise: K itself unless rows of K floats are a multiple of 4 KiB
+    apart (then every row of a 64-row tile would start in the same memory channel: measured 10x slower), else K + 32."""
+    return K + 32 if K % 1024 == 0 else K
+
+
+def pool_act_backward_chwn(g_out, y, k, s, act, pad_planes=False):
     """Backward of [fused activation -> MaxPool2d(k, s)] (k = 0: activation only) on [..., H, W, B] planes: gradient w.r.t.
-    the layer's pre-activation from the gradient w.r.t. the (pooled) output and the ACTIVATED output y (bbb_pool_act_bwd_chwn)."""
+    the layer's pre-activation from the gradient w.r.t. the (pooled) output and the ACTIVATED output y (bbb_pool_act_bwd_chwn).
+    pad_planes: return a view of y's shape into a [planes, padded_plane_pitch(H*W*B)] buffer (see there)."""
     require_device(g_out, y)
     g_out, y = g_out.contiguous(), y.contiguous()
     *lead, H, W, B = y.shape
     planes = 1
     for v in lead:
         planes *= v
-    g_pre = torch.empty_like(y)
+    K = H * W * B
+    pitch = padded_plane_pitch(K) if pad_planes else K
+    if pitch != K:
+        buf = torch.empty((planes, pitch), dtype=torch.float32, device=y.device)
+        g_pre = buf[:, :K].view(*lead, H, W, B)
+    else:
+        buf = g_pre = torch.empty_like(y)
     with torch.cuda.device(y.device):
-        check(_lib.lib().bbb_pool_act_bwd_chwn(g_out.data_ptr(), y.data_ptr(), g_pre.data_ptr(), planes, H, W, B, int(k), int(s),
-                                               ACT_CODE[act], cur_stream(y.device)), "bbb_pool_act_bwd_chwn")
+        check(_lib.lib().bbb_pool_act_bwd_chwn(g_out.data_ptr(), y.data_ptr(), buf.data_ptr(), planes, H, W, B, int(k), int(s),
+                                               ACT_CODE[act], pitch if pitch != K else 0, cur_stream(y.device)), "bbb_pool_act_bwd_chwn")
     return g_pre
 
 
@@ -806,7 +819,12 @@ def conv2d_chwn_input_grad(g_pre, w, x_hw, padding, dilation):
     qh, qw = dh * (kh - 1) - ph, dw * (kw - 1) - pw
     if qh < 0 or qw < 0:
         raise _lib.BBBHipError("conv2d_chwn_input_grad: padding larger than the kernel reach")
-    w_t = w.flip(3, 4).transpose(1, 2).contiguous()                     # [E, Cin, Cout, kh, kw]
+    w = w.contiguous()
+    E, Cout, Cin = w.shape[0], w.shape[1], w.shape[2]
+    w_t = torch.empty((E, Cin, Cout, kh, kw), dtype=torch.float32, device=w.device)   # flipped taps, channels transposed
+    with torch.cuda.device(w.device):
+        check(_lib.lib().bbb_flip_transpose_w(w.data_ptr(), w_t.data_ptr(), E, Cout, Cin, kh * kw, cur_stream(w.device)),
+              "bbb_flip_transpose_w")
     gx = conv2d_chwn_forward(g_pre, w_t, None, 1, (qh, qw), (dh, dw))
     if gx.shape[2] != x_hw[0] or gx.shape[3] != x_hw[1]:
         raise _lib.BBBHipError("conv2d_chwn_input_grad: geometry mismatch (stride-1 layers only)")
@@ -873,6 +891,12 @@ def conv2d_chwn_weight_grad(g_pre, x, w_shape, stride, padding, dilation):
     y = conv2d_chwn_forward(xr, gr, None, (dh, dw), (ph, pw), (sh, sw))  # [E*S, Cout, kh', kw', Cin], kh' >= kh
     if S > 1:
         y = y.reshape(E, S, *y.shape[1:]).sum(1)
+    if y.shape[2] == kh and y.shape[3] == kw:                           # [E, Cout, kh*kw, Cin] -> [E, Cout, Cin, kh*kw]
+        y = y.contiguous()
+        gw = torch.empty((E, Cout, Cin, kh, kw), dtype=torch.float32, device=y.device)
+        T = kh * kw
+        if _transpose_batched(y, gw, T, Cin, E * Cout, 1, T * Cin, 0, Cin, Cin * T, 0, T):
+            return gw
     return y[:, :, :kh, :kw, :].permute(0, 1, 4, 2, 3).contiguous()
 
 
@@ -886,7 +910,6 @@ def conv2d_chwn_weight_grad_shared_input(g_pre, x_nchw, w_shape, stride, padding
     place) and are summed in a fixed order.  g_pre [E, Cout, Ho, Wo, B], x_nchw [B, Cin, H, W] -> [E, Cout, Cin, kh, kw]."""
     E, Cout, Ho, Wo, B = g_pre.shape
     _, _, Cin, kh, kw = w_shape
-    g_pre = g_pre.contiguous()
     x_nchw = x_nchw.contiguous()
     dd, ho, wo = _desc(x_nchw.unsqueeze(0), torch.empty((1, Cout, Cin, kh, kw), device="meta"), stride, padding, dilation, 1, False,
                        False, None)
@@ -913,14 +936,17 @@ def conv2d_chwn_weight_grad_shared_input(g_pre, x_nchw, w_shape, stride, padding
     d.w_draw_stride = Ks
     d.b_draw_stride = 0
     d.act = 0
-    # G's rows are K floats apart -- 128 KiB for 64 pixels x 512 images, a power of two: the 64 rows of a weight tile would all
-    # sit in the same memory channel (measured: the launch ran 10x slower).  One copy into rows of pitch K + 32 fixes that.
-    pitch = K + 32 if (K & (K - 1)) == 0 or K % 1024 == 0 else K
-    if pitch != K:
-        gp = torch.empty((M, pitch), dtype=torch.float32, device=g_pre.device)
-        gp[:, :K] = g_pre.view(M, K)
-    else:
+    # G's rows must not be a multiple of 4 KiB apart (128 KiB for 64 pixels x 512 images: the 64 rows of a weight tile would
+    # all sit in the same memory channel).  pool_act_backward_chwn(pad_planes=True) already wrote g_pre at the padded pitch;
+    # anything else is copied once.
+    pitch = padded_plane_pitch(K)
+    if g_pre.is_contiguous() and pitch == K:
         gp = g_pre
+    elif g_pre.stride(1) == pitch and g_pre.stride(0) == Cout * pitch and g_pre[0, 0].is_contiguous():
+        gp = g_pre                                                     # a view into the padded [M, pitch] buffer
+    else:
+        gp = torch.empty((M, pitch), dtype=torch.float32, device=g_pre.device)
+        gp[:, :K] = g_pre.reshape(M, K)
     d.w_row_pitch = pitch
     y = torch.empty((S, M, Jp), dtype=torch.float32, device=g_pre.device)
     with torch.cuda.device(g_pre.device):

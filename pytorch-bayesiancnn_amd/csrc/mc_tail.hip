@@ -200,6 +200,21 @@ __global__ __launch_bounds__(256) void im2col_pbj_kernel(const float* __restrict
     out[i] = v;
 }
 
+// Weights of the input-gradient convolution (training extension): out[e][ci][n][r][q] = w[e][n][ci][kh-1-r][kw-1-q] -- the
+// spatial flip and the channel transpose of conv2d_chwn_input_grad in one pass (coalesced writes; reads hit L2).
+__global__ __launch_bounds__(256) void flip_transpose_w_kernel(const float* __restrict__ w, float* __restrict__ out, int64_t total,
+                                                               int Cout, int Cin, int khkw) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int t = (int)(i % khkw);
+    int64_t r = i / khkw;
+    const int n = (int)(r % Cout);
+    r /= Cout;
+    const int ci = (int)(r % Cin);
+    const int64_t e = r / Cin;
+    out[i] = w[((e * Cout + n) * Cin + ci) * khkw + (khkw - 1 - t)];
+}
+
 // Batched strided transpose (training extension: the operand permutations of the role-swapped weight-gradient launch):
 //   out[i1*ob1 + i2*ob2 + c*oc + r] = in[i1*ib1 + i2*ib2 + r*ir + c],  r < R, c < C, (i1, i2) < (nb1, nb2)
 // i.e. every batch entry is an [R][C] matrix with contiguous columns that lands as a [C][R] matrix with contiguous rows.
@@ -398,5 +413,15 @@ extern "C" int bbb_im2col_pbj(const float* x, float* out, const bbb_conv_desc_t*
     if (blocks > 0x7fffffffLL) return BBB_ESHAPE;
     hipLaunchKernelGGL(im2col_pbj_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, out, total, d->batch, d->cin,
                        d->h, d->w, wo, d->kh, d->kw, d->stride_h, d->stride_w, d->pad_h, d->pad_w, d->dil_h, d->dil_w, J, Jp);
+    return (int)hipGetLastError();
+}
+
+extern "C" int bbb_flip_transpose_w(const float* w, float* out, int64_t draws, int cout, int cin, int khkw, void* stream) {
+    if (w == nullptr || out == nullptr || draws <= 0 || cout <= 0 || cin <= 0 || khkw <= 0) return BBB_EINVAL;
+    if ((((uintptr_t)w | (uintptr_t)out) & 3u) != 0) return BBB_EALIGN;
+    const int64_t total = draws * cout * cin * khkw;
+    const int64_t blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffffLL) return BBB_ESHAPE;
+    hipLaunchKernelGGL(flip_transpose_w_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, out, total, cout, cin, khkw);
     return (int)hipGetLastError();
 }

@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void maxpool_chwn_kernel(const float* __restri
 // scattered, so no atomics and a deterministic result.
 __global__ __launch_bounds__(256) void pool_act_bwd_chwn_kernel(const float* __restrict__ g_out, const float* __restrict__ y,
                                                                 float* __restrict__ g_pre, int64_t total4, int H, int W, int Hp,
-                                                                int Wp, int B4, int k, int s, int act) {
+                                                                int Wp, int B4, int k, int s, int act, int64_t out_pitch4) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total4) return;
     const int b4 = (int)(i % B4);
@@ -393,7 +393,9 @@ __global__ __launch_bounds__(256) void pool_act_bwd_chwn_kernel(const float* __r
         else if (act == 2) d = me[u] > 20.0f ? 1.0f : -expm1f(-me[u]);      // y = softplus(v) -> sigmoid(v) = 1 - exp(-y)
         o[u] = g[u] * d;
     }
-    reinterpret_cast<f32x4*>(g_pre)[i] = o;
+    // out_pitch4 != 0: planes are written at that pitch (in 16-byte units) instead of densely -- see bbb_pool_act_bwd_chwn
+    const int64_t oi = out_pitch4 ? pl * out_pitch4 + (i - pl * (int64_t)H * W * B4) : i;
+    reinterpret_cast<f32x4*>(g_pre)[oi] = o;
 }
 
 int fill(const bbb_conv_desc_t* d, PConvArgs& a) {
@@ -511,17 +513,18 @@ extern "C" int bbb_maxpool_chwn(const float* x, float* y, int64_t planes, int h,
 }
 
 extern "C" int bbb_pool_act_bwd_chwn(const float* g_out, const float* y, float* g_pre, int64_t planes, int h, int w, int batch,
-                                     int k, int s, int act, void* stream) {
+                                     int k, int s, int act, int64_t out_plane_pitch, void* stream) {
     if (g_out == nullptr || y == nullptr || g_pre == nullptr || planes <= 0 || h <= 0 || w <= 0 || batch <= 0 || k < 0 ||
         (k > 0 && s <= 0) || act < 0 || act > 2)
         return BBB_EINVAL;
     if (batch % 4 != 0 || (k > 0 && (h < k || w < k))) return BBB_ESHAPE;
     if ((((uintptr_t)g_out | (uintptr_t)y | (uintptr_t)g_pre) & 15u) != 0) return BBB_EALIGN;
+    if (out_plane_pitch != 0 && (out_plane_pitch < (int64_t)h * w * batch || out_plane_pitch % 4 != 0)) return BBB_EINVAL;
     const int hp = k > 0 ? (h - k) / s + 1 : h, wp = k > 0 ? (w - k) / s + 1 : w;
     const int64_t total4 = planes * h * w * (batch / 4);
     const int64_t blocks = (total4 + 255) / 256;
     if (blocks > 0x7fffffffLL) return BBB_ESHAPE;
     hipLaunchKernelGGL(pool_act_bwd_chwn_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g_out, y, g_pre, total4, h, w,
-                       hp, wp, batch / 4, k, s, act);
+                       hp, wp, batch / 4, k, s, act, out_plane_pitch / 4);
     return (int)hipGetLastError();
 }

@@ -42,6 +42,7 @@ def test_bench_json_contract_default():
     st = j["stats"]
     assert st["p10"] <= st["median"] <= st["p90"]
     assert "error" not in j["dropin_loop"] and j["dropin_loop"]["value"] > 0
+    assert "error" not in j["training_step"] and j["training_step"]["path"] == "chwn-autograd"
     # every other BASELINE configuration is measured, each with its own roofline
     assert set(j["configs"]) == {"configs[1]", "configs[2]", "configs[3]", "configs[4]"}
     for name, c in j["configs"].items():

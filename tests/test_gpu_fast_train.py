@@ -37,6 +37,8 @@ def test_pool_act_backward_kernel_vs_torch(env, k, s, act, H):
     y = (F.softplus(v) if act == "softplus" else (F.relu(v) if act == "relu" else v)).contiguous()
     g_out = go.float().permute(1, 2, 3, 0).contiguous()
     got = env["ops"].pool_act_backward_chwn(g_out, y, k, s, act)
+    got_p = env["ops"].pool_act_backward_chwn(g_out, y, k, s, act, pad_planes=True)
+    assert torch.equal(got, got_p)
     want = vt.grad.permute(1, 2, 3, 0).float()
     np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=2e-6)
 
