@@ -409,8 +409,8 @@ def dropin_loop(dev, steps):
     dt_ag = timed(torch.enable_grad())
     return {"value": round(B * E / dt_ng, 1), "unit": "samples/s", "ms_per_step": round(1e3 * dt_ng, 4),
             "autograd_enabled": {"value": round(B * E / dt_ag, 1), "ms_per_step": round(1e3 * dt_ag, 4),
-                                 "note": "what the UNMODIFIED validate_model gets: it does not disable autograd, so the forwards "
-                                         "run on the reference-layout kernels (conv_gemm_kernel) and record an autograd graph"},
+                                 "note": "what the UNMODIFIED validate_model gets: it does not disable autograd, so every forward "
+                                         "also records one autograd node (same batch-innermost kernels, bbb_hip/fast_train.py)"},
             "note": "for j in range(10): net(x) through the drop-in layers + torch log_softmax / logmeanexp, eager launches.  Under "
                     "torch.no_grad() each net(x) runs on the batch-innermost inference kernels (one draw per call); the headline "
                     "uses the batched ensemble entry point (all draws per launch, one hipGraph) instead"}
