@@ -28,53 +28,57 @@ def _layers():
 
 
 def train_path_ok(net, x):
-    """The fast autograd path covers: a 4-d CUDA fp32 batch with B % 4 == 0; a flat model (ensemble.flat_children) of BBB conv /
-    linear layers sharing one prior, each optionally followed by ReLU / Softplus(1, 20) and then MaxPool2d (no padding, floor),
-    and a FlattenLayer that keeps one row per image; stride-1 convolutions everywhere except the first layer; the model ends in
-    a Bayesian linear layer; no eps replay."""
+    """The fast autograd path covers: a 4-d CUDA fp32 batch with B % 4 == 0; a flat model (ensemble.flat_children) of Bayesian
+    conv / linear layers of ONE kind (all BBB or all BBB_LRT) sharing one prior, each optionally followed by ReLU /
+    Softplus(1, 20) and then MaxPool2d (no padding, floor), and a FlattenLayer that keeps one row per image; stride-1
+    convolutions and channel counts that are multiples of 4 everywhere except the first layer; the model ends in a Bayesian
+    linear layer; no eps replay.  Returns "bbb", "lrt" or None."""
     from . import ensemble
+    from layers.lrt import BBBConv2d as LRTConv2d, BBBLinear as LRTLinear
     _BBBLayer, BBBConv2d, BBBLinear, _LRTLayer, FlattenLayer = _layers()
     if not torch.is_tensor(x) or not x.is_cuda or x.dim() != 4 or x.dtype != torch.float32 or x.shape[0] % 4 != 0:
-        return False
+        return None
     mods = ensemble.flat_children(net)
-    if not mods or not isinstance(mods[-1], BBBLinear):
-        return False
+    if not mods or not isinstance(mods[-1], (BBBLinear, LRTLinear)):
+        return None
     first = True
     pri = set()
+    kinds = set()
     i = 0
     while i < len(mods):
         m = mods[i]
-        if isinstance(m, _LRTLayer):
-            return False
-        if isinstance(m, _BBBLayer):
+        if isinstance(m, (_BBBLayer, _LRTLayer)):
+            kinds.add("lrt" if isinstance(m, _LRTLayer) else "bbb")
             if m.eps_source is not None or not m.W_mu.is_cuda or not m.use_bias:
-                return False
+                return None
             pri.add((m.prior_mu, m.prior_sigma))
-            if isinstance(m, BBBConv2d):
+            if isinstance(m, (BBBConv2d, LRTConv2d)):
                 if not first and ops._pair(m.stride) != (1, 1):
-                    return False
+                    return None
                 (ph, pw), (dh, dw) = ops._pair(m.padding), ops._pair(m.dilation)
                 if dh * (m.kernel_size[0] - 1) < ph or dw * (m.kernel_size[1] - 1) < pw:
-                    return False
+                    return None
                 if not first and m.in_channels % 4 != 0:
-                    return False
+                    return None
             elif not first and m.in_features % 4 != 0:
-                return False
+                return None
             first = False
             if i + 1 < len(mods) and ensemble._act_name(mods[i + 1]) is not None:
                 i += 1
         elif isinstance(m, nn.MaxPool2d):
             k, s = m.kernel_size, m.stride
             if not (isinstance(k, int) and isinstance(s, int) and m.padding == 0 and m.dilation == 1 and not m.ceil_mode):
-                return False
+                return None
         elif isinstance(m, FlattenLayer):
             pass
         else:
-            return False                     # a stand-alone activation or anything else: not on this path
+            return None                      # a stand-alone activation or anything else: not on this path
         i += 1
-    if len(pri) != 1 or len(ensemble.bayesian_layers(net)) * 2 > _lib.MAX_SEGMENTS:
-        return False
-    return ensemble.output_rows(net, tuple(x.shape)) == x.shape[0]
+    if len(pri) != 1 or len(kinds) != 1 or len(ensemble.bayesian_layers(net)) * 2 > _lib.MAX_SEGMENTS:
+        return None
+    if ensemble.output_rows(net, tuple(x.shape)) != x.shape[0]:
+        return None
+    return next(iter(kinds))
 
 
 class _MCForward(torch.autograd.Function):
@@ -182,11 +186,135 @@ def ws_shape(rec):
     return (E,) + tuple(m.W_mu.shape)
 
 
+def _inverse_act(y, act):
+    """Pre-activation from the activated output (what the LRT backward needs to recover sqrt(act_var) * eps = v - act_mu)."""
+    if act == "softplus":
+        return torch.where(y > 20.0, y, y + torch.log(-torch.expm1(-y)))
+    return y                                  # ReLU: exact where y > 0; elsewhere the incoming gradient is zero anyway
+
+
+class _MCForwardLRT(torch.autograd.Function):
+    """Local-reparameterisation layers (layers/BBB_LRT/BBBConv.py:62-81): (x, W_mu0, W_var0, b_mu0, b_var0, ...) -> logits
+    [E, C, B] batch-innermost.  Forward = the dual-accumulator LRT GEMM (act_mu, act_var, sample + activation in the epilogue);
+    for the first layer, whose input and weights are the same for every draw, the two contractions run once and
+    bbb_lrt_sample_chwn draws the E outputs.  Backward: out = act_mu + sqrt(act_var) * eps gives d/d act_mu = g and
+    d/d act_var = g * (v - act_mu) / (2 act_var) with v recovered from the stored activated output; then two weight gradients
+    (g_mu with x, g_var with x^2) and, below the first layer, g_x = dgrad(g_mu, W_mu) + 2 x * dgrad(g_var, W_var), all on the
+    forward GEMM kernel (fast_train module docstring)."""
+
+    @staticmethod
+    def forward(ctx, cfg, x, *params):
+        from . import ensemble
+        from layers.lrt import BBBConv2d as LRTConv2d
+        _BBBLayer, BBBConv2d, BBBLinear, _LRTLayer, FlattenLayer = _layers()
+        net, E, seed, call0 = cfg["net"], cfg["draws"], cfg["seed"], cfg["call0"]
+        mods = ensemble.flat_children(net)
+        B = x.shape[0]
+        h = ops.to_batch_innermost(x.detach()).unsqueeze(0)
+        tape, li, i = [], 0, 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, _LRTLayer):
+                w_mu, w_var, b_mu, b_var = (t.detach() for t in params[4 * li:4 * li + 4])
+                is_conv = isinstance(m, LRTConv2d)
+                geom = (m.stride, m.padding, m.dilation) if is_conv else (1, 0, 1)
+                x_in = h if is_conv else h.reshape(h.shape[0], m.in_features, 1, 1, B)
+                if not is_conv:
+                    shp = (m.out_features, m.in_features, 1, 1)
+                    w_mu, w_var = w_mu.reshape(shp), w_var.reshape(shp)
+                act = ensemble._act_name(mods[i + 1]) if i + 1 < len(mods) else None
+                sid = m._stream_base + 2
+                shared = x_in.shape[0] == 1 and E > 1
+                if shared:
+                    _, am, av = ops.lrt_conv2d_chwn_forward(x_in, w_mu, w_var, b_mu, b_var, seed, call0, sid, *geom, sample=False,
+                                                            want_moments=True, act=None)
+                    y = ops.lrt_sample_chwn(am, av, E, seed, call0, sid, act=act)
+                else:
+                    y, am, av = ops.lrt_conv2d_chwn_forward(x_in, w_mu, w_var, b_mu, b_var, seed, call0, sid, *geom, sample=True,
+                                                            want_moments=True, act=act)
+                rec = dict(layer=m, x=x_in, w_mu=w_mu, w_var=w_var, y=y, am=am, av=av, act=act, geom=geom, pool=None, first=(li == 0))
+                if act is not None:
+                    i += 1
+                h = y
+                if i + 1 < len(mods) and isinstance(mods[i + 1], nn.MaxPool2d):
+                    pool = mods[i + 1]
+                    h = ops.maxpool_chwn(y, pool.kernel_size, pool.stride)
+                    rec["pool"] = (pool.kernel_size, pool.stride)
+                    i += 1
+                rec["out_shape"] = tuple(h.shape)
+                tape.append(rec)
+                li += 1
+            elif isinstance(m, nn.MaxPool2d):
+                raise _lib.BBBHipError("fast_train: pooling must follow a Bayesian layer")
+            elif isinstance(m, FlattenLayer):
+                h = h.reshape(h.shape[0], m.num_features, 1, 1, B)
+            i += 1
+        ctx.cfg, ctx.tape = cfg, tape
+        ctx.x_nchw = x.detach()
+        return h.reshape(h.shape[0], -1, B)
+
+    @staticmethod
+    def backward(ctx, g_logits):
+        tape = ctx.tape
+        grads = [None] * (4 * len(tape))
+        g = g_logits.contiguous()
+        for li in range(len(tape) - 1, -1, -1):
+            rec = tape[li]
+            y, am, av, x_in, act = rec["y"], rec["am"], rec["av"], rec["x"], rec["act"]
+            w_mu, w_var = rec["w_mu"], rec["w_var"]
+            stride, padding, dilation = rec["geom"]
+            g = g.reshape(rec["out_shape"])
+            if rec["pool"] is not None:
+                g_pre = ops.pool_act_backward_chwn(g, y, rec["pool"][0], rec["pool"][1], act)
+            elif act is not None:
+                g_pre = ops.pool_act_backward_chwn(g, y, 0, 1, act)
+            else:
+                g_pre = g
+            v = _inverse_act(y, act)
+            t = torch.where(y > 0, v - am, torch.zeros_like(v)) if act is not None else v - am      # sqrt(act_var) * eps
+            g_var = g_pre * t / (2.0 * av)
+            g_mu = g_pre
+            if am.shape[0] == 1 and g_mu.shape[0] > 1:      # first layer: one pair of moments feeds every draw
+                g_mu, g_var = g_mu.sum(0, keepdim=True), g_var.sum(0, keepdim=True)
+            grads[4 * li + 2] = g_mu.sum(dim=(0, 2, 3, 4))
+            grads[4 * li + 3] = g_var.sum(dim=(0, 2, 3, 4))
+            wshape = (1,) + tuple(w_mu.shape)
+            if x_in.shape[1] % 4 == 0:
+                gw_mu = ops.conv2d_chwn_weight_grad(g_mu, x_in, wshape, stride, padding, dilation).sum(0)
+                gw_var = ops.conv2d_chwn_weight_grad(g_var, x_in * x_in, wshape, stride, padding, dilation).sum(0)
+            else:
+                xn = ctx.x_nchw
+                gw_mu = ops.conv2d_chwn_weight_grad_shared_input(g_mu, xn, wshape, stride, padding, dilation)[0]
+                gw_var = ops.conv2d_chwn_weight_grad_shared_input(g_var, xn * xn, wshape, stride, padding, dilation)[0]
+            m = rec["layer"]
+            grads[4 * li] = gw_mu.reshape(m.W_mu.shape)
+            grads[4 * li + 1] = gw_var.reshape(m.W_mu.shape)
+            if not rec["first"]:
+                hw = (x_in.shape[2], x_in.shape[3])
+                g = ops.conv2d_chwn_input_grad(g_mu, w_mu.unsqueeze(0), hw, padding, dilation) \
+                    + 2.0 * x_in * ops.conv2d_chwn_input_grad(g_var, w_var.unsqueeze(0), hw, padding, dilation)
+        return (None, None, *grads)
+
+
 def mc_logits_autograd(net, x, draws, seed, call0):
     """Differentiable batched forward: -> (logits [E, C, B] batch-innermost, kl of one forward), gradients flow to every
     layer's W_mu, W_rho, bias_mu, bias_rho.  Call only when train_path_ok(net, x)."""
     from . import ensemble
     _lib.require_device(x)
+    kind = train_path_ok(net, x)
+    if kind == "lrt":
+        layers = ensemble.bayesian_layers(net)
+        mus, rhos = [], []
+        for l in layers:
+            m, r, _ = l._param_lists()
+            mus += m
+            rhos += r
+        kl, s2 = ops.kl_only(mus, rhos, layers[0].prior_mu, layers[0].prior_sigma, want_sigma=True, sigma_squared=True)
+        flat = []
+        for li, l in enumerate(layers):
+            flat += [l.W_mu, s2[2 * li], l.bias_mu, s2[2 * li + 1]]
+        cfg = dict(net=net, draws=int(draws), seed=seed, call0=call0)
+        return _MCForwardLRT.apply(cfg, x, *flat), kl
     params = []
     for l in ensemble.bayesian_layers(net):
         params += [l.W_mu, l.W_rho, l.bias_mu, l.bias_rho]

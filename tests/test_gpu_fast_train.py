@@ -62,13 +62,14 @@ def test_chwn_wgrad_dgrad_vs_torch_float64(env, Cin, Cout, kk, pad, H):
         np.testing.assert_allclose(gx[e].cpu().numpy(), xt.grad.permute(1, 2, 3, 0).float().cpu().numpy(), rtol=2e-4, atol=2e-4)
 
 
-@pytest.mark.parametrize("net_type,cin,B", [("alexnet", 3, 16), ("3conv3fc", 3, 8), ("alexnet", 3, 64)])
-def test_fast_autograd_matches_reference_layout_autograd(env, net_type, cin, B):
+@pytest.mark.parametrize("net_type,cin,B,lt", [("alexnet", 3, 16, "bbb"), ("3conv3fc", 3, 8, "bbb"), ("alexnet", 3, 64, "bbb"),
+                                              ("alexnet", 3, 16, "lrt"), ("3conv3fc", 3, 8, "lrt")])
+def test_fast_autograd_matches_reference_layout_autograd(env, net_type, cin, B, lt):
     """Same noise, same loss: every parameter gradient of the fast path equals the reference-layout path's.
     (BayesianLeNet's second conv has 6 input channels: not a multiple of 4, so it stays on the reference-layout path.)"""
     ens = env["ens"]
     torch.manual_seed(1)
-    net = env["zoo"].getModel(net_type, cin, 10, P.CONFIG_PRIORS, "bbb", "softplus").cuda()
+    net = env["zoo"].getModel(net_type, cin, 10, P.CONFIG_PRIORS, lt, "softplus").cuda()
     env["rng"].assign_stream_ids(net)
     x = torch.rand(B, cin, 32, 32, device="cuda")
     y = torch.randint(0, 10, (B,), device="cuda")
@@ -122,12 +123,14 @@ def test_dropin_forward_with_autograd_uses_the_fast_kernels(env):
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
 
 
-def test_alexnet_training_iterations_vs_cpu_port(env):
+@pytest.mark.parametrize("lt", ["bbb", "lrt"])
+def test_alexnet_training_iterations_vs_cpu_port(env, lt):
     """3 iterations of the reference's batch loop (main_bayesian.py:40-58) on BayesianAlexNet, num_ens = 2: the GPU fast path
-    (train.train_step + FusedAdam) vs the CPU port with torch.optim.Adam, both consuming the SAME Philox noise."""
+    (train.train_step + FusedAdam) vs the CPU port with torch.optim.Adam, both consuming the SAME Philox noise (weight noise
+    for BBB layers, activation noise keyed by the NCHW output index for BBB_LRT layers)."""
     T = env["train"]
     torch.manual_seed(3)
-    net = env["zoo"].getModel("alexnet", 3, 10, P.CONFIG_PRIORS, "bbb", "softplus").cuda()
+    net = env["zoo"].getModel("alexnet", 3, 10, P.CONFIG_PRIORS, lt, "softplus").cuda()
     env["rng"].assign_stream_ids(net)
     names = [n for n, m in net.named_children() if hasattr(m, "W_mu")]
     params = {"_prior_mu": 0, "_prior_sigma": 0.1}
@@ -163,7 +166,7 @@ def test_alexnet_training_iterations_vs_cpu_port(env):
             c = call + i * E + j
             eps = lambda name, kind, shape, c=c: torch.from_numpy(
                 O.normal_eps(seed, c, sid[name] + KIND[kind], int(np.prod(shape))).reshape(shape))
-            lg, k = P.forward("alexnet", params, xb, "bbb", "softplus", eps_fn=eps)
+            lg, k = P.forward("alexnet", params, xb, lt, "softplus", eps_fn=eps)
             outs.append(F.log_softmax(lg, dim=1))
             klsum = klsum + k
         lo = P.logmeanexp(torch.stack(outs, dim=2), 2)
@@ -171,7 +174,7 @@ def test_alexnet_training_iterations_vs_cpu_port(env):
         loss.backward()
         copt.step()
         want.append(loss.item())
-    print("[fast-train alexnet] losses gpu", losses, "cpu", want)
+    print(f"[fast-train alexnet {lt}] losses gpu", losses, "cpu", want)
     np.testing.assert_allclose(losses, want, rtol=2e-5)
     for n in names:
         m = getattr(net, n)
