@@ -488,13 +488,14 @@ def _loop_logits(net, x, draws, seed, call0, eps=None):
     stats["path"] = "loop"
     saved = dict(rng._state)
     try:
-        rng.manual_seed(seed, call=call0)
+        rng.manual_seed(seed, call=call0)            # pinned for the loop: torch's generator is not touched
         outs, kl = [], None
         for _ in range(draws):
             y, k = net(x)
             outs.append(y)
             kl = k
     finally:
+        rng._state.clear()
         rng._state.update(saved)
     return torch.stack(outs), kl
 

@@ -103,7 +103,7 @@ def fast_forward(wrapper, x):
     seed, call = rng.next_calls(1)
     out = ensemble._mc_logits_chwn(wrapper, x, 1, seed, call)
     if out is None:
-        rng._state["call"] = call                # nothing was launched: give the call index back
+        rng.rewind((seed, call))                 # nothing was launched: give the call index back
         return None
     logits, kl = out                             # [1, C, B']
     for l in layers:
