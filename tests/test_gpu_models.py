@@ -325,8 +325,11 @@ def test_graphed_pipeline_steps_match_eager_sequence(env):
 
 
 def test_graphed_step_multirank_logic_simulated(env, monkeypatch):
-    """World-size-2 graphed steps simulated on one GPU: each "rank" captures its own draw block; their (lse, kl)
-    blocks combined as combine_ranks does must equal the single-device step at the same noise calls, replay after replay."""
+    """World-size-2 graphed steps simulated on one GPU: each "rank" captures its own work, packs (lse block, kl share) into its
+    send buffer, and its post-graph reduces what the collective delivered.  The collective itself is replaced by a recorder
+    that (a) keeps every rank's send buffer and (b) hands the rank a gathered buffer assembled from the ranks simulated so far;
+    with both ranks' buffers in hand the reduction must equal the single-device step at the same noise calls, replay after
+    replay -- and the post-graph of the LAST simulated rank, which sees real data from both, must return exactly that."""
     import torch.distributed as dist
     ens = env["ens"]
     torch.manual_seed(6)
@@ -334,34 +337,45 @@ def test_graphed_step_multirank_logic_simulated(env, monkeypatch):
     env["rng"].assign_stream_ids(net)
     x = torch.rand(32, 1, 32, 32, device="cuda")
     E, world = 5, 2
-    captured = {}
+    sends = {r: [] for r in range(world)}
+    cur = {}
 
-    def fake_combine(lse, kl_local, num_ens, group, kl_mode="sum", shape=None, device=None):
-        captured[group] = (lse.clone(), kl_local.clone())
-        return lse, kl_local
+    def fake_gather(recv, send, group):
+        r, i = cur["rank"], cur["step"]
+        sends[r].append(send.clone())
+        n = send.numel()
+        for q in range(world):                       # ranks already simulated contribute their recorded buffer of step i
+            blk = sends[q][i] if len(sends[q]) > i else torch.full_like(send, -float("inf"))
+            if len(sends[q]) <= i:
+                blk[-1] = 0
+            recv[q * n:(q + 1) * n].copy_(blk)
 
-    monkeypatch.setattr(ens, "combine_ranks", fake_combine)
+    monkeypatch.setattr(ens, "_all_gather", fake_gather)
     monkeypatch.setattr(dist, "get_world_size", lambda group=None: world)
-    steps = {}
+    last_out = []
     for rank in range(world):
         monkeypatch.setattr(dist, "get_rank", lambda group=None, r=rank: r)
         env["rng"].manual_seed(11, call=20)
         g = ens.GraphedMC(net, x, E, group=f"rank{rank}")
         assert (g.lo, g.hi) == ens.draw_range(E, rank, world)
-        outs = []
-        for r in range(3):
-            g.step()
+        cur["rank"] = rank
+        for i in range(3):
+            cur["step"] = i
+            lo, kl = g.step()
             torch.cuda.synchronize()
-            outs.append(captured[f"rank{rank}"])
-        steps[rank] = outs
+            if rank == world - 1:
+                last_out.append((lo.clone(), kl.clone()))
     monkeypatch.undo()
+    n = sends[0][0].numel()
     with torch.no_grad():
-        for r in range(3):
-            env["rng"].manual_seed(11, call=20 + r * E)
+        for i in range(3):
+            env["rng"].manual_seed(11, call=20 + i * E)
             want, kl = ens.mc_forward(net, x, E)
-            got = torch.logsumexp(torch.stack([steps[0][r][0], steps[1][r][0]]), 0) - float(np.log(E))
+            blocks = torch.stack([sends[q][i][:-1].view(32, 10) for q in range(world)])
+            got = torch.logsumexp(blocks, 0) - float(np.log(E))
             np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=3e-6, atol=3e-6)
-            assert abs((steps[0][r][1] + steps[1][r][1]).item() - kl.item()) <= 2e-6 * kl.item()
+            assert abs((sends[0][i][-1] + sends[1][i][-1]).item() - kl.item()) <= 2e-6 * kl.item()
+            assert torch.equal(last_out[i][0], got) and abs(last_out[i][1].item() - kl.item()) <= 2e-6 * kl.item()
 
 
 # ---------------------------------------------------------------- uncertainty estimation (N2)
