@@ -5,6 +5,9 @@
   ops       tensor-level entry points + autograd wiring
   ensemble  the num_ens Monte-Carlo loop of main_bayesian.py:43-53 / 73-80, batched over draws and
             sharded over GPUs
+  fast_train  one autograd node for the batched forward on the inference kernels (training extension)
+  train     train_step / FusedAdam / GraphedTrainStep / data-parallel gradient averaging
+  metrics   ELBO, get_beta, device-side accuracy (metrics.py upstream, without the per-step host sync)
   zoo       BBBLeNet / BBBAlexNet / BBB3Conv3FC built from a topology table (same constructor surface as
             the reference's models/BayesianModels/*.py, for hosts without the reference checkout)
 The drop-in boundary itself is the sibling package ``layers``.

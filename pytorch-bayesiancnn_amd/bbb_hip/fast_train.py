@@ -17,7 +17,7 @@ E forwards, KL, log_softmax / logmeanexp (the small tail stays in torch), ELBO, 
 import torch
 import torch.nn as nn
 
-from . import _lib, ops, rng
+from . import _lib, ops
 
 
 def _layers():
@@ -79,6 +79,12 @@ def train_path_ok(net, x):
     if ensemble.output_rows(net, tuple(x.shape)) != x.shape[0]:
         return None
     return next(iter(kinds))
+
+
+def ws_shape(rec):
+    m = rec["layer"]
+    E = rec["w"].shape[0]
+    return (E,) + tuple(m.W_mu.shape)
 
 
 class _MCForward(torch.autograd.Function):
@@ -178,12 +184,6 @@ class _MCForward(torch.autograd.Function):
         for a, b in zip(gmu, grho):
             out += [a, b]
         return tuple(out)
-
-
-def ws_shape(rec):
-    m = rec["layer"]
-    E = rec["w"].shape[0]
-    return (E,) + tuple(m.W_mu.shape)
 
 
 def _inverse_act(y, act):
