@@ -210,6 +210,24 @@ def build_net(cfg, dev):
     return net, x
 
 
+def mfma_loop_ceiling():
+    """TFLOP/s of a loop of nothing but v_mfma_f32_32x32x2_f32 on this box (profiles/probe/mfma_ceiling.hip, built by build.sh as
+    its own library -- a measurement aid, not part of libbbb_hip.so): the ceiling a kernel built on that instruction can
+    approach, next to the guide's nominal 157.3.  None when the probe library is not there."""
+    import ctypes
+    path = os.path.join(ROOT, "profiles", "probe", "libmfma_probe.so")
+    if not os.path.exists(path):
+        return None
+    try:
+        lib = ctypes.CDLL(path)
+        lib.probe_mfma_f32_ceiling.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_void_p]
+        v = ctypes.c_double(0.0)
+        rc = lib.probe_mfma_f32_ceiling(ctypes.byref(v), 5, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        return round(v.value, 1) if rc == 0 and v.value > 0 else None
+    except Exception:
+        return None
+
+
 def gemm_roofline(agg, timer_steps, precision, metric_cfg):
     """Dominant kernel of the step: all conv / linear launches.  FLOPs counted = in-bounds taps only (what the fp32 kernel
     multiplies; the bf16 kernel also multiplies the zero taps of first layers, which is not counted as useful work)."""
@@ -534,6 +552,12 @@ def main():
             fps = head["roofline"].get("flop_per_step")
             if fps and world == 1:
                 peak = head["roofline"]["peak"]
+                ceil = mfma_loop_ceiling() if cfg["precision"] != "bf16" else None
+                if ceil:
+                    out["roofline"]["mfma_loop_ceiling"] = {
+                        "value": ceil, "unit": "TFLOP/s", "frac_of_it": round(head["roofline"]["achieved"] / ceil, 4),
+                        "note": "a loop of nothing but v_mfma_f32_32x32x2_f32 (4 accumulators per wave, 8 waves per CU, no memory), "
+                                "timed on this box in this run: what the instruction sustains against the nominal peak"}
                 out["roofline"]["sustained_in_timed_region"] = {
                     "achieved": round(fps / (head["ms_per_step"] * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
                     "frac": round(fps / (head["ms_per_step"] * 1e-3) / 1e12 / peak, 4),

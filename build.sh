@@ -25,3 +25,8 @@ for o in build/*.o; do
 done
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o bbb_hip/libbbb_hip.so
 echo "built $(pwd)/bbb_hip/libbbb_hip.so"
+# measurement aid for bench.py only (pure-MFMA-loop ceiling of the box); deliberately NOT linked into the product library
+if [ ! -f ../profiles/probe/libmfma_probe.so ] || [ ../profiles/probe/mfma_ceiling.hip -nt ../profiles/probe/libmfma_probe.so ]; then
+  "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared ../profiles/probe/mfma_ceiling.hip -o ../profiles/probe/libmfma_probe.so
+  echo "built $(cd ../profiles/probe && pwd)/libmfma_probe.so"
+fi

@@ -1,0 +1,65 @@
+// Measurement aid for bench.py (NOT part of libbbb_hip.so, not on any product path): what a loop of nothing but
+// v_mfma_f32_32x32x2_f32 reaches on the box the bench runs on.  MI355X_MICROARCH.md's dense fp32 matrix peak (157.3 TFLOP/s =
+// 256 CUs x 4 SIMDs x 64 FLOP/cycle x 2.4 GHz) assumes an MFMA issued every 64 cycles at 2.4 GHz; this loop -- 4 independent
+// accumulators per wave, 2 workgroups of 4 waves per CU, operands in registers, no LDS, no global memory -- is the practical
+// ceiling any kernel built on that instruction can approach.  bench.py prints it next to roofline.peak.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace {
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void mfma_loop_kernel(float* out, int iters, float a0, float b0) {
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+    const float a = a0 + threadIdx.x * 1e-3f, b = b0 + threadIdx.x * 2e-3f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[i][r];
+    out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
+}
+}  // namespace
+
+// tflops_out[0] = best of `reps` timed launches (HIP events on `stream`), in TFLOP/s.  Returns a hipError_t.
+extern "C" int probe_mfma_f32_ceiling(double* tflops_out, int reps, void* stream) {
+    if (tflops_out == nullptr || reps <= 0) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    int dev = 0, cus = 0;
+    hipError_t er = hipGetDevice(&dev);
+    if (er != hipSuccess) return (int)er;
+    er = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (er != hipSuccess) return (int)er;
+    const int blocks = cus * 2, iters = 4096;                    // 16384 MFMAs per wave: ~0.45 ms per launch
+    float* out = nullptr;
+    er = hipMalloc(&out, (size_t)blocks * 256 * sizeof(float));
+    if (er != hipSuccess) return (int)er;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    double best = 0.0;
+    for (int r = 0; r < reps + 1; ++r) {                           // first launch is a warm-up
+        hipEventRecord(e0, st);
+        hipLaunchKernelGGL(mfma_loop_kernel, dim3(blocks), dim3(256), 0, st, out, iters, 1.0f, 0.5f);
+        hipEventRecord(e1, st);
+        er = hipEventSynchronize(e1);
+        if (er != hipSuccess) break;
+        float ms = 0.0f;
+        hipEventElapsedTime(&ms, e0, e1);
+        const double tf = (double)blocks * 4.0 * iters * 4.0 * 4096.0 / ((double)ms * 1e9);
+        if (r > 0 && tf > best) best = tf;
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    hipFree(out);
+    *tflops_out = best;
+    return (int)er;
+}

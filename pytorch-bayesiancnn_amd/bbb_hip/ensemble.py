@@ -60,14 +60,40 @@ def unit_range(num_ens, slices, rank, world):
     return draw_range(num_ens * slices, rank, world)
 
 
+def _structure(net):
+    """Static analysis of `net`, cached on the module: the answers below are asked on every forward of a drop-in loop
+    (`for j in range(E): net(x)`), and walking the module tree each time cost more host time than launching the kernels.
+    The cache is keyed on the identity of net's direct children; code that rewires a NESTED container of an already
+    used model calls invalidate(net)."""
+    sig = tuple(map(id, net._modules.values()))
+    st = net.__dict__.get("_bbb_structure")
+    if st is None or st["sig"] != sig:
+        st = {"sig": sig, "layers": [m for m in net.modules() if isinstance(m, (_BBBLayer, _LRTLayer))],
+              "params": list(net.parameters()), "rows": {}, "train": {}}
+        net.__dict__["_bbb_structure"] = st
+    return st
+
+
+def invalidate(net):
+    """Forget the cached structure of `net` (after replacing modules inside one of its nested containers)."""
+    net.__dict__.pop("_bbb_structure", None)
+
+
 def bayesian_layers(net):
-    return [m for m in net.modules() if isinstance(m, (_BBBLayer, _LRTLayer))]
+    return _structure(net)["layers"]
+
+
+def any_requires_grad(net):
+    return any(p.requires_grad for p in _structure(net)["params"])
 
 
 def flat_children(net):
     """The model as the flat list of modules ModuleWrapper.forward runs: nn.Sequential and plain ModuleWrapper
     containers (no forward of their own, like the reference's models) are expanded recursively.  Returns None if a
     Bayesian layer sits inside any other kind of module -- the batched paths cannot see through an arbitrary forward."""
+    st = _structure(net)
+    if "flat" in st:
+        return st["flat"]
     from layers.misc import ModuleWrapper
     out = []
 
@@ -82,14 +108,18 @@ def flat_children(net):
 
     walk(net)
     direct = {id(m) for m in out if isinstance(m, (_BBBLayer, _LRTLayer))}
-    if direct != {id(m) for m in bayesian_layers(net)}:
-        return None
+    if direct != {id(m) for m in st["layers"]}:
+        out = None
+    st["flat"] = out
     return out
 
 
 def output_rows(net, x_shape):
     """Rows of the model's output for an input of shape x_shape (B, except where FlattenLayer cuts a larger feature map into
     several rows per image: the reference's view(-1, num_features), layers/misc.py:35)."""
+    cache = _structure(net)["rows"]
+    if x_shape in cache:
+        return cache[x_shape]
     B, C, H, W = x_shape
     rows = B
     for m in flat_children(net) or []:
@@ -105,6 +135,7 @@ def output_rows(net, x_shape):
         elif isinstance(m, FlattenLayer):
             rows = rows * C * H * W // m.num_features
             C, H, W = m.num_features, 1, 1
+    cache[tuple(x_shape)] = rows
     return rows
 
 
@@ -261,11 +292,17 @@ def _chwn_ok(net, x):
     """The batch-innermost fast path handles: 4-d input, B % 4 == 0, no autograd, and only module kinds it
     knows how to run in that layout (Bayesian layers, ReLU/Softplus, MaxPool2d without padding, FlattenLayer
     that flattens whole images)."""
-    if torch.is_grad_enabled() and any(p.requires_grad for p in net.parameters()):
+    if torch.is_grad_enabled() and any_requires_grad(net):
         return False
     if x.dim() != 4 or x.shape[0] % 4 != 0:
         return False
-    mods = flat_children(net)
+    st = _structure(net)
+    if "chwn_mods" not in st:
+        st["chwn_mods"] = _chwn_mods_ok(flat_children(net))
+    return st["chwn_mods"]
+
+
+def _chwn_mods_ok(mods):
     if mods is None:
         return False
     for m in mods:

@@ -34,10 +34,27 @@ def train_path_ok(net, x):
     convolutions and channel counts that are multiples of 4 everywhere except the first layer; the model ends in a Bayesian
     linear layer; no eps replay.  Returns "bbb", "lrt" or None."""
     from . import ensemble
-    from layers.lrt import BBBConv2d as LRTConv2d, BBBLinear as LRTLinear
-    _BBBLayer, BBBConv2d, BBBLinear, _LRTLayer, FlattenLayer = _layers()
     if not torch.is_tensor(x) or not x.is_cuda or x.dim() != 4 or x.dtype != torch.float32 or x.shape[0] % 4 != 0:
         return None
+    # what never changes for a given model and input shape is analysed once (ensemble._structure); what can change between
+    # calls (eps replay switched on, a layer moved off the device) is re-checked every time
+    cache = ensemble._structure(net)["train"]
+    key = tuple(x.shape)
+    if key not in cache:
+        cache[key] = _train_path_static(net, x)
+    kind = cache[key]
+    if kind is None:
+        return None
+    for m in ensemble.bayesian_layers(net):
+        if m.eps_source is not None or not m.W_mu.is_cuda:
+            return None
+    return kind
+
+
+def _train_path_static(net, x):
+    from . import ensemble
+    from layers.lrt import BBBConv2d as LRTConv2d, BBBLinear as LRTLinear
+    _BBBLayer, BBBConv2d, BBBLinear, _LRTLayer, FlattenLayer = _layers()
     mods = ensemble.flat_children(net)
     if not mods or not isinstance(mods[-1], (BBBLinear, LRTLinear)):
         return None
@@ -49,7 +66,7 @@ def train_path_ok(net, x):
         m = mods[i]
         if isinstance(m, (_BBBLayer, _LRTLayer)):
             kinds.add("lrt" if isinstance(m, _LRTLayer) else "bbb")
-            if m.eps_source is not None or not m.W_mu.is_cuda or not m.use_bias:
+            if not m.use_bias:
                 return None
             pri.add((m.prior_mu, m.prior_sigma))
             if isinstance(m, (BBBConv2d, LRTConv2d)):

@@ -11,7 +11,7 @@ import ctypes
 import torch
 
 from . import _lib, rng
-from ._lib import Segment, ConvDesc, check, ptr, require_device, cur_stream
+from ._lib import Segment, ConvDesc, check, ptr, require_device, cur_stream, on_device
 
 _scratch = {}
 
@@ -66,7 +66,7 @@ def reparam_kl_forward(mus, rhos, prior_mu, prior_sigma, stream_ids, seed, call0
     nparts = L.bbb_reparam_partials(segs, len(mus))
     parts = _partials(dev, nparts) if want_kl else None
     flags = (_lib.SIGMA_SQUARED if sigma_squared else 0) | (_lib.KL_TEXTBOOK if textbook_kl else 0)
-    with torch.cuda.device(dev):
+    with on_device(dev):
         rc = L.bbb_reparam_kl_fwd(segs, len(mus), draws, float(prior_mu), float(prior_sigma), seed, call0 & 0xFFFFFFFF,
                                   flags, ptr(parts), ptr(kl), 0, rng.call_dev_ptr(dev), cur_stream(dev))
     check(rc, "bbb_reparam_kl_fwd")
@@ -91,7 +91,7 @@ def reparam_kl_backward(mus, rhos, gws, gkl, prior_mu, prior_sigma, stream_ids, 
     if gkl is not None:
         gkl = gkl.to(device=dev, dtype=torch.float32).contiguous()
     flags = _lib.KL_TEXTBOOK if textbook_kl else 0
-    with torch.cuda.device(dev):
+    with on_device(dev):
         rc = _lib.lib().bbb_reparam_kl_bwd(segs, len(mus), draws, float(prior_mu), float(prior_sigma), seed,
                                            call0 & 0xFFFFFFFF, flags, ptr(gkl), pm, pr, rng.call_dev_ptr(dev), cur_stream(dev))
     check(rc, "bbb_reparam_kl_bwd")
@@ -100,7 +100,7 @@ def reparam_kl_backward(mus, rhos, gws, gkl, prior_mu, prior_sigma, stream_ids, 
 
 def eps_dump(n, seed, call, stream_id, device, start=0):
     out = torch.empty(n, dtype=torch.float32, device=device)
-    with torch.cuda.device(out.device):
+    with on_device(out.device):
         check(_lib.lib().bbb_eps_dump(out.data_ptr(), n, start, seed, call & 0xFFFFFFFF, stream_id, cur_stream(out.device)),
               "bbb_eps_dump")
     return out
@@ -147,7 +147,7 @@ def conv2d_forward(x, w, bias, stride=1, padding=0, dilation=1, act=None):
         raise _lib.BBBHipError("leading (draw) dims of x and w must be 1 or equal")
     d, ho, wo = _desc(x, w, stride, padding, dilation, E, x.shape[0] == 1 and E > 1, w.shape[0] == 1 and E > 1, act)
     y = torch.empty((E, x.shape[1], w.shape[1], ho, wo), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with on_device(x.device):
         check(_lib.lib().bbb_conv2d_fwd(ctypes.byref(d), x.data_ptr(), w.data_ptr(), ptr(bias), y.data_ptr(),
                                         cur_stream(x.device)), "bbb_conv2d_fwd")
     return y
@@ -174,7 +174,7 @@ def lrt_conv2d_forward(x, w_mu, w_var, b_mu, b_var, seed, call0, stream_id, stri
         eps = eps.contiguous()
         if eps.numel() != y.numel():
             raise _lib.BBBHipError("external eps must have the output's shape")
-    with torch.cuda.device(x.device):
+    with on_device(x.device):
         check(_lib.lib().bbb_lrt_conv2d_fwd(ctypes.byref(d), x.data_ptr(), w_mu.data_ptr(), w_var.data_ptr(), ptr(b_mu),
                                             ptr(b_var), y.data_ptr(), ptr(am), ptr(av), ptr(eps), seed,
                                             call0 & 0xFFFFFFFF, stream_id, 1 if sample else 0, rng.call_dev_ptr(x.device),
@@ -229,7 +229,7 @@ def conv2d_chwn_forward(x, w, bias, stride=1, padding=0, dilation=1, act=None, o
         if out.numel() != E * w.shape[1] * ho * wo * x.shape[4] or not out.is_contiguous() or out.dtype != torch.float32:
             raise _lib.BBBHipError("out= must be a contiguous fp32 tensor of the output's size")
         y = out.view(shape)
-    with torch.cuda.device(x.device):
+    with on_device(x.device):
         check(_lib.lib().bbb_conv2d_chwn_fwd(ctypes.byref(d), x.data_ptr(), w.data_ptr(), ptr(bias), y.data_ptr(),
                                              cur_stream(x.device)), "bbb_conv2d_chwn_fwd")
     return y
@@ -259,7 +259,7 @@ def lrt_conv2d_chwn_forward(x, w_mu, w_var, b_mu, b_var, seed, call0, stream_id,
     av = torch.empty(shape, dtype=torch.float32, device=x.device) if want_moments else None
     if eps is not None:
         eps = eps.contiguous()
-    with torch.cuda.device(x.device):
+    with on_device(x.device):
         check(_lib.lib().bbb_lrt_conv2d_chwn_fwd(ctypes.byref(d), x.data_ptr(), w_mu.data_ptr(), w_var.data_ptr(), ptr(b_mu),
                                                  ptr(b_var), y.data_ptr(), ptr(am), ptr(av), ptr(eps), seed,
                                                  call0 & 0xFFFFFFFF, stream_id, 1 if sample else 0,
@@ -275,7 +275,7 @@ def lrt_sample_chwn(act_mu, act_var, draws, seed, call0, stream_id, act=None):
     act_mu, act_var = act_mu.contiguous(), act_var.contiguous()
     C, Ho, Wo, B = act_mu.shape[-4:]
     y = torch.empty((draws, C, Ho, Wo, B), dtype=torch.float32, device=act_mu.device)
-    with torch.cuda.device(act_mu.device):
+    with on_device(act_mu.device):
         check(_lib.lib().bbb_lrt_sample_chwn(act_mu.data_ptr(), act_var.data_ptr(), y.data_ptr(), draws, C, Ho * Wo, B,
                                              {None: 0, "relu": 1, "softplus": 2}[act], seed, call0 & 0xFFFFFFFF, stream_id,
                                              rng.call_dev_ptr(act_mu.device), cur_stream(act_mu.device)), "bbb_lrt_sample_chwn")
@@ -292,7 +292,7 @@ def maxpool_chwn(x, k, s):
         planes *= v
     ho, wo = (H - k) // s + 1, (W - k) // s + 1
     y = torch.empty((*lead, ho, wo, B), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with on_device(x.device):
         check(_lib.lib().bbb_maxpool_chwn(x.data_ptr(), y.data_ptr(), planes, H, W, B, int(k), int(s), cur_stream(x.device)),
               "bbb_maxpool_chwn")
     return y
@@ -343,7 +343,7 @@ def sample_weights_bf16(mus, rhos, prior_mu, prior_sigma, stream_ids, seed, call
     kl = torch.empty((), dtype=torch.float32, device=dev)
     L = _lib.lib()
     parts = _partials(dev, L.bbb_reparam_partials(segs, len(mus)))
-    with torch.cuda.device(dev):
+    with on_device(dev):
         rc = L.bbb_reparam_kl_fwd(segs, len(mus), draws, float(prior_mu), float(prior_sigma), seed, call0 & 0xFFFFFFFF,
                                   0, ptr(parts), ptr(kl), 0, rng.call_dev_ptr(dev), cur_stream(dev))
     check(rc, "bbb_reparam_kl_fwd")
@@ -357,7 +357,7 @@ def to_batch_innermost_bf16(x):
     B = x.shape[0]
     plane = x.numel() // B
     y = torch.empty(tuple(x.shape[1:]) + (B,), dtype=torch.bfloat16, device=x.device)
-    with torch.cuda.device(x.device):
+    with on_device(x.device):
         check(_lib.lib().bbb_nchw_to_chwn_bf16(x.data_ptr(), y.data_ptr(), B, plane, cur_stream(x.device)), "bbb_nchw_to_chwn_bf16")
     return y
 
@@ -400,7 +400,7 @@ def conv2d_chwn_bf16_forward(x, w, bias, cin_khkw, stride=1, padding=0, dilation
         if out.numel() != E * w.shape[1] * ho * wo * B or not out.is_contiguous() or out.dtype != dt:
             raise _lib.BBBHipError("out= must be a contiguous tensor of the output's size and dtype")
         y = out.view(shape)
-    with torch.cuda.device(x.device):
+    with on_device(x.device):
         check(_lib.lib().bbb_conv2d_chwn_bf16_fwd(ctypes.byref(d), x.data_ptr(), w.data_ptr(), ptr(bias), y.data_ptr(),
                                                   (1 if out_f32 else 0) | (2 if tap_major else 0), cur_stream(x.device)),
               "bbb_conv2d_chwn_bf16_fwd")
@@ -417,7 +417,7 @@ def maxpool_chwn_bf16(x, k, s):
         planes *= v
     ho, wo = (H - k) // s + 1, (W - k) // s + 1
     y = torch.empty((*lead, ho, wo, B), dtype=torch.bfloat16, device=x.device)
-    with torch.cuda.device(x.device):
+    with on_device(x.device):
         check(_lib.lib().bbb_maxpool_chwn_bf16(x.data_ptr(), y.data_ptr(), planes, H, W, B, int(k), int(s), cur_stream(x.device)),
               "bbb_maxpool_chwn_bf16")
     return y
@@ -429,7 +429,7 @@ def mc_tail_cb(logits, mean_over=0):
     logits = logits.contiguous()
     E, C, B = logits.shape
     out = torch.empty((B, C), dtype=torch.float32, device=logits.device)
-    with torch.cuda.device(logits.device):
+    with on_device(logits.device):
         check(_lib.lib().bbb_mc_tail_cb(logits.data_ptr(), E, B, C, int(mean_over), out.data_ptr(), cur_stream(logits.device)),
               "bbb_mc_tail_cb")
     return out
@@ -442,7 +442,7 @@ def mc_tail_units(logits, slices, unit_off, mean_over=0):
     logits = logits.contiguous()
     U, C, Bs = logits.shape
     out = torch.empty((int(slices) * Bs, C), dtype=torch.float32, device=logits.device)
-    with torch.cuda.device(logits.device):
+    with on_device(logits.device):
         check(_lib.lib().bbb_mc_tail_units(logits.data_ptr(), U, int(slices), int(unit_off) % int(slices), Bs, C, int(mean_over),
                                            out.data_ptr(), cur_stream(logits.device)), "bbb_mc_tail_units")
     return out
@@ -454,7 +454,7 @@ def uncertainty(logits, normalized=False):
     logits = logits.contiguous()
     T, B, C = logits.shape
     outs = [torch.empty((B, C), dtype=torch.float32, device=logits.device) for _ in range(3)]
-    with torch.cuda.device(logits.device):
+    with on_device(logits.device):
         check(_lib.lib().bbb_uncertainty(logits.data_ptr(), T, B, C, 1 if normalized else 0, outs[0].data_ptr(),
                                          outs[1].data_ptr(), outs[2].data_ptr(), cur_stream(logits.device)), "bbb_uncertainty")
     return tuple(outs)
@@ -466,7 +466,7 @@ def to_batch_innermost(x):
     x = x.contiguous()
     B = x.shape[0]
     out = torch.empty(tuple(x.shape[1:]) + (B,), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with on_device(x.device):
         check(_lib.lib().bbb_transpose2d(x.data_ptr(), out.data_ptr(), B, x.numel() // B, cur_stream(x.device)), "bbb_transpose2d")
     return out
 
@@ -478,7 +478,7 @@ def mc_tail(logits, mean_over=0):
     logits = logits.contiguous()
     E, B, C = logits.shape
     out = torch.empty((B, C), dtype=torch.float32, device=logits.device)
-    with torch.cuda.device(logits.device):
+    with on_device(logits.device):
         check(_lib.lib().bbb_mc_tail(logits.data_ptr(), E, B, C, int(mean_over), out.data_ptr(), cur_stream(logits.device)),
               "bbb_mc_tail")
     return out
@@ -597,7 +597,7 @@ def lrt_sample_nchw(act_mu, act_var, seed, call0, stream_id):
     E = act_mu.shape[0]
     n = act_mu.numel() // E
     y = torch.empty_like(act_mu)
-    with torch.cuda.device(act_mu.device):
+    with on_device(act_mu.device):
         check(_lib.lib().bbb_lrt_sample_nchw(act_mu.data_ptr(), act_var.data_ptr(), y.data_ptr(), n, E, seed, call0 & 0xFFFFFFFF,
                                              stream_id, rng.call_dev_ptr(act_mu.device), cur_stream(act_mu.device)),
               "bbb_lrt_sample_nchw")
@@ -804,7 +804,7 @@ def pool_act_backward_chwn(g_out, y, k, s, act, pad_planes=False):
         g_pre = buf[:, :K].view(*lead, H, W, B)
     else:
         buf = g_pre = torch.empty_like(y)
-    with torch.cuda.device(y.device):
+    with on_device(y.device):
         check(_lib.lib().bbb_pool_act_bwd_chwn(g_out.data_ptr(), y.data_ptr(), buf.data_ptr(), planes, H, W, B, int(k), int(s),
                                                ACT_CODE[act], pitch if pitch != K else 0, cur_stream(y.device)), "bbb_pool_act_bwd_chwn")
     return g_pre
@@ -822,7 +822,7 @@ def conv2d_chwn_input_grad(g_pre, w, x_hw, padding, dilation):
     w = w.contiguous()
     E, Cout, Cin = w.shape[0], w.shape[1], w.shape[2]
     w_t = torch.empty((E, Cin, Cout, kh, kw), dtype=torch.float32, device=w.device)   # flipped taps, channels transposed
-    with torch.cuda.device(w.device):
+    with on_device(w.device):
         check(_lib.lib().bbb_flip_transpose_w(w.data_ptr(), w_t.data_ptr(), E, Cout, Cin, kh * kw, cur_stream(w.device)),
               "bbb_flip_transpose_w")
     gx = conv2d_chwn_forward(g_pre, w_t, None, 1, (qh, qw), (dh, dw))
@@ -835,7 +835,7 @@ def _transpose_batched(src, out, rows, cols, nb1, nb2, ib1, ib2, ir, ob1, ob2, o
     nb = nb1 * nb2
     if nb > 65535 or (rows + 31) // 32 > 65535:
         return False
-    with torch.cuda.device(src.device):
+    with on_device(src.device):
         check(_lib.lib().bbb_transpose_batched(src.data_ptr(), out.data_ptr(), rows, cols, nb1, nb2, ib1, ib2, ir, ob1, ob2, oc,
                                                cur_stream(src.device)), "bbb_transpose_batched")
     return True
@@ -919,7 +919,7 @@ def conv2d_chwn_weight_grad_shared_input(g_pre, x_nchw, w_shape, stride, padding
     Jp = (J + 3) // 4 * 4
     K = P_ * B
     xk = torch.empty((P_, B, Jp), dtype=torch.float32, device=g_pre.device)
-    with torch.cuda.device(g_pre.device):
+    with on_device(g_pre.device):
         check(_lib.lib().bbb_im2col_pbj(x_nchw.data_ptr(), xk.data_ptr(), ctypes.byref(dd), cur_stream(g_pre.device)), "bbb_im2col_pbj")
     M = E * Cout
     wgs = -(-M // 64) * -(-Jp // 64)
@@ -949,7 +949,7 @@ def conv2d_chwn_weight_grad_shared_input(g_pre, x_nchw, w_shape, stride, padding
         gp[:, :K] = g_pre.reshape(M, K)
     d.w_row_pitch = pitch
     y = torch.empty((S, M, Jp), dtype=torch.float32, device=g_pre.device)
-    with torch.cuda.device(g_pre.device):
+    with on_device(g_pre.device):
         check(_lib.lib().bbb_conv2d_chwn_fwd(ctypes.byref(d), xk.data_ptr(), gp.data_ptr(), 0, y.data_ptr(),
                                              cur_stream(g_pre.device)), "bbb_conv2d_chwn_fwd")
     gw = y.sum(0) if S > 1 else y[0]

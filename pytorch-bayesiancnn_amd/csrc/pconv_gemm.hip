@@ -203,29 +203,44 @@ __global__ __launch_bounds__(kThreads) void pconv_gemm_kernel(const PConvArgs p)
 
     const int lrow = lane & 31, lk = lane >> 5;
 
+    // Operand reads from LDS run PD k-steps ahead of the MFMAs that use them (a small register ring): a wave never waits a
+    // full LDS round trip between k-steps, so even a workgroup that is alone on its CU (launch tails, small launches)
+    // keeps its matrix pipe fed inside a tile.
+    constexpr int PD = (BM >= 128) ? 2 : 4;
     auto mma_tile = [&](bool more) {
+        float ra[PD + 1][NT], ra2[PD + 1][NT], rb[PD + 1][MT];
+        auto fetch = [&](int kk, int slot) {
+            const int krow = kk * 2 + lk;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) rb[slot][mt] = Xs[0][krow * LDX + wm + mt * 32 + lrow];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                ra[slot][nt] = Ws[0][0][krow * LDW + wn + nt * 32 + lrow];
+                if (LRT) ra2[slot][nt] = Ws[0][WSETS - 1][krow * LDW + wn + nt * 32 + lrow];
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < PD; ++i) fetch(i, i);
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
             if (ILV && kk < NLOADS) {
                 if (more) load_one(kk, wregA, xregA);
                 __builtin_amdgcn_sched_barrier(0);     // keep this load ahead of k-step kk's MFMAs, behind kk-1's
             }
-            const int krow = kk * 2 + lk;
-            float b[MT];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) b[mt] = Xs[0][krow * LDX + wm + mt * 32 + lrow];
+            if (kk + PD < BK / 2) fetch(kk + PD, (kk + PD) % (PD + 1));
+            const int s = kk % (PD + 1);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const float a = Ws[0][0][krow * LDW + wn + nt * 32 + lrow];
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[mt], acc[nt][mt], 0, 0, 0);
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[s][nt], rb[s][mt], acc[nt][mt], 0, 0, 0);
                 if (LRT) {
-                    const float a2 = Ws[0][WSETS - 1][krow * LDW + wn + nt * 32 + lrow];
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
-                        accv[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b[mt] * b[mt], accv[nt][mt], 0, 0, 0);
+                        accv[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra2[s][nt], rb[s][mt] * rb[s][mt], accv[nt][mt], 0, 0, 0);
                 }
             }
+            if (!ILV) __builtin_amdgcn_sched_barrier(0);
         }
     };
 

@@ -85,10 +85,10 @@ def fast_forward(wrapper, x):
     mods = ensemble.flat_children(wrapper)
     if not mods or not isinstance(mods[-1], BayesianLayer) or not hasattr(mods[-1], "out_features"):
         return None
-    layers = [m for m in mods if isinstance(m, BayesianLayer)]
+    layers = ensemble.bayesian_layers(wrapper)
     if any(l.eps_source is not None for l in layers) or not all(l.W_mu.is_cuda for l in layers):
         return None
-    if torch.is_grad_enabled() and any(p.requires_grad for p in wrapper.parameters()):
+    if torch.is_grad_enabled() and ensemble.any_requires_grad(wrapper):
         # training / the reference's validate loop (which does not disable autograd): the same kernels behind ONE autograd node
         from bbb_hip import fast_train
         if not ensemble.fast_autograd or not fast_train.train_path_ok(wrapper, x):
