@@ -387,6 +387,38 @@ def test_plan_slices_and_output_rows():
     assert [type(m).__name__ for m in ensemble.flat_children(net)][:3] == ["BBBConv2d", "Softplus", "MaxPool2d"]
 
 
+def test_cached_model_structure_follows_the_module_tree():
+    """ensemble._structure: what the per-forward checks ask about a model is analysed once and cached on the module; replacing
+    a direct child rebuilds it, a change inside a nested container needs invalidate()."""
+    import copy
+    from torch import nn
+    import layers
+    from bbb_hip import ensemble, zoo
+    pri = {"prior_mu": 0, "prior_sigma": 0.1, "posterior_mu_initial": (0, 0.1), "posterior_rho_initial": (-5, 0.1)}
+    net = zoo.BBBLeNet(10, 1, pri, "bbb", "softplus")
+    n_layers = len(ensemble.bayesian_layers(net))
+    flat = ensemble.flat_children(net)
+    assert ensemble.flat_children(net) is flat and n_layers == 5                    # served from the cache
+    assert "_bbb_structure" not in net.state_dict() and len(net.state_dict()) == 4 * n_layers
+    net.extra = layers.BBB_Linear(10, 10, priors=pri)                                # a new direct child: new signature
+    assert len(ensemble.bayesian_layers(net)) == n_layers + 1 and ensemble.flat_children(net) is not flat
+    twin = copy.deepcopy(net)                                                       # the copy analyses its OWN modules
+    assert all(a is not b for a, b in zip(ensemble.bayesian_layers(net), ensemble.bayesian_layers(twin)))
+    assert ensemble.bayesian_layers(twin)[0] is next(twin.modules().__iter__()).conv1
+    seq = nn.Sequential(layers.BBB_Linear(8, 8, priors=pri), nn.ReLU())
+    wrap = layers.ModuleWrapper()
+    wrap.body = seq
+    wrap.head = layers.BBB_Linear(8, 4, priors=pri)
+    assert len(ensemble.bayesian_layers(wrap)) == 2 and len(ensemble.flat_children(wrap)) == 3
+    seq.append(layers.BBB_Linear(8, 8, priors=pri))                                  # nested edit: invisible to the signature ...
+    assert len(ensemble.bayesian_layers(wrap)) == 2
+    ensemble.invalidate(wrap)                                                       # ... until the caller says so
+    assert len(ensemble.bayesian_layers(wrap)) == 3 and len(ensemble.flat_children(wrap)) == 4
+    for p_ in wrap.parameters():
+        p_.requires_grad_(False)
+    assert not ensemble.any_requires_grad(wrap)                                     # flags are read live, not cached
+
+
 _DP_WORKER = r'''
 import os, sys
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
