@@ -2,7 +2,7 @@
 fp32 GEMM layers run back-to-back on the main stream."""
 import ctypes, json, os, sys
 HERE = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, os.path.join(HERE, '..', '..', '..', 'pytorch-bayesiancnn_amd'))
+sys.path.insert(0, os.path.join(HERE, '..', '..', 'pytorch-bayesiancnn_amd'))
 import torch
 from bbb_hip import ops
 lib = ctypes.CDLL(os.path.join(HERE, 'libclk.so'))
