@@ -43,23 +43,22 @@ extern "C" int probe_mfma_f32_ceiling(double* tflops_out, int reps, void* stream
     er = hipMalloc(&out, (size_t)blocks * 256 * sizeof(float));
     if (er != hipSuccess) return (int)er;
     hipEvent_t e0, e1;
-    hipEventCreate(&e0);
-    hipEventCreate(&e1);
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipFree(out); return (int)hipErrorUnknown; }
     double best = 0.0;
     for (int r = 0; r < reps + 1; ++r) {                           // first launch is a warm-up
-        hipEventRecord(e0, st);
+        (void)hipEventRecord(e0, st);
         hipLaunchKernelGGL(mfma_loop_kernel, dim3(blocks), dim3(256), 0, st, out, iters, 1.0f, 0.5f);
-        hipEventRecord(e1, st);
+        (void)hipEventRecord(e1, st);
         er = hipEventSynchronize(e1);
         if (er != hipSuccess) break;
         float ms = 0.0f;
-        hipEventElapsedTime(&ms, e0, e1);
+        (void)hipEventElapsedTime(&ms, e0, e1);
         const double tf = (double)blocks * 4.0 * iters * 4.0 * 4096.0 / ((double)ms * 1e9);
         if (r > 0 && tf > best) best = tf;
     }
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
-    hipFree(out);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(out);
     *tflops_out = best;
     return (int)er;
 }
