@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define BBB_ABI_VERSION 4
+#define BBB_ABI_VERSION 5
 #define BBB_MAX_SEGMENTS 16
 
 #define BBB_EINVAL (-1)   /* bad argument (null pointer, non-positive size, too many segments) */
@@ -95,7 +95,10 @@ int64_t bbb_reparam_partials(const bbb_segment_t* segs, int nseg);
  *   grad_mu  = sum_e gw[e] + gkl * (mu - mu0) / sigma^2
  *   grad_rho = (sum_e gw[e]*eps[e] + gkl * (1/sigma - sigma0^2/sigma^3 - (mu-mu0)^2/sigma^3)) * sigmoid(rho)
  * eps is regenerated from (seed, call0 + e, stream_id), never stored.  In each segment `w` holds the
- * incoming gradient gw [draws][n] (may be NULL = 0), `sigma` is unused, `eps` optional external noise.
+ * incoming gradient gw [draws][n] (may be NULL = 0), `eps` optional external noise, and `sigma` (may be NULL = 0) the
+ * incoming gradient gs [n] w.r.t. the forward's sigma output -- sigma^2 with BBB_SIGMA_SQUARED in flags, the LRT layers'
+ * variance operand (layers/BBB_LRT/BBBConv.py:64-69) -- which adds gs * sigmoid(rho), resp. gs * 2 sigma * sigmoid(rho), to
+ * grad_rho.
  * grad_mu / grad_rho are arrays of nseg device pointers given on the host.  gkl: device float
  * (d loss / d kl), NULL = 0.  call_dev: as in bbb_reparam_kl_fwd (a captured training step regenerates the forward's noise).
  */
@@ -213,6 +216,19 @@ int bbb_maxpool_chwn(const float* x, float* y, int64_t planes, int h, int w, int
  */
 int bbb_pool_act_bwd_chwn(const float* g_out, const float* y, float* g_pre, int64_t planes, int h, int w, int batch,
                           int k, int s, int act, int64_t out_plane_pitch, void* stream);
+
+/*
+ * The same pass for a local-reparameterisation layer (layers/BBB_LRT/BBBConv.py:71-81: out = act_mu + sqrt(act_var) * eps, then
+ * the activation, then the pool): besides g_mu = the gradient w.r.t. act_mu (what bbb_pool_act_bwd_chwn calls g_pre) it writes
+ *   g_var = g_mu * (v - act_mu) / (2 * act_var),   v = the pre-activation recovered from y (Softplus: y + log(1 - exp(-y)) below
+ *           the threshold of 20; ReLU: y, and no gradient where y == 0; act = 0: y itself)
+ * -- the gradient w.r.t. act_var, since sqrt(act_var) * eps = v - act_mu.  act_mu / act_var: [moment_planes][h][w][B] with
+ * moment_planes == planes, or a divisor of it when consecutive groups of moment_planes planes (the draws of a first layer whose
+ * input and weights every draw shares) were sampled from ONE pair of moments.  g_mu and g_var share out_plane_pitch.
+ */
+int bbb_lrt_pool_act_bwd_chwn(const float* g_out, const float* y, const float* act_mu, const float* act_var, float* g_mu,
+                              float* g_var, int64_t planes, int64_t moment_planes, int h, int w, int batch, int k, int s, int act,
+                              int64_t out_plane_pitch, void* stream);
 
 /*
  * E noise draws from ONE pair of LRT moments, batch-innermost: y[e] = act(act_mu + sqrt(act_var) * eps[e]) with eps exactly

@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede CDLL: shares torch's HIP runtime)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BBB_HIP_LIB") or os.path.join(_HERE, "libbbb_hip.so")   # env override: experiments only
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_SEGMENTS = 16
 SIGMA_SQUARED = 1
 KL_TEXTBOOK = 2
@@ -59,6 +59,8 @@ _SIGNATURES = {
     "bbb_lrt_sample_nchw": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_u64, c_u32, c_u32, c_void_p, c_void_p]),
     "bbb_maxpool_chwn": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "bbb_pool_act_bwd_chwn": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_i64, c_void_p]),
+    "bbb_lrt_pool_act_bwd_chwn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_int, c_int, c_int,
+                                          c_int, c_int, c_int, c_i64, c_void_p]),
     "bbb_conv2d_chwn_bf16_fwd": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_u32, c_void_p]),
     "bbb_maxpool_chwn_bf16": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "bbb_nchw_to_chwn_bf16": (c_int, [c_void_p, c_void_p, c_int, c_i64, c_void_p]),

@@ -281,24 +281,20 @@ class _MCForwardLRT(torch.autograd.Function):
             w_mu, w_var = rec["w_mu"], rec["w_var"]
             stride, padding, dilation = rec["geom"]
             g = g.reshape(rec["out_shape"])
-            if rec["pool"] is not None:
-                g_pre = ops.pool_act_backward_chwn(g, y, rec["pool"][0], rec["pool"][1], act)
-            elif act is not None:
-                g_pre = ops.pool_act_backward_chwn(g, y, 0, 1, act)
-            else:
-                g_pre = g
-            v = _inverse_act(y, act)
-            t = torch.where(y > 0, v - am, torch.zeros_like(v)) if act is not None else v - am      # sqrt(act_var) * eps
-            g_var = g_pre * t / (2.0 * av)
-            g_mu = g_pre
+            # one pass: pooling / activation backward AND the split into d/d act_mu, d/d act_var (was ~10 ATen kernels per layer)
+            k, s = rec["pool"] if rec["pool"] is not None else (0, 1)
+            pad = rec["first"] and x_in.shape[1] % 4 != 0                # feeds conv2d_chwn_weight_grad_shared_input
+            g_mu, g_var = ops.lrt_pool_act_backward_chwn(g, y, am, av, k, s, act, pad_planes=pad)
             if am.shape[0] == 1 and g_mu.shape[0] > 1:      # first layer: one pair of moments feeds every draw
                 g_mu, g_var = g_mu.sum(0, keepdim=True), g_var.sum(0, keepdim=True)
             grads[4 * li + 2] = g_mu.sum(dim=(0, 2, 3, 4))
             grads[4 * li + 3] = g_var.sum(dim=(0, 2, 3, 4))
             wshape = (1,) + tuple(w_mu.shape)
             if x_in.shape[1] % 4 == 0:
-                gw_mu = ops.conv2d_chwn_weight_grad(g_mu, x_in, wshape, stride, padding, dilation).sum(0)
-                gw_var = ops.conv2d_chwn_weight_grad(g_var, x_in * x_in, wshape, stride, padding, dilation).sum(0)
+                gw_mu = ops.conv2d_chwn_weight_grad(g_mu, x_in, wshape, stride, padding, dilation)
+                gw_var = ops.conv2d_chwn_weight_grad(g_var, x_in * x_in, wshape, stride, padding, dilation)
+                gw_mu = gw_mu[0] if gw_mu.shape[0] == 1 else gw_mu.sum(0)
+                gw_var = gw_var[0] if gw_var.shape[0] == 1 else gw_var.sum(0)
             else:
                 xn = ctx.x_nchw
                 gw_mu = ops.conv2d_chwn_weight_grad_shared_input(g_mu, xn, wshape, stride, padding, dilation)[0]
@@ -308,8 +304,8 @@ class _MCForwardLRT(torch.autograd.Function):
             grads[4 * li + 1] = gw_var.reshape(m.W_mu.shape)
             if not rec["first"]:
                 hw = (x_in.shape[2], x_in.shape[3])
-                g = ops.conv2d_chwn_input_grad(g_mu, w_mu.unsqueeze(0), hw, padding, dilation) \
-                    + 2.0 * x_in * ops.conv2d_chwn_input_grad(g_var, w_var.unsqueeze(0), hw, padding, dilation)
+                g = torch.addcmul(ops.conv2d_chwn_input_grad(g_mu, w_mu.unsqueeze(0), hw, padding, dilation), x_in,
+                                  ops.conv2d_chwn_input_grad(g_var, w_var.unsqueeze(0), hw, padding, dilation), value=2.0)
         return (None, None, *grads)
 
 

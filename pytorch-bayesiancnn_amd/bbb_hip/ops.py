@@ -74,8 +74,9 @@ def reparam_kl_forward(mus, rhos, prior_mu, prior_sigma, stream_ids, seed, call0
 
 
 def reparam_kl_backward(mus, rhos, gws, gkl, prior_mu, prior_sigma, stream_ids, seed, call0, draws, eps=None,
-                        textbook_kl=False):
-    """grad_mu[i], grad_rho[i] for every tensor (see bbb_reparam_kl_bwd)."""
+                        textbook_kl=False, gsigmas=None, sigma_squared=False):
+    """grad_mu[i], grad_rho[i] for every tensor (see bbb_reparam_kl_bwd).  gsigmas: gradients w.r.t. the forward's sigma
+    (sigma_squared: sigma^2) outputs, entries may be None."""
     require_device(*mus, *rhos)
     dev = mus[0].device
     mus = [m.contiguous() for m in mus]
@@ -83,14 +84,17 @@ def reparam_kl_backward(mus, rhos, gws, gkl, prior_mu, prior_sigma, stream_ids, 
     gws = [None if g is None else g.contiguous() for g in gws]
     if eps is not None:
         eps = [e.contiguous() for e in eps]
-    segs = _segments(mus, rhos, gws, None, eps, stream_ids, draws)
+    if gsigmas is not None:
+        gsigmas = [None if g is None else g.to(dtype=torch.float32).contiguous() for g in gsigmas]
+        require_device(*gsigmas)
+    segs = _segments(mus, rhos, gws, gsigmas, eps, stream_ids, draws)
     gmu = [torch.empty_like(m) for m in mus]
     grho = [torch.empty_like(m) for m in mus]
     pm = (ctypes.c_void_p * len(mus))(*[g.data_ptr() for g in gmu])
     pr = (ctypes.c_void_p * len(mus))(*[g.data_ptr() for g in grho])
     if gkl is not None:
         gkl = gkl.to(device=dev, dtype=torch.float32).contiguous()
-    flags = _lib.KL_TEXTBOOK if textbook_kl else 0
+    flags = (_lib.KL_TEXTBOOK if textbook_kl else 0) | (_lib.SIGMA_SQUARED if (sigma_squared and gsigmas is not None) else 0)
     with on_device(dev):
         rc = _lib.lib().bbb_reparam_kl_bwd(segs, len(mus), draws, float(prior_mu), float(prior_sigma), seed,
                                            call0 & 0xFFFFFFFF, flags, ptr(gkl), pm, pr, rng.call_dev_ptr(dev), cur_stream(dev))
@@ -535,16 +539,16 @@ class _KLOnly(torch.autograd.Function):
         params = ctx.saved_tensors
         cfg = ctx.cfg
         mus, rhos = list(params[0::2]), list(params[1::2])
+        # d sigma / d rho = sigmoid(rho), d sigma^2 / d rho = 2 sigma sigmoid(rho): folded into the backward kernel (the LRT
+        # training step spent ~70 ATen launches per step on these twelve small tensors)
+        gs = None
+        if gsig and any(g is not None for g in gsig):
+            gs = [gsig[i] if i < len(gsig) else None for i in range(len(mus))]
         gmu, grho = reparam_kl_backward(mus, rhos, [None] * len(mus), gkl, cfg["prior_mu"], cfg["prior_sigma"],
-                                        cfg["stream_ids"], 0, 0, 1, textbook_kl=cfg.get("textbook_kl", False))
+                                        cfg["stream_ids"], 0, 0, 1, textbook_kl=cfg.get("textbook_kl", False), gsigmas=gs,
+                                        sigma_squared=cfg.get("sigma_squared", False))
         out = [None]
-        for i, (a, b) in enumerate(zip(gmu, grho)):
-            if gsig and gsig[i] is not None:
-                # d sigma/d rho = sigmoid(rho); d sigma^2/d rho = 2 sigma sigmoid(rho)   (training extension, torch ops)
-                sg = torch.sigmoid(rhos[i])
-                if cfg.get("sigma_squared", False):
-                    sg = sg * 2.0 * torch.nn.functional.softplus(rhos[i])
-                b = b + gsig[i] * sg
+        for a, b in zip(gmu, grho):
             out += [a, b]
         return tuple(out)
 
@@ -808,6 +812,34 @@ def pool_act_backward_chwn(g_out, y, k, s, act, pad_planes=False):
         check(_lib.lib().bbb_pool_act_bwd_chwn(g_out.data_ptr(), y.data_ptr(), buf.data_ptr(), planes, H, W, B, int(k), int(s),
                                                ACT_CODE[act], pitch if pitch != K else 0, cur_stream(y.device)), "bbb_pool_act_bwd_chwn")
     return g_pre
+
+
+def lrt_pool_act_backward_chwn(g_out, y, act_mu, act_var, k, s, act, pad_planes=False):
+    """pool_act_backward_chwn for a local-reparameterisation layer: -> (g_mu, g_var), the gradients w.r.t. act_mu and act_var
+    (bbb_lrt_pool_act_bwd_chwn).  act_mu / act_var: y's shape, or one draw's worth ([1, C, H, W, B]) when every draw was sampled
+    from the same pair of moments."""
+    require_device(g_out, y, act_mu, act_var)
+    g_out, y, act_mu, act_var = g_out.contiguous(), y.contiguous(), act_mu.contiguous(), act_var.contiguous()
+    *lead, H, W, B = y.shape
+    planes = 1
+    for v in lead:
+        planes *= v
+    mom_planes = act_mu.numel() // (H * W * B)
+    if act_mu.shape != act_var.shape or act_mu.numel() != mom_planes * H * W * B or planes % max(mom_planes, 1) != 0:
+        raise _lib.BBBHipError("lrt_pool_act_backward_chwn: act_mu / act_var must hold y's planes, or one draw's worth of them")
+    K = H * W * B
+    pitch = padded_plane_pitch(K) if pad_planes else K
+    if pitch != K:
+        bufs = [torch.empty((planes, pitch), dtype=torch.float32, device=y.device) for _ in range(2)]
+        outs = [b[:, :K].view(*lead, H, W, B) for b in bufs]
+    else:
+        bufs = outs = [torch.empty_like(y), torch.empty_like(y)]
+    with on_device(y.device):
+        check(_lib.lib().bbb_lrt_pool_act_bwd_chwn(g_out.data_ptr(), y.data_ptr(), act_mu.data_ptr(), act_var.data_ptr(),
+                                                   bufs[0].data_ptr(), bufs[1].data_ptr(), planes, mom_planes, H, W, B, int(k), int(s),
+                                                   ACT_CODE[act], pitch if pitch != K else 0, cur_stream(y.device)),
+              "bbb_lrt_pool_act_bwd_chwn")
+    return outs[0], outs[1]
 
 
 def conv2d_chwn_input_grad(g_pre, w, x_hw, padding, dilation):

@@ -361,9 +361,15 @@ __global__ __launch_bounds__(256) void maxpool_chwn_kernel(const float* __restri
 //   g_pre = g_act * act'(pre-activation), written from y alone: Softplus' = sigmoid(v) = 1 - exp(-y), ReLU' = [y > 0].
 // Overlapping windows (k > s: Bayesian3Conv3FC pools 3x3 / 2) make up to ceil(k/s)^2 windows per element; nothing is
 // scattered, so no atomics and a deterministic result.
+// LRT layers (am != NULL): the layer's output was act(act_mu + sqrt(act_var) * eps), so besides g_pre (= the gradient w.r.t.
+// act_mu) the same pass writes the gradient w.r.t. act_var, g_pre * (v - act_mu) / (2 act_var), with the pre-activation v
+// recovered from the stored activated output (softplus: y + log(1 - exp(-y)); nothing flows where ReLU clipped).  act_mu /
+// act_var hold mom_planes planes: all of them, or one draw's worth when every draw shares one pair of moments (first layer).
 __global__ __launch_bounds__(256) void pool_act_bwd_chwn_kernel(const float* __restrict__ g_out, const float* __restrict__ y,
                                                                 float* __restrict__ g_pre, int64_t total4, int H, int W, int Hp,
-                                                                int Wp, int B4, int k, int s, int act, int64_t out_pitch4) {
+                                                                int Wp, int B4, int k, int s, int act, int64_t out_pitch4,
+                                                                const float* __restrict__ am, const float* __restrict__ av,
+                                                                float* __restrict__ g_var, int64_t mom_planes) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total4) return;
     const int b4 = (int)(i % B4);
@@ -411,6 +417,21 @@ __global__ __launch_bounds__(256) void pool_act_bwd_chwn_kernel(const float* __r
     // out_pitch4 != 0: planes are written at that pitch (in 16-byte units) instead of densely -- see bbb_pool_act_bwd_chwn
     const int64_t oi = out_pitch4 ? pl * out_pitch4 + (i - pl * (int64_t)H * W * B4) : i;
     reinterpret_cast<f32x4*>(g_pre)[oi] = o;
+    if (am != nullptr) {
+        const int64_t in_plane = i - pl * (int64_t)H * W * B4;
+        const int64_t mi = (pl % mom_planes) * ((int64_t)H * W * B4) + in_plane;
+        const f32x4 a4 = reinterpret_cast<const f32x4*>(am)[mi];
+        const f32x4 v4 = reinterpret_cast<const f32x4*>(av)[mi];
+        f32x4 gv;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float v = me[u];
+            if (act == 2 && !(v > 20.0f)) v = v + logf(-expm1f(-v));
+            const float t = (act != 0 && !(me[u] > 0.0f)) ? 0.0f : v - a4[u];        // sqrt(act_var) * eps
+            gv[u] = (o[u] * t) / (2.0f * v4[u]);
+        }
+        reinterpret_cast<f32x4*>(g_var)[oi] = gv;
+    }
 }
 
 int fill(const bbb_conv_desc_t* d, PConvArgs& a) {
@@ -527,8 +548,9 @@ extern "C" int bbb_maxpool_chwn(const float* x, float* y, int64_t planes, int h,
     return (int)hipGetLastError();
 }
 
-extern "C" int bbb_pool_act_bwd_chwn(const float* g_out, const float* y, float* g_pre, int64_t planes, int h, int w, int batch,
-                                     int k, int s, int act, int64_t out_plane_pitch, void* stream) {
+namespace {
+int pool_act_bwd_launch(const float* g_out, const float* y, float* g_pre, int64_t planes, int h, int w, int batch, int k, int s, int act,
+                        int64_t out_plane_pitch, const float* am, const float* av, float* g_var, int64_t mom_planes, void* stream) {
     if (g_out == nullptr || y == nullptr || g_pre == nullptr || planes <= 0 || h <= 0 || w <= 0 || batch <= 0 || k < 0 ||
         (k > 0 && s <= 0) || act < 0 || act > 2)
         return BBB_EINVAL;
@@ -540,6 +562,22 @@ extern "C" int bbb_pool_act_bwd_chwn(const float* g_out, const float* y, float* 
     const int64_t blocks = (total4 + 255) / 256;
     if (blocks > 0x7fffffffLL) return BBB_ESHAPE;
     hipLaunchKernelGGL(pool_act_bwd_chwn_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g_out, y, g_pre, total4, h, w,
-                       hp, wp, batch / 4, k, s, act, out_plane_pitch / 4);
+                       hp, wp, batch / 4, k, s, act, out_plane_pitch / 4, am, av, g_var, mom_planes);
     return (int)hipGetLastError();
+}
+}  // namespace
+
+extern "C" int bbb_pool_act_bwd_chwn(const float* g_out, const float* y, float* g_pre, int64_t planes, int h, int w, int batch,
+                                     int k, int s, int act, int64_t out_plane_pitch, void* stream) {
+    return pool_act_bwd_launch(g_out, y, g_pre, planes, h, w, batch, k, s, act, out_plane_pitch, nullptr, nullptr, nullptr, 1, stream);
+}
+
+extern "C" int bbb_lrt_pool_act_bwd_chwn(const float* g_out, const float* y, const float* act_mu, const float* act_var, float* g_mu,
+                                         float* g_var, int64_t planes, int64_t moment_planes, int h, int w, int batch, int k, int s,
+                                         int act, int64_t out_plane_pitch, void* stream) {
+    if (act_mu == nullptr || act_var == nullptr || g_var == nullptr) return BBB_EINVAL;
+    if (moment_planes <= 0 || planes % moment_planes != 0) return BBB_EINVAL;
+    if ((((uintptr_t)act_mu | (uintptr_t)act_var | (uintptr_t)g_var) & 15u) != 0) return BBB_EALIGN;
+    return pool_act_bwd_launch(g_out, y, g_mu, planes, h, w, batch, k, s, act, out_plane_pitch, act_mu, act_var, g_var, moment_planes,
+                               stream);
 }

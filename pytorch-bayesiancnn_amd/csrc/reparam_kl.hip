@@ -419,6 +419,8 @@ __global__ __launch_bounds__(kThreads) void reparam_kl_bwd_kernel(const ReparamA
     const float mu0 = a.prior_mu, sig0 = a.prior_sigma;
     const bool textbook = (a.flags & BBB_KL_TEXTBOOK) != 0;
     const float gkl = a.gkl ? *a.gkl : 0.0f;
+    const bool sq = (a.flags & BBB_SIGMA_SQUARED) != 0;
+    const float* __restrict__ gsig = sg.sigma;                  // backward: gradient w.r.t. the sigma (or sigma^2) output, or NULL
     const bool aligned = ((((uintptr_t)sg.mu | (uintptr_t)sg.rho | (uintptr_t)sg.w | (uintptr_t)sg.eps |
                             (uintptr_t)gmu_out | (uintptr_t)grho_out) & 15u) == 0) && ((sg.draw_stride & 3) == 0);
 #pragma unroll
@@ -478,8 +480,11 @@ __global__ __launch_bounds__(kThreads) void reparam_kl_bwd_kernel(const ReparamA
                 kmu = d / (sig0 * sig0);
                 ksig = sigma / (sig0 * sig0) - is;
             }
+            // the sigma output of the forward (the LRT layers' variance operand): d sigma / d rho = sigmoid(rho),
+            // d sigma^2 / d rho = 2 sigma sigmoid(rho)
+            const float gs = (gsig != nullptr && j < cnt) ? gsig[i0 + j] * (sq ? 2.0f * sigma : 1.0f) : 0.0f;
             gm[j] = acc_mu[j] + gkl * kmu;
-            gr[j] = (acc_sig[j] + gkl * ksig) * sgm;
+            gr[j] = (acc_sig[j] + gkl * ksig + gs) * sgm;
         }
         if (aligned && cnt == 4) {
             f32x4 a4, b4;

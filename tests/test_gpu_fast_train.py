@@ -43,6 +43,46 @@ def test_pool_act_backward_kernel_vs_torch(env, k, s, act, H):
     np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=2e-6)
 
 
+@pytest.mark.parametrize("k,s,act,H,shared", [(2, 2, "softplus", 8, False), (3, 2, "relu", 9, False), (0, 1, None, 4, False),
+                                              (0, 1, "softplus", 4, True), (2, 2, "relu", 6, True)])
+def test_lrt_pool_act_backward_kernel_vs_torch_float64(env, k, s, act, H, shared):
+    """bbb_lrt_pool_act_bwd_chwn: out = pool(act(act_mu + sqrt(act_var) * eps)); gradients w.r.t. act_mu and act_var from torch
+    autograd in float64 (layers/BBB_LRT/BBBConv.py:71-81); `shared`: E draws sampled from ONE pair of moments (first layer)."""
+    g = torch.Generator(device="cuda").manual_seed(100 + k * 10 + H)
+    E, C, B = 3, 4, 8
+    Em = 1 if shared else E
+    am = torch.randn(Em, C, H, H, B, device="cuda", generator=g)
+    av = torch.rand(Em, C, H, H, B, device="cuda", generator=g) * 0.5 + 0.05
+    eps = torch.randn(E, C, H, H, B, device="cuda", generator=g)
+    am64, av64 = am.double().requires_grad_(True), av.double().requires_grad_(True)
+    pre = am64 + torch.sqrt(av64) * eps.double()
+    a = F.softplus(pre) if act == "softplus" else (F.relu(pre) if act == "relu" else pre)
+    a4 = a.permute(0, 4, 1, 2, 3).reshape(E * B, C, H, H)
+    out = F.max_pool2d(a4, k, s) if k else a4
+    go = torch.randn(out.shape, device="cuda", generator=g, dtype=torch.float64)
+    out.backward(go)
+    y = a.detach().float().contiguous()                                        # what the forward kernel stored
+    Hp = out.shape[-1]
+    g_out = go.float().reshape(E, B, C, Hp, Hp).permute(0, 2, 3, 4, 1).contiguous()
+    g_mu, g_var = env["ops"].lrt_pool_act_backward_chwn(g_out, y, am, av, k, s, act)
+    g_mu_p, g_var_p = env["ops"].lrt_pool_act_backward_chwn(g_out, y, am, av, k, s, act, pad_planes=True)
+    assert torch.equal(g_mu, g_mu_p) and torch.equal(g_var, g_var_p)
+    assert torch.equal(g_mu, env["ops"].pool_act_backward_chwn(g_out, y, k, s, act) if (k or act) else g_out)
+    if shared:
+        g_mu, g_var = g_mu.sum(0, keepdim=True), g_var.sum(0, keepdim=True)
+    # the kernel recovers the pre-activation from the fp32 activated output: where softplus saturates towards 0 the
+    # recovered value loses relative accuracy exactly as the torch expression the backward used before (y + log(-expm1(-y)))
+    np.testing.assert_allclose(g_mu.cpu().numpy(), am64.grad.float().cpu().numpy(), rtol=3e-5, atol=3e-6)
+    np.testing.assert_allclose(g_var.cpu().numpy(), av64.grad.float().cpu().numpy(), rtol=2e-3, atol=2e-4)
+    v = torch.where(y > 20.0, y, y + torch.log(-torch.expm1(-y))) if act == "softplus" else y
+    t = torch.where(y > 0, v - am, torch.zeros_like(v)) if act is not None else v - am
+    g_pre = env["ops"].pool_act_backward_chwn(g_out, y, k, s, act) if (k or act) else g_out
+    old = g_pre * t / (2.0 * av)                                               # the ATen expression this kernel replaced
+    if shared:
+        old = old.sum(0, keepdim=True)
+    np.testing.assert_allclose(g_var.cpu().numpy(), old.cpu().numpy(), rtol=2e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize("Cin,Cout,kk,pad,H", [(8, 12, 3, 1, 6), (64, 32, 5, 2, 4), (16, 10, 1, 0, 1)])
 def test_chwn_wgrad_dgrad_vs_torch_float64(env, Cin, Cout, kk, pad, H):
     ops = env["ops"]

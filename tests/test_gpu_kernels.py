@@ -118,6 +118,33 @@ def test_reparam_backward_matches_oracle_grads(ops):
     np.testing.assert_allclose(gr[0].cpu().numpy(), (gw * eps).sum(0) * sgm + 0.37 * krho, rtol=2e-4, atol=2e-4)
 
 
+@pytest.mark.parametrize("squared", [False, True])
+def test_reparam_backward_takes_the_sigma_output_gradient(ops, squared):
+    """The forward's sigma / sigma^2 output (the LRT layers' variance operand, layers/BBB_LRT/BBBConv.py:64-69) is
+    differentiable: its incoming gradient enters grad_rho through d sigma / d rho = sigmoid(rho) (x 2 sigma when squared),
+    inside bbb_reparam_kl_bwd; checked against torch autograd in float64 through ops.kl_only."""
+    g = torch.Generator(device="cuda").manual_seed(11)
+    shapes = [(6, 5, 3, 3), (6,), (10, 7)]
+    mus = [(torch.randn(sh, device="cuda", generator=g) * 0.1).requires_grad_(True) for sh in shapes]
+    rhos = [(torch.randn(sh, device="cuda", generator=g) * 0.5 - 3).requires_grad_(True) for sh in shapes]
+    gs = [torch.randn(sh, device="cuda", generator=g) for sh in shapes]
+    kl, sig = ops.kl_only(mus, rhos, 0.0, 0.1, want_sigma=True, sigma_squared=squared)
+    loss = 0.37 * kl + sum((a * b).sum() for a, b in zip(sig[:2], gs[:2]))          # the third sigma output gets no gradient
+    loss.backward()
+    mus64 = [m.detach().double().requires_grad_(True) for m in mus]
+    rhos64 = [r.detach().double().requires_grad_(True) for r in rhos]
+    ref = 0.0
+    for i, (m, r) in enumerate(zip(mus64, rhos64)):
+        sg = torch.log1p(torch.exp(r))
+        ref = ref + 0.37 * 0.5 * (2 * torch.log(sg / 0.1) - 1 + (0.1 / sg) ** 2 + ((m - 0.0) / sg) ** 2).sum()   # metrics.py:28
+        if i < 2:
+            ref = ref + ((sg * sg if squared else sg) * gs[i].double()).sum()
+    ref.backward()
+    for m, m64, r, r64 in zip(mus, mus64, rhos, rhos64):
+        np.testing.assert_allclose(m.grad.cpu().numpy(), m64.grad.float().cpu().numpy(), rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(r.grad.cpu().numpy(), r64.grad.float().cpu().numpy(), rtol=2e-4, atol=2e-4)
+
+
 # ---------------------------------------------------------------- conv / linear on the fp32 matrix cores
 CONV_CASES = [
     # B, Cin, H, W, Cout, kh, kw, stride, pad, dil, E, x_shared

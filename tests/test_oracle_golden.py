@@ -245,7 +245,8 @@ def test_bf16_storage_model_is_a_small_perturbation_of_the_fp32_oracle():
 def test_port_times_like_the_live_reference():
     """bench.py's cpu_baseline uses the port where /root/reference does not exist (the GPU box): besides producing the same
     bits, the port must COST the same as the unmodified modules on the same cores.  One AlexNet draw at bs=256, interleaved
-    runs, minimum of 7 each, within 5 % (three attempts: shared build hosts are noisy)."""
+    runs, minimum of 9 each, within 5 % in at least one of up to eight attempts (shared build hosts are noisy: a neighbour's
+    burst shifts one attempt by 10 % or more, a real difference between the two code paths shifts all of them)."""
     import subprocess
     code = r"""
 import sys, time; sys.dont_write_bytecode = True
@@ -264,10 +265,11 @@ def t_port():
 with torch.no_grad():
     for _ in range(2): t_ref(); t_port()
     best = None
-    for attempt in range(3):
+    for attempt in range(8):
         a, b = [], []
-        for _ in range(7):
-            a.append(t_ref()); b.append(t_port())
+        for i in range(9):
+            if i %% 2: a.append(t_ref()); b.append(t_port())
+            else: b.append(t_port()); a.append(t_ref())
         r = min(b) / min(a)
         best = r if best is None or abs(r - 1) < abs(best - 1) else best
         if abs(r - 1) <= 0.05: break
