@@ -452,8 +452,39 @@ def training_step(dev, steps):
         train.train_step(net, opt, x, y, cfg["E"], 0.1, 50000.0)
     torch.cuda.synchronize(dev)
     dt = (time.perf_counter() - t0) / steps
-    return {"ms_per_step": round(1e3 * dt, 4), "value": round(cfg["B"] * cfg["E"] / dt, 1), "unit": "samples/s (forward + backward + Adam)",
-            "path": path, "note": "BayesianAlexNet bs=512 num_ens=10, fp32; round 1 (reference-layout autograd path): 8.3 ms"}
+    out = {"ms_per_step": round(1e3 * dt, 4), "value": round(cfg["B"] * cfg["E"] / dt, 1), "unit": "samples/s (forward + backward + Adam)",
+           "path": path, "note": "BayesianAlexNet bs=512 num_ens=10, fp32; round 1 (reference-layout autograd path): 8.3 ms"}
+    del net, x, y, opt
+    # the reference's own defaults (config_bayesian.py:1-18: layer_type 'lrt', batch_size 256, train_ens 1): eager and as one hipGraph
+    try:
+        from bbb_hip import rng, zoo
+        torch.manual_seed(0)
+        net = zoo.getModel("alexnet", 3, 10, PRIORS, "lrt", "softplus").to(dev)
+        rng.assign_stream_ids(net)
+        x = torch.rand(256, 3, 32, 32, device=dev)
+        y = torch.randint(0, 10, (256,), device=dev)
+        d = {}
+        for mode in ("eager", "hipgraph"):
+            opt = train.FusedAdam(net.parameters(), lr=1e-3, capturable=(mode == "hipgraph"))
+            if mode == "hipgraph":
+                g = train.GraphedTrainStep(net, opt, x, y, 1, 0.1, 50000.0, warmup=3)
+                step = g.step
+            else:
+                step = lambda: train.train_step(net, opt, x, y, 1, 0.1, 50000.0)
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(2 * steps):
+                step()
+            torch.cuda.synchronize(dev)
+            d[mode + "_ms_per_step"] = round(1e3 * (time.perf_counter() - t0) / (2 * steps), 4)
+        d["path"] = ensemble.stats["path"]
+        d["note"] = "BayesianAlexNet, layer_type lrt, bs=256, num_ens=1 = the reference's config_bayesian.py defaults; forward + backward + Adam"
+        out["reference_default_config"] = d
+    except Exception as exc:
+        out["reference_default_config"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:160])}
+    return out
 
 
 def main():

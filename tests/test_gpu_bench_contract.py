@@ -43,6 +43,8 @@ def test_bench_json_contract_default():
     assert st["p10"] <= st["median"] <= st["p90"]
     assert "error" not in j["dropin_loop"] and j["dropin_loop"]["value"] > 0
     assert "error" not in j["training_step"] and j["training_step"]["path"] == "chwn-autograd"
+    dflt = j["training_step"]["reference_default_config"]             # config_bayesian.py defaults: lrt, bs 256, num_ens 1
+    assert "error" not in dflt and dflt["path"] == "chwn-autograd" and 0 < dflt["hipgraph_ms_per_step"] <= dflt["eager_ms_per_step"] * 1.5
     # every other BASELINE configuration is measured, each with its own roofline
     assert set(j["configs"]) == {"configs[1]", "configs[2]", "configs[3]", "configs[4]"}
     for name, c in j["configs"].items():
