@@ -58,3 +58,22 @@ def test_bench_json_contract_other_config_as_headline():
     j = _run(["--config", "configs[1]", "--pipeline", "1", "--no-extras"])
     assert j["dtype"] == "bf16" and j["n_gpus"] == 1 and "3Conv3FC" in j["metric"]
     _check_roofline(j["roofline"], 2500.0)
+
+
+def test_bench_n_gt_1_flow_rehearsed_on_one_device():
+    """The driver's N > 1 invocation (one process per GPU under torch.distributed.run), rehearsed on ONE MI355X: both ranks pinned
+    to device 0 and gloo instead of RCCL (bench.py's documented test hooks) -- launch, rendezvous on 127.0.0.1, work-unit
+    sharding, one all_gather per step, max-over-ranks timing, rank 0 printing the one JSON line.  The number is meaningless
+    (two processes share a GPU and gloo stages through the host); the flow is what is checked."""
+    env = dict(os.environ, BBB_BENCH_DEVICE="0", BBB_BENCH_BACKEND="gloo")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 6 and j["scaling"] == "strong" and j["value"] > 0
+    assert j["config"]["global_batch"] == 512 and j["config"]["num_ens_total"] == 10          # the metric's workload, not 2x of it
+    assert "work units" in j["config"]["parallelism"] and j["weak_scaling"]["num_ens_total"] == 20
+    assert abs(j["value"] - 512 * 10 / (j["ms_per_step"] * 1e-3)) <= 1e-3 * j["value"]
