@@ -5,7 +5,7 @@ One step = main_bayesian.py:73-80 of the reference: num_ens x net(x) + log_softm
 forward only, no_grad, inputs resident in HBM.  Synthetic data: torch.manual_seed(0), parameters from the
 layers' own reset_parameters with config_bayesian.priors, x ~ U[0,1).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: re-executes itself under torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -506,8 +506,25 @@ def main():
         args.pipeline = 3 if world == 1 else 4
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world == 1 and args.gpus > 1:
-        raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` as typed: become the launcher -- one process per GPU under torch.distributed.run
+        # (rendezvous on 127.0.0.1, a free port), same arguments.  Under the driver's own torch.distributed.run
+        # invocation WORLD_SIZE is already set and this branch is not taken.
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this driver
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        if os.environ.get("BBB_BENCH_PRINT_LAUNCH") == "1":          # test hook (CPU suite): show the launch, do not exec
+            print(json.dumps({"launch": cmd}))
+            return
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch one process per GPU (python bench.py --gpus N does it itself)"
+                         % (args.gpus, world))
     # test hooks (single-GPU rehearsal of the N > 1 code path): BBB_BENCH_DEVICE pins every rank to one device,
     # BBB_BENCH_BACKEND=gloo replaces RCCL.  Never set by the driver.
     dev_index = int(os.environ.get("BBB_BENCH_DEVICE", local_rank))
@@ -580,6 +597,10 @@ def main():
                        if world > 1 else "single",
                        "launch": "hipGraph replay, %d step(s) in flight" % max(1, args.pipeline)},
         }
+        if world > 1:
+            out["config"]["ranks_seen"] = torch.distributed.get_world_size(group)
+            out["config"]["units_per_rank"] = [(lambda r: r[1] - r[0])(ensemble.unit_range(cfg["E"], S, r, world)) for r in range(world)]
+            out["config"]["backend"] = backend
         if args.config != "metric":
             out["metric"] = "MC-forward samples/sec, " + cfg["what"]
         if head.get("roofline"):

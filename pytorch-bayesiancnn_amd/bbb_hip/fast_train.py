@@ -156,11 +156,14 @@ class _MCForward(torch.autograd.Function):
         logits = h.reshape(E, -1, B)
         ctx.cfg, ctx.tape, ctx.meta = cfg, tape, (mus, rhos, ids, pm, ps, tuple(x.shape))
         ctx.x_nchw = x.detach()
+        ctx.versions = [(p, p._version) for p in params]      # backward re-reads the live (mu, rho): they must not have moved
         return logits, kl
 
     @staticmethod
     def backward(ctx, g_logits, g_kl):
         cfg, tape = ctx.cfg, ctx.tape
+        _check_versions(ctx.versions)
+        cfg["spent"] = True                                    # layers/_fused.py: no further draws are served from this graph
         mus, rhos, ids, pm, ps, x_shape = ctx.meta
         E, seed, call0 = cfg["draws"], cfg["seed"], cfg["call0"]
         B = x_shape[0]
@@ -201,6 +204,16 @@ class _MCForward(torch.autograd.Function):
         for a, b in zip(gmu, grho):
             out += [a, b]
         return tuple(out)
+
+
+def _check_versions(versions):
+    """What autograd's saved-tensor check would raise: a parameter (or sigma^2 operand) changed in place between the forward
+    that recorded this node and its backward, which re-reads the live storage."""
+    for p, v in versions:
+        if p._version != v:
+            raise RuntimeError("one of the variables needed for gradient computation has been modified by an inplace operation: "
+                               "a Bayesian layer's parameter changed between the forward and this backward (optimizer.step() "
+                               "before a delayed backward?)")
 
 
 def _inverse_act(y, act):
@@ -268,11 +281,14 @@ class _MCForwardLRT(torch.autograd.Function):
             i += 1
         ctx.cfg, ctx.tape = cfg, tape
         ctx.x_nchw = x.detach()
+        ctx.versions = [(p, p._version) for p in params]
         return h.reshape(h.shape[0], -1, B)
 
     @staticmethod
     def backward(ctx, g_logits):
         tape = ctx.tape
+        _check_versions(ctx.versions)
+        ctx.cfg["spent"] = True
         grads = [None] * (4 * len(tape))
         g = g_logits.contiguous()
         for li in range(len(tape) - 1, -1, -1):
@@ -327,9 +343,13 @@ def mc_logits_autograd(net, x, draws, seed, call0):
         for li, l in enumerate(layers):
             flat += [l.W_mu, s2[2 * li], l.bias_mu, s2[2 * li + 1]]
         cfg = dict(net=net, draws=int(draws), seed=seed, call0=call0)
-        return _MCForwardLRT.apply(cfg, x, *flat), kl
+        logits = _MCForwardLRT.apply(cfg, x, *flat)
+        logits.bbb_cfg = cfg
+        return logits, kl
     params = []
     for l in ensemble.bayesian_layers(net):
         params += [l.W_mu, l.W_rho, l.bias_mu, l.bias_rho]
     cfg = dict(net=net, draws=int(draws), seed=seed, call0=call0)
-    return _MCForward.apply(cfg, x, *params)
+    logits, kl = _MCForward.apply(cfg, x, *params)
+    logits.bbb_cfg = cfg
+    return logits, kl

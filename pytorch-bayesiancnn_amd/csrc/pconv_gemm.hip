@@ -25,41 +25,15 @@
 #include "../../include/bbb_hip.h"
 #include "bbb_common.cuh"
 #include "pconv_args.h"
+#include "pconv_body.cuh"
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int kThreads = 256;
-constexpr int BN = 64;
-constexpr int BK = 32;
-constexpr int LDW = BN + 1;
-constexpr int KCH = 256;                 // k_eff entries per decode chunk (one entry per thread)
-constexpr int TPC = KCH / BK;            // tiles per chunk
-
-
+using namespace pconv;
 
 template <int BM, bool LRT, bool ILV>
 __global__ __launch_bounds__(kThreads) void pconv_gemm_kernel(const PConvArgs p) {
-    constexpr int LDX = BM + 4;
-    constexpr int NT = (BM >= 128) ? 2 : 1;              // 32-channel MFMA tiles per wave
-    constexpr int MT = (BM == 256) ? 2 : 1;              // 32-image MFMA tiles per wave
-    constexpr int WSETS = LRT ? 2 : 1;
-    constexpr int XL = BM / 4;                 // lanes per X row (float4 each)
-    constexpr int XRPP = kThreads / XL;        // X rows per pass
-    constexpr int XPASS = BK / XRPP;
-
-    // ONE LDS stage per operand; the second stage of the pipeline is the register file (loads for tile t+1 are
-    // issued before tile t's MFMAs and written to LDS after them, inside one loop iteration: no loop-carried
-    // in-flight registers, which hipcc would otherwise "fix" with copies behind a vmcnt(0)).  Small LDS + modest
-    // VGPR use => 4 workgroups per CU; latency is hidden by occupancy, not by prefetch depth.
-    __shared__ __attribute__((aligned(16))) float Xs[1][BK * LDX];
-    __shared__ float Ws[1][WSETS][BK * LDW];
-    __shared__ int32_t kt_w[2][KCH];   // (k_eff -> weight offset, x row) for a chunk of 256 k_eff = 8 tiles,
-    __shared__ int32_t kt_x[2][KCH];   // filled by all 256 threads at once, double buffered
-
-    // ---- block -> (draw, channel tile, pixel, batch tile); weight-tile sharers on one XCD ----
+    // ---- block -> work item; weight-tile sharers on one XCD ----
     // Work items (group g = (draw, channel tile), m-tile j) in g-major order are cut into 8 equal contiguous chunks,
     // one per XCD (workgroup id mod 8 is the XCD the dispatcher places it on): perfectly balanced, and the
     // workgroups that share a weight tile run on the same XCD at the same time.  (A wrong placement guess costs
@@ -69,267 +43,7 @@ __global__ __launch_bounds__(kThreads) void pconv_gemm_kernel(const PConvArgs p)
     const int64_t item = (int64_t)xcd * p.per_xcd + (bid >> 3);
     const int64_t item_end = (int64_t)(xcd + 1) * p.per_xcd;
     if (item >= item_end || item >= (int64_t)p.G * p.Mtiles) return;
-    const int g = (int)(item / p.Mtiles);
-    const int j = (int)(item - (int64_t)g * p.Mtiles);
-    const int e = g / p.Ntiles;
-    // work units (ensemble sharding): slab e is unit u = unit_off + e -> weight set u / S, input slab e (or u % S)
-    const int ue = p.unit_off + e;
-    const int ew = p.unit_div > 1 ? ue / p.unit_div : e;
-    const int ex = p.x_mod > 0 ? ue % p.x_mod : e;
-    const int n0 = (g - e * p.Ntiles) * BN;
-    const int pix = j / p.nbt;
-    const int b0 = (j - pix * p.nbt) * BM;
-    const int oh = pix / p.Wo, ow = pix - oh * p.Wo;
-    // in-bounds tap ranges for this pixel
-    const int ihb = oh * p.sh - p.ph, iwb = ow * p.sw - p.pw;
-    int r_lo = ihb < 0 ? (-ihb + p.dh - 1) / p.dh : 0;
-    int q_lo = iwb < 0 ? (-iwb + p.dw - 1) / p.dw : 0;
-    int r_hi = (p.H - 1 - ihb) >= 0 ? (p.H - 1 - ihb) / p.dh + 1 : 0;
-    int q_hi = (p.W - 1 - iwb) >= 0 ? (p.W - 1 - iwb) / p.dw + 1 : 0;
-    r_hi = r_hi < p.kh ? r_hi : p.kh;
-    q_hi = q_hi < p.kw ? q_hi : p.kw;
-    const int nr = r_hi > r_lo ? r_hi - r_lo : 0;
-    const int nq = q_hi > q_lo ? q_hi - q_lo : 0;
-    const int nrq = nr * nq;
-    const int Keff = p.Cin * nrq;
-    const int ntiles = (Keff + BK - 1) / BK;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = (BM >= 128) ? 0 : (wave >> 1) * 32;
-    const int wm = (BM >= 128) ? wave * 32 * MT : (wave & 1) * 32;
-
-    // Buffer descriptors (wave-uniform): out-of-range offsets read as 0, which is how invalid k / channel / image
-    // lanes are masked without a branch around every load (a branch would make hipcc wait vmcnt(0) per element).
-    constexpr uint32_t kOOB = 0xFFFFFFF0u;
-    constexpr uint32_t kWInv = 0x7FFFFFF0u;    // invalid weight k: slab bytes < 2^30, so row + kWInv is out of range
-    const uint32_t kXInv = p.x_inv;            // invalid x row: + column bytes (< one row) neither wraps nor lands in range
-    const int64_t w_elems = (int64_t)p.Cout * p.Kp;                  // Kp = weight row pitch (= K unless the caller passed one)
-    const int64_t x_elems = (int64_t)p.Cin * p.H * p.W * p.B;
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.x + (int64_t)ex * p.x_ds), 0, (int)(x_elems * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.w + (int64_t)ew * p.w_ds), 0, (int)(w_elems * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t w2rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(LRT ? p.w2 + (int64_t)ew * p.w_ds : p.w), 0, (int)(w_elems * 4), 0x00020000);
-
-    // loaders
-    const int wkl = tid & 31, wnl = tid >> 5;            // weights: lane -> k, 8 channel rows per pass
-    const int xb4 = (tid % XL) * 4, xkr = tid / XL;      // x: lane -> 4 images, XRPP k rows per pass
-    // No per-lane masking of channels >= Cout or images >= B: such rows / columns of D are never stored, GEMM
-    // columns do not mix, and reads past a slab come back as 0 from the buffer unit.  Only invalid k must be zero
-    // (on both operands), which the table encodes as out-of-range offsets.
-    const uint32_t xcol = (uint32_t)(b0 + xb4) * 4u;                 // byte offset of this lane's 4 images in a row
-    uint32_t wrow[8];                                                // byte offset of this lane's 8 channel rows
-#pragma unroll
-    for (int ps = 0; ps < 8; ++ps) wrow[ps] = (uint32_t)(n0 + wnl + ps * 8) * (uint32_t)p.Kp * 4u;
-
-    float wregA[WSETS][8];
-    f32x4 xregA[XPASS];
-
-    // k_eff -> (ci, r, q) with float-reciprocal division + fix-up (exact for k_eff < 2^24)
-    const float inv_nrq = nrq > 0 ? 1.0f / (float)nrq : 0.0f;
-    const float inv_nq = nq > 0 ? 1.0f / (float)nq : 0.0f;
-    auto fill_chunk = [&](int chunk) {
-        const int k = chunk * KCH + tid;
-        uint32_t wo = kWInv, xo = kXInv;
-        if (k < Keff) {
-            int ci = (int)((float)k * inv_nrq);
-            int rq = k - ci * nrq;
-            if (rq < 0) { --ci; rq += nrq; } else if (rq >= nrq) { ++ci; rq -= nrq; }
-            int rr = (int)((float)rq * inv_nq);
-            int qq = rq - rr * nq;
-            if (qq < 0) { --rr; qq += nq; } else if (qq >= nq) { ++rr; qq -= nq; }
-            const int r = r_lo + rr, q = q_lo + qq;
-            wo = (uint32_t)(ci * p.khkw + r * p.kw + q) * 4u;                                    // byte offset in a row
-            xo = (uint32_t)((ci * p.H + ihb + r * p.dh) * p.W + iwb + q * p.dw) * (uint32_t)p.B * 4u;   // row byte offset
-        }
-        kt_w[chunk & 1][tid] = (int32_t)wo;
-        kt_x[chunk & 1][tid] = (int32_t)xo;
-    };
-
-    // Staging loads are split into an address phase (table lookups + adds, before the tile's MFMAs) and the individual
-    // buffer loads.  ILV = true: mma_tile() interleaves the loads BETWEEN the MFMAs of the current tile - a VMEM
-    // instruction costs the issuing wave 100-200 cycles, and among MFMAs that time hides in the 64-cycle shadows of the
-    // matrix pipe (s_memtime: the load phase of a lone workgroup was as long as its MFMA phase).  Measured: +8-10 % on
-    // launches of <= ~1.5 workgroup rounds (latency-bound), -5-15 % on multi-round launches where four co-resident
-    // workgroups already keep the pipe busy and the interleaved loads only delay MFMA issue.  The launcher picks.
-    constexpr int NLOADS = 8 + XPASS;
-    uint32_t loff[NLOADS];
-    auto load_addr = [&](int tile) {
-        const int buf = (tile / TPC) & 1;
-        const int kb = (tile % TPC) * BK;
-        const uint32_t wob = (uint32_t)kt_w[buf][kb + wkl];
-#pragma unroll
-        for (int ps = 0; ps < 8; ++ps) loff[ps] = wrow[ps] + wob;
-#pragma unroll
-        for (int ps = 0; ps < XPASS; ++ps) loff[8 + ps] = (uint32_t)kt_x[buf][kb + xkr + ps * XRPP] + xcol;
-    };
-    auto load_one = [&](int i, float (&wreg)[WSETS][8], f32x4 (&xreg)[XPASS]) {
-        if (i < XPASS) {          // x rows first: they are the wider transfers
-            xreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, loff[8 + i], 0, 0));
-        } else {
-            const int ps = i - XPASS;
-            wreg[0][ps] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrs, loff[ps], 0, 0));
-            if (LRT) wreg[WSETS - 1][ps] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(w2rs, loff[ps], 0, 0));
-        }
-    };
-    auto load_tile = [&](int tile, float (&wreg)[WSETS][8], f32x4 (&xreg)[XPASS]) {
-        load_addr(tile);
-#pragma unroll
-        for (int i = 0; i < NLOADS; ++i) load_one(i, wreg, xreg);
-    };
-
-    auto store_tile = [&](int, float (&wreg)[WSETS][8], f32x4 (&xreg)[XPASS]) {
-        constexpr int buf = 0;
-#pragma unroll
-        for (int s = 0; s < WSETS; ++s)
-#pragma unroll
-            for (int ps = 0; ps < 8; ++ps) Ws[buf][s][wkl * LDW + wnl + ps * 8] = wreg[s][ps];
-#pragma unroll
-        for (int ps = 0; ps < XPASS; ++ps)
-            *reinterpret_cast<f32x4*>(&Xs[buf][(xkr + ps * XRPP) * LDX + xb4]) = xreg[ps];
-    };
-
-    f32x16 acc[NT][MT];
-    f32x16 accv[NT][MT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int u = 0; u < MT; ++u)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[t][u][r] = 0.0f; accv[t][u][r] = 0.0f; }
-
-    const int lrow = lane & 31, lk = lane >> 5;
-
-    // Operand reads from LDS run PD k-steps ahead of the MFMAs that use them (a small register ring): a wave never waits a
-    // full LDS round trip between k-steps, so even a workgroup that is alone on its CU (launch tails, small launches)
-    // keeps its matrix pipe fed inside a tile.
-    constexpr int PD = (BM >= 128) ? 2 : 4;
-    auto mma_tile = [&](bool more) {
-        float ra[PD + 1][NT], ra2[PD + 1][NT], rb[PD + 1][MT];
-        auto fetch = [&](int kk, int slot) {
-            const int krow = kk * 2 + lk;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) rb[slot][mt] = Xs[0][krow * LDX + wm + mt * 32 + lrow];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                ra[slot][nt] = Ws[0][0][krow * LDW + wn + nt * 32 + lrow];
-                if (LRT) ra2[slot][nt] = Ws[0][WSETS - 1][krow * LDW + wn + nt * 32 + lrow];
-            }
-        };
-#pragma unroll
-        for (int i = 0; i < PD; ++i) fetch(i, i);
-#pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
-            if (ILV && kk < NLOADS) {
-                if (more) load_one(kk, wregA, xregA);
-                __builtin_amdgcn_sched_barrier(0);     // keep this load ahead of k-step kk's MFMAs, behind kk-1's
-            }
-            if (kk + PD < BK / 2) fetch(kk + PD, (kk + PD) % (PD + 1));
-            const int s = kk % (PD + 1);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[s][nt], rb[s][mt], acc[nt][mt], 0, 0, 0);
-                if (LRT) {
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-                        accv[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra2[s][nt], rb[s][mt] * rb[s][mt], accv[nt][mt], 0, 0, 0);
-                }
-            }
-            if (!ILV) __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-
-    if (ntiles > 0) {
-        fill_chunk(0);
-        __syncthreads();
-        load_tile(0, wregA, xregA);
-        if (KCH < Keff) fill_chunk(1);
-        store_tile(0, wregA, xregA);
-        __syncthreads();
-        for (int t = 0; t < ntiles; ++t) {
-            const bool more = (t + 1) < ntiles;
-            if (more) {
-                if (ILV) load_addr(t + 1);                            // loads themselves are issued inside mma_tile()
-                else     load_tile(t + 1, wregA, xregA);              // all loads up front (large launches)
-            }
-            // decode chunk c+1 early in chunk c (c >= 1; chunk 1 is decoded in the prologue): its buffer was last
-            // read by load_tile(TPC*c - 1), several barriers ago
-            if ((t % TPC) == 1 && t / TPC >= 1 && (t / TPC + 1) * KCH < Keff) fill_chunk(t / TPC + 1);
-            mma_tile(more);
-            __syncthreads();                                          // every wave is done reading the LDS stage
-            if (more) store_tile(0, wregA, xregA);
-            __syncthreads();
-        }
-    }
-
-    // ---- epilogue: rows = channels, lanes = images; bias via buffer loads, stores via buffer stores
-    //      (out-of-range channel / image lanes get an out-of-range offset: no branches, no per-element waits) ----
-    const int HoWo = p.Ho * p.Wo;
-    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.bias ? p.bias + (int64_t)ew * p.b_ds : p.w), 0, p.bias ? p.Cout * 4 : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
-        p.y + (int64_t)e * p.y_ds, 0, (int)((int64_t)p.Cout * HoWo * p.B * 4), 0x00020000);
-    float bv[NT][16];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int n = n0 + wn + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-            bv[nt][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brs, (uint32_t)n * 4u, 0, 0));
-        }
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int b = b0 + wm + mt * 32 + lrow;
-        const bool b_ok = b < p.B;
-        if (!LRT) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int n = n0 + wn + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                    const uint32_t off = (b_ok & (n < p.Cout)) ? (uint32_t)(((int64_t)n * HoWo + pix) * p.B + b) * 4u : kOOB;
-                    const float v = bbb::apply_act(acc[nt][mt][r] + bv[nt][r], p.act);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), yrs, off, 0, 0);
-                }
-        } else if (b_ok) {
-            const int64_t ybase = (int64_t)e * p.y_ds + (int64_t)pix * p.B + b;
-            const float* __restrict__ b2g = p.bias2 ? p.bias2 + (int64_t)ew * p.b_ds : nullptr;
-            const int bglob = b + p.b_off + (p.unit_div > 1 ? (ue % p.unit_div) * p.B : 0);      // image index that keys the noise
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int n = n0 + wn + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                    if (n < p.Cout) {
-                        const int64_t o = ybase + (int64_t)n * HoWo * p.B;
-                        float v = acc[nt][mt][r] + bv[nt][r];
-                        const float var = 1e-16f + (accv[nt][mt][r] + (b2g ? b2g[n] : 0.0f));
-                        if (p.y_mu) p.y_mu[o] = v;
-                        if (p.y_var) p.y_var[o] = var;
-                        if (p.sample) {
-                            float z;
-                            if (p.eps_ext) {
-                                z = p.eps_ext[o];
-                            } else {   // canonical NCHW element index of this draw's [B][Cout][Ho][Wo] slab
-                                const uint64_t idx = (uint64_t)(((int64_t)bglob * p.Cout + n) * HoWo + pix);
-                                float z4[4];
-                                bbb::normal4(idx >> 2, p.stream_id, p.call0 + (p.call_dev ? *p.call_dev : 0u) + (uint32_t)ew, p.k0, p.k1, z4);
-                                const int c = (int)(idx & 3);
-                                z = c == 0 ? z4[0] : c == 1 ? z4[1] : c == 2 ? z4[2] : z4[3];
-                            }
-                            v = v + __builtin_amdgcn_sqrtf(var) * z;
-                        }
-                        p.y[o] = bbb::apply_act(v, p.act);
-                    }
-                }
-            }
-        }
-    }
+    pconv_item<BM, LRT, ILV, false>(p, item);
 }
 
 // maxpool over [planes][H][W][B] (planes = draws * channels), B innermost; 4 images per thread.

@@ -71,16 +71,54 @@ def leave(scope):
             l._presampled = None
 
 
+speculation = {"enabled": True, "max_draws": 32}
+
+
+class _Spec:
+    """Speculative draw batching behind `net(x)` (main_bayesian.py:73-80 calls net(inputs) num_ens times on the SAME tensor):
+    when a call repeats the previous call's input, the next K draws are computed in ONE batched launch -- call indices
+    call .. call+K-1, i.e. exactly the noise the next K calls of the loop would use -- and those calls are served from the
+    result (the generator offset still advances by one call per net(x)).  Bit-identical to the loop by the noise contract
+    (draw j of a batched launch == net(x) number j).  K follows the length of the previous streak of identical inputs
+    (a validation loop settles on K = num_ens at the FIRST call of each batch), or doubles 2, 4, 8 while no history exists.
+    The cache is dropped when the input object, its version counter, any parameter's version counter, the generator
+    position or the autograd mode changes."""
+    __slots__ = ("xref", "xver", "pver", "grad", "seed", "next_call", "logits", "kl", "idx", "streak", "last_streak", "batches")
+
+    def __init__(self):
+        self.xref = None
+        self.logits = None
+        self.streak = 0
+        self.last_streak = 0
+        self.batches = 0
+
+
+def _hooks_present(wrapper, mods):
+    import torch.nn.modules.module as _m
+    if _m._global_forward_hooks or _m._global_forward_pre_hooks:
+        return True
+    if wrapper._forward_hooks or wrapper._forward_pre_hooks:
+        return True
+    for m in mods:
+        if m._forward_hooks or m._forward_pre_hooks:
+            return True
+    return False
+
+
 def fast_forward(wrapper, x):
-    """Whole-model inference forward on the batch-innermost path of bbb_hip.ensemble (pixel-major GEMMs that skip padding
-    taps, activation fused into the epilogue, HIP pooling): one draw, the same kernels -- hence the same bits -- as draw j
-    of a batched mc_forward under the same call index.  Applies when nothing needs autograd (torch.no_grad(), or frozen
-    parameters), the input is a CUDA [B, C, H, W] batch with B % 4 == 0, the model is made of modules that path knows, it
-    ends in a Bayesian linear layer, no layer replays external noise, and this is the outermost wrapper of the forward.
-    Returns (output, kl) or None (-> the reference-layout path below, which also serves training)."""
+    """Whole-model forward on the batch-innermost path of bbb_hip.ensemble (pixel-major GEMMs that skip padding
+    taps, activation fused into the epilogue, HIP pooling): the same kernels -- hence the same bits -- as draw j
+    of a batched mc_forward under the same call index.  Applies when the input is a CUDA [B, C, H, W] batch with B % 4 == 0
+    that does not itself require a gradient, the model is made of modules that path knows, it ends in a Bayesian linear layer,
+    no layer replays external noise, no module of it carries forward hooks (the fused path does not call the children), and
+    this is the outermost wrapper of the forward.  With autograd enabled the same kernels run behind ONE autograd node
+    (bbb_hip.fast_train).  Consecutive calls on the same input are batched speculatively (_Spec).
+    Returns (output, kl) or None (-> the reference-layout path below, which also serves input gradients and hooks)."""
     from ._base import BayesianLayer
     if isinstance(wrapper, BayesianLayer) or rng._scope or not torch.is_tensor(x) or not x.is_cuda or x.dim() != 4:
         return None
+    if x.requires_grad and torch.is_grad_enabled():
+        return None                                   # saliency / adversarial inputs: the reference-layout path has d/dx
     from bbb_hip import ensemble
     mods = ensemble.flat_children(wrapper)
     if not mods or not isinstance(mods[-1], BayesianLayer) or not hasattr(mods[-1], "out_features"):
@@ -88,24 +126,69 @@ def fast_forward(wrapper, x):
     layers = ensemble.bayesian_layers(wrapper)
     if any(l.eps_source is not None for l in layers) or not all(l.W_mu.is_cuda for l in layers):
         return None
-    if torch.is_grad_enabled() and ensemble.any_requires_grad(wrapper):
+    if _hooks_present(wrapper, mods):
+        return None
+    grad = torch.is_grad_enabled() and ensemble.any_requires_grad(wrapper)
+    if grad:
         # training / the reference's validate loop (which does not disable autograd): the same kernels behind ONE autograd node
         from bbb_hip import fast_train
         if not ensemble.fast_autograd or not fast_train.train_path_ok(wrapper, x):
             return None
-        seed, call = rng.next_calls(1)
-        logits, kl = fast_train.mc_logits_autograd(wrapper, x, 1, seed, call)
+    elif not ensemble._chwn_ok(wrapper, x):
+        return None
+
+    # ---- speculative draw batching ----
+    sp = wrapper.__dict__.get("_bbb_spec")
+    if sp is None:
+        sp = wrapper.__dict__["_bbb_spec"] = _Spec()
+    pver = tuple(p._version for p in ensemble._structure(wrapper)["params"])
+    same_x = sp.xref is not None and sp.xref() is x and sp.xver == x._version and sp.pver == pver and sp.grad == grad
+    can_spec = speculation["enabled"] and rng._graph_counter["tensor"] is None and not torch.cuda.is_current_stream_capturing()
+    seed, call = rng.get_state()
+    if same_x and grad and sp.logits is not None and getattr(sp.logits, "bbb_cfg", {}).get("spent"):
+        sp.logits = None                              # that graph's backward has run: its remaining draws cannot be used
+    if same_x and can_spec and sp.logits is not None and sp.idx < sp.logits.shape[0] and sp.seed == seed and sp.next_call == call:
+        rng.next_calls(1)                             # the generator moves exactly as the loop would move it
+        j = sp.idx
+        sp.idx += 1
+        sp.next_call = (call + 1) & 0xFFFFFFFF
+        sp.streak += 1
         for l in layers:
             l._kl = None
-        return logits[0].t(), kl
-    if not ensemble._chwn_ok(wrapper, x):
-        return None
+        out = sp.logits[j].t()
+        return (out if grad else out.contiguous()), sp.kl
+    if same_x:
+        sp.streak += 1
+    else:
+        if sp.streak:
+            sp.last_streak = sp.streak
+        sp.streak, sp.batches = 1, 0
+    K = 1
+    if can_spec:
+        done = sp.streak - 1                          # calls of this streak already answered
+        if sp.last_streak > done + 1:
+            K = sp.last_streak - done                 # history: the loop makes last_streak calls per input
+        elif done >= 1:
+            K = 2 << min(sp.batches, 8)               # no (or exhausted) history: 2, 4, 8, ...
+        K = max(1, min(K, int(speculation["max_draws"])))
     seed, call = rng.next_calls(1)
-    out = ensemble._mc_logits_chwn(wrapper, x, 1, seed, call)
-    if out is None:
-        rng.rewind((seed, call))                 # nothing was launched: give the call index back
-        return None
-    logits, kl = out                             # [1, C, B']
+    if grad:
+        from bbb_hip import fast_train
+        logits, kl = fast_train.mc_logits_autograd(wrapper, x, K, seed, call)
+    else:
+        out = ensemble._mc_logits_chwn(wrapper, x, K, seed, call)
+        if out is None:
+            rng.rewind((seed, call))                  # nothing was launched: give the call index back
+            return None
+        logits, kl = out                              # [K, C, B']
     for l in layers:
         l._kl = None
-    return logits[0].t().contiguous(), kl
+    import weakref
+    sp.xref, sp.xver, sp.pver, sp.grad = weakref.ref(x), x._version, pver, grad
+    if K > 1:
+        sp.seed, sp.next_call, sp.logits, sp.kl, sp.idx = seed, (call + 1) & 0xFFFFFFFF, logits, kl, 1
+        sp.batches += 1
+    else:
+        sp.logits = None
+    out0 = logits[0].t()
+    return (out0 if grad else out0.contiguous()), kl

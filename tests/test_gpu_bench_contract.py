@@ -77,3 +77,19 @@ def test_bench_n_gt_1_flow_rehearsed_on_one_device():
     assert j["config"]["global_batch"] == 512 and j["config"]["num_ens_total"] == 10          # the metric's workload, not 2x of it
     assert "work units" in j["config"]["parallelism"] and j["weak_scaling"]["num_ens_total"] == 20
     assert abs(j["value"] - 512 * 10 / (j["ms_per_step"] * 1e-3)) <= 1e-3 * j["value"]
+
+
+def test_bench_gpus_2_as_typed_launches_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT torch.distributed.run: bench.py re-executes itself under the launcher (one process
+    per GPU, rendezvous on 127.0.0.1 with a free port).  Rehearsed on one MI355X through the same hooks as above."""
+    env = dict(os.environ, BBB_BENCH_DEVICE="0", BBB_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--no-extras"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 4 and j["warmup"] == 2 and j["scaling"] == "strong" and j["value"] > 0
+    assert j["config"]["ranks_seen"] == 2 and sum(j["config"]["units_per_rank"]) == 10 and j["config"]["backend"] == "gloo"

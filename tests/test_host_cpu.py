@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol(built):
     h = _lib.lib()                      # CDLL + argtypes for every symbol; raises if one is missing
     for name in decl:
         assert hasattr(h, name)
-    assert h.bbb_abi_version() == 5
+    assert h.bbb_abi_version() == 6
     assert b"gfx950" in h.bbb_build_info()
 
 
@@ -49,6 +49,8 @@ int main(void) {
   printf("%zu %zu %zu %zu %zu\n", sizeof(bbb_segment_t), offsetof(bbb_segment_t, n), offsetof(bbb_segment_t, stream_id),
          sizeof(bbb_conv_desc_t), offsetof(bbb_conv_desc_t, x_draw_stride));
   printf("%zu %zu\n", offsetof(bbb_conv_desc_t, act), offsetof(bbb_conv_desc_t, draws));
+  printf("%zu %zu %zu %zu\n", sizeof(bbb_chain_stage_t), offsetof(bbb_chain_stage_t, conv), offsetof(bbb_chain_stage_t, x),
+         offsetof(bbb_chain_stage_t, y));
   return 0; }
 '''
     import tempfile
@@ -59,9 +61,9 @@ int main(void) {
         subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe], check=True)
         out = subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()
     got = [int(v) for v in out]
-    S, C = _lib.Segment, _lib.ConvDesc
+    S, C, K = _lib.Segment, _lib.ConvDesc, _lib.ChainStage
     assert got == [ctypes.sizeof(S), S.n.offset, S.stream_id.offset, ctypes.sizeof(C), C.x_draw_stride.offset,
-                   C.act.offset, C.draws.offset]
+                   C.act.offset, C.draws.offset, ctypes.sizeof(K), K.conv.offset, K.x.offset, K.y.offset]
 
 
 def test_argument_errors_without_a_gpu(built):
@@ -84,6 +86,16 @@ def test_argument_errors_without_a_gpu(built):
     assert h.bbb_mc_tail(None, 1, 1, 1, 0, None, None) == -1
     assert h.bbb_eps_dump(None, 4, 0, 0, 0, 0, None) == -1
     assert h.bbb_maxpool_chwn(None, None, 1, 4, 4, 4, 2, 2, None) == -1
+    # the persistent chain launch validates its stage table on the host
+    st = (_lib.ChainStage * 2)()
+    assert h.bbb_chain_fwd(st, 0, 0, None, 0, None) == -1                                          # no stages / no workspace
+    assert h.bbb_chain_fwd(st, 13, 0, None, 0, None) == -1                                         # > BBB_CHAIN_MAX_STAGES
+    assert h.bbb_chain_workspace(2, 10) > 0 and h.bbb_chain_workspace(2, 65) == 0 and h.bbb_chain_workspace(13, 1) == 0
+    ws = (ctypes.c_int32 * int(h.bbb_chain_workspace(2, 2)))()
+    st[0].conv.draws = 2
+    assert h.bbb_chain_fwd(st, 1, 0, ws, len(ws), None) == -1                                      # stage 0: null x / y
+    st[0].conv.draws = 70
+    assert h.bbb_chain_fwd(st, 1, 0, ws, len(ws), None) == -3                                      # more slabs than it schedules
 
 
 def test_product_path_refuses_cpu_tensors(built):
@@ -389,7 +401,8 @@ def test_plan_slices_and_output_rows():
 
 def test_cached_model_structure_follows_the_module_tree():
     """ensemble._structure: what the per-forward checks ask about a model is analysed once and cached on the module; replacing
-    a direct child rebuilds it, a change inside a nested container needs invalidate()."""
+    a direct child rebuilds it, and so does any module / parameter registration anywhere (torch's global registration hooks
+    bump an epoch): nested edits and swapped Parameters are seen without invalidate()."""
     import copy
     from torch import nn
     import layers
@@ -410,10 +423,18 @@ def test_cached_model_structure_follows_the_module_tree():
     wrap.body = seq
     wrap.head = layers.BBB_Linear(8, 4, priors=pri)
     assert len(ensemble.bayesian_layers(wrap)) == 2 and len(ensemble.flat_children(wrap)) == 3
-    seq.append(layers.BBB_Linear(8, 8, priors=pri))                                  # nested edit: invisible to the signature ...
-    assert len(ensemble.bayesian_layers(wrap)) == 2
-    ensemble.invalidate(wrap)                                                       # ... until the caller says so
+    seq.append(layers.BBB_Linear(8, 8, priors=pri))                                  # nested edit: the registration epoch moved
     assert len(ensemble.bayesian_layers(wrap)) == 3 and len(ensemble.flat_children(wrap)) == 4
+    seq[2] = layers.BBB_Linear(8, 8, priors=pri)                                    # replacing a nested module
+    assert ensemble.bayesian_layers(wrap)[1] is seq[2]
+    old = ensemble._structure(wrap)["params"]
+    wrap.head.W_mu = nn.Parameter(torch.zeros_like(wrap.head.W_mu))                 # swapping a Parameter object
+    assert any(p is wrap.head.W_mu for p in ensemble._structure(wrap)["params"]) and ensemble._structure(wrap)["params"] is not old
+    st = ensemble._structure(wrap)
+    assert ensemble._structure(wrap) is st                                          # and nothing is rebuilt when nothing changed
+    del seq[2]                                                                      # deleting goes around the hooks ...
+    ensemble.invalidate(wrap)                                                       # ... so that still needs the explicit call
+    assert len(ensemble.bayesian_layers(wrap)) == 2
     for p_ in wrap.parameters():
         p_.requires_grad_(False)
     assert not ensemble.any_requires_grad(wrap)                                     # flags are read live, not cached
@@ -515,3 +536,19 @@ def test_metrics_helpers_match_the_oracle():
     v = M.ELBO(50)(lo, y, torch.tensor(7.0), 0.3).item()
     assert abs(v - O.elbo(lo.numpy(), y.numpy(), 7.0, 0.3, 50)) < 1e-4
     assert abs(M.acc(lo, lo.argmax(1)).item() - 1.0) < 1e-7
+
+
+def test_bench_gpus_n_builds_its_own_launcher_command():
+    """`python bench.py --gpus 4` with no WORLD_SIZE re-executes itself under torch.distributed.run, one process per GPU,
+    rendezvous on 127.0.0.1, original arguments kept (the exec itself is covered by the -m gpu contract test)."""
+    import json as _json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["BBB_BENCH_PRINT_LAUNCH"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "7", "--warmup", "3"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    cmd = _json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])["launch"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "7", "--warmup", "3"] and cmd[-7].endswith("bench.py")
