@@ -256,6 +256,12 @@ __global__ __launch_bounds__(kThreads, 4) void pchain_kernel(const ChainArgs a) 
         } else {
             pool_item(st, e, item_in_slab);
         }
+#ifdef PCHAIN_PROFILE
+        if (tid == 0 && p_items < 30) {                     // per-item log: start, end (100 MHz ticks), stage, slab
+            uint32_t* lg = reinterpret_cast<uint32_t*>(a.ws + a.prof_off + 2048 * 16) + ((size_t)blockIdx.x * 32 + p_items) * 4;
+            lg[0] = (uint32_t)pt; lg[1] = (uint32_t)__builtin_amdgcn_s_memrealtime(); lg[2] = (uint32_t)stage; lg[3] = (uint32_t)e;
+        }
+#endif
         PROF_ADD(p_exec, pt);
         ++p_items;
         // ---- publish: the write-through stores of EVERY wave have left, then one counter increment ----
@@ -409,7 +415,7 @@ extern "C" int bbb_chain_fwd(const bbb_chain_stage_t* stages, int nstages, uint3
     a.ws = workspace;
 #ifdef PCHAIN_PROFILE
     a.prof_off = (kWsWords + 15) / 16 * 16;              // 64-byte aligned; the caller over-allocates
-    if (workspace_ints < a.prof_off + 2048 * 16) return BBB_EINVAL;
+    if (workspace_ints < a.prof_off + 2048 * 16 + 1024 * 32 * 4) return BBB_EINVAL;
 #endif
     int device = 0;
     if (hipGetDevice(&device) != hipSuccess) return (int)hipGetLastError();
