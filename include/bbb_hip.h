@@ -201,6 +201,28 @@ int bbb_lrt_conv2d_chwn_fwd(const bbb_conv_desc_t* d, const float* x, const floa
                             const uint32_t* call_dev, void* stream);
 
 /*
+ * Split-contraction forms of the two batch-innermost entry points above (ABI 6), for SMALL launches: a single draw of a late
+ * AlexNet layer is a few dozen workgroups, each bounded by its serial k loop (conv4: 48 tiles of 32 k on 128 of the 256 CUs).
+ * With k_split = S > 1 every (pixel, 64 channels, 64 images) item is computed by S workgroups over consecutive k ranges; each
+ * writes its partial accumulator tile to `scratch`, and the last to arrive adds the S tiles in range order (a fixed order: the
+ * result does not depend on timing), applies bias / activation / the LRT sampling step and stores y.  Same contraction as the
+ * unsplit entry points with the partial sums rounded separately: results agree to ~1e-7 relative, bitwise run to run.
+ *   bbb_conv2d_chwn_splitk_scratch: the library's plan for this geometry -> *k_split (1 = do not split: call the plain entry
+ *     point) and the scratch bytes the split launch needs.  lrt != 0: plan for the LRT entry point (two accumulator sets).
+ *   scratch: device memory, 256-byte aligned, ZERO-FILLED before its first use (arrival tickets live at its start and every
+ *     launch leaves them zero again); one scratch buffer per stream in flight.
+ * k_split must be the planned value (BBB_EINVAL otherwise); k_split <= 1 behaves exactly like the plain entry point.
+ */
+int64_t bbb_conv2d_chwn_splitk_scratch(const bbb_conv_desc_t* d, int lrt, int32_t* k_split);
+int bbb_conv2d_chwn_splitk_fwd(const bbb_conv_desc_t* d, const float* x, const float* w, const float* bias, float* y,
+                               int k_split, void* scratch, int64_t scratch_bytes, void* stream);
+int bbb_lrt_conv2d_chwn_splitk_fwd(const bbb_conv_desc_t* d, const float* x, const float* w_mu, const float* w_var,
+                                   const float* b_mu, const float* b_var, float* y,
+                                   float* act_mu_out, float* act_var_out, const float* eps_ext,
+                                   uint64_t seed, uint32_t call0, uint32_t stream_id, int sample,
+                                   const uint32_t* call_dev, int k_split, void* scratch, int64_t scratch_bytes, void* stream);
+
+/*
  * One Monte-Carlo step's chain of layers in ONE persistent launch (ABI 6).  Replaces the per-layer sequence of
  * bbb_conv2d_chwn_fwd / bbb_maxpool_chwn calls that ModuleWrapper.forward (layers/misc.py:16-25) makes for a model such as
  * models/BayesianModels/BayesianAlexNet.py:35-53, for all num_ens draws of main_bayesian.py:73-80 at once: resident workgroups

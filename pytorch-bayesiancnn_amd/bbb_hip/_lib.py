@@ -81,6 +81,12 @@ _SIGNATURES = {
     "bbb_flip_transpose_w": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_void_p]),
     "bbb_im2col_pbj": (c_int, [c_void_p, c_void_p, ctypes.POINTER(ConvDesc), c_void_p]),
     "bbb_transpose_batched": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_void_p]),
+    "bbb_conv2d_chwn_splitk_scratch": (c_i64, [ctypes.POINTER(ConvDesc), c_int, ctypes.POINTER(c_i32)]),
+    "bbb_conv2d_chwn_splitk_fwd": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_i64,
+                                           c_void_p]),
+    "bbb_lrt_conv2d_chwn_splitk_fwd": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                               c_void_p, c_void_p, c_void_p, c_u64, c_u32, c_u32, c_int, c_void_p, c_int, c_void_p, c_i64,
+                                               c_void_p]),
     "bbb_chain_workspace": (c_i64, [c_int, c_int]),
     "bbb_chain_fwd": (c_int, [ctypes.POINTER(ChainStage), c_int, c_u32, c_void_p, c_i64, c_void_p]),
     "bbb_abi_version": (c_int, []),

@@ -423,10 +423,12 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
                         if timers is not None else None
                     is_logits = logits_buf is not None and i == last_bayes and not is_conv
                     dst = logits_buf[e0:e1] if is_logits else None
+                    # (operands bound as defaults: bench.py's LaunchRecorder replays these closures after the loop has moved on)
                     y = _run(timers, "conv_gemm", fl,
-                             lambda: ops.conv2d_chwn_bf16_forward(h5, w, b, ckk, *geom, act=act, out_f32=(i == last_bayes and tail_is_last),
-                                                                  out=dst, tap_major=is_conv and ops.bf16_tap_major(tuple(mod.W_mu.shape)),
-                                                                  **ukw2))
+                             lambda h5=h5, w=w, b=b, ckk=ckk, geom=geom, act=act, dst=dst, ukw2=ukw2, mod=mod, is_conv=is_conv, i=i:
+                             ops.conv2d_chwn_bf16_forward(h5, w, b, ckk, *geom, act=act, out_f32=(i == last_bayes and tail_is_last),
+                                                          out=dst, tap_major=is_conv and ops.bf16_tap_major(tuple(mod.W_mu.shape)),
+                                                          **ukw2))
                 elif isinstance(mod, _BBBLayer):
                     w, b = sampled[mod]
                     if not ukw:
@@ -437,7 +439,8 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
                     fl = conv_flops(B, h5.shape[1], h5.shape[2], h5.shape[3], w.shape[1], w.shape[3], w.shape[4], *geom, Es) \
                         if timers is not None else None
                     dst = logits_buf[e0:e1] if (logits_buf is not None and i == last_bayes and not is_conv) else None
-                    y = _run(timers, "conv_gemm", fl, lambda: ops.conv2d_chwn_forward(h5, w, b, *geom, act=act, out=dst, **ukw2))
+                    y = _run(timers, "conv_gemm", fl, lambda h5=h5, w=w, b=b, geom=geom, act=act, dst=dst, ukw2=ukw2:
+                             ops.conv2d_chwn_forward(h5, w, b, *geom, act=act, out=dst, **ukw2))
                 else:
                     w_var, b_var = variances[mod]
                     w_mu = mod.W_mu
@@ -451,16 +454,18 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
                         # same input AND same (mu, sigma^2) weights for every draw: the two contractions run once, the E
                         # draws differ only in the epilogue noise (bitwise the same result as E full launches)
                         _, am, av = _run(timers, "lrt_gemm", fl,
-                                         lambda: ops.lrt_conv2d_chwn_forward(h5, w_mu, w_var, mod.bias_mu if mod.use_bias else None,
-                                                                             b_var, seed, call0 + e0, mod._stream_base + 2, *geom,
-                                                                             sample=False, want_moments=True, act=None))
+                                         lambda h5=h5, w_mu=w_mu, w_var=w_var, b_var=b_var, mod=mod, geom=geom:
+                                         ops.lrt_conv2d_chwn_forward(h5, w_mu, w_var, mod.bias_mu if mod.use_bias else None,
+                                                                     b_var, seed, call0 + e0, mod._stream_base + 2, *geom,
+                                                                     sample=False, want_moments=True, act=None))
                         y = _run(timers, "lrt_sample", None,
                                  lambda: ops.lrt_sample_chwn(am, av, Es, seed, call0 + e0, mod._stream_base + 2, act=act))
                     else:
                         y = _run(timers, "lrt_gemm", fl,
-                                 lambda: ops.lrt_conv2d_chwn_forward(h5, w_mu, w_var, mod.bias_mu if mod.use_bias else None, b_var,
-                                                                     seed, call0 + e0, mod._stream_base + 2, *geom, sample=True,
-                                                                     act=act, **ukw2)[0])
+                                 lambda h5=h5, w_mu=w_mu, w_var=w_var, b_var=b_var, mod=mod, geom=geom, act=act, ukw2=ukw2:
+                                 ops.lrt_conv2d_chwn_forward(h5, w_mu, w_var, mod.bias_mu if mod.use_bias else None, b_var,
+                                                             seed, call0 + e0, mod._stream_base + 2, *geom, sample=True,
+                                                             act=act, **ukw2)[0])
                 h = y
                 if act is not None:
                     i += 1

@@ -187,6 +187,27 @@ def lrt_conv2d_forward(x, w_mu, w_var, b_mu, b_var, seed, call0, stream_id, stri
     return y, am, av
 
 
+split_k = True     # small batch-innermost launches split their contraction over several workgroups per output tile
+                   # (bbb_conv2d_chwn_splitk_fwd); False: never (tests that compare differently sized launches bit for bit)
+
+
+def _split_scratch(d, lrt, device):
+    """(k_split, scratch tensor | None) for this launch: the library's plan + a zero-initialised per-(device, stream) buffer
+    (arrival tickets at its start stay zero from launch to launch)."""
+    if not split_k:
+        return 1, None
+    ks = ctypes.c_int32(1)
+    need = _lib.lib().bbb_conv2d_chwn_splitk_scratch(ctypes.byref(d), 1 if lrt else 0, ctypes.byref(ks))
+    if ks.value <= 1 or need <= 0:
+        return 1, None
+    key = (device.index, "splitk", cur_stream(device))
+    buf = _scratch.get(key)
+    if buf is None or buf.numel() < need:
+        buf = torch.zeros(max(int(need), 1 << 22), dtype=torch.uint8, device=device)
+        _scratch[key] = buf
+    return ks.value, buf
+
+
 def _apply_units(d, units, x_per_slice):
     """units = (S, off) or None: the launch's slabs are work units u = off + e of the draw-major (draw, batch slice) grid
     (see bbb_conv_desc_t).  x_per_slice: the input is an [S][...] per-slice tensor shared by all draws (first layer)."""
@@ -234,8 +255,13 @@ def conv2d_chwn_forward(x, w, bias, stride=1, padding=0, dilation=1, act=None, o
             raise _lib.BBBHipError("out= must be a contiguous fp32 tensor of the output's size")
         y = out.view(shape)
     with on_device(x.device):
-        check(_lib.lib().bbb_conv2d_chwn_fwd(ctypes.byref(d), x.data_ptr(), w.data_ptr(), ptr(bias), y.data_ptr(),
-                                             cur_stream(x.device)), "bbb_conv2d_chwn_fwd")
+        ks, scr = _split_scratch(d, False, x.device)
+        if ks > 1:
+            check(_lib.lib().bbb_conv2d_chwn_splitk_fwd(ctypes.byref(d), x.data_ptr(), w.data_ptr(), ptr(bias), y.data_ptr(), ks,
+                                                        scr.data_ptr(), scr.numel(), cur_stream(x.device)), "bbb_conv2d_chwn_splitk_fwd")
+        else:
+            check(_lib.lib().bbb_conv2d_chwn_fwd(ctypes.byref(d), x.data_ptr(), w.data_ptr(), ptr(bias), y.data_ptr(),
+                                                 cur_stream(x.device)), "bbb_conv2d_chwn_fwd")
     return y
 
 
@@ -264,11 +290,13 @@ def lrt_conv2d_chwn_forward(x, w_mu, w_var, b_mu, b_var, seed, call0, stream_id,
     if eps is not None:
         eps = eps.contiguous()
     with on_device(x.device):
-        check(_lib.lib().bbb_lrt_conv2d_chwn_fwd(ctypes.byref(d), x.data_ptr(), w_mu.data_ptr(), w_var.data_ptr(), ptr(b_mu),
-                                                 ptr(b_var), y.data_ptr(), ptr(am), ptr(av), ptr(eps), seed,
-                                                 call0 & 0xFFFFFFFF, stream_id, 1 if sample else 0,
-                                                 rng.call_dev_ptr(x.device), cur_stream(x.device)),
-              "bbb_lrt_conv2d_chwn_fwd")
+        ks, scr = _split_scratch(d, True, x.device)
+        check(_lib.lib().bbb_lrt_conv2d_chwn_splitk_fwd(ctypes.byref(d), x.data_ptr(), w_mu.data_ptr(), w_var.data_ptr(), ptr(b_mu),
+                                                        ptr(b_var), y.data_ptr(), ptr(am), ptr(av), ptr(eps), seed,
+                                                        call0 & 0xFFFFFFFF, stream_id, 1 if sample else 0,
+                                                        rng.call_dev_ptr(x.device), ks, ptr(scr), 0 if scr is None else scr.numel(),
+                                                        cur_stream(x.device)),
+              "bbb_lrt_conv2d_chwn_splitk_fwd")
     return y, am, av
 
 

@@ -21,4 +21,7 @@ struct PConvArgs {
     uint32_t x_inv;      // byte offset that marks an invalid image row: x_inv + any column offset is out of range and does not wrap
     const uint32_t* call_dev;
     int32_t unit_div, unit_off, x_mod, b_off;   // work units (include/bbb_hip.h, bbb_conv_desc_t); unit_div <= 1: slab = draw
+    int32_t ksplit;      // split contraction (pconv_body.cuh, SPLIT): k ranges per item, 0 / 1 = none
+    int32_t* tickets;    // [items] arrival counters, zero between launches
+    float* part;         // [items][ksplit][sets][64][BM] partial accumulator tiles
 };

@@ -27,9 +27,16 @@ constexpr int TPC = KCH / BK;            // tiles per chunk
 // write-through (sc1) so that no release fence is needed before the completion counter, and the image-row loads bypass the
 // CU's L1 (sc1), which is never refreshed by other CUs' stores (MI355X: per-XCD L2s are not coherent either, but a line is
 // only ever read after its final value has been written through, so no L2 holds a stale copy).
-template <int BM, bool LRT, bool ILV, bool PUB>
-__device__ __forceinline__ void pconv_item(const PConvArgs& p, const int64_t item) {
+// SPLIT: the item's contraction is cut into p.ksplit consecutive ranges of k tiles, one per workgroup (`ks` = this
+// workgroup's range) -- launches of a few dozen to a few hundred items cannot fill 256 CUs, and a lone workgroup is bounded by
+// its serial k loop (conv4 at one draw: 48 tiles on 128 of the 256 CUs).  Every workgroup writes its raw accumulator tile(s) to
+// scratch (write-through, 16 bytes per lane), takes a ticket, and the LAST arriver adds the ksplit partial tiles in range
+// order 0, 1, ... (whoever it is: the sum does not depend on timing), applies the epilogue and stores the output.  The
+// partial sums round differently from the unsplit fmaf chain: results agree with an unsplit launch to ~1e-7 relative.
+template <int BM, bool LRT, bool ILV, bool PUB, bool SPLIT = false>
+__device__ __forceinline__ void pconv_item(const PConvArgs& p, const int64_t item, const int ks = 0) {
     static_assert(!(LRT && PUB), "the LRT epilogue has no write-through form yet");
+    static_assert(!(SPLIT && PUB), "split launches publish partial tiles, not outputs");
     constexpr int LDX = BM + 4;
     constexpr int NT = (BM >= 128) ? 2 : 1;              // 32-channel MFMA tiles per wave
     constexpr int MT = (BM == 256) ? 2 : 1;              // 32-image MFMA tiles per wave
@@ -226,27 +233,135 @@ __device__ __forceinline__ void pconv_item(const PConvArgs& p, const int64_t ite
         }
     };
 
-    if (ntiles > 0) {
-        fill_chunk(0);
+    int t0 = 0, t1 = ntiles;
+    if constexpr (SPLIT) {
+        t0 = (int)((int64_t)ks * ntiles / p.ksplit);
+        t1 = (int)((int64_t)(ks + 1) * ntiles / p.ksplit);
+    }
+    if (t1 > t0) {
+        const int c0 = t0 / TPC;                                      // first decode chunk of this range (0 when not split)
+        fill_chunk(c0);
         __syncthreads();
-        load_tile(0, wregA, xregA);
-        if (KCH < Keff) fill_chunk(1);
+        load_tile(t0, wregA, xregA);
+        if ((c0 + 1) * KCH < Keff) fill_chunk(c0 + 1);
         store_tile(0, wregA, xregA);
         __syncthreads();
-        for (int t = 0; t < ntiles; ++t) {
-            const bool more = (t + 1) < ntiles;
+        for (int t = t0; t < t1; ++t) {
+            const bool more = (t + 1) < t1;
             if (more) {
                 if (ILV) load_addr(t + 1);                            // loads themselves are issued inside mma_tile()
                 else     load_tile(t + 1, wregA, xregA);              // all loads up front (large launches)
             }
-            // decode chunk c+1 early in chunk c (c >= 1; chunk 1 is decoded in the prologue): its buffer was last
+            // decode chunk c+1 early in chunk c (c >= c0 + 1; chunk c0 + 1 is decoded in the prologue): its buffer was last
             // read by load_tile(TPC*c - 1), several barriers ago
-            if ((t % TPC) == 1 && t / TPC >= 1 && (t / TPC + 1) * KCH < Keff) fill_chunk(t / TPC + 1);
+            if ((t % TPC) == 1 && t / TPC >= c0 + 1 && (t / TPC + 1) * KCH < Keff) fill_chunk(t / TPC + 1);
             mma_tile(more);
             __syncthreads();                                          // every wave is done reading the LDS stage
             if (more) store_tile(0, wregA, xregA);
             __syncthreads();
         }
+    }
+
+    if constexpr (SPLIT) {
+        // ---- split contraction: partial tile(s) -> scratch, ticket, last arriver combines ----
+        constexpr int TILE = 64 * BM;                                 // elements of one accumulator set's tile
+        constexpr int TW = (BK * LDX) / 1024 >= 4 ? 4 : 2;            // wave tiles the X stage can hold (see the PUB epilogue)
+        __shared__ int s_last;
+        const int S = p.ksplit;
+        const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
+            p.part + (int64_t)item * S * (WSETS * TILE), 0, S * WSETS * TILE * 4, 0x00020000);
+        float* const T = &Xs[0][(wave % TW) * 1024];
+#pragma unroll
+        for (int set = 0; set < WSETS; ++set)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int pass = 0; pass < 4 / TW; ++pass) {
+                        if ((wave / TW) == pass) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r)
+                                T[((r & 3) + 8 * (r >> 2) + 4 * lk) * 32 + lrow] = set == 0 ? acc[nt][mt][r] : accv[nt][mt][r];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const int nl = (lane >> 3) + 8 * i, b4 = (lane & 7) * 4;
+                                const f32x4 v4 = *reinterpret_cast<const f32x4*>(&T[nl * 32 + b4]);
+                                const uint32_t off = (uint32_t)(((ks * WSETS + set) * 64 + wn + nt * 32 + nl) * BM + wm + mt * 32 + b4) * 4u;
+                                __builtin_amdgcn_raw_buffer_store_b128(
+                                    __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(uint32_t)))) uint32_t, v4), prs, off, 0, 16);
+                            }
+                        }
+                        if (TW < 4) __syncthreads();                  // the other pair of waves reuses the tiles
+                    }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // every wave's write-through stores have left
+        __syncthreads();
+        if (tid == 0) {
+            const int old = __hip_atomic_fetch_add(p.tickets + item, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = old == S - 1;
+            if (old == S - 1) __hip_atomic_store(p.tickets + item, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch
+        }
+        __syncthreads();
+        if (!s_last) return;
+        // the last arriver: every partial tile of this item is in memory.  Thread -> (channel row, 4 consecutive images).
+        const int HoWo = p.Ho * p.Wo;
+        const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
+            p.y + (int64_t)e * p.y_ds, 0, (int)((int64_t)p.Cout * HoWo * p.B * 4), 0x00020000);
+        const float* __restrict__ b1g = p.bias ? p.bias + (int64_t)ew * p.b_ds : nullptr;
+        const float* __restrict__ b2g = (LRT && p.bias2) ? p.bias2 + (int64_t)ew * p.b_ds : nullptr;
+#pragma unroll
+        for (int q = 0; q < BM / 16; ++q) {
+            const int f = q * kThreads + tid;
+            const int nl = f / (BM / 4), b4 = (f % (BM / 4)) * 4;
+            f32x4 sum[WSETS];
+#pragma unroll
+            for (int set = 0; set < WSETS; ++set) {
+                sum[set] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, (uint32_t)((set * 64 + nl) * BM + b4) * 4u, 0, 16));
+                for (int k2 = 1; k2 < S; ++k2) {
+                    const f32x4 v = __builtin_bit_cast(
+                        f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, (uint32_t)(((k2 * WSETS + set) * 64 + nl) * BM + b4) * 4u, 0, 16));
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) sum[set][c] += v[c];
+                }
+            }
+            const int n = n0 + nl, bb = b0 + b4;
+            if (n < p.Cout && bb < p.B) {
+                const float bn = b1g ? b1g[n] : 0.0f;
+                f32x4 o;
+                if constexpr (!LRT) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) o[c] = bbb::apply_act(sum[0][c] + bn, p.act);
+                } else {
+                    const float b2n = b2g ? b2g[n] : 0.0f;
+                    const int64_t obase = (int64_t)e * p.y_ds + ((int64_t)n * HoWo + pix) * p.B + bb;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        float v = sum[0][c] + bn;
+                        const float var = 1e-16f + (sum[WSETS - 1][c] + b2n);
+                        if (p.y_mu) p.y_mu[obase + c] = v;
+                        if (p.y_var) p.y_var[obase + c] = var;
+                        if (p.sample) {
+                            float z;
+                            if (p.eps_ext) {
+                                z = p.eps_ext[obase + c];
+                            } else {
+                                const int bglob = bb + c + p.b_off + (p.unit_div > 1 ? (ue % p.unit_div) * p.B : 0);
+                                const uint64_t idx = (uint64_t)(((int64_t)bglob * p.Cout + n) * HoWo + pix);
+                                float z4[4];
+                                bbb::normal4(idx >> 2, p.stream_id, p.call0 + (p.call_dev ? *p.call_dev : 0u) + (uint32_t)ew, p.k0, p.k1, z4);
+                                const int cc = (int)(idx & 3);
+                                z = cc == 0 ? z4[0] : cc == 1 ? z4[1] : cc == 2 ? z4[2] : z4[3];
+                            }
+                            v = v + __builtin_amdgcn_sqrtf(var) * z;
+                        }
+                        o[c] = bbb::apply_act(v, p.act);
+                    }
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(uint32_t)))) uint32_t, o),
+                                                       yrs, (uint32_t)(((int64_t)n * HoWo + pix) * p.B + bb) * 4u, 0, 0);
+            }
+        }
+        return;
     }
 
     // ---- epilogue: rows = channels, lanes = images; bias via buffer loads, stores via buffer stores

@@ -46,6 +46,19 @@ __global__ __launch_bounds__(kThreads) void pconv_gemm_kernel(const PConvArgs p)
     pconv_item<BM, LRT, ILV, false>(p, item);
 }
 
+// Split contraction (pconv_body.cuh, SPLIT): block -> (item, k range).  The ksplit blocks of an item are consecutive, so they
+// land on the same XCD chunk as their item's weight-tile sharers.
+template <int BM, bool LRT, bool ILV>
+__global__ __launch_bounds__(kThreads) void pconv_gemm_splitk_kernel(const PConvArgs p) {
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7;
+    const int64_t blk = (int64_t)xcd * p.per_xcd + (bid >> 3);
+    const int64_t blk_end = (int64_t)(xcd + 1) * p.per_xcd;
+    if (blk >= blk_end || blk >= (int64_t)p.G * p.Mtiles * p.ksplit) return;
+    const int64_t item = blk / p.ksplit;
+    pconv_item<BM, LRT, ILV, false, true>(p, item, (int)(blk - item * p.ksplit));
+}
+
 // maxpool over [planes][H][W][B] (planes = draws * channels), B innermost; 4 images per thread.
 __global__ __launch_bounds__(256) void maxpool_chwn_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t total4,
                                                            int H, int W, int Ho, int Wo, int B4, int k, int s) {
@@ -196,6 +209,14 @@ int launch(PConvArgs& a, int draws, hipStream_t st) {
     if (mt > 0x7fffffffLL) return BBB_ESHAPE;
     a.Mtiles = (int)mt;
     const int64_t items = (int64_t)a.G * mt;
+    if (a.ksplit > 1) {
+        // split contraction: only planned for launches that took the 64-image tile (split_plan below)
+        if (bm != 64 || items * a.ksplit > 0x7fffffffLL) return BBB_EINVAL;
+        const int64_t perb = (items * a.ksplit + 7) / 8;
+        a.per_xcd = (int32_t)perb;
+        hipLaunchKernelGGL((pconv_gemm_splitk_kernel<64, LRT, true>), dim3((unsigned)(8 * perb)), dim3(kThreads), 0, st, a);
+        return (int)hipGetLastError();
+    }
     const int64_t per = (items + 7) / 8;
     const int64_t blocks = 8 * per;
     if (blocks > 0x7fffffffLL) return BBB_ESHAPE;
@@ -216,6 +237,73 @@ int launch(PConvArgs& a, int draws, hipStream_t st) {
 
 }  // namespace
 
+namespace {
+// How a small launch is split along the contraction: -> k ranges per item (1 = not split), scratch bytes, item count.
+// Depends on the launch's size (few items), hence results of differently sized launches agree to rounding, not bitwise.
+constexpr int64_t kTicketBytes = 4096;          // 512 items x 4 bytes, rounded up
+
+int split_plan(const PConvArgs& a, int draws, bool lrt, int64_t& bytes, int64_t& items_out) {
+    bytes = 0;
+    const int ntl = (a.Cout + BN - 1) / BN;
+    const int64_t pixels = (int64_t)a.Ho * a.Wo;
+    const int64_t nb128 = pixels * ((a.B + 127) / 128) * ntl * draws;
+    if (!lrt && nb128 >= 768) return 1;                                  // the launcher takes 128-image tiles: large enough
+    const int64_t items = pixels * ((a.B + 63) / 64) * ntl * draws;
+    items_out = items;
+    // Measured (profiles/r03_notes.md section 2, AlexNet bs 512, one draw): conv4 42 -> 28 us and conv5 28 -> 17 us with four
+    // ranges, conv2 43 -> 35 us with two; three ranges of 8 tiles on conv3's 192 items lose 2 us; from ~400 items up a split
+    // only adds partial-tile traffic (and costs 15-20 % when several steps are in flight).
+    if (items > 384) return 1;
+    // longest contraction of any pixel, in 32-k tiles (taps that can fall inside the image)
+    const int nr = a.kh < (a.H - 1) / a.dh + 1 ? a.kh : (a.H - 1) / a.dh + 1;
+    const int nq = a.kw < (a.W - 1) / a.dw + 1 ? a.kw : (a.W - 1) / a.dw + 1;
+    const int tiles = (a.Cin * nr * nq + BK - 1) / BK;
+    int s = 4;
+    const int min_tiles = items <= 128 ? 8 : 12;                         // tiles per range
+    if (tiles / min_tiles < s) s = tiles / min_tiles;
+    const int64_t want = (768 + items - 1) / items;                      // ~3 workgroups per CU are enough
+    if (want < s) s = (int)want;
+    if (s < 2) return 1;
+    // tickets live in a FIXED region at the start of the scratch (split launches have < 512 items), so that launches of
+    // different sizes sharing one scratch buffer never put partial tiles where another launch expects zeroed tickets
+    bytes = kTicketBytes + items * s * (lrt ? 2 : 1) * 64 * 64 * 4;
+    return s;
+}
+
+int split_setup(PConvArgs& a, int draws, bool lrt, int k_split, void* scratch, int64_t scratch_bytes) {
+    if (k_split <= 1) return 0;
+    int64_t need = 0, items = 0;
+    const int s = split_plan(a, draws, lrt, need, items);
+    if (k_split != s || scratch == nullptr || scratch_bytes < need || (((uintptr_t)scratch) & 255u) != 0) return BBB_EINVAL;
+    a.ksplit = k_split;
+    a.tickets = static_cast<int32_t*>(scratch);
+    a.part = reinterpret_cast<float*>(static_cast<char*>(scratch) + kTicketBytes);
+    return 0;
+}
+}  // namespace
+
+extern "C" int64_t bbb_conv2d_chwn_splitk_scratch(const bbb_conv_desc_t* d, int lrt, int32_t* k_split) {
+    PConvArgs a = {};
+    if (k_split) *k_split = 1;
+    if (fill(d, a) != 0) return 0;
+    int64_t need = 0, items = 0;
+    const int s = split_plan(a, d->draws, lrt != 0, need, items);
+    if (k_split) *k_split = s;
+    return s > 1 ? need : 0;
+}
+
+extern "C" int bbb_conv2d_chwn_splitk_fwd(const bbb_conv_desc_t* d, const float* x, const float* w, const float* bias, float* y,
+                                          int k_split, void* scratch, int64_t scratch_bytes, void* stream) {
+    PConvArgs a = {};
+    int rc = fill(d, a);
+    if (rc != 0) return rc;
+    if (x == nullptr || w == nullptr || y == nullptr) return BBB_EINVAL;
+    if ((((uintptr_t)x | (uintptr_t)y) & 15u) != 0 || (((uintptr_t)w | (uintptr_t)bias) & 3u) != 0) return BBB_EALIGN;
+    a.x = x; a.w = w; a.bias = bias; a.y = y;
+    if ((rc = split_setup(a, d->draws, false, k_split, scratch, scratch_bytes)) != 0) return rc;
+    return launch<false>(a, d->draws, (hipStream_t)stream);
+}
+
 extern "C" int bbb_conv2d_chwn_fwd(const bbb_conv_desc_t* d, const float* x, const float* w, const float* bias, float* y,
                                    void* stream) {
     PConvArgs a = {};
@@ -227,13 +315,15 @@ extern "C" int bbb_conv2d_chwn_fwd(const bbb_conv_desc_t* d, const float* x, con
     return launch<false>(a, d->draws, (hipStream_t)stream);
 }
 
-extern "C" int bbb_lrt_conv2d_chwn_fwd(const bbb_conv_desc_t* d, const float* x, const float* w_mu, const float* w_var,
-                                       const float* b_mu, const float* b_var, float* y, float* act_mu_out,
-                                       float* act_var_out, const float* eps_ext, uint64_t seed, uint32_t call0,
-                                       uint32_t stream_id, int sample, const uint32_t* call_dev, void* stream) {
+extern "C" int bbb_lrt_conv2d_chwn_splitk_fwd(const bbb_conv_desc_t* d, const float* x, const float* w_mu, const float* w_var,
+                                              const float* b_mu, const float* b_var, float* y, float* act_mu_out,
+                                              float* act_var_out, const float* eps_ext, uint64_t seed, uint32_t call0,
+                                              uint32_t stream_id, int sample, const uint32_t* call_dev, int k_split,
+                                              void* scratch, int64_t scratch_bytes, void* stream) {
     PConvArgs a = {};
-    const int rc = fill(d, a);
+    int rc = fill(d, a);
     if (rc != 0) return rc;
+    if (k_split > 1 && (rc = split_setup(a, d->draws, true, k_split, scratch, scratch_bytes)) != 0) return rc;
     if (x == nullptr || w_mu == nullptr || w_var == nullptr || y == nullptr) return BBB_EINVAL;
     if ((b_mu == nullptr) != (b_var == nullptr)) return BBB_EINVAL;
     if (d->w_draw_stride != 0 || d->b_draw_stride != 0) return BBB_EINVAL;
@@ -247,6 +337,14 @@ extern "C" int bbb_lrt_conv2d_chwn_fwd(const bbb_conv_desc_t* d, const float* x,
     a.sample = sample ? 1 : 0;
     a.call_dev = call_dev;
     return launch<true>(a, d->draws, (hipStream_t)stream);
+}
+
+extern "C" int bbb_lrt_conv2d_chwn_fwd(const bbb_conv_desc_t* d, const float* x, const float* w_mu, const float* w_var,
+                                       const float* b_mu, const float* b_var, float* y, float* act_mu_out,
+                                       float* act_var_out, const float* eps_ext, uint64_t seed, uint32_t call0,
+                                       uint32_t stream_id, int sample, const uint32_t* call_dev, void* stream) {
+    return bbb_lrt_conv2d_chwn_splitk_fwd(d, x, w_mu, w_var, b_mu, b_var, y, act_mu_out, act_var_out, eps_ext, seed, call0, stream_id,
+                                          sample, call_dev, 1, nullptr, 0, stream);
 }
 
 extern "C" int bbb_maxpool_chwn(const float* x, float* y, int64_t planes, int h, int w, int batch, int k, int s, void* stream) {

@@ -4,7 +4,7 @@ the same instruction sequence, so the comparison is BITWISE, and the scheduler's
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("unsplit")]   # bitwise comparisons across launch sizes
 
 PRI = {"prior_mu": 0, "prior_sigma": 0.1, "posterior_mu_initial": (0, 0.1), "posterior_rho_initial": (-5, 0.1)}
 

@@ -291,8 +291,15 @@ def test_conv2d_chwn_matches_oracle_and_nchw_kernel(ops, case):
     y = ops.conv2d_chwn_forward(xd.permute(0, 2, 3, 4, 1).contiguous(), dev(w), dev(b), s, p, d)      # [E, Cout, Ho, Wo, B]
     y = y.permute(0, 4, 1, 2, 3).contiguous()
     y_nchw = ops.conv2d_forward(xd, dev(w), dev(b), s, p, d)
-    # skipping padding taps only drops exact zeros from the fmaf chain: same bits as the NCHW kernel
-    assert torch.equal(y, y_nchw)
+    # skipping padding taps only drops exact zeros from the fmaf chain: same bits as the NCHW kernel (small launches split
+    # their contraction over several workgroups by default, which rounds the partial sums separately: compared unsplit)
+    saved, ops.split_k = ops.split_k, False
+    try:
+        y_unsplit = ops.conv2d_chwn_forward(xd.permute(0, 2, 3, 4, 1).contiguous(), dev(w), dev(b), s, p, d).permute(0, 4, 1, 2, 3).contiguous()
+    finally:
+        ops.split_k = saved
+    assert torch.equal(y_unsplit, y_nchw)
+    assert float((y - y_unsplit).abs().max()) <= 4e-6 * max(1.0, float(y_unsplit.abs().max()))
     for e in range(E):
         np.testing.assert_allclose(y[e].cpu().numpy(), O.conv2d(x[0 if shared else e], w[e], b[e], s, p, d), rtol=2e-5, atol=2e-5)
 

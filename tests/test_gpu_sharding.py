@@ -12,7 +12,7 @@ import torch.nn as nn
 
 import ref_port_torch as P
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("unsplit")]   # bitwise comparisons across launch sizes
 
 
 @pytest.fixture(scope="module")
