@@ -184,10 +184,15 @@ def profile_traffic(kind):
     """HBM bytes per launch-group from the committed PMC summaries (profiles/r02_pmc_FETCH_SIZE.txt / _WRITE_SIZE.txt, written
     by profiles/collect.sh): (read_bytes, written_bytes, source) or None.  FETCH_SIZE x2 = the gfx950 wide-load correction."""
     out = {}
+    tag = None
+    for t in ("r03", "r02"):                       # the newest committed PMC passes
+        if all(os.path.exists(os.path.join(ROOT, "profiles", f"{t}_pmc_{c}.txt")) for c in ("FETCH_SIZE", "WRITE_SIZE")):
+            tag = t
+            break
+    if tag is None:
+        return None
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
-        path = os.path.join(ROOT, "profiles", f"r02_pmc_{c}.txt")
-        if not os.path.exists(path):
-            return None
+        path = os.path.join(ROOT, "profiles", f"{tag}_pmc_{c}.txt")
         kb = None
         for line in open(path):
             m = re.match(r"\s*STEP_TOTAL\s+%s\s+(\S+)\s+KB_per_step=([0-9.]+)" % kind, line)
@@ -198,7 +203,7 @@ def profile_traffic(kind):
         out[c] = kb * 1024.0
     rd = 2.0 * out["FETCH_SIZE"]
     return rd, out["WRITE_SIZE"], "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 wide-load correction) + WRITE_SIZE, separate passes: " \
-        "profiles/r02_pmc_FETCH_SIZE.txt, profiles/r02_pmc_WRITE_SIZE.txt (STEP_TOTAL %s rows)" % kind
+        "profiles/%s_pmc_FETCH_SIZE.txt, profiles/%s_pmc_WRITE_SIZE.txt (STEP_TOTAL %s rows)" % (tag, tag, kind)
 
 
 def build_net(cfg, dev):
@@ -556,6 +561,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline measurement only (profiling runs)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches on one stream (profiling runs: rocprofv3 --pmc per launch)")
+    ap.add_argument("--no-roofline", action="store_true",
+                    help="skip the per-launch roofline passes (profiling runs: the trace then ends with the timed region's graph replays)")
     ap.add_argument("--pipeline", type=int, default=None,
                     help="independent MC steps in flight (hipGraph lanes on separate streams); default 3, and 4 when N > 1 "
                          "(a rank's share of a step is a few small launches: measured 124 vs 140 us per step for the 8-rank share)")
@@ -631,7 +638,7 @@ def main():
         return
 
     extras = rank == 0 and world == 1 and not args.no_extras
-    head, net, x = run_config(cfg, args.steps, args.warmup, args.pipeline, dev, group, world, want_roofline=True,
+    head, net, x = run_config(cfg, args.steps, args.warmup, args.pipeline, dev, group, world, want_roofline=not args.no_roofline,
                               stat_blocks=5 if extras else 0, timer_steps=min(args.steps, 10))
     n_params = sum(p.numel() for n, p in net.named_parameters() if n.endswith("_mu"))
 

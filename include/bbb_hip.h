@@ -296,9 +296,11 @@ int bbb_lrt_pool_act_bwd_chwn(const float* g_out, const float* y, const float* a
  * is the same for every draw (the first layer of a model) this replaces E identical pairs of contractions by one.
  *   act_mu, act_var: [channels][pixels][batch] (the act_mu_out / act_var_out of a draws = 1, sample = 0 launch)
  *   y: [draws][channels][pixels][batch]
+ *   b_offset: global index of local image 0 (batch-parallel shards; bbb_conv_desc_t::b_offset of the GEMM form), ABI 6
  */
 int bbb_lrt_sample_chwn(const float* act_mu, const float* act_var, float* y, int draws, int channels, int pixels, int batch,
-                        int act, uint64_t seed, uint32_t call0, uint32_t stream_id, const uint32_t* call_dev, void* stream);
+                        int b_offset, int act, uint64_t seed, uint32_t call0, uint32_t stream_id, const uint32_t* call_dev,
+                        void* stream);
 
 /*
  * The LRT sampling step alone, reference layout: y = act_mu + sqrt(act_var) * eps over `draws` contiguous slabs of n

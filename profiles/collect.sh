@@ -24,6 +24,18 @@ rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- $BENCH > /tmp/kt/log.txt 2>
   echo "## only the fp32 HIP-event pass of the metric config (the 10 eager single-stream steps behind the first spin kernel = what roofline.avg_us was timed on)"
   python $R/profiles/summarize_rocpd.py $DB --after-spin 1 --steps 10; } > "$OUT/${TAG}_bench_kernel_stats.txt" 2>&1
 
+# the TIMED REGION's launch mode: kernel trace of the hipGraph replays themselves (no roofline / extras passes in the process), one
+# lane and the default three lanes; per-layer rows (--by-grid).  With several lanes in flight kernels of different steps overlap,
+# so their durations add up to more than the wall time; the single-lane table is the per-kernel in-graph duration.
+{ for P in 1 3; do
+    rm -rf /tmp/kg && mkdir -p /tmp/kg
+    rocprofv3 --kernel-trace -d /tmp/kg -o kg -- python $R/bench.py --steps 50 --warmup 10 --pipeline $P --no-extras --no-roofline > /tmp/kg/log.txt 2>&1
+    echo "# rocprofv3 --kernel-trace -- python bench.py --steps 50 --warmup 10 --pipeline $P --no-extras --no-roofline   ($TAG; the last 50 steps = the timed region's graph replays)"
+    grep '^{' /tmp/kg/log.txt | cut -c1-400
+    python $R/profiles/summarize_rocpd.py $(find /tmp/kg -name '*.db' | head -1) --last-steps 50 --by-grid
+    echo
+  done; } > "$OUT/${TAG}_graph_kernel_stats.txt" 2>&1
+
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pm && mkdir -p /tmp/pm
   rocprofv3 --kernel-trace --pmc $C -d /tmp/pm -o pm -- $EAGER > /tmp/pm/log.txt 2>&1

@@ -3,7 +3,10 @@
 usage: summarize_rocpd.py results.db [--after-spin N [--steps K]]   (the same numbers as `rocprofv3 --stats`, as text)
 --after-spin N: only the kernels between the N-th at::cuda::spin_kernel (1-based) and the next one (or the end) --
 bench.py parks the GPU behind such a kernel before its HIP-event-bracketed eager pass, so this isolates exactly the
-launches the JSON's roofline block was timed on."""
+launches the JSON's roofline block was timed on.
+--last-steps K: only the last K Monte-Carlo steps of the trace (a step ends with its mc_tail kernel): with
+`bench.py --no-extras --no-roofline` these are the hipGraph replays of the timed region.  --by-grid: one row per
+(kernel, grid size), i.e. per layer."""
 import re
 import sqlite3
 import sys
@@ -35,9 +38,16 @@ def main():
                         hi = i + 1
                         break
         rows = rows[lo:hi]
+    if "--last-steps" in sys.argv:
+        want = int(sys.argv[sys.argv.index("--last-steps") + 1])
+        tails = [i for i, r in enumerate(rows) if "mc_tail" in r[0]]
+        if len(tails) > want:
+            rows = rows[tails[-want - 1] + 1:tails[-1] + 1]
+    by_grid = "--by-grid" in sys.argv
     agg = {}
     for name, s, e, gx, gy, gz, wx in rows:
-        a = agg.setdefault(short(name), [0, 0, 1 << 62, 0])
+        key = short(name) + (f"  [grid {gx // max(wx, 1)}]" if by_grid and "pconv" in name else "")
+        a = agg.setdefault(key, [0, 0, 1 << 62, 0])
         d = e - s
         a[0] += 1
         a[1] += d

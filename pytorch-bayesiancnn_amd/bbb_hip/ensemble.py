@@ -351,11 +351,12 @@ def _check_precision(precision, net, x, fast_path_allowed):
                                "4-d input with B % 8 == 0, BBB layers + ReLU/Softplus/MaxPool2d/FlattenLayer)")
 
 
-def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precision="fp32", units=None):
+def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precision="fp32", units=None, b_offset=0):
     """Inference path of mc_logits in the batch-innermost layout ([E, C, H, W, B]): pixel-major GEMMs that
     skip padding taps, activation fused into the GEMM epilogue, pooling on contiguous image vectors.
     units = (S, lo, hi): instead of `draws` whole draws starting at call0, run the work units lo..hi-1 of the draw-major
-    (draw, batch slice) grid with S slices per draw (call0 = the call index of draw 0); returns logits [hi-lo, C, B/S]."""
+    (draw, batch slice) grid with S slices per draw (call0 = the call index of draw 0); returns logits [hi-lo, C, B/S].
+    b_offset: global index of x's first image (batch-parallel shards): LRT activation noise is keyed by the global image."""
     layers = bayesian_layers(net)
     bbb = [l for l in layers if isinstance(l, _BBBLayer)]
     lrt = [l for l in layers if isinstance(l, _LRTLayer)]
@@ -399,6 +400,7 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
         B = xt.shape[-1]
         Es = e1 - e0
         h = xt
+        boff = int(b_offset)           # global index of the first local "image" (rows multiply at a flatten that cuts images up)
         per_slice = bool(ukw)          # work units: until the first Bayesian layer, h is one block per batch slice
         i = 0
         while i < len(children):
@@ -459,13 +461,13 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
                                                                      b_var, seed, call0 + e0, mod._stream_base + 2, *geom,
                                                                      sample=False, want_moments=True, act=None))
                         y = _run(timers, "lrt_sample", None,
-                                 lambda: ops.lrt_sample_chwn(am, av, Es, seed, call0 + e0, mod._stream_base + 2, act=act))
+                                 lambda am=am, av=av, mod=mod, act=act, boff=boff: ops.lrt_sample_chwn(am, av, Es, seed, call0 + e0, mod._stream_base + 2, act=act, b_offset=boff))
                     else:
                         y = _run(timers, "lrt_gemm", fl,
-                                 lambda h5=h5, w_mu=w_mu, w_var=w_var, b_var=b_var, mod=mod, geom=geom, act=act, ukw2=ukw2:
+                                 lambda h5=h5, w_mu=w_mu, w_var=w_var, b_var=b_var, mod=mod, geom=geom, act=act, ukw2=ukw2, boff=boff:
                                  ops.lrt_conv2d_chwn_forward(h5, w_mu, w_var, mod.bias_mu if mod.use_bias else None, b_var,
                                                              seed, call0 + e0, mod._stream_base + 2, *geom, sample=True,
-                                                             act=act, **ukw2)[0])
+                                                             act=act, b_offset=boff, **ukw2)[0])
                 h = y
                 if act is not None:
                     i += 1
@@ -482,6 +484,7 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
                     if chw % mod.num_features != 0 or bf16:
                         return None
                     rows = h.permute(0, 4, 1, 2, 3).reshape(h.shape[0], -1, mod.num_features)     # [E|1, B', F]
+                    boff *= chw // mod.num_features
                     B = rows.shape[1]
                     if B % 4 != 0:
                         return None
@@ -698,7 +701,7 @@ def mc_logits(net, x, draws, seed, call0, fuse_act=True, timers=None, eps=None, 
     return h, kl
 
 
-def _local_lse(net, x, draws, seed, call0, mean_over, fuse_act=True, timers=None, streams=1, precision="fp32", units=None):
+def _local_lse(net, x, draws, seed, call0, mean_over, fuse_act=True, timers=None, streams=1, precision="fp32", units=None, b_offset=0):
     """(log-sum-exp over the local draws of the per-draw log_softmax [B, C], kl of one forward), staying in the
     batch-innermost layout end to end when the fast path applies.  units = (S, lo, hi): the local work is the unit range
     lo..hi-1 instead of `draws` whole draws (call0 = call index of draw 0); rows of slices without a local unit are -inf."""
@@ -710,10 +713,12 @@ def _local_lse(net, x, draws, seed, call0, mean_over, fuse_act=True, timers=None
         lse = _run(timers, "mc_tail", 0, lambda: ops.mc_tail_units(out[0], units[0], units[1], mean_over=mean_over))
         return lse, out[1]
     if fuse_act and _chwn_ok(net, x):
-        out = _mc_logits_chwn(net, x, draws, seed, call0, timers, streams, precision)
+        out = _mc_logits_chwn(net, x, draws, seed, call0, timers, streams, precision, b_offset=b_offset)
         if out is not None:
             lse = _run(timers, "mc_tail", 0, lambda: ops.mc_tail_cb(out[0], mean_over=mean_over))
             return lse, out[1]
+    if b_offset:
+        raise _lib.BBBHipError("a batch offset needs the batch-innermost inference path (checked: this model / input does not fit it)")
     if precision != "fp32":
         raise _lib.BBBHipError("this model / input does not fit the batch-innermost path, which is the only bf16 path")
     if fuse_act and fast_autograd and torch.is_grad_enabled() and timers is None:
@@ -813,10 +818,12 @@ def mc_forward_batch_parallel(net, x_local, num_ens, group=None, gather=False, f
     world = 1 if group is None else torch.distributed.get_world_size(group)
     rank = 0 if group is None else torch.distributed.get_rank(group)
     rng.assign_stream_ids(net)
-    if any(isinstance(l, _LRTLayer) for l in bayesian_layers(net)) and world > 1:
-        raise _lib.BBBHipError("batch-parallel LRT inference is not wired up (activation noise needs the global image index)")
+    if b_offset is None:
+        b_offset = rank * x_local.shape[0]
+    if not any(isinstance(l, _LRTLayer) for l in bayesian_layers(net)):
+        b_offset = 0                                  # weight noise does not depend on the batch
     seed, call0 = rng.next_calls(num_ens)
-    lse, kl1 = _local_lse(net, x_local, num_ens, seed, call0, num_ens, fuse_act=fuse_act, precision=precision)
+    lse, kl1 = _local_lse(net, x_local, num_ens, seed, call0, num_ens, fuse_act=fuse_act, precision=precision, b_offset=int(b_offset))
     kl = kl1 * float(num_ens)
     if gather and world > 1:
         import torch.distributed as dist

@@ -62,8 +62,10 @@ def _train_path_static(net, x):
     pri = set()
     kinds = set()
     i = 0
+    after_layer = False                  # the previous module was a Bayesian layer (+ its fused activation): a pool may follow
     while i < len(mods):
         m = mods[i]
+        poolable, after_layer = after_layer, False
         if isinstance(m, (_BBBLayer, _LRTLayer)):
             kinds.add("lrt" if isinstance(m, _LRTLayer) else "bbb")
             if not m.use_bias:
@@ -77,15 +79,18 @@ def _train_path_static(net, x):
                     return None
                 if not first and m.in_channels % 4 != 0:
                     return None
-            elif not first and m.in_features % 4 != 0:
-                return None
+            elif m.in_features % 4 != 0:
+                return None              # (a first linear layer too: its weight gradient takes the 4-aligned channel path)
             first = False
+            after_layer = True
             if i + 1 < len(mods) and ensemble._act_name(mods[i + 1]) is not None:
                 i += 1
         elif isinstance(m, nn.MaxPool2d):
             k, s = m.kernel_size, m.stride
             if not (isinstance(k, int) and isinstance(s, int) and m.padding == 0 and m.dilation == 1 and not m.ceil_mode):
                 return None
+            if not poolable:
+                return None              # a leading pool, or a pool after a pool / flatten: the node's backward pairs pools with layers
         elif isinstance(m, FlattenLayer):
             pass
         else:

@@ -300,7 +300,7 @@ def lrt_conv2d_chwn_forward(x, w_mu, w_var, b_mu, b_var, seed, call0, stream_id,
     return y, am, av
 
 
-def lrt_sample_chwn(act_mu, act_var, draws, seed, call0, stream_id, act=None):
+def lrt_sample_chwn(act_mu, act_var, draws, seed, call0, stream_id, act=None, b_offset=0):
     """E draws y[e] = act(act_mu + sqrt(act_var) * eps[e]) from one pair of LRT moments [1|-, C, Ho, Wo, B] ->
     [E, C, Ho, Wo, B]; eps as the LRT GEMM epilogue would draw it for draw e."""
     require_device(act_mu, act_var)
@@ -308,7 +308,7 @@ def lrt_sample_chwn(act_mu, act_var, draws, seed, call0, stream_id, act=None):
     C, Ho, Wo, B = act_mu.shape[-4:]
     y = torch.empty((draws, C, Ho, Wo, B), dtype=torch.float32, device=act_mu.device)
     with on_device(act_mu.device):
-        check(_lib.lib().bbb_lrt_sample_chwn(act_mu.data_ptr(), act_var.data_ptr(), y.data_ptr(), draws, C, Ho * Wo, B,
+        check(_lib.lib().bbb_lrt_sample_chwn(act_mu.data_ptr(), act_var.data_ptr(), y.data_ptr(), draws, C, Ho * Wo, B, int(b_offset),
                                              {None: 0, "relu": 1, "softplus": 2}[act], seed, call0 & 0xFFFFFFFF, stream_id,
                                              rng.call_dev_ptr(act_mu.device), cur_stream(act_mu.device)), "bbb_lrt_sample_chwn")
     return y

@@ -18,22 +18,31 @@ class FusedAdam(torch.optim.Optimizer):
     so state_dicts are interchangeable with torch.optim.Adam.
     capturable=True keeps 'step' on the device (torch's capturable convention) and lets the kernel derive the bias
     corrections from it, so the step can be part of a captured hipGraph (GraphedTrainStep).  The learning rate of a
-    capturable group also lives on the device (group['lr_dev']): `sync_lr()` copies group['lr'] there, which is how a
-    scheduler's change reaches a step that was captured earlier."""
+    capturable group also lives on the device (a private per-group scalar, kept OUT of param_groups so that state_dict() holds
+    exactly what torch.optim.Adam's does): `sync_lr()` copies group['lr'] there, which is how a scheduler's change reaches a
+    step that was captured earlier."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, capturable=False):
         if not 0.0 <= lr or not 0.0 <= eps or not (0.0 <= betas[0] < 1.0 and 0.0 <= betas[1] < 1.0):
             raise ValueError("invalid Adam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, capturable=bool(capturable)))
+        self._lr_dev = {}          # group index -> [device scalar, last value pushed]
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        for rec in self._lr_dev.values():     # the captured step keeps reading OUR scalars: refresh them from the loaded lr
+            rec[1] = None
+        if self._lr_dev and not torch.cuda.is_current_stream_capturing():
+            self.sync_lr()
 
     def sync_lr(self):
         """Push every capturable group's current lr to its device scalar (call outside a graph capture, e.g. after
         scheduler.step(); GraphedTrainStep.step does it before each replay)."""
-        for group in self.param_groups:
-            t = group.get("lr_dev")
-            if t is not None and group.get("_lr_pushed") != float(group["lr"]):
-                t.fill_(float(group["lr"]))
-                group["_lr_pushed"] = float(group["lr"])
+        for gi, group in enumerate(self.param_groups):
+            rec = self._lr_dev.get(gi)
+            if rec is not None and rec[1] != float(group["lr"]):
+                rec[0].fill_(float(group["lr"]))
+                rec[1] = float(group["lr"])
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -67,12 +76,15 @@ class FusedAdam(torch.optim.Optimizer):
                 if any(not t.is_cuda for t in steps):
                     raise _lib.BBBHipError("capturable FusedAdam needs its 'step' state on the device")
                 torch._foreach_add_(steps, 1.0)              # one launch; all tensors of a group step together
-                if group.get("lr_dev") is None:
-                    group["lr_dev"] = torch.full((), float(group["lr"]), dtype=torch.float32, device=steps[0].device)
-                    group["_lr_pushed"] = float(group["lr"])
+                # the device-side learning rate lives in a private dict keyed by group index, NOT in param_groups: state_dict()
+                # stays interchangeable with torch.optim.Adam's, and load_state_dict / map_location cannot swap or move the
+                # scalar a captured step reads
+                gi = self.param_groups.index(group)
+                if gi not in self._lr_dev:
+                    self._lr_dev[gi] = [torch.full((), float(group["lr"]), dtype=torch.float32, device=steps[0].device), float(group["lr"])]
                 elif not torch.cuda.is_current_stream_capturing():
                     self.sync_lr()
-                lr_dev = group["lr_dev"].data_ptr()
+                lr_dev = self._lr_dev[gi][0].data_ptr()
             for step, items in by_step.items():
                 for s0 in range(0, len(items), _lib.MAX_SEGMENTS):
                     part = items[s0:s0 + _lib.MAX_SEGMENTS]

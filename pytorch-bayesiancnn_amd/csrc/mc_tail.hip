@@ -248,7 +248,7 @@ template <int PPT>
 __global__ __launch_bounds__(256) void lrt_sample_chwn_kernel(const float* __restrict__ mu, const float* __restrict__ var,
                                                               float* __restrict__ y, int E, int C, int HW, int B, int act,
                                                               uint32_t k0, uint32_t k1, uint32_t call0, uint32_t stream_id,
-                                                              const uint32_t* __restrict__ call_dev) {
+                                                              const uint32_t* __restrict__ call_dev, int b_off) {
     const int64_t HWq = HW / PPT;
     const int64_t total = (int64_t)E * C * HWq * B;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void lrt_sample_chwn_kernel(const float* __res
     const int n = (int)(t % C);
     const int e = (int)(t / C);
     const uint32_t call = call0 + (call_dev ? *call_dev : 0u) + (uint32_t)e;
-    const uint64_t idx0 = (uint64_t)(((int64_t)b * C + n) * HW + (int64_t)q * PPT);
+    const uint64_t idx0 = (uint64_t)(((int64_t)(b + b_off) * C + n) * HW + (int64_t)q * PPT);   // keyed by the GLOBAL image index
     float z4[4];
     bbb::normal4(idx0 >> 2, stream_id, call, k0, k1, z4);
 #pragma unroll
@@ -356,10 +356,10 @@ extern "C" const char* bbb_build_info(void) {
 }
 
 extern "C" int bbb_lrt_sample_chwn(const float* act_mu, const float* act_var, float* y, int draws, int channels, int pixels,
-                                   int batch, int act, uint64_t seed, uint32_t call0, uint32_t stream_id,
+                                   int batch, int b_offset, int act, uint64_t seed, uint32_t call0, uint32_t stream_id,
                                    const uint32_t* call_dev, void* stream) {
     if (act_mu == nullptr || act_var == nullptr || y == nullptr || draws <= 0 || channels <= 0 || pixels <= 0 || batch <= 0 ||
-        act < 0 || act > 2)
+        b_offset < 0 || act < 0 || act > 2)
         return BBB_EINVAL;
     if ((((uintptr_t)act_mu | (uintptr_t)act_var | (uintptr_t)y) & 3u) != 0) return BBB_EALIGN;
     const bool quad = pixels % 4 == 0;
@@ -369,10 +369,10 @@ extern "C" int bbb_lrt_sample_chwn(const float* act_mu, const float* act_var, fl
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     if (quad)
         hipLaunchKernelGGL(lrt_sample_chwn_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, act_mu, act_var, y,
-                           draws, channels, pixels, batch, act, k0, k1, call0, stream_id, call_dev);
+                           draws, channels, pixels, batch, act, k0, k1, call0, stream_id, call_dev, b_offset);
     else
         hipLaunchKernelGGL(lrt_sample_chwn_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, act_mu, act_var, y,
-                           draws, channels, pixels, batch, act, k0, k1, call0, stream_id, call_dev);
+                           draws, channels, pixels, batch, act, k0, k1, call0, stream_id, call_dev, b_offset);
     return (int)hipGetLastError();
 }
 

@@ -4,7 +4,7 @@ against the oracle's bf16 storage model and against the fp32 path.  Stated toler
   * one GEMM launch, bf16 output: half a bf16 ulp of the result (2^-9 relative) on top of that;
   * whole model vs the oracle's bf16 model (same rounding points, fp64 accumulate): a hidden activation that lands
     within accumulation error of a rounding boundary flips by one bf16 ulp (0.4 %) and the flips spread through the
-    next layers -> logits within 2e-2 * max|logit|;
+    next layers -> logits within 1e-2 * max|logit| (measured <= 6e-3);
   * whole Monte-Carlo step vs the fp32 path (the reference's arithmetic): log-probabilities within 2e-2 of their
     largest magnitude (measured: 0.5 %), KL identical (it never touches bf16).
 Run with -m gpu."""
@@ -149,7 +149,7 @@ def test_model_bf16_vs_oracle_bf16_model(env, net_type, B, cin, hw):
         want, kl_o = O.model_forward_bf16(net_type, npar, x.numpy(), "softplus", _oracle_eps_fn(names, seed, call0 + e))
         got = logits[e].cpu().numpy()
         scale = float(np.abs(want).max())
-        np.testing.assert_allclose(got, want, rtol=0, atol=2e-2 * scale)
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-2 * scale)
         assert abs(kl.item() - kl_o) <= 2e-6 * kl_o
         # and the bf16 result is a perturbation of the fp32 one, not something else
         np.testing.assert_allclose(got, logits32[e].cpu().numpy(), rtol=0, atol=6e-2 * scale)

@@ -124,7 +124,7 @@ def test_metric_config_alexnet10_bbb_bs512_ens10_vs_oracle(env):
 
 def test_config1_3conv3fc_bs256_bf16_vs_oracle(env):
     """configs[1]: Bayesian3Conv3FC, BBB layers, bf16 storage, batch 256.  The reference has no bf16 mode; the oracle is the same
-    algorithm with this project's rounding points (bbb_numpy.model_forward_bf16).  Bound: 2e-2 of max|logit|; the
+    algorithm with this project's rounding points (bbb_numpy.model_forward_bf16).  Bound: 1e-2 of max|logit| (SURVEY.md 8c suggests 2e-2; measured 5.7-6.1e-3, so the tighter bound is held); the
     fp32 path on the same draw is compared too (1e-5)."""
     net, params, sid = build(env, "3conv3fc", "bbb", 10)
     x = torch.rand(256, 3, 32, 32)
@@ -145,7 +145,7 @@ def test_config1_3conv3fc_bs256_bf16_vs_oracle(env):
         e32 = float(np.abs(l32[j].cpu().numpy() - want32).max()) / scale
         report(f"cfg1 3conv3fc bs256 draw {j}", scale=scale, bf16_vs_bf16_oracle=e16, fp32_vs_f64=e32,
                bf16_model_vs_fp32_model=float(np.abs(want16 - want32).max()) / scale)
-        assert e16 <= 2e-2
+        assert e16 <= 1e-2
         assert e32 <= 1e-5
         assert abs(kl16.item() - klw) <= 2e-6 * klw
 
@@ -221,5 +221,46 @@ def test_config4_alexnet_224_bs64_vs_oracle(env):
     scale = float(lt.abs().max())
     err = float(np.abs(logits[0].cpu().numpy() - lt.numpy()).max()) / scale
     report("cfg4 alexnet 224 bs64", scale=scale, dev_vs_cpu_ref=err)
+    assert err <= 2e-5
+    assert abs(kl.item() - float(klt)) <= 5e-6 * float(klt)
+
+
+def test_config4_alexnet_224_bs512_shard_vs_oracle(env):
+    """configs[4] at the size bench.py times: the 512-image shard one GPU holds of the batch-4096 run (3x224x224), one draw vs
+    the reference's CPU ops on all 512 x 49 output rows."""
+    net, params, sid = build(env, "alexnet", "bbb", 10, seed=2)
+    torch.manual_seed(1)
+    x = torch.rand(512, 3, 224, 224)
+    xd = x.cuda()
+    seed, call0 = 5, 0
+    with torch.no_grad():
+        logits, kl = env["ens"].mc_logits(net, xd, 1, seed, call0)
+        assert_fast_path(env)
+        lt, klt = P.forward("alexnet", params, x, "bbb", "softplus", eps_fn=eps_torch(seed, call0, sid))
+    assert tuple(logits.shape) == (1, 512 * 49, 10) and tuple(lt.shape) == (512 * 49, 10)
+    scale = float(lt.abs().max())
+    err = float(np.abs(logits[0].cpu().numpy() - lt.numpy()).max()) / scale
+    report("cfg4 alexnet 224 bs512", scale=scale, dev_vs_cpu_ref=err)
+    assert err <= 2e-5
+    assert abs(kl.item() - float(klt)) <= 5e-6 * float(klt)
+
+
+def test_alexnet_224_lrt_vs_oracle(env):
+    """The 224x224 shape through the LOCAL-REPARAMETERISATION layers (the reference's default layer type,
+    config_bayesian.py:1-18): activation noise replayed on the CPU from the device's stream, keyed by the canonical NCHW
+    element index -- through the flatten quirk, where the classifier's noise rows are the 49 cuts of each image."""
+    net, params, sid = build(env, "alexnet", "lrt", 10, seed=3)
+    torch.manual_seed(2)
+    x = torch.rand(32, 3, 224, 224)
+    xd = x.cuda()
+    seed, call0 = 9, 4
+    with torch.no_grad():
+        logits, kl = env["ens"].mc_logits(net, xd, 1, seed, call0)
+        assert_fast_path(env)
+        lt, klt = P.forward("alexnet", params, x, "lrt", "softplus", eps_fn=eps_torch(seed, call0, sid))
+    assert tuple(logits.shape) == (1, 32 * 49, 10)
+    scale = float(lt.abs().max())
+    err = float(np.abs(logits[0].cpu().numpy() - lt.numpy()).max()) / scale
+    report("alexnet 224 lrt bs32", scale=scale, dev_vs_cpu_ref=err)
     assert err <= 2e-5
     assert abs(kl.item() - float(klt)) <= 5e-6 * float(klt)

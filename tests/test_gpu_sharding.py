@@ -113,6 +113,29 @@ def test_batch_parallel_shards_equal_the_full_batch(env):
     assert torch.equal(torch.cat(parts), full)
 
 
+@pytest.mark.parametrize("hw,B", [(32, 64), (224, 16)])
+def test_batch_parallel_lrt_shards_draw_the_full_batchs_noise(env, hw, B):
+    """Local-reparameterisation layers draw noise per ACTIVATION, keyed by the GLOBAL image index: a shard that is told where
+    its images sit in the full batch (b_offset; default rank * B_local) reproduces the full batch's rows bit for bit -- also
+    through the 224x224 flatten quirk, where one image becomes 49 rows of the classifier's input."""
+    ens = env["ens"]
+    net = build(env, "alexnet", "lrt", 10, seed=5)
+    x = torch.rand(B, 3, hw, hw, device="cuda")
+    E, half = 2, B // 2
+    with torch.no_grad():
+        env["rng"].manual_seed(13, call=0)
+        full, kl = ens.mc_forward(net, x, E)
+        rows = full.shape[0] // 2
+        for r in range(2):
+            env["rng"].manual_seed(13, call=0)
+            lo, kl_r = ens.mc_forward_batch_parallel(net, x[r * half:(r + 1) * half], E, b_offset=r * half)
+            assert kl_r.item() == kl.item()
+            assert torch.equal(lo, full[r * rows:(r + 1) * rows]), r
+        env["rng"].manual_seed(13, call=0)
+        wrong, _ = ens.mc_forward_batch_parallel(net, x[half:], E, b_offset=0)         # without the offset: other noise
+        assert not torch.equal(wrong, full[rows:])
+
+
 class _Block(nn.Sequential):
     pass
 

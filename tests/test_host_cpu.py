@@ -552,3 +552,54 @@ def test_bench_gpus_n_builds_its_own_launcher_command():
     assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
     assert cmd[-6:] == ["--gpus", "4", "--steps", "7", "--warmup", "3"] and cmd[-7].endswith("bench.py")
+
+
+def test_fast_train_static_check_rejects_pools_it_cannot_pair():
+    """fast_train._train_path_static: a MaxPool2d that does not follow a Bayesian layer (+ activation) -- a
+    leading pool, a pool after a pool -- and a linear layer whose in_features is not a multiple of 4 send the model to the
+    reference-layout training path instead of failing inside the fused node."""
+    from torch import nn
+    import layers
+    from bbb_hip import fast_train, zoo
+    pri = {"prior_mu": 0, "prior_sigma": 0.1, "posterior_mu_initial": (0, 0.1), "posterior_rho_initial": (-5, 0.1)}
+    x = torch.zeros(8, 3, 32, 32)
+    assert fast_train._train_path_static(zoo.BBBAlexNet(10, 3, pri, "bbb", "softplus"), x) == "bbb"
+    assert fast_train._train_path_static(zoo.BBBAlexNet(10, 3, pri, "lrt", "relu"), x) == "lrt"
+
+    class Net(layers.ModuleWrapper):
+        def __init__(self, variant):
+            super().__init__()
+            if variant == "leading_pool":
+                self.p0 = nn.MaxPool2d(2, 2)
+            self.c1 = layers.BBB_Conv2d(3, 8, 3, padding=1, priors=pri)
+            self.a1 = nn.ReLU()
+            self.p1 = nn.MaxPool2d(2, 2)
+            if variant == "pool_pool":
+                self.p2 = nn.MaxPool2d(2, 2)
+            side = {"ok": 16, "leading_pool": 8, "pool_pool": 8, "odd_linear": 16}[variant]
+            feat = 8 * side * side
+            self.fl = layers.FlattenLayer(feat)
+            if variant == "odd_linear":
+                self.f0 = layers.BBB_Linear(feat, 30, priors=pri)
+                self.f1 = layers.BBB_Linear(30, 10, priors=pri)
+            else:
+                self.f1 = layers.BBB_Linear(feat, 10, priors=pri)
+
+    assert fast_train._train_path_static(Net("ok"), x) == "bbb"
+    for bad in ("leading_pool", "pool_pool", "odd_linear"):
+        assert fast_train._train_path_static(Net(bad), x) is None, bad
+
+
+def test_fused_adam_state_dict_is_torch_adams():
+    """The device-side learning rate of a capturable FusedAdam lives outside param_groups: state_dict() has torch.optim.Adam's
+    keys only and round-trips through load_state_dict."""
+    from bbb_hip import train
+    p = [torch.nn.Parameter(torch.zeros(4))]
+    opt = train.FusedAdam(p, lr=1e-3, capturable=True)
+    ref = torch.optim.Adam([torch.nn.Parameter(torch.zeros(4))], lr=1e-3, capturable=True)
+    assert set(opt.state_dict()["param_groups"][0]) <= set(ref.state_dict()["param_groups"][0])
+    assert all(not torch.is_tensor(v) for v in opt.state_dict()["param_groups"][0].values())
+    sd = opt.state_dict()
+    sd["param_groups"][0]["lr"] = 5e-4
+    opt.load_state_dict(sd)
+    assert opt.param_groups[0]["lr"] == 5e-4 and opt._lr_dev == {}
