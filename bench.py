@@ -710,7 +710,11 @@ def main():
                 if name == args.config:
                     continue
                 try:
-                    r, n2, x2 = run_config(c, max(10, args.steps // 2), 5, args.pipeline, dev, want_roofline=True, timer_steps=3)
+                    # single-draw configurations are a dozen 10-20 us launches per step: four steps in flight instead of three
+                    # (measured, profiles/r03_notes.md section 4: configs[1] 0.066 -> 0.055 ms, configs[2] 0.182 -> 0.164 ms)
+                    depth = args.pipeline + 1 if (c["E"] == 1 and c["hw"] == 32 and args.pipeline == 3) else args.pipeline
+                    r, n2, x2 = run_config(c, max(10, args.steps // 2), 5, depth, dev, want_roofline=True, timer_steps=3)
+                    r["steps_in_flight"] = depth
                     del n2, x2
                     r["workload"] = c["what"]
                     r["dtype"] = "bf16" if c["precision"] == "bf16" else "f32"
