@@ -203,7 +203,7 @@ int launch(PConvArgs& a, int draws, hipStream_t st) {
     // AlexNet layer (3 instead of 4 workgroups per CU); the launcher never selects it.
     // LRT stages two weight tiles and keeps two accumulator sets: 64-wide only.
     const int64_t nb128 = pixels * ((a.B + 127) / 128) * a.G;
-    int bm = (LRT || nb128 < 768) ? 64 : 128;
+    int bm = (LRT || nb128 < 768) ? 64 : 128;        // (round 3 re-measured 600 / 300: conv4 +10 %, conv5 +25 % slower with 128)
     a.nbt = (a.B + bm - 1) / bm;
     const int64_t mt = pixels * a.nbt;
     if (mt > 0x7fffffffLL) return BBB_ESHAPE;
@@ -221,7 +221,9 @@ int launch(PConvArgs& a, int draws, hipStream_t st) {
     const int64_t blocks = 8 * per;
     if (blocks > 0x7fffffffLL) return BBB_ESHAPE;
     a.per_xcd = (int32_t)per;
-    const bool ilv = items <= 1536;      // <= 1.5 rounds of 4 workgroups x 256 CUs: latency-bound launch
+    // staging loads interleaved with the MFMAs (ILV): round 1 measured it a loss beyond ~1.5 rounds of workgroups; re-measured in
+    // round 3 on the current kernel (profiles/r03_notes.md section 3) it is a 1-2 % gain up to ~12k items, one or three steps in flight
+    const bool ilv = items <= 12000;
     const dim3 grid((unsigned)blocks), block(kThreads);
     if constexpr (!LRT) {
         if (bm == 128) {
