@@ -353,6 +353,14 @@ int bbb_mc_tail_cb(const float* logits, int draws, int batch, int classes, int m
 int bbb_mc_tail_units(const float* logits, int units, int slices, int unit_off, int batch_slice, int classes, int mean_over,
                       float* lse_out, void* stream);
 
+/* bbb_mc_tail_units + the end of a captured Monte-Carlo step in the same launch (ABI 6): kl_out = kl_in * kl_scale (kl_in: the KL
+ * of ONE forward from bbb_reparam_kl_fwd; the reference sums it once per forward, main_bayesian.py:76-77; kl_out NULL = skip) and
+ * *counter += counter_add (the device-side call counter that bbb_reparam_kl_fwd / the LRT entry points read through `call_dev`:
+ * all of a step's readers run before its tail, so the next replay of the graph draws fresh noise; counter NULL = skip). */
+int bbb_mc_tail_units_step(const float* logits, int units, int slices, int unit_off, int batch_slice, int classes, int mean_over,
+                           float* lse_out, const float* kl_in, float kl_scale, float* kl_out, uint32_t* counter,
+                           uint32_t counter_add, void* stream);
+
 /*
  * Uncertainty decomposition over `draws` stochastic forwards (uncertainty_estimation.py:37-58 per image, :61-102 per
  * batch): logits [draws][B][C] -> pred = mean logits, epistemic = mean (p_hat - p_bar)^2, aleatoric = p_bar - mean p_hat^2,

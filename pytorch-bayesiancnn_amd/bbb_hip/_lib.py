@@ -76,6 +76,8 @@ _SIGNATURES = {
     "bbb_mc_tail": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "bbb_mc_tail_cb": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "bbb_mc_tail_units": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "bbb_mc_tail_units_step": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
+                                       c_u32, c_void_p]),
     "bbb_uncertainty": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "bbb_transpose2d": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_void_p]),
     "bbb_flip_transpose_w": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_void_p]),

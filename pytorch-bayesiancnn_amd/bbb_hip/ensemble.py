@@ -701,20 +701,32 @@ def mc_logits(net, x, draws, seed, call0, fuse_act=True, timers=None, eps=None, 
     return h, kl
 
 
-def _local_lse(net, x, draws, seed, call0, mean_over, fuse_act=True, timers=None, streams=1, precision="fp32", units=None, b_offset=0):
+def _local_lse(net, x, draws, seed, call0, mean_over, fuse_act=True, timers=None, streams=1, precision="fp32", units=None, b_offset=0,
+               step_end=None):
     """(log-sum-exp over the local draws of the per-draw log_softmax [B, C], kl of one forward), staying in the
     batch-innermost layout end to end when the fast path applies.  units = (S, lo, hi): the local work is the unit range
-    lo..hi-1 instead of `draws` whole draws (call0 = call index of draw 0); rows of slices without a local unit are -inf."""
+    lo..hi-1 instead of `draws` whole draws (call0 = call index of draw 0); rows of slices without a local unit are -inf.
+    step_end = (scale, counter, counter_add) (a captured step, GraphedMC): the tail launch also writes kl * scale and advances the
+    device-side call counter; then the second return value is the SCALED kl, and step_end[3] is set to True -- on the paths without
+    the fused tail the caller does both itself."""
     _check_precision(precision, net, x, fuse_act)
     if units is not None and units[0] > 1:
         out = _mc_logits_chwn(net, x, draws, seed, call0, timers, 1, precision, units=units)
         if out is None:
             raise _lib.BBBHipError("work units need the batch-innermost path (checked by units_ok before planning)")
+        if step_end is not None and timers is None:
+            lse, klf = ops.mc_tail_units(out[0], units[0], units[1], mean_over=mean_over, step_end=(out[1], step_end[0], step_end[1], step_end[2]))
+            step_end[3] = True
+            return lse, klf
         lse = _run(timers, "mc_tail", 0, lambda: ops.mc_tail_units(out[0], units[0], units[1], mean_over=mean_over))
         return lse, out[1]
     if fuse_act and _chwn_ok(net, x):
         out = _mc_logits_chwn(net, x, draws, seed, call0, timers, streams, precision, b_offset=b_offset)
         if out is not None:
+            if step_end is not None and timers is None:
+                lse, klf = ops.mc_tail_cb(out[0], mean_over=mean_over, step_end=(out[1], step_end[0], step_end[1], step_end[2]))
+                step_end[3] = True
+                return lse, klf
             lse = _run(timers, "mc_tail", 0, lambda: ops.mc_tail_cb(out[0], mean_over=mean_over))
             return lse, out[1]
     if b_offset:
@@ -923,18 +935,22 @@ class GraphedMC:
 
     def _step_body(self, streams):
         n_loc = self.hi - self.lo
+        single = self.world == 1 and not self._force_combine
+        if single:
+            scale = float(self.num_ens) if self.kl_mode == "sum" else 1.0
+        else:
+            scale = float(n_loc) / self.S
+        # the tail launch of the fast path also scales the KL and advances the noise counter (two element-wise launches less)
+        end = [scale, self.counter, self.stride, False]
         if self.S > 1:
-            lse, kl1 = _local_lse(self.net, self.x, self.num_ens, self.seed, self.call0, 0, precision=self.precision,
-                                  units=(self.S, self.lo, self.hi))
+            lse, kl = _local_lse(self.net, self.x, self.num_ens, self.seed, self.call0, 0, precision=self.precision,
+                                 units=(self.S, self.lo, self.hi), step_end=end)
         else:
-            lse, kl1 = _local_lse(self.net, self.x, n_loc, self.seed, self.call0 + self.lo,
-                                  self.num_ens if (self.world == 1 and not self._force_combine) else 0, streams=streams,
-                                  precision=self.precision)
-        if self.world == 1 and not self._force_combine:
-            kl = kl1 * float(self.num_ens) if self.kl_mode == "sum" else kl1 * 1.0
-        else:
-            kl = kl1 * (float(n_loc) / self.S)
-        self.counter.add_(self.stride)               # part of the graph: next replay of this lane
+            lse, kl = _local_lse(self.net, self.x, n_loc, self.seed, self.call0 + self.lo, self.num_ens if single else 0,
+                                 streams=streams, precision=self.precision, step_end=end)
+        if not end[3]:
+            kl = kl * scale
+            self.counter.add_(self.stride)           # part of the graph: next replay of this lane
         if self.multi:                               # pack what this rank contributes to the step's one collective
             self.send[:-1].copy_(lse.reshape(-1))
             self.send[-1:].copy_(kl.reshape(1))

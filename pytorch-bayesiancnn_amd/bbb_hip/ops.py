@@ -557,29 +557,37 @@ def maxpool_chwn_bf16(x, k, s):
     return y
 
 
-def mc_tail_cb(logits, mean_over=0):
+def mc_tail_cb(logits, mean_over=0, step_end=None):
     """mc_tail for batch-innermost logits [E, C, B] -> [B, C]."""
-    require_device(logits)
-    logits = logits.contiguous()
-    E, C, B = logits.shape
-    out = torch.empty((B, C), dtype=torch.float32, device=logits.device)
-    with on_device(logits.device):
-        check(_lib.lib().bbb_mc_tail_cb(logits.data_ptr(), E, B, C, int(mean_over), out.data_ptr(), cur_stream(logits.device)),
-              "bbb_mc_tail_cb")
-    return out
+    return mc_tail_units(logits, 1, 0, mean_over, step_end)
 
 
-def mc_tail_units(logits, slices, unit_off, mean_over=0):
+def mc_tail_units(logits, slices, unit_off, mean_over=0, step_end=None):
     """mc_tail_cb for a rank's work units: logits [U, C, Bs] (unit u = unit_off + e is draw u // slices, batch slice
-    u % slices) -> [slices * Bs, C]; -inf rows for slices the rank holds no unit of."""
+    u % slices) -> [slices * Bs, C]; -inf rows for slices the rank holds no unit of.
+    step_end = (kl_one_forward, scale, counter | None, counter_add): the end of a captured Monte-Carlo step in the same launch
+    (bbb_mc_tail_units_step) -> returns (lse, kl_one_forward * scale) and adds counter_add to the int32 device counter."""
     require_device(logits)
     logits = logits.contiguous()
     U, C, Bs = logits.shape
+    if U > (512 if int(slices) == 1 else 4096):
+        raise _lib.BBBHipError("too many draws / units for one tail launch")
     out = torch.empty((int(slices) * Bs, C), dtype=torch.float32, device=logits.device)
+    L = _lib.lib()
     with on_device(logits.device):
-        check(_lib.lib().bbb_mc_tail_units(logits.data_ptr(), U, int(slices), int(unit_off) % int(slices), Bs, C, int(mean_over),
-                                           out.data_ptr(), cur_stream(logits.device)), "bbb_mc_tail_units")
-    return out
+        if step_end is None:
+            check(L.bbb_mc_tail_units(logits.data_ptr(), U, int(slices), int(unit_off) % int(slices), Bs, C, int(mean_over),
+                                      out.data_ptr(), cur_stream(logits.device)), "bbb_mc_tail_units")
+            return out
+        kl_in, scale, counter, add = step_end
+        require_device(kl_in)
+        kl_out = torch.empty((), dtype=torch.float32, device=logits.device)
+        if counter is not None and (counter.dtype != torch.int32 or not counter.is_cuda):
+            raise _lib.BBBHipError("the call counter must be an int32 device tensor")
+        check(L.bbb_mc_tail_units_step(logits.data_ptr(), U, int(slices), int(unit_off) % int(slices), Bs, C, int(mean_over),
+                                       out.data_ptr(), kl_in.data_ptr(), float(scale), kl_out.data_ptr(), ptr(counter),
+                                       int(add) & 0xFFFFFFFF, cur_stream(logits.device)), "bbb_mc_tail_units_step")
+    return out, kl_out
 
 
 def uncertainty(logits, normalized=False):

@@ -67,10 +67,21 @@ constexpr int kCbRows = 16;
 // Work units (ensemble sharding, include/bbb_hip.h): the E slabs are units u = off + e of the draw-major (draw, batch slice)
 // grid with S slices of Bs images; image b = s*Bs + bl reduces over the local units of ITS slice, e = e0, e0 + S, ...
 // (e0 = (s - off) mod S), and gets -inf when the rank holds none.  S = 1, off = 0 is the plain [E][C][B] case.
+// Step epilogue riding on the tail launch (a captured Monte-Carlo step otherwise spends two more element-wise launches on
+// them): kl_out = kl_in * kl_scale (the KL of ONE forward times the number of forwards this rank ran, main_bayesian.py:76-77)
+// and counter += counter_add (the device-side noise call counter of include/bbb_hip.h `call_dev`: every kernel that reads it
+// runs before the tail of the same step).
 __global__ __launch_bounds__(kCbThreads * kCbRows) void mc_tail_cb_kernel(const float* __restrict__ logits, int E, int Bs, int S,
-                                                                          int off, int C, float sub, float* __restrict__ out) {
+                                                                          int off, int C, float sub, float* __restrict__ out,
+                                                                          const float* __restrict__ kl_in, float kl_scale,
+                                                                          float* __restrict__ kl_out, uint32_t* counter,
+                                                                          uint32_t counter_add) {
     extern __shared__ float lz[];                       // [ceil(E/S)][64]
     const int tx = threadIdx.x, ty = threadIdx.y, ny = blockDim.y;
+    if (blockIdx.x == 0 && tx == 0 && ty == 0) {
+        if (kl_out != nullptr) *kl_out = *kl_in * kl_scale;
+        if (counter != nullptr) *counter += counter_add;
+    }
     const int B = Bs * S;
     const int b = blockIdx.x * kCbThreads + tx;
     const bool ok = b < B;
@@ -293,8 +304,10 @@ __global__ __launch_bounds__(256) void lrt_sample_nchw_kernel(const float* __res
 
 }  // namespace
 
-extern "C" int bbb_mc_tail_units(const float* logits, int units, int slices, int unit_off, int batch_slice, int classes,
-                                 int mean_over, float* lse_out, void* stream) {
+extern "C" int bbb_mc_tail_units_step(const float* logits, int units, int slices, int unit_off, int batch_slice, int classes,
+                                      int mean_over, float* lse_out, const float* kl_in, float kl_scale, float* kl_out,
+                                      uint32_t* counter, uint32_t counter_add, void* stream) {
+    if ((kl_out != nullptr && kl_in == nullptr) || (((uintptr_t)kl_in | (uintptr_t)kl_out | (uintptr_t)counter) & 3u) != 0) return BBB_EINVAL;
     if (logits == nullptr || lse_out == nullptr || units <= 0 || slices <= 0 || unit_off < 0 || batch_slice <= 0 || classes <= 0 ||
         mean_over < 0 || units > 4096)
         return BBB_EINVAL;
@@ -307,8 +320,15 @@ extern "C" int bbb_mc_tail_units(const float* logits, int units, int slices, int
     const int mx = per_slice > classes ? per_slice : classes;
     const int ny = mx < kCbRows ? mx : kCbRows;
     hipLaunchKernelGGL(mc_tail_cb_kernel, dim3(blocks), dim3(kCbThreads, ny), (size_t)per_slice * kCbThreads * sizeof(float),
-                       (hipStream_t)stream, logits, units, batch_slice, slices, unit_off, classes, sub, lse_out);
+                       (hipStream_t)stream, logits, units, batch_slice, slices, unit_off, classes, sub, lse_out, kl_in, kl_scale, kl_out,
+                       counter, counter_add);
     return (int)hipGetLastError();
+}
+
+extern "C" int bbb_mc_tail_units(const float* logits, int units, int slices, int unit_off, int batch_slice, int classes, int mean_over,
+                                 float* lse_out, void* stream) {
+    return bbb_mc_tail_units_step(logits, units, slices, unit_off, batch_slice, classes, mean_over, lse_out, nullptr, 0.0f, nullptr,
+                                  nullptr, 0u, stream);
 }
 
 extern "C" int bbb_mc_tail_cb(const float* logits, int draws, int batch, int classes, int mean_over, float* lse_out,
