@@ -371,6 +371,43 @@ __device__ __forceinline__ void pconv_item(const PConvArgs& p, const int64_t ite
         const_cast<float*>(p.bias ? p.bias + (int64_t)ew * p.b_ds : p.w), 0, p.bias ? p.Cout * 4 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
         p.y + (int64_t)e * p.y_ds, 0, (int)((int64_t)p.Cout * HoWo * p.B * 4), 0x00020000);
+    if constexpr (!LRT) {
+        // Every wave transposes its 32 x 32 accumulator tile(s) through LDS (the X stage is free after the k loop) so that a
+        // lane ends up with FOUR consecutive images of one channel: 8 16-byte stores and 8 bias loads per lane instead of 32 +
+        // 32 four-byte ones (measured neutral for the per-layer kernel at 4 workgroups per CU -- profiles/r03_notes.md section 3 --
+        // and required for PUB, whose write-through (sc1) stores are one fabric write per lane: 4-byte ones cost ~6x the time per
+        // byte).  Same values, same bits as the MFMA-layout epilogue of rounds 1-2.
+        // The stage holds TW wave tiles at a time (BM = 64: two passes).
+        constexpr int TW = (BK * LDX) / 1024 >= 4 ? 4 : 2;               // wave tiles the X stage can hold
+        float* const T = &Xs[0][(wave % TW) * 1024];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                for (int pass = 0; pass < 4 / TW; ++pass) {
+                    if ((wave / TW) == pass) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * lk) * 32 + lrow] = acc[nt][mt][r];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int nl = (lane >> 3) + 8 * i, b4 = (lane & 7) * 4;
+                            const int n = n0 + wn + nt * 32 + nl, bb = b0 + wm + mt * 32 + b4;
+                            const float bn = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brs, (uint32_t)n * 4u, 0, 0));
+                            f32x4 v4 = *reinterpret_cast<const f32x4*>(&T[nl * 32 + b4]);
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) v4[c] = bbb::apply_act(v4[c] + bn, p.act);
+                            const uint32_t off = ((bb < p.B) & (n < p.Cout)) ? (uint32_t)(((int64_t)n * HoWo + pix) * p.B + bb) * 4u : kOOB;
+                            __builtin_amdgcn_raw_buffer_store_b128(
+                                __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(uint32_t)))) uint32_t, v4), yrs, off, 0, AUX_Y);
+                        }
+                    }
+                    if (TW < 4) __syncthreads();                         // the other pair of waves reuses the tiles
+                }
+            }
+        return;
+    }
+    // ---- LRT epilogue (MFMA layout: rows = channels, lanes = images) ----
     float bv[NT][16];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -383,46 +420,7 @@ __device__ __forceinline__ void pconv_item(const PConvArgs& p, const int64_t ite
     for (int mt = 0; mt < MT; ++mt) {
         const int b = b0 + wm + mt * 32 + lrow;
         const bool b_ok = b < p.B;
-        if (!LRT && PUB) {
-            // Write-through (sc1) stores are one fabric write per LANE: as 4-byte stores they cost ~6x the time per byte of
-            // 16-byte ones (measured: the whole chain 2x slower).  So every wave transposes its 32 x 32 tile through LDS (the
-            // X stage is free after the k loop) and each lane stores FOUR consecutive images of one channel: the same values,
-            // 16 bytes per lane.  The stage holds TW wave tiles at a time (BM = 64: two passes).
-            constexpr int TW = (BK * LDX) / 1024 >= 4 ? 4 : 2;               // wave tiles the X stage can hold
-            float* const T = &Xs[0][(wave % TW) * 1024];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-                for (int pass = 0; pass < 4 / TW; ++pass) {
-                    const bool mine = (wave / TW) == pass;
-                    if (mine) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            T[((r & 3) + 8 * (r >> 2) + 4 * lk) * 32 + lrow] = bbb::apply_act(acc[nt][mt][r] + bv[nt][r], p.act);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int nl = (lane >> 3) + 8 * i, b4 = (lane & 7) * 4;
-                            const f32x4 v4 = *reinterpret_cast<const f32x4*>(&T[nl * 32 + b4]);
-                            const int n = n0 + wn + nt * 32 + nl, bb = b0 + wm + mt * 32 + b4;
-                            const uint32_t off = ((bb < p.B) & (n < p.Cout)) ? (uint32_t)(((int64_t)n * HoWo + pix) * p.B + bb) * 4u : kOOB;
-                            __builtin_amdgcn_raw_buffer_store_b128(
-                                __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(uint32_t)))) uint32_t, v4), yrs, off, 0, AUX_Y);
-                        }
-                    }
-                    if (TW < 4) __syncthreads();                         // the other pair of waves reuses the tiles
-                }
-            }
-        } else if (!LRT) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int n = n0 + wn + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                    const uint32_t off = (b_ok & (n < p.Cout)) ? (uint32_t)(((int64_t)n * HoWo + pix) * p.B + b) * 4u : kOOB;
-                    const float v = bbb::apply_act(acc[nt][mt][r] + bv[nt][r], p.act);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), yrs, off, 0, AUX_Y);
-                }
-        } else if (b_ok) {
+        if (b_ok) {
             const int64_t ybase = (int64_t)e * p.y_ds + (int64_t)pix * p.B + b;
             const float* __restrict__ b2g = p.bias2 ? p.bias2 + (int64_t)ew * p.b_ds : nullptr;
             const int bglob = b + p.b_off + (p.unit_div > 1 ? (ue % p.unit_div) * p.B : 0);      // image index that keys the noise
