@@ -390,7 +390,8 @@ def run_config(cfg, steps, warmup, pipeline, dev, group=None, world=1, want_roof
         else:
             gstep = ensemble.GraphedMC(net, x, E, group=group, precision=prec)
         step = gstep.step
-        step()
+        for _ in range(max(1, pipeline)):            # setup: every lane's graph is replayed once (first replay = its upload)
+            step()
         torch.cuda.synchronize(dev)
         for _ in range(warmup):
             step()
