@@ -187,6 +187,7 @@ def lrt_conv2d_forward(x, w_mu, w_var, b_mu, b_var, seed, call0, stream_id, stri
     return y, am, av
 
 
+_split_plans = {}
 split_k = True     # small batch-innermost launches split their contraction over several workgroups per output tile
                    # (bbb_conv2d_chwn_splitk_fwd); False: never (tests that compare differently sized launches bit for bit)
 
@@ -196,16 +197,21 @@ def _split_scratch(d, lrt, device):
     (arrival tickets at its start stay zero from launch to launch)."""
     if not split_k:
         return 1, None
-    ks = ctypes.c_int32(1)
-    need = _lib.lib().bbb_conv2d_chwn_splitk_scratch(ctypes.byref(d), 1 if lrt else 0, ctypes.byref(ks))
-    if ks.value <= 1 or need <= 0:
+    pkey = (bytes(d), bool(lrt))                       # the plan depends on the geometry only: asked once per shape
+    plan = _split_plans.get(pkey)
+    if plan is None:
+        ks = ctypes.c_int32(1)
+        need = _lib.lib().bbb_conv2d_chwn_splitk_scratch(ctypes.byref(d), 1 if lrt else 0, ctypes.byref(ks))
+        plan = _split_plans[pkey] = (ks.value, int(need))
+    ks_v, need = plan
+    if ks_v <= 1 or need <= 0:
         return 1, None
     key = (device.index, "splitk", cur_stream(device))
     buf = _scratch.get(key)
     if buf is None or buf.numel() < need:
         buf = torch.zeros(max(int(need), 1 << 22), dtype=torch.uint8, device=device)
         _scratch[key] = buf
-    return ks.value, buf
+    return ks_v, buf
 
 
 def _apply_units(d, units, x_per_slice):

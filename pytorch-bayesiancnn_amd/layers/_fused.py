@@ -82,7 +82,7 @@ class _Spec:
     (draw j of a batched launch == net(x) number j).  K follows the length of the previous streak of identical inputs
     (a validation loop settles on K = num_ens at the FIRST call of each batch), or doubles 2, 4, 8 while no history exists.
     The cache is dropped when the input object, its version counter, any parameter's version counter, the generator
-    position or the autograd mode changes."""
+    position, the autograd mode or the model's structure (a replaced layer / Parameter, moved storage) changes."""
     __slots__ = ("xref", "xver", "pver", "grad", "seed", "next_call", "logits", "kl", "idx", "streak", "last_streak", "batches")
 
     def __init__(self):
@@ -141,7 +141,10 @@ def fast_forward(wrapper, x):
     sp = wrapper.__dict__.get("_bbb_spec")
     if sp is None:
         sp = wrapper.__dict__["_bbb_spec"] = _Spec()
-    pver = tuple(p._version for p in ensemble._structure(wrapper)["params"])
+    st = ensemble._structure(wrapper)
+    # parameter versions AND storage addresses (module.to() / .data assignments replace storage without a version bump), plus the
+    # identity of the cached structure (a replaced layer or Parameter object rebuilds it)
+    pver = (id(st),) + tuple((p._version, p.data_ptr()) for p in st["params"])
     same_x = sp.xref is not None and sp.xref() is x and sp.xver == x._version and sp.pver == pver and sp.grad == grad
     can_spec = speculation["enabled"] and rng._graph_counter["tensor"] is None and not torch.cuda.is_current_stream_capturing()
     seed, call = rng.get_state()
