@@ -9,7 +9,9 @@
 namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__global__ __launch_bounds__(256) void mfma_loop_kernel(float* out, int iters, float a0, float b0) {
+__global__ __launch_bounds__(256) void mfma_loop_kernel(float* out, int iters, float a0, float b0, unsigned long long* clk) {
+    // shader clock over the loop: s_memtime counts shader-clock cycles, wall_clock64 a constant 100 MHz
+    const unsigned long long c0 = __builtin_readcyclecounter(), w0 = wall_clock64();
     f32x16 acc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -26,10 +28,15 @@ __global__ __launch_bounds__(256) void mfma_loop_kernel(float* out, int iters, f
 #pragma unroll
         for (int r = 0; r < 16; ++r) s += acc[i][r];
     out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && clk != nullptr) {
+        clk[0] = __builtin_readcyclecounter() - c0;
+        clk[1] = wall_clock64() - w0;
+    }
 }
 }  // namespace
 
-// tflops_out[0] = best of `reps` timed launches (HIP events on `stream`), in TFLOP/s.  Returns a hipError_t.
+// tflops_out[0] = best of `reps` timed launches (HIP events on `stream`), in TFLOP/s; tflops_out[1] = the shader clock (GHz) the
+// kernel itself measured during that launch (0 if unavailable).  Returns a hipError_t.
 extern "C" int probe_mfma_f32_ceiling(double* tflops_out, int reps, void* stream) {
     if (tflops_out == nullptr || reps <= 0) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
@@ -40,25 +47,32 @@ extern "C" int probe_mfma_f32_ceiling(double* tflops_out, int reps, void* stream
     if (er != hipSuccess) return (int)er;
     const int blocks = cus * 2, iters = 4096;                    // 16384 MFMAs per wave: ~0.45 ms per launch
     float* out = nullptr;
-    er = hipMalloc(&out, (size_t)blocks * 256 * sizeof(float));
+    er = hipMalloc(&out, (size_t)blocks * 256 * sizeof(float) + 64);
     if (er != hipSuccess) return (int)er;
+    unsigned long long* clk = reinterpret_cast<unsigned long long*>(out + (size_t)blocks * 256);
+    double best_clk = 0.0;
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipFree(out); return (int)hipErrorUnknown; }
     double best = 0.0;
     for (int r = 0; r < reps + 1; ++r) {                           // first launch is a warm-up
         (void)hipEventRecord(e0, st);
-        hipLaunchKernelGGL(mfma_loop_kernel, dim3(blocks), dim3(256), 0, st, out, iters, 1.0f, 0.5f);
+        hipLaunchKernelGGL(mfma_loop_kernel, dim3(blocks), dim3(256), 0, st, out, iters, 1.0f, 0.5f, clk);
         (void)hipEventRecord(e1, st);
         er = hipEventSynchronize(e1);
         if (er != hipSuccess) break;
         float ms = 0.0f;
         (void)hipEventElapsedTime(&ms, e0, e1);
         const double tf = (double)blocks * 4.0 * iters * 4.0 * 4096.0 / ((double)ms * 1e9);
-        if (r > 0 && tf > best) best = tf;
+        if (r > 0 && tf > best) {
+            best = tf;
+            unsigned long long h[2] = {0, 0};
+            if (hipMemcpy(h, clk, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess && h[1] > 0) best_clk = (double)h[0] / (double)h[1] * 0.1;
+        }
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     (void)hipFree(out);
-    *tflops_out = best;
+    tflops_out[0] = best;
+    tflops_out[1] = best_clk;
     return (int)er;
 }
