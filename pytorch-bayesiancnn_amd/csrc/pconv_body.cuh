@@ -8,6 +8,10 @@
 #include "bbb_common.cuh"
 #include "pconv_args.h"
 
+#ifdef PCONV_STAMPS
+static __device__ unsigned long long g_pconv_ts[8 * 4 * 8];   // experiment builds: per-phase cycle sums of sampled workgroups
+#endif
+
 namespace pconv {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -246,20 +250,46 @@ __device__ __forceinline__ void pconv_item(const PConvArgs& p, const int64_t ite
         if ((c0 + 1) * KCH < Keff) fill_chunk(c0 + 1);
         store_tile(0, wregA, xregA);
         __syncthreads();
+#ifdef PCONV_STAMPS_TILE
+        unsigned long long ts_acc[5] = {0, 0, 0, 0, 0}, ts_first = __builtin_readcyclecounter();
+#define TS_MARK(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); ts_acc[i] += n_ - ts_last; ts_last = n_; } while (0)
+#else
+#define TS_MARK(i) do { } while (0)
+#endif
         for (int t = t0; t < t1; ++t) {
+#ifdef PCONV_STAMPS_TILE
+            unsigned long long ts_last = __builtin_readcyclecounter();
+#endif
             const bool more = (t + 1) < t1;
             if (more) {
                 if (ILV) load_addr(t + 1);                            // loads themselves are issued inside mma_tile()
                 else     load_tile(t + 1, wregA, xregA);              // all loads up front (large launches)
             }
+            TS_MARK(0);
             // decode chunk c+1 early in chunk c (c >= c0 + 1; chunk c0 + 1 is decoded in the prologue): its buffer was last
             // read by load_tile(TPC*c - 1), several barriers ago
             if ((t % TPC) == 1 && t / TPC >= c0 + 1 && (t / TPC + 1) * KCH < Keff) fill_chunk(t / TPC + 1);
             mma_tile(more);
+            TS_MARK(1);
             __syncthreads();                                          // every wave is done reading the LDS stage
+            TS_MARK(2);
             if (more) store_tile(0, wregA, xregA);
+            TS_MARK(3);
             __syncthreads();
+            TS_MARK(4);
         }
+#ifdef PCONV_STAMPS_TILE
+        {   // one sampled workgroup per XCD, from the middle of the launch
+            const int bid_ = blockIdx.x;
+            if ((bid_ >> 3) == p.per_xcd / 2 && lane == 0) {
+                unsigned long long* o = g_pconv_ts + ((bid_ & 7) * 4 + wave) * 8;
+                for (int i = 0; i < 5; ++i) o[i] = ts_acc[i];
+                o[5] = __builtin_readcyclecounter() - ts_first;
+                o[6] = (unsigned long long)(t1 - t0);
+                o[7] = 1;
+            }
+        }
+#endif
     }
 
     if constexpr (SPLIT) {
