@@ -107,3 +107,44 @@ def test_models_with_split_launches_stay_inside_the_bound(lt, classes):
             if rep == 0:
                 first = loop
         assert torch.equal(first, loop)
+
+
+def _split_cases(n, seed):
+    rs = np.random.RandomState(seed)
+    out = []
+    while len(out) < n:
+        k = int(rs.choice([3, 5]))
+        H, W = int(rs.randint(1, 6)), int(rs.randint(1, 6))
+        p_, d_, s_ = int(rs.randint(0, 3)), int(rs.choice([1, 1, 2])), int(rs.choice([1, 1, 2]))
+        if H + 2 * p_ < d_ * (k - 1) + 1 or W + 2 * p_ < d_ * (k - 1) + 1:
+            continue
+        Cin, Cout = int(rs.choice([32, 64, 130, 192])), int(rs.choice([10, 64, 65, 130]))
+        B, E = int(rs.choice([64, 136, 264])), int(rs.choice([1, 2]))
+        if _plan(B, Cin, H, W, Cout, k, s_, p_, E)[0] < 2:
+            continue
+        out.append((B, Cin, H, W, Cout, k, s_, p_, d_, E))
+    return out
+
+
+@pytest.mark.parametrize("c", _split_cases(10, 77), ids=lambda c: "x".join(map(str, c)))
+def test_split_launches_random_geometry_vs_oracle(c):
+    """Ragged channel / image tiles, strides, dilations and paddings through the SPLIT launch (the plan says so for each case)."""
+    from bbb_hip import ops
+    B, Cin, H, W, Cout, k, s_, p_, d_, E = c
+    rs = np.random.default_rng(sum(c))
+    x = rs.standard_normal((E, B, Cin, H, W)).astype(np.float32)
+    w = (rs.standard_normal((E, Cout, Cin, k, k)) * 0.1).astype(np.float32)
+    b = rs.standard_normal((E, Cout)).astype(np.float32)
+    xd = torch.from_numpy(x).cuda().permute(0, 2, 3, 4, 1).contiguous()
+    y = ops.conv2d_chwn_forward(xd, torch.from_numpy(w).cuda(), torch.from_numpy(b).cuda(), s_, p_, d_, act="softplus")
+    saved, ops.split_k = ops.split_k, False
+    try:
+        yu = ops.conv2d_chwn_forward(xd, torch.from_numpy(w).cuda(), torch.from_numpy(b).cuda(), s_, p_, d_, act="softplus")
+    finally:
+        ops.split_k = saved
+    assert float((y - yu).abs().max()) <= TOL * max(1.0, float(yu.abs().max()))
+    for e in range(E):
+        pre = O.conv2d(x[e], w[e], b[e], s_, p_, d_)
+        mag = O.conv2d(np.abs(x[e]), np.abs(w[e]), np.abs(b[e]), s_, p_, d_)
+        got = y[e].permute(3, 0, 1, 2).cpu().numpy()
+        assert (np.abs(got - O.softplus_act(pre)) <= 2e-5 * mag + 2e-6).all()
