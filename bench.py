@@ -37,6 +37,7 @@ import subprocess
 import sys
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # before HIP initialises: one hardware queue per lane (bbb_hip/__init__.py)
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "pytorch-bayesiancnn_amd"))
 sys.dont_write_bytecode = True

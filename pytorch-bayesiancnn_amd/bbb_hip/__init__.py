@@ -12,5 +12,13 @@
             the reference's models/BayesianModels/*.py, for hosts without the reference checkout)
 The drop-in boundary itself is the sibling package ``layers``.
 """
-from . import _lib, rng, ops  # noqa: F401
-from ._lib import BBBHipError, LIB_PATH  # noqa: F401
+import os as _os
+
+# HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) round-robin, and hipGraph branches take slots too: with 4,
+# the lanes of a GraphedPipeline end up sharing a queue depending on how many streams the process created before (measured: the
+# same 4-lane pipeline 0.087 or 0.115 ms per step).  8 queues keep every lane on its own.  Read by the HIP runtime when it
+# initialises (the first device call), so this must run before that; a value the user exported wins.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+from . import _lib, rng, ops  # noqa: E402,F401
+from ._lib import BBBHipError, LIB_PATH  # noqa: E402,F401

@@ -385,7 +385,7 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
         kl = k2 if kl is None else kl + k2
     to_cb = ops.to_batch_innermost_bf16 if bf16 else ops.to_batch_innermost
     if S > 1:                                                   # [S, C, H, W, B/S]: one batch-innermost block per slice
-        xt = torch.stack([to_cb(x[s * B:(s + 1) * B]) for s in range(S)])
+        xt = torch.stack([to_cb(x[s * B:(s + 1) * B]) for s in range(S)]) if bf16 else ops.to_batch_innermost_slices(x, S)
     else:
         xt = to_cb(x).unsqueeze(0)                              # [1, C, H, W, B], shared by all draws
     children = flat_children(net)
@@ -587,6 +587,19 @@ def _side_streams(device, n):
     if key not in _stream_pool:
         _stream_pool[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
     return _stream_pool[key]
+
+
+_lane_pool = {}
+
+
+def _lane_streams(device, n):
+    """The first n streams of the device's lane pool (created once, in order, so that lanes 0..n-1 always sit on the same
+    hardware queues)."""
+    key = torch.device(device).index
+    pool = _lane_pool.setdefault(key, [])
+    while len(pool) < max(n, 4):                         # created back to back: consecutive streams land on distinct queues
+        pool.append(torch.cuda.Stream(device=device))
+    return pool[:n]
 
 
 def _loop_logits(net, x, draws, seed, call0, eps=None):
@@ -995,9 +1008,12 @@ class GraphedPipeline:
 
     def __init__(self, net, x, num_ens, depth=2, streams=1, kl_mode="sum", group=None, precision="fp32"):
         seed_call = rng.next_calls(0)
+        # lane streams come from a per-device pool and are REUSED by later pipelines: HIP maps streams onto a handful of hardware
+        # queues round-robin, and a process that keeps creating streams (one pipeline per configuration, as bench.py does) ends up
+        # with lanes that share a queue and stop overlapping (measured: the same 3-lane pipeline 15-18 % slower when built late)
+        pool = _lane_streams(x.device, depth)
         self.lanes = [GraphedMC(net, x, num_ens, streams=streams, kl_mode=kl_mode, lane=l, lanes=depth,
-                                stream=torch.cuda.Stream(device=x.device), seed_call=seed_call, group=group,
-                                precision=precision)
+                                stream=pool[l], seed_call=seed_call, group=group, precision=precision)
                       for l in range(depth)]
         self.i = 0
         self.dev = x.device

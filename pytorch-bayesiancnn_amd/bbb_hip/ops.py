@@ -619,6 +619,19 @@ def to_batch_innermost(x):
     return out
 
 
+def to_batch_innermost_slices(x, slices):
+    """[S*Bs, C, H, W] -> [S, C, H, W, Bs]: one batch-innermost block per batch slice (the input of a rank's work units), as ONE
+    batched transpose launch."""
+    require_device(x)
+    x = x.contiguous()
+    Bs = x.shape[0] // slices
+    plane = x.numel() // x.shape[0]
+    out = torch.empty((slices,) + tuple(x.shape[1:]) + (Bs,), dtype=torch.float32, device=x.device)
+    if not _transpose_batched(x, out, Bs, plane, slices, 1, Bs * plane, 0, plane, plane * Bs, 0, Bs):
+        raise _lib.BBBHipError("to_batch_innermost_slices: too many slices")
+    return out
+
+
 def mc_tail(logits, mean_over=0):
     """logits [E, B, C] -> [B, C]: log-sum-exp over draws of the per-draw log_softmax, minus log(mean_over)
     when mean_over > 0 (== utils.logmeanexp of the stacked log_softmax when mean_over == E)."""
