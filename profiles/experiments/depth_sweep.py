@@ -17,7 +17,7 @@ for name in sys.argv[1:] or list(bench.CONFIGS):
     cfg = bench.CONFIGS[name]
     net, x = bench.build_net(cfg, dev)
     row = {"config": name}
-    for depth in (1, 2, 3, 4, 6, 8):
+    for depth in (1, 2, 3, 4, 5, 6, 8, 12):
         with torch.no_grad():
             pipe = ensemble.GraphedPipeline(net, x, cfg["E"], depth=depth, precision=cfg["precision"]) if depth > 1 else \
                 ensemble.GraphedMC(net, x, cfg["E"], precision=cfg["precision"])
