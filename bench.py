@@ -511,17 +511,23 @@ def training_step(dev, steps):
     net, x = build_net(cfg, dev)
     y = torch.randint(0, cfg["classes"], (cfg["B"],), device=dev)
     opt = train.FusedAdam(net.parameters(), lr=1e-3)
-    for _ in range(3):
-        train.train_step(net, opt, x, y, cfg["E"], 0.1, 50000.0)
-    path = ensemble.stats["path"]
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        train.train_step(net, opt, x, y, cfg["E"], 0.1, 50000.0)
-    torch.cuda.synchronize(dev)
-    dt = (time.perf_counter() - t0) / steps
+    res = {}
+    for mode, graph in (("launch_by_launch", False), ("default", None)):      # default: train_step captures itself after 3 calls
+        for _ in range(5):
+            train.train_step(net, opt, x, y, cfg["E"], 0.1, 50000.0, graph=graph)
+        if mode == "launch_by_launch":
+            path = ensemble.stats["path"]
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            train.train_step(net, opt, x, y, cfg["E"], 0.1, 50000.0, graph=graph)
+        torch.cuda.synchronize(dev)
+        res[mode] = (time.perf_counter() - t0) / steps
+    dt = res["default"]
     out = {"ms_per_step": round(1e3 * dt, 4), "value": round(cfg["B"] * cfg["E"] / dt, 1), "unit": "samples/s (forward + backward + Adam)",
-           "path": path, "note": "BayesianAlexNet bs=512 num_ens=10, fp32; round 1 (reference-layout autograd path): 8.3 ms"}
+           "launch_by_launch_ms_per_step": round(1e3 * res["launch_by_launch"], 4), "path": path,
+           "note": "BayesianAlexNet bs=512 num_ens=10, fp32, train.train_step as called (it captures itself as one hipGraph after 3 "
+                   "identical calls; graph=False = launch_by_launch); round 1 (reference-layout autograd path): 8.3 ms"}
     del net, x, y, opt
     # the reference's own defaults (config_bayesian.py:1-18: layer_type 'lrt', batch_size 256, train_ens 1): eager and as one hipGraph
     try:
@@ -532,14 +538,16 @@ def training_step(dev, steps):
         x = torch.rand(256, 3, 32, 32, device=dev)
         y = torch.randint(0, 10, (256,), device=dev)
         d = {}
-        for mode in ("eager", "hipgraph"):
+        for mode in ("eager", "default", "hipgraph"):
             opt = train.FusedAdam(net.parameters(), lr=1e-3, capturable=(mode == "hipgraph"))
             if mode == "hipgraph":
                 g = train.GraphedTrainStep(net, opt, x, y, 1, 0.1, 50000.0, warmup=3)
                 step = g.step
-            else:
+            elif mode == "default":                           # train_step as a user calls it: self-capturing
                 step = lambda: train.train_step(net, opt, x, y, 1, 0.1, 50000.0)
-            for _ in range(3):
+            else:
+                step = lambda: train.train_step(net, opt, x, y, 1, 0.1, 50000.0, graph=False)
+            for _ in range(5):
                 step()
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()

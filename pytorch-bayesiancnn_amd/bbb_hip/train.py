@@ -5,6 +5,8 @@ per GPU, each with its own shard of the batch), ONE all-reduce of the flattened 
 
 Not part of the forward metric; forward-only inference is `bbb_hip.ensemble`.
 """
+import weakref
+
 import torch
 import torch.nn.functional as F
 
@@ -27,6 +29,17 @@ class FusedAdam(torch.optim.Optimizer):
             raise ValueError("invalid Adam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, capturable=bool(capturable)))
         self._lr_dev = {}          # group index -> [device scalar, last value pushed]
+
+    def make_capturable(self):
+        """Switch every group to the capturable convention in place: 'step' counts move to the device (same values)."""
+        for group in self.param_groups:
+            if group.get("capturable", False):
+                continue
+            for p in group["params"]:
+                st = self.state.get(p)
+                if st and "step" in st and not st["step"].is_cuda:
+                    st["step"] = st["step"].to(device=p.device, dtype=torch.float32)
+            group["capturable"] = True
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
@@ -134,11 +147,65 @@ def elbo(log_outputs, target, kl, beta, train_size):
     return F.nll_loss(log_outputs, target, reduction="mean") * train_size + beta * kl
 
 
-def train_step(net, optimizer, x, target, num_ens, beta, train_size, dp_group=None):
+auto_graph = {"enabled": True, "after": 3}      # train_step captures itself once this many identical calls in a row were seen
+_auto = weakref.WeakKeyDictionary()              # net -> {"key", "streak", "graphed"}
+
+
+def _python_hooks(net, optimizer):
+    """Anything a graph replay would silently skip: module / tensor / optimizer hooks."""
+    import torch.nn.modules.module as _m
+    if (_m._global_forward_hooks or _m._global_forward_pre_hooks or _m._global_backward_hooks or _m._global_backward_pre_hooks
+            or optimizer._optimizer_step_pre_hooks or optimizer._optimizer_step_post_hooks):
+        return True
+    for m in net.modules():
+        if m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks:
+            return True
+    return any(getattr(p, "_backward_hooks", None) for p in net.parameters())
+
+
+def _auto_key(net, optimizer, x, target, num_ens, train_size):
+    """What a captured step bakes in; None = this call cannot be a graph replay (-> eager)."""
+    if not (auto_graph["enabled"] and isinstance(optimizer, FusedAdam) and torch.is_tensor(x) and x.is_cuda and target.is_cuda
+            and torch.is_grad_enabled() and not x.requires_grad and not torch.cuda.is_current_stream_capturing()):
+        return None
+    groups = tuple((tuple(g["betas"]), float(g["eps"]), tuple((id(p), p.requires_grad) for p in g["params"]))
+                   for g in optimizer.param_groups)
+    from . import rng
+    return (id(optimizer), tuple(x.shape), x.dtype, tuple(target.shape), target.dtype, int(num_ens), float(train_size), net.training,
+            ensemble._epoch[0], groups, rng.next_calls(0)[0])               # the noise seed is a constant of the captured kernels
+
+
+def train_step(net, optimizer, x, target, num_ens, beta, train_size, dp_group=None, graph=None):
     """One iteration of train_model's batch loop (main_bayesian.py:40-58): zero_grad, num_ens stochastic forwards
     (batched over draws), kl / num_ens, logmeanexp, ELBO, backward, [gradient all-reduce], optimizer.step.
     dp_group: data-parallel process group whose ranks hold different shards of the batch (parameters replicated).
-    Returns (loss, log_outputs, kl) detached."""
+    Returns (loss, log_outputs, kl) detached.
+
+    A fixed-shape loop is host-bound when run launch by launch (~40 launches + autograd bookkeeping per iteration), so by default
+    (graph=None) the step captures ITSELF: once the same (optimizer, shapes, num_ens, train_size, parameter set) was seen
+    auto_graph["after"] times in a row, single-process, with a FusedAdam and no Python hooks on the model, the call runs one more
+    eager iteration on a capture stream, records it as a GraphedTrainStep and replays that from then on (beta and the learning
+    rate stay run-time values; a non-capturable FusedAdam is switched to capturable in place).  Any change of the key drops the
+    graph and returns to launch-by-launch steps.  graph=False: never capture.  Same noise calls, same results as the eager
+    sequence (tests/test_gpu_train.py)."""
+    key = _auto_key(net, optimizer, x, target, num_ens, train_size) if (graph is not False and dp_group is None) else None
+    st = _auto.get(net)
+    if key is None or st is None or st["key"] != key:
+        st = {"key": key, "streak": 0, "graphed": None}
+        if key is not None:
+            _auto[net] = st
+        else:
+            _auto.pop(net, None)
+    if key is not None:
+        if st["graphed"] is not None:
+            loss, log_outputs, kl = st["graphed"].step(x, target, beta)
+            return loss.clone(), log_outputs.clone(), kl.clone()          # the graph's outputs are overwritten by the next replay
+        st["streak"] += 1
+        if st["streak"] > int(auto_graph["after"]) and not _python_hooks(net, optimizer):
+            optimizer.make_capturable()
+            g = GraphedTrainStep(net, optimizer, x, target, num_ens, beta, train_size, warmup=1)   # the warm-up IS this iteration
+            st["graphed"] = g
+            return g.warm_loss.clone(), g.warm_log_outputs.clone(), g.warm_kl.clone()
     optimizer.zero_grad()
     log_outputs, kl = ensemble.mc_forward(net, x, num_ens, kl_mode="mean")
     loss = elbo(log_outputs, target, kl, beta, train_size)
@@ -176,8 +243,9 @@ class GraphedTrainStep:
         with torch.cuda.stream(self.stream), rng.device_call_offset(self.counter):
             for _ in range(max(1, int(warmup))):
                 self.opt.zero_grad(set_to_none=True)
-                self._body()
+                self.warm_loss, self.warm_log_outputs, self.warm_kl = self._body()      # results of the last eager iteration
                 rng.next_calls(self.num_ens)
+        self._next_call = rng.next_calls(0)[1]
         torch.cuda.current_stream(dev).wait_stream(self.stream)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
@@ -204,7 +272,12 @@ class GraphedTrainStep:
             self.beta.fill_(float(beta))
         if hasattr(self.opt, "sync_lr"):
             self.opt.sync_lr()
+        seed, call = rng.next_calls(0)
+        if call != self._next_call:                  # someone else drew noise in between (a validation pass): follow the host counter
+            d = (call - self.call0) & 0xFFFFFFFF
+            self.counter.fill_(d - (1 << 32) if d >= (1 << 31) else d)     # the kernels add it modulo 2^32
         self.graph.replay()
         self.replays += 1
         rng.next_calls(self.num_ens)                 # keep the host-side noise counter in step with the device's
+        self._next_call = call + self.num_ens
         return self.loss, self.log_outputs, self.kl

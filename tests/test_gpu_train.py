@@ -170,3 +170,56 @@ def test_graphed_train_step_equals_eager_steps(env, layer_type):
     # a new batch through the static buffers
     loss2, _, _ = g.step(torch.rand_like(x), y)
     assert np.isfinite(loss2.item())
+
+
+@pytest.mark.parametrize("layer_type", ["bbb", "lrt"])
+def test_train_step_captures_itself_and_keeps_the_eager_sequence(env, layer_type):
+    """train_step's default: after auto_graph["after"] identical calls the step runs as one hipGraph.  Same losses and parameters
+    as graph=False; a validation pass in between (it draws noise: the host call counter moves) is followed; a new batch shape
+    drops the graph."""
+    T = env["train"]
+    B, E, lr, beta, n = 32, 2, 1e-3, 0.1, 1000.0
+    torch.manual_seed(3)
+    x = torch.rand(B, 1, 32, 32, device="cuda")
+    y = torch.randint(0, 10, (B,), device="cuda")
+    xv = torch.rand(B, 1, 32, 32, device="cuda")
+
+    def run(graph):
+        torch.manual_seed(11)
+        net = env["zoo"].BBBLeNet(10, 1, P.CONFIG_PRIORS, layer_type, "softplus").cuda()
+        env["rng"].assign_stream_ids(net)
+        env["rng"].manual_seed(77, call=0)
+        opt = T.FusedAdam(net.parameters(), lr=lr)
+        losses, captured = [], []
+        for it in range(9):
+            if it == 6:
+                with torch.no_grad():
+                    net(xv)                                            # consumes one noise call outside the training step
+            losses.append(T.train_step(net, opt, x, y, E, beta * (1 + it), n, graph=graph)[0].item())
+            st = T._auto.get(net)
+            captured.append(bool(st and st["graphed"] is not None))
+        return net, opt, losses, captured
+
+    net_e, opt_e, eager, cap_e = run(False)
+    net_g, opt_g, auto, cap_g = run(None)
+    assert not any(cap_e)
+    assert cap_g == [False] * 3 + [True] * 6                              # calls 1-3 eager, call 4 eager on the capture stream + capture
+    np.testing.assert_allclose(auto, eager, rtol=2e-5)
+    for (na, a), (nb, b) in zip(net_e.named_parameters(), net_g.named_parameters()):
+        np.testing.assert_allclose(b.detach().cpu().numpy(), a.detach().cpu().numpy(), rtol=2e-5, atol=1e-7, err_msg=na)
+    assert env["rng"].get_state()[1] == 9 * E + 1
+    assert float(opt_g.state[next(iter(net_g.parameters()))]["step"].item()) == 9.0
+    # returned tensors are the caller's own (not the graph's static outputs)
+    l1 = T.train_step(net_g, opt_g, x, y, E, beta, n)[0]
+    v1 = l1.item()
+    T.train_step(net_g, opt_g, x, y, E, beta, n)
+    assert l1.item() == v1
+    # another batch shape: back to launch-by-launch steps, graph dropped
+    T.train_step(net_g, opt_g, x[:16], y[:16], E, beta, n)
+    assert T._auto[net_g]["graphed"] is None
+    # a forward hook is something a replay would skip: never captured
+    h = net_g.register_forward_hook(lambda *a: None)
+    for _ in range(6):
+        T.train_step(net_g, opt_g, x, y, E, beta, n)
+    assert T._auto[net_g]["graphed"] is None
+    h.remove()
