@@ -372,8 +372,9 @@ def reparam_probe(net, dev, n_params, E):
 
 
 def run_config(cfg, steps, warmup, pipeline, dev, group=None, world=1, want_roofline=True, stat_blocks=0, timer_steps=5,
-               total_ens=None):
-    """Throughput of one configuration: hipGraph lanes, K timed steps between device syncs (max over ranks) -> dict."""
+               total_ens=None, steps_per_launch=1):
+    """Throughput of one configuration: hipGraph lanes, K timed steps between device syncs (max over ranks) -> dict.
+    steps_per_launch > 1 (one-draw configurations): every lane's graph holds that many consecutive steps (GraphedPipeline)."""
     from bbb_hip import ensemble
     net, x = build_net(cfg, dev)
     E = cfg["E"] if total_ens is None else total_ens
@@ -387,19 +388,22 @@ def run_config(cfg, steps, warmup, pipeline, dev, group=None, world=1, want_roof
     out = {}
     with torch.no_grad():
         if pipeline > 1:
-            gstep = ensemble.GraphedPipeline(net, x, E, depth=pipeline, group=group, precision=prec)
+            gstep = ensemble.GraphedPipeline(net, x, E, depth=pipeline, group=group, precision=prec, steps_per_launch=steps_per_launch)
         else:
             gstep = ensemble.GraphedMC(net, x, E, group=group, precision=prec)
         step = gstep.step
-        for _ in range(max(1, pipeline)):            # setup: every lane's graph is replayed once (first replay = its upload)
+        flush = gstep.sync if steps_per_launch > 1 else (lambda: None)      # a partly filled group is launched before the clock stops
+        for _ in range(max(1, pipeline) * steps_per_launch):   # setup: every lane's graph is replayed once (first replay = its upload)
             step()
         torch.cuda.synchronize(dev)
         for _ in range(warmup):
             step()
+        flush()
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
             lo, kl = step()
+        flush()
         barrier()
         elapsed = time.perf_counter() - t0
         lo, kl = lo.clone(), kl.clone()
@@ -441,17 +445,27 @@ def run_config(cfg, steps, warmup, pipeline, dev, group=None, world=1, want_roof
             # park the GPU behind a ~40 ms spin kernel so that every launch below is already queued when its turn comes:
             # the event brackets then hold kernel time only, not host launch latency
             torch.cuda._sleep(int(1.0e8))
+            if steps_per_launch > 1:                     # the launches of the timed region: steps_per_launch batches, one draw each
+                from bbb_hip import rng
+                xg = x.repeat(steps_per_launch, 1, 1, 1)
+
+                def one_pass(t):
+                    seed, call0 = rng.next_calls(steps_per_launch)
+                    ensemble._local_lse(net, xg, steps_per_launch, seed, call0, 1, timers=t, precision=prec, per_draw_x=True)
+            else:
+                def one_pass(t):
+                    ensemble.mc_forward(net, x, E, timers=t, precision=prec)
             for _ in range(timer_steps):
-                ensemble.mc_forward(net, x, E, timers=timers, precision=prec)
+                one_pass(timers)
             torch.cuda.synchronize(dev)
-            eager = gemm_roofline(timers.summary(), timer_steps, prec, cfg is CONFIGS["metric"])
+            eager = gemm_roofline(timers.summary(), timer_steps * steps_per_launch, prec, cfg is CONFIGS["metric"])
             # the same launches in the timed region's launch mode: every GEMM launch of the step replayed 20x back to back
             # inside its own hipGraph (no host, no event packets between kernels), HIP events around the replay
             rec = LaunchRecorder()
-            ensemble.mc_forward(net, x, E, timers=rec, precision=prec)
+            one_pass(rec)
             torch.cuda.synchronize(dev)
             ing = rec.time_in_graphs(dev)
-            roof = gemm_roofline(ing, 1, prec, cfg is CONFIGS["metric"]) if ing else None
+            roof = gemm_roofline(ing, steps_per_launch, prec, cfg is CONFIGS["metric"]) if ing else None
             if roof is not None and eager is not None:
                 roof["timed_by"] = ("per launch: a hipGraph of %d back-to-back replays of that launch (the timed region's launch mode), HIP events "
                                     "around the graph on its stream, median of 5; summed over the step's %d conv/linear launches" % (rec.reps, roof["launches"]))
@@ -727,9 +741,20 @@ def main():
                 try:
                     # single-draw configurations are a dozen 10-20 us launches per step: four steps in flight instead of three
                     # (measured, profiles/r03_notes.md section 4: configs[1] 0.066 -> 0.055 ms, configs[2] 0.182 -> 0.164 ms)
-                    depth = args.pipeline + 1 if (c["E"] == 1 and c["hw"] == 32 and args.pipeline == 3) else args.pipeline
-                    r, n2, x2 = run_config(c, max(10, args.steps // 2), 5, depth, dev, want_roofline=True, timer_steps=3)
+                    small = c["E"] == 1 and c["hw"] == 32 and args.pipeline == 3
+                    depth = args.pipeline + 1 if small else args.pipeline
+                    # ... and FOUR consecutive steps per launch (GraphedPipeline steps_per_launch: four batches, each with its own
+                    # weight draw and noise calls, in one set of launches; same per-step results as one step per launch,
+                    # tests/test_gpu_steps_per_launch.py): configs[1] 0.054 -> 0.036 ms, configs[2] 0.164 -> 0.131 ms
+                    spl = 4 if small else 1
+                    nst = max(10, args.steps // 2)
+                    nst = -(-nst // (spl * depth)) * spl * depth
+                    r, n2, x2 = run_config(c, nst, 5, depth, dev, want_roofline=True, timer_steps=3, steps_per_launch=spl)
                     r["steps_in_flight"] = depth
+                    if spl > 1:
+                        r["steps_per_launch"] = spl
+                        r1, _, _ = run_config(c, nst, 5, depth, dev, want_roofline=False, steps_per_launch=1)
+                        r["one_step_per_launch"] = {"ms_per_step": r1["ms_per_step"], "value": r1["value"]}
                     del n2, x2
                     r["workload"] = c["what"]
                     r["dtype"] = "bf16" if c["precision"] == "bf16" else "f32"

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define BBB_ABI_VERSION 6
+#define BBB_ABI_VERSION 7
 #define BBB_MAX_SEGMENTS 16
 
 #define BBB_EINVAL (-1)   /* bad argument (null pointer, non-positive size, too many segments) */
@@ -332,6 +332,9 @@ int bbb_conv2d_chwn_bf16_fwd(const bbb_conv_desc_t* d, const void* x, const void
 int bbb_maxpool_chwn_bf16(const void* x, void* y, int64_t planes, int h, int w, int batch, int k, int s, void* stream);
 /* fp32 [batch][plane] (an NCHW tensor, plane = C*H*W) -> bf16 [plane][batch] (batch-innermost), nearest-even. */
 int bbb_nchw_to_chwn_bf16(const float* x, void* y, int batch, int64_t plane, void* stream);
+/* The same for `slices` batches stored back to back (ABI 7): x [slices][batch][plane] -> y [slices][plane][batch], one launch
+ * (a rank's batch slices; the batches of several one-draw steps that share a launch). */
+int bbb_nchw_to_chwn_bf16_slices(const float* x, void* y, int batch, int64_t plane, int slices, void* stream);
 
 /*
  * Monte-Carlo tail (main_bayesian.py:49,53 / :78,80 + utils.py:14-22): per draw log_softmax over

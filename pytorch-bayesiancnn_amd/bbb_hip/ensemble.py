@@ -351,12 +351,14 @@ def _check_precision(precision, net, x, fast_path_allowed):
                                "4-d input with B % 8 == 0, BBB layers + ReLU/Softplus/MaxPool2d/FlattenLayer)")
 
 
-def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precision="fp32", units=None, b_offset=0):
+def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precision="fp32", units=None, b_offset=0, per_draw_x=False):
     """Inference path of mc_logits in the batch-innermost layout ([E, C, H, W, B]): pixel-major GEMMs that
     skip padding taps, activation fused into the GEMM epilogue, pooling on contiguous image vectors.
     units = (S, lo, hi): instead of `draws` whole draws starting at call0, run the work units lo..hi-1 of the draw-major
     (draw, batch slice) grid with S slices per draw (call0 = the call index of draw 0); returns logits [hi-lo, C, B/S].
-    b_offset: global index of x's first image (batch-parallel shards): LRT activation noise is keyed by the global image."""
+    b_offset: global index of x's first image (batch-parallel shards): LRT activation noise is keyed by the global image.
+    per_draw_x: x holds `draws` batches back to back ([draws * B, C, H, W]) and draw e runs on batch e -- several one-draw steps
+    in one set of launches (GraphedMC steps > 1); returns logits [draws, C, B]."""
     layers = bayesian_layers(net)
     bbb = [l for l in layers if isinstance(l, _BBBLayer)]
     lrt = [l for l in layers if isinstance(l, _LRTLayer)]
@@ -364,6 +366,12 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
     bf16 = precision == "bf16"
     E, B = draws, x.shape[0]
     ukw = {}
+    if per_draw_x:
+        if units is not None and units[0] > 1:
+            raise _lib.BBBHipError("per-draw inputs and work units do not combine")
+        if B % draws or (B // draws) % (8 if bf16 else 4):
+            raise _lib.BBBHipError("per-draw inputs: every batch must hold a multiple of 4 (bf16: 8) images")
+        B = B // draws
     if units is not None and units[0] > 1:
         S, lo, hi = units
         if B % S or (B // S) % (8 if bf16 else 4):
@@ -384,8 +392,9 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
         variances, k2 = _variances_all(lrt, timers)
         kl = k2 if kl is None else kl + k2
     to_cb = ops.to_batch_innermost_bf16 if bf16 else ops.to_batch_innermost
-    if S > 1:                                                   # [S, C, H, W, B/S]: one batch-innermost block per slice
-        xt = torch.stack([to_cb(x[s * B:(s + 1) * B]) for s in range(S)]) if bf16 else ops.to_batch_innermost_slices(x, S)
+    if S > 1 or (per_draw_x and draws > 1):                     # [S, C, H, W, B/S]: one batch-innermost block per slice / per draw
+        nblk = S if S > 1 else draws
+        xt = ops.to_batch_innermost_bf16_slices(x, nblk) if bf16 else ops.to_batch_innermost_slices(x, nblk)
     else:
         xt = to_cb(x).unsqueeze(0)                              # [1, C, H, W, B], shared by all draws
     children = flat_children(net)
@@ -399,7 +408,7 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
         nonlocal logits_buf
         B = xt.shape[-1]
         Es = e1 - e0
-        h = xt
+        h = xt[e0:e1] if (per_draw_x and draws > 1) else xt
         boff = int(b_offset)           # global index of the first local "image" (rows multiply at a flatten that cuts images up)
         per_slice = bool(ukw)          # work units: until the first Bayesian layer, h is one block per batch slice
         i = 0
@@ -545,7 +554,7 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
 
     nsplit = max(1, min(int(streams), E))
     out = None
-    if use_chain and timers is None and not bf16 and not lrt and bbb and xt.shape[-1] % 128 == 0:
+    if use_chain and timers is None and not bf16 and not lrt and bbb and xt.shape[-1] % 128 == 0 and not per_draw_x:
         out = run_chain()
         if out is not None:
             stats["launch"] = "chain"
@@ -597,8 +606,14 @@ def _lane_streams(device, n):
     hardware queues)."""
     key = torch.device(device).index
     pool = _lane_pool.setdefault(key, [])
-    while len(pool) < max(n, 4):                         # created back to back: consecutive streams land on distinct queues
-        pool.append(torch.cuda.Stream(device=device))
+    while len(pool) < max(n, 4):                         # created AND first used back to back
+        st = torch.cuda.Stream(device=device)
+        # a HIP stream gets its hardware queue at its first launch, and queues are spread over the 4 compute pipes in creation
+        # order: four lanes that first ran back to back sit on four pipes; a lane first used after other streams had their first
+        # launch can share a pipe with another lane (measured: the same 4-lane pipeline 0.057 or 0.100 ms per step)
+        with torch.cuda.stream(st):
+            torch.zeros(1, device=device)
+        pool.append(st)
     return pool[:n]
 
 
@@ -715,7 +730,7 @@ def mc_logits(net, x, draws, seed, call0, fuse_act=True, timers=None, eps=None, 
 
 
 def _local_lse(net, x, draws, seed, call0, mean_over, fuse_act=True, timers=None, streams=1, precision="fp32", units=None, b_offset=0,
-               step_end=None):
+               step_end=None, per_draw_x=False):
     """(log-sum-exp over the local draws of the per-draw log_softmax [B, C], kl of one forward), staying in the
     batch-innermost layout end to end when the fast path applies.  units = (S, lo, hi): the local work is the unit range
     lo..hi-1 instead of `draws` whole draws (call0 = call index of draw 0); rows of slices without a local unit are -inf.
@@ -723,6 +738,18 @@ def _local_lse(net, x, draws, seed, call0, mean_over, fuse_act=True, timers=None
     device-side call counter; then the second return value is the SCALED kl, and step_end[3] is set to True -- on the paths without
     the fused tail the caller does both itself."""
     _check_precision(precision, net, x, fuse_act)
+    if per_draw_x:
+        # `draws` one-draw steps on `draws` batches in one set of launches: -> [draws * B, C], block g = log_softmax of step g
+        # (its log-mean-exp over one draw), through the work-unit tail with one "slice" per step
+        out = _mc_logits_chwn(net, x, draws, seed, call0, timers, 1, precision, per_draw_x=True)
+        if out is None:
+            raise _lib.BBBHipError("several steps per launch need the batch-innermost path")
+        if step_end is not None and timers is None:
+            lse, klf = ops.mc_tail_units(out[0], draws, 0, mean_over=1, step_end=(out[1], step_end[0], step_end[1], step_end[2]))
+            step_end[3] = True
+            return lse, klf
+        lse = _run(timers, "mc_tail", 0, lambda: ops.mc_tail_units(out[0], draws, 0, mean_over=1))
+        return lse, out[1]
     if units is not None and units[0] > 1:
         out = _mc_logits_chwn(net, x, draws, seed, call0, timers, 1, precision, units=units)
         if out is None:
@@ -876,11 +903,26 @@ class GraphedMC:
     preallocated send buffer; step() then issues the ONE all_gather of the step eagerly on the lane's stream (collectives stay
     outside the graphs) and replays a second small graph that reduces the gathered blocks over ranks -- three host calls per
     step (replay, all_gather, replay), which matters when 8 ranks leave each GPU only ~0.1 ms of work per step.
-    step() returns (log_outputs [B, C], kl): buffers overwritten by the lane's next replay."""
+    step() returns (log_outputs [B, C], kl): buffers overwritten by the lane's next replay.
+    steps > 1 (num_ens == 1, single process, batch-innermost path): the graph holds `steps` consecutive one-draw steps -- `steps`
+    batches, each with its own weight draw and its own noise calls, exactly what `steps` separate replays would compute -- as ONE
+    set of launches (a one-draw step of a small model is a chain of ~10 launch-latency-bound kernels; `steps` of them per launch
+    fill the same chain with `steps` times the work).  step(x) then only stores the batch in the next slot and replays when the
+    last slot is filled (flush() replays a partly filled group); the (log_outputs, kl) it returns are that slot's views of the
+    graph's output, valid once the group has been replayed and the lane's stream synchronised."""
 
     def __init__(self, net, x, num_ens, streams=1, kl_mode="sum", lane=0, lanes=1, stream=None, seed_call=None, group=None,
-                 precision="fp32"):
+                 precision="fp32", steps=1):
         _lib.require_device(x)
+        self.steps, self.slot = int(steps), 0
+        if self.steps > 1:
+            if int(num_ens) != 1 or group is not None:
+                raise _lib.BBBHipError("steps > 1 batches ONE-draw steps of a single process (num_ens == 1, no group)")
+            with torch.no_grad():
+                if not units_ok(net, x):
+                    raise _lib.BBBHipError("steps > 1 needs the batch-innermost path (model / input shape not covered)")
+            self.B = x.shape[0]
+            x = x.repeat(self.steps, 1, 1, 1)                  # the group's input buffer: slot g = rows [g*B, (g+1)*B)
         # a lane of a pipeline gets its OWN input buffer: several steps are in flight, so the next batch must not be
         # written into memory an earlier step is still reading
         self.net, self.x, self.num_ens, self.group, self.kl_mode = net, (x.clone() if int(lanes) > 1 else x), int(num_ens), group, kl_mode
@@ -893,14 +935,14 @@ class GraphedMC:
         import os as _os
         self._force_combine = group is not None and _os.environ.get("BBB_FORCE_COMBINE") == "1"   # test hook: N > 1 code path at world 1
         dev = x.device
-        self.stride = int(lanes) * self.num_ens
-        self.start = int(lane) * self.num_ens
+        self.stride = int(lanes) * self.num_ens * self.steps
+        self.start = int(lane) * self.num_ens * self.steps
         self.counter = torch.full((1,), self.start, dtype=torch.int32, device=dev)
         self.seed, self.call0 = seed_call if seed_call is not None else rng.next_calls(0)
         self.own_stream = stream is not None
         self.stream = stream if stream is not None else torch.cuda.Stream(device=dev)
         self.lse = self.kl_local = None
-        self.shape = (output_rows(net, tuple(x.shape)), getattr(net, "num_classes", None))
+        self.shape = (output_rows(net, tuple(x.shape)) // self.steps, getattr(net, "num_classes", None))
         self.multi = self.world > 1 or self._force_combine
         if self.multi:
             if self.shape[1] is None:
@@ -955,7 +997,10 @@ class GraphedMC:
             scale = float(n_loc) / self.S
         # the tail launch of the fast path also scales the KL and advances the noise counter (two element-wise launches less)
         end = [scale, self.counter, self.stride, False]
-        if self.S > 1:
+        if self.steps > 1:
+            lse, kl = _local_lse(self.net, self.x, self.steps, self.seed, self.call0, 1, precision=self.precision, step_end=end,
+                                 per_draw_x=True)
+        elif self.S > 1:
             lse, kl = _local_lse(self.net, self.x, self.num_ens, self.seed, self.call0, 0, precision=self.precision,
                                  units=(self.S, self.lo, self.hi), step_end=end)
         else:
@@ -969,11 +1014,34 @@ class GraphedMC:
             self.send[-1:].copy_(kl.reshape(1))
         return lse, kl
 
+    def flush(self):
+        """steps > 1: replay a partly filled group now (its empty slots recompute the batches they still hold)."""
+        if self.steps > 1 and self.slot > 0:
+            ctx = torch.cuda.stream(self.stream) if self.own_stream else _null_ctx()
+            with ctx:
+                self.graph.replay()
+            self.replays += 1
+            rng.next_calls(self.steps - self.slot)   # the graph consumed the calls of the empty slots too
+            self.slot = 0
+
     def step(self, x=None):
         """Replay the step; `x` (optional) is copied into this lane's input buffer first, on the lane's stream."""
         producer = torch.cuda.current_stream(self.x.device) if (x is not None and self.own_stream) else None
         ctx = torch.cuda.stream(self.stream) if self.own_stream else _null_ctx()
         with ctx:
+            if self.steps > 1:
+                g, B = self.slot, self.B
+                if x is not None:
+                    if producer is not None:
+                        self.stream.wait_stream(producer)
+                    self.x[g * B:(g + 1) * B].copy_(x, non_blocking=True)
+                self.slot += 1
+                rng.next_calls(1)
+                if self.slot == self.steps:
+                    self.graph.replay()
+                    self.replays += 1
+                    self.slot = 0
+                return self.lse[g * B:(g + 1) * B], self.kl_local
             if x is not None:
                 if producer is not None:
                     self.stream.wait_stream(producer)              # whoever produced x on the caller's stream
@@ -1004,16 +1072,20 @@ class GraphedPipeline:
     step's kernels fill its ramp, its tail and the CUs its imbalance leaves idle.  Every step still does all of its
     work with its own noise (lane l, replay r = noise calls of step r*depth + l).
     step() returns the (log_outputs, kl) buffers of the lane just enqueued; call sync() (or synchronize the device)
-    before reading them."""
+    before reading them.
+    steps_per_launch = G > 1 (num_ens == 1): every lane's graph holds G consecutive steps (GraphedMC steps=G): step i goes to
+    slot i % G of lane (i // G) % depth and the lane replays when its G slots are filled -- same noise calls per step as G = 1;
+    sync() replays partly filled groups first."""
 
-    def __init__(self, net, x, num_ens, depth=2, streams=1, kl_mode="sum", group=None, precision="fp32"):
+    def __init__(self, net, x, num_ens, depth=2, streams=1, kl_mode="sum", group=None, precision="fp32", steps_per_launch=1):
         seed_call = rng.next_calls(0)
         # lane streams come from a per-device pool and are REUSED by later pipelines: HIP maps streams onto a handful of hardware
         # queues round-robin, and a process that keeps creating streams (one pipeline per configuration, as bench.py does) ends up
         # with lanes that share a queue and stop overlapping (measured: the same 3-lane pipeline 15-18 % slower when built late)
         pool = _lane_streams(x.device, depth)
+        self.G = int(steps_per_launch)
         self.lanes = [GraphedMC(net, x, num_ens, streams=streams, kl_mode=kl_mode, lane=l, lanes=depth,
-                                stream=pool[l], seed_call=seed_call, group=group, precision=precision)
+                                stream=pool[l], seed_call=seed_call, group=group, precision=precision, steps=self.G)
                       for l in range(depth)]
         self.i = 0
         self.dev = x.device
@@ -1021,10 +1093,15 @@ class GraphedPipeline:
     def step(self, x=None):
         """Enqueue the next step on the next lane.  Pass the batch as `x` (copied into that lane's own buffer); without it
         the lane re-uses the batch it already holds."""
-        lane = self.lanes[self.i % len(self.lanes)]
+        lane = self.lanes[(self.i // self.G) % len(self.lanes)]
         self.i += 1
         return lane.step(x)
 
     def sync(self):
+        if self.G > 1:
+            # a partly filled group: only the lane currently being filled can have one; later steps start a fresh group
+            for lane in self.lanes:
+                lane.flush()
+            self.i = -(-self.i // self.G) * self.G
         for lane in self.lanes:
             lane.stream.synchronize()

@@ -502,6 +502,19 @@ def to_batch_innermost_bf16(x):
     return y
 
 
+def to_batch_innermost_bf16_slices(x, slices):
+    """fp32 [S*Bs, C, H, W] -> bf16 [S, C, H, W, Bs] in one launch."""
+    require_device(x)
+    x = x.contiguous()
+    Bs = x.shape[0] // slices
+    plane = x.numel() // x.shape[0]
+    y = torch.empty((slices,) + tuple(x.shape[1:]) + (Bs,), dtype=torch.bfloat16, device=x.device)
+    with on_device(x.device):
+        check(_lib.lib().bbb_nchw_to_chwn_bf16_slices(x.data_ptr(), y.data_ptr(), Bs, plane, int(slices), cur_stream(x.device)),
+              "bbb_nchw_to_chwn_bf16_slices")
+    return y
+
+
 def conv2d_chwn_bf16_forward(x, w, bias, cin_khkw, stride=1, padding=0, dilation=1, act=None, out_f32=False, out=None,
                              tap_major=False, units=None, n_units=None, x_per_slice=False):
     """bf16 batch-innermost conv.  x: [E|1, Cin, H, W, B] bf16 (B % 8 == 0); w: [E|1, Cout, Kp] bf16 as written by

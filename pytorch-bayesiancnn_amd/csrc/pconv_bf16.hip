@@ -436,6 +436,8 @@ __global__ __launch_bounds__(256) void maxpool_chwn_bf16_kernel(const u32x4* __r
 // fp32 NCHW [B][C][H][W] -> bf16 [C][H][W][B]: 32x32 tile transpose through LDS (planes = C*H*W)
 __global__ __launch_bounds__(256) void nchw_to_chwn_bf16_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, int B, int P) {
     __shared__ float tile[32][33];
+    x += (int64_t)blockIdx.z * B * P;                 // batch slice blockIdx.z: its own [B][P] -> [P][B] block
+    y += (int64_t)blockIdx.z * B * P;
     const int p0 = blockIdx.x * 32, bb0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int r = ty; r < 32; r += 8) {
@@ -537,9 +539,13 @@ extern "C" int bbb_maxpool_chwn_bf16(const void* x, void* y, int64_t planes, int
 }
 
 extern "C" int bbb_nchw_to_chwn_bf16(const float* x, void* y, int batch, int64_t plane, void* stream) {
-    if (x == nullptr || y == nullptr || batch <= 0 || plane <= 0 || plane > 0x7fffffffLL) return BBB_EINVAL;
+    return bbb_nchw_to_chwn_bf16_slices(x, y, batch, plane, 1, stream);
+}
+
+extern "C" int bbb_nchw_to_chwn_bf16_slices(const float* x, void* y, int batch, int64_t plane, int slices, void* stream) {
+    if (x == nullptr || y == nullptr || batch <= 0 || plane <= 0 || plane > 0x7fffffffLL || slices <= 0 || slices > 65535) return BBB_EINVAL;
     if (((uintptr_t)x & 3u) != 0 || ((uintptr_t)y & 1u) != 0) return BBB_EALIGN;
-    const dim3 grid((unsigned)((plane + 31) / 32), (unsigned)((batch + 31) / 32));
+    const dim3 grid((unsigned)((plane + 31) / 32), (unsigned)((batch + 31) / 32), (unsigned)slices);
     if (grid.y > 65535u) return BBB_ESHAPE;
     hipLaunchKernelGGL(nchw_to_chwn_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, reinterpret_cast<uint16_t*>(y), batch,
                        (int)plane);

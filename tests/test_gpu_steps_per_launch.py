@@ -1,0 +1,87 @@
+"""Several one-draw Monte-Carlo steps per launch (GraphedPipeline steps_per_launch, GraphedMC steps): every step must be what
+the one-step-per-replay pipeline computes for the same batch and the same noise calls -- bit for bit on the fp32 BBB / LRT kernels
+(split contraction off: it is planned per launch size), to bf16 storage rounding on the bf16 path.  Run with -m gpu."""
+import pytest
+import torch
+
+import ref_port_torch as P
+
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("unsplit")]
+
+
+@pytest.fixture(scope="module")
+def env():
+    import layers  # noqa: F401
+    from bbb_hip import ensemble, rng, zoo
+    return dict(ens=ensemble, rng=rng, zoo=zoo)
+
+
+def _net(env, kind, layer_type, classes=10):
+    torch.manual_seed(4)
+    net = env["zoo"].getModel(kind, 3, classes, P.CONFIG_PRIORS, layer_type, "softplus").cuda()
+    env["rng"].assign_stream_ids(net)
+    return net
+
+
+def _run(env, net, batches, G, depth, precision):
+    env["rng"].manual_seed(21, call=0)
+    with torch.no_grad():
+        pipe = env["ens"].GraphedPipeline(net, batches[0], 1, depth=depth, precision=precision, steps_per_launch=G)
+        outs, views = [], []
+        for i, xb in enumerate(batches):
+            views.append(pipe.step(xb))
+            if G == 1 or (i + 1) % (depth * G) == 0 or i + 1 == len(batches):
+                pipe.sync()                                              # (flushes a partly filled group)
+                outs += [(lo.clone(), kl.clone()) for lo, kl in views]
+                views = []
+    return outs, env["rng"].get_state()[1]
+
+
+@pytest.mark.parametrize("kind,layer_type,precision,B", [("alexnet", "bbb", "fp32", 128), ("alexnet", "lrt", "fp32", 64),
+                                                         ("3conv3fc", "bbb", "fp32", 32), ("3conv3fc", "bbb", "bf16", 64)])
+def test_grouped_steps_equal_single_steps(env, kind, layer_type, precision, B):
+    net = _net(env, kind, layer_type)
+    torch.manual_seed(9)
+    batches = [torch.rand(B, 3, 32, 32, device="cuda") for _ in range(11)]
+    ref, calls1 = _run(env, net, batches, 1, 3, precision)
+    got, calls4 = _run(env, net, batches, 4, 3, precision)
+    assert calls1 == 11 and calls4 == 12                                 # the flushed group consumed its empty slot's call too
+    for i, ((lo_r, kl_r), (lo_g, kl_g)) in enumerate(zip(ref, got)):
+        assert lo_g.shape == lo_r.shape == (B, 10)
+        assert torch.equal(kl_g, kl_r)
+        if precision == "fp32":
+            assert torch.equal(lo_g, lo_r), f"step {i}: max diff {float((lo_g - lo_r).abs().max()):.3e}"
+        else:       # bf16: the in-workgroup k-group choice depends on the launch size -> fp32 summation order -> bf16 rounding flips
+            assert float((lo_g - lo_r).abs().max()) <= 2e-2 * float(lo_r.abs().max())
+    # two different batches in one group really got different weights AND different inputs
+    assert not torch.equal(got[0][0], got[1][0])
+
+
+def test_grouped_steps_keep_going_after_a_flush(env):
+    """sync() in the middle of a group, then more steps: still the single-step sequence (call indices realigned to group starts)."""
+    net = _net(env, "alexnet", "bbb")
+    torch.manual_seed(10)
+    batches = [torch.rand(64, 3, 32, 32, device="cuda") for _ in range(10)]
+    env["rng"].manual_seed(33, call=0)
+    with torch.no_grad():
+        pipe = env["ens"].GraphedPipeline(net, batches[0], 1, depth=2, steps_per_launch=4)
+        first = [pipe.step(b) for b in batches[:2]]
+        pipe.sync()
+        first = [lo.clone() for lo, _ in first]
+        rest = [pipe.step(b) for b in batches[2:6]]                      # a full group on the next lane: calls 4..7
+        pipe.sync()
+        rest = [lo.clone() for lo, _ in rest]
+        single = []
+        for call, xb in zip([0, 1, 4, 5, 6, 7], batches[:6]):
+            env["rng"].manual_seed(33, call=call)
+            single.append(env["ens"].mc_forward(net, xb, 1)[0])
+    for a, b in zip(first + rest, single):
+        assert torch.equal(a, b)
+
+
+def test_grouped_steps_refuse_what_they_do_not_cover(env):
+    from bbb_hip._lib import BBBHipError
+    net = _net(env, "alexnet", "bbb")
+    x = torch.rand(64, 3, 32, 32, device="cuda")
+    with torch.no_grad(), pytest.raises(BBBHipError):
+        env["ens"].GraphedPipeline(net, x, 2, depth=2, steps_per_launch=4)          # num_ens > 1
