@@ -12,10 +12,13 @@ dev = torch.device("cuda:0")
 torch.cuda.set_device(0)
 
 
-def per_launch(net, x, E):
+def per_launch(net, x, E, per_draw=False):
     rec = bench.LaunchRecorder()
     with torch.no_grad():
-        ensemble._mc_logits_chwn(net, x, E, 7, 3, timers=rec, precision="bf16")
+        if per_draw:          # E one-draw steps on E batches in one set of launches (GraphedPipeline steps_per_launch)
+            ensemble._mc_logits_chwn(net, x.repeat(E, 1, 1, 1), E, 7, 3, timers=rec, precision="bf16", per_draw_x=True)
+        else:
+            ensemble._mc_logits_chwn(net, x, E, 7, 3, timers=rec, precision="bf16")
     torch.cuda.synchronize()
     out = []
     st = torch.cuda.Stream()
@@ -58,6 +61,12 @@ def time_steps(net, x, E, lanes, n=400):
     return round(best * 1e3, 4)
 
 
+cfg = dict(bench.CONFIGS["configs[1]"])
+net, x = bench.build_net(cfg, dev)
+for G in (1, 2, 4, 8):
+    print(json.dumps({"config": "configs[1]", "steps_per_launch": G, "us_per_launch": per_launch(net, x, G, per_draw=True)}), flush=True)
+if len(sys.argv) > 1 and sys.argv[1] == "short":
+    sys.exit(0)
 for name in ("configs[1]", "metric"):
     cfg = dict(bench.CONFIGS[name])
     net, x = bench.build_net(cfg, dev)

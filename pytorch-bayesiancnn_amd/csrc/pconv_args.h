@@ -24,4 +24,5 @@ struct PConvArgs {
     int32_t ksplit;      // split contraction (pconv_body.cuh, SPLIT): k ranges per item, 0 / 1 = none
     int32_t* tickets;    // [items] arrival counters, zero between launches
     float* part;         // [items][ksplit][sets][64][BM] partial accumulator tiles
+    int32_t px_run;      // pconv_bf16_smallk_kernel: consecutive output pixels per workgroup
 };

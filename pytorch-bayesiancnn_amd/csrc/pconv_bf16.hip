@@ -362,6 +362,199 @@ __global__ __launch_bounds__(64 * WN * WM * KG + (WS ? 256 : 0)) void pconv_bf16
     }
 }
 
+// ---- first layers: rows of at most 128 k (3Conv3FC conv1: K = 75, LeNet conv1: K = 25) ----
+// With so short a contraction the general kernel is all fixed cost: one workgroup per output pixel = offset table, weight
+// tile, two barriers and an epilogue for 2 tiles of MFMAs, ~10 us of dependent latencies per workgroup (measured: conv1 of
+// 3Conv3FC bs 256, four draws: 62 us for 5 GFLOP).  Here a workgroup keeps the weight tile of its 32 / 64 channels in
+// REGISTERS (MFMA A operands, read once from global memory) and walks `px_run` consecutive output pixels for its 256 images:
+// per pixel one image-row tile [K][256] through LDS (the next pixel's rows in flight in registers while this one multiplies
+// and runs its epilogue), KS MFMA steps, and the bf16 epilogue through a wave-private LDS transpose: 62 -> 31 us.  What is
+// left is the epilogue's VALU work: softplus is two quarter-rate transcendentals per output element, ~18 us for those 33.5 M
+// elements on 1024 SIMDs.  (A variant that staged the input strip of the whole run once and addressed it per pixel -- 2.5x
+// fewer image-row fetches, but one workgroup per CU -- measured 45 us: profiles/r03_notes.md section 10.)
+// Same MFMA sequence per output element as the general kernel with one k-group (extra all-zero steps add +0): bit-identical.
+template <int NT, int KS>
+__global__ __launch_bounds__(256) void pconv_bf16_smallk_kernel(const PConvArgs p) {
+    constexpr int BM = 256, BN = 32 * NT, KR = KS * 16, LDXB = BM + 32, TP = 64 + 8;
+    constexpr int XPASS = KR / 8;                                 // 32 lanes x 16 B per row, 8 rows per pass
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+    uint16_t* Xs = smem;                                          // [KR][LDXB]
+    uint16_t* Tall = Xs + KR * LDXB;                              // [4 waves][BN][TP] epilogue staging
+    int32_t* kt = reinterpret_cast<int32_t*>(Tall + 4 * BN * TP); // [px_run][KR] image-row offsets
+
+    const int bid = blockIdx.x, xcd = bid & 7;
+    const int64_t item = (int64_t)xcd * p.per_xcd + (bid >> 3);
+    const int64_t item_end = (int64_t)(xcd + 1) * p.per_xcd;
+    const int HoWo = p.Ho * p.Wo;
+    const int runs = (HoWo + p.px_run - 1) / p.px_run;
+    const int64_t per_g = (int64_t)runs * p.nbt;
+    if (item >= item_end || item >= (int64_t)p.G * per_g) return;
+    const int g = (int)(item / per_g);
+    const int rem = (int)(item - (int64_t)g * per_g);
+    const int run = rem / p.nbt;
+    const int b0 = (rem - run * p.nbt) * BM;
+    const int pix0 = run * p.px_run;
+    const int npx = p.px_run < HoWo - pix0 ? p.px_run : HoWo - pix0;
+    const int e = g / p.Ntiles;
+    const int ue = p.unit_off + e;
+    const int ew = p.unit_div > 1 ? ue / p.unit_div : e;
+    const int ex = p.x_mod > 0 ? ue % p.x_mod : e;
+    const int n0 = (g - e * p.Ntiles) * BN;
+    const int Kp = p.Kp;
+
+    const int tid = (int)threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave * 64;
+    const int lrow = lane & 31, lk = lane >> 5;
+
+    constexpr uint32_t kOOB = 0xFFFFFFF0u;
+    const uint32_t kXInv = p.x_inv;
+    const uint16_t* xb = reinterpret_cast<const uint16_t*>(p.x) + (int64_t)ex * p.x_ds;
+    const uint16_t* wb = reinterpret_cast<const uint16_t*>(p.w) + (int64_t)ew * p.w_ds;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(xb), 0, (int)((int64_t)p.Cin * p.H * p.W * p.B * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(wb), 0, (int)((int64_t)p.Cout * Kp * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.bias ? p.bias + (int64_t)ew * p.b_ds : reinterpret_cast<const float*>(p.w)), 0, p.bias ? p.Cout * 4 : 0, 0x00020000);
+    char* yb = reinterpret_cast<char*>(p.y) + (int64_t)e * p.y_ds * 2;
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(yb, 0, (int)((int64_t)p.Cout * HoWo * p.B * 2), 0x00020000);
+
+    // image-row offsets of every (pixel of the run, k): reference (ci, r, q) order, padding taps and k >= K invalid
+    {
+        const float inv_khkw = 1.0f / (float)p.khkw, inv_kw = 1.0f / (float)p.kw, inv_kr = 1.0f / (float)KR, inv_wo = 1.0f / (float)p.Wo;
+        for (int i = tid; i < npx * KR; i += 256) {
+            int pi = (int)((float)i * inv_kr);
+            int k = i - pi * KR;
+            if (k < 0) { --pi; k += KR; } else if (k >= KR) { ++pi; k -= KR; }
+            const int pix = pix0 + pi;
+            int oh = (int)((float)pix * inv_wo);
+            int ow = pix - oh * p.Wo;
+            if (ow < 0) { --oh; ow += p.Wo; } else if (ow >= p.Wo) { ++oh; ow -= p.Wo; }
+            uint32_t xo = kXInv;
+            if (k < p.K) {
+                int ci = (int)((float)k * inv_khkw);
+                int rq = k - ci * p.khkw;
+                if (rq < 0) { --ci; rq += p.khkw; } else if (rq >= p.khkw) { ++ci; rq -= p.khkw; }
+                int r = (int)((float)rq * inv_kw);
+                int q = rq - r * p.kw;
+                if (q < 0) { --r; q += p.kw; } else if (q >= p.kw) { ++r; q -= p.kw; }
+                const int ih = oh * p.sh - p.ph + r * p.dh, iw = ow * p.sw - p.pw + q * p.dw;
+                if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) xo = (uint32_t)((ci * p.H + ih) * p.W + iw) * (uint32_t)p.B * 2u;
+            }
+            kt[i] = (int32_t)xo;
+        }
+    }
+    // weights: MFMA A operands straight from global memory (row n, 8 consecutive k per lane), kept for the whole run
+    bf16x8 a[NT][KS];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            const int n = n0 + nt * 32 + lrow, k = kk * 16 + lk * 8;
+            const uint32_t off = (n < p.Cout && k < Kp) ? (uint32_t)(n * Kp + k) * 2u : kOOB;
+            a[nt][kk] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, off, 0, 0));
+        }
+    f32x4 bq[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4)
+            bq[nt][r4] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, (uint32_t)(n0 + nt * 32 + 8 * r4 + 4 * lk) * 4u, 0, 0));
+
+    const int xkr = tid >> 5, xb8 = (tid & 31) * 8;
+    const uint32_t xcol = (uint32_t)(b0 + xb8) * 2u;
+    u32x4 xreg[XPASS];
+    auto load_x = [&](int pi) {
+#pragma unroll
+        for (int ps = 0; ps < XPASS; ++ps)
+            xreg[ps] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (uint32_t)kt[pi * KR + xkr + ps * 8] + xcol, 0, 0));
+    };
+    auto store_x = [&]() {
+#pragma unroll
+        for (int ps = 0; ps < XPASS; ++ps) *reinterpret_cast<u32x4*>(&Xs[(xkr + ps * 8) * LDXB + xb8]) = xreg[ps];
+    };
+    const int tg = lane >> 4, tt = lane & 15;
+    const int tr_off = ((8 * (tg >> 1) + (tt >> 2)) * LDXB + wm + 16 * (tg & 1) + 4 * (tt & 3));
+    typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+    uint16_t* T = Tall + wave * (BN * TP);
+
+    __syncthreads();                                               // offset table visible
+    load_x(0);
+    store_x();
+    __syncthreads();
+    for (int pi = 0; pi < npx; ++pi) {
+        const bool more = pi + 1 < npx;
+        if (more) load_x(pi + 1);
+        f32x16 acc[NT][2];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[nt][mt][r] = 0.0f;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            bf16x8 b[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const s16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(&Xs[tr_off + mt * 32 + kk * 16 * LDXB]));
+                const s16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(&Xs[tr_off + mt * 32 + (kk * 16 + 4) * LDXB]));
+                b[mt] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[nt][kk], b[mt], acc[nt][mt], 0, 0, 0);
+        }
+        // epilogue of this pixel: bias + activation + rounding in registers, wave-private LDS transpose, 16-byte stores -- BEFORE
+        // the next pixel's rows go to LDS, so that their loads (issued above) have the whole epilogue to arrive
+        const int pix = pix0 + pi;
+        auto stage_block = [&](auto act) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int nl = nt * 32 + 8 * r4 + 4 * lk;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt)
+                            T[(nl + i) * TP + mt * 32 + lrow] = f2bf(act(acc[nt][mt][r4 * 4 + i] + bq[nt][r4][i]));
+                }
+        };
+        if (p.act == 2)      stage_block([](float v) { return bbb::apply_act(v, 2); });
+        else if (p.act == 1) stage_block([](float v) { return fmaxf(v, 0.0f); });
+        else                 stage_block([](float v) { return v; });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int ps = 0; ps < 4 * NT; ++ps) {
+            const int v = ps * 64 + lane;
+            const int row = v >> 3, grp = v & 7;
+            const u32x4 q = *reinterpret_cast<const u32x4*>(&T[row * TP + grp * 8]);
+            const int n = n0 + row, b = b0 + wm + grp * 8;
+            const uint32_t off = ((b < p.B) & (n < p.Cout)) ? (uint32_t)(((int64_t)n * HoWo + pix) * p.B + b) * 2u : kOOB;
+            __builtin_amdgcn_raw_buffer_store_b128(q, yrs, off, 0, 0);
+        }
+        __syncthreads();                                           // every wave has read this pixel's rows
+        if (more) store_x();
+        __syncthreads();                                           // the next pixel's rows are in LDS
+    }
+}
+
+template <int NT, int KS>
+int launch_smallk(const PConvArgs& a, int64_t blocks, hipStream_t st) {
+    constexpr int kSmem = (KS * 16 * (256 + 32) + 4 * 32 * NT * 72) * 2 + 16 * KS * 16 * 4;      // px_run <= 16
+    static_assert(kSmem <= 160 * 1024, "LDS");
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(&pconv_bf16_smallk_kernel<NT, KS>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, kSmem);
+        if (er != hipSuccess) return (int)er;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((pconv_bf16_smallk_kernel<NT, KS>), dim3((unsigned)blocks), dim3(256), kSmem, st, a);
+    return (int)hipGetLastError();
+}
+
 template <bool OUT_F32, int WN, int WM, int KG, bool WS>
 int launch_cfg(const PConvArgs& a, int64_t blocks, hipStream_t st) {
     constexpr int kStageB = (BK * (64 * WM + 32) + 64 * WN * LDWB) * 2;
@@ -493,6 +686,25 @@ extern "C" int bbb_conv2d_chwn_bf16_fwd(const bbb_conv_desc_t* d, const void* x,
         (d->x_unit_mod > 0 && d->x_unit_mod != d->unit_div) || d->w_row_pitch != 0)
         return BBB_EINVAL;
     a.unit_div = d->unit_div; a.unit_off = d->unit_div > 1 ? d->unit_off : 0; a.x_mod = d->x_unit_mod;
+    if (!tap_major && !out_f32 && Kp <= 128 && (int64_t)ho * wo >= 16) {
+        // a first layer with a short contraction: weights in registers, a run of pixels per workgroup (pconv_bf16_smallk_kernel)
+        const int nt = a.Cout <= 32 ? 1 : 2;
+        const int ks = Kp <= 32 ? 2 : (Kp <= 80 ? 5 : 8);
+        a.Ntiles = (a.Cout + 32 * nt - 1) / (32 * nt);
+        a.G = a.Ntiles * d->draws;
+        a.nbt = (a.B + 255) / 256;
+        const int64_t npix = (int64_t)a.G * a.nbt * ho * wo;      // (pixel, channel tile, image tile) units of the launch
+        int run = (int)(npix / 512);                              // >= 512 workgroups (2 per CU) before runs get longer
+        run = run < 1 ? 1 : (run > 16 ? 16 : run);
+        a.px_run = run;
+        const int64_t items = (int64_t)a.G * a.nbt * (((int64_t)ho * wo + run - 1) / run);
+        const int64_t per = (items + 7) / 8;
+        if (8 * per > 0x7fffffffLL) return BBB_ESHAPE;
+        a.per_xcd = (int32_t)per;
+        hipStream_t st = (hipStream_t)stream;
+        if (nt == 1) return ks == 2 ? launch_smallk<1, 2>(a, 8 * per, st) : ks == 5 ? launch_smallk<1, 5>(a, 8 * per, st) : launch_smallk<1, 8>(a, 8 * per, st);
+        return ks == 2 ? launch_smallk<2, 2>(a, 8 * per, st) : ks == 5 ? launch_smallk<2, 5>(a, 8 * per, st) : launch_smallk<2, 8>(a, 8 * per, st);
+    }
     // tile shape: LDS-pipe cycles per unit of useful work (see the kernel comment), including the waste of ragged
     // channel / image tiles: 128x128 -> 256, 64x256 -> 288, 64x128 (two waves) -> 320
     auto waste = [](int n, int t) { return (double)(((n + t - 1) / t) * t) / (double)n; };

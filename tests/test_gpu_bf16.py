@@ -83,6 +83,28 @@ def test_conv_bf16_vs_oracle(env, B, Cin, H, W, Cout, k, s, p, d, E, xs, out_f32
         assert (err <= tol).all(), f"draw {e}: max excess {(err - tol).max():.3e}"
 
 
+@pytest.mark.parametrize("B,Cin,H,W,Cout,k,s,p,E,xs", [
+    (256, 3, 32, 32, 32, 5, 1, 2, 4, False),      # 3Conv3FC conv1, four one-draw steps in one launch: runs of 8 pixels
+    (264, 3, 32, 32, 32, 5, 1, 2, 1, True),       # ragged second image tile, runs of 4
+    (64, 1, 32, 32, 6, 5, 1, 0, 3, True),         # LeNet conv1: K = 25 (two MFMA steps), 6 channels
+    (40, 6, 9, 7, 70, 3, 2, 1, 2, False),         # K = 54, three channel tiles of 32, stride 2, 63 % 16 != 0 pixels
+    (16, 8, 10, 10, 40, 4, 1, 1, 2, False),       # K = 128: eight steps, two 32-channel register tiles
+])
+def test_short_row_first_layer_kernel_equals_the_general_kernel(env, B, Cin, H, W, Cout, k, s, p, E, xs):
+    """Rows of <= 128 k with bf16 output run on pconv_bf16_smallk_kernel (weights in registers, a run of pixels per workgroup);
+    the fp32-output form of the same launch runs on the general kernel.  Same MFMA sequence per element -> the rounded fp32
+    output must equal the bf16 output bit for bit."""
+    torch.manual_seed(B + Cout)
+    x = _bf(torch.randn(1 if xs else E, Cin, H, W, B, device="cuda"))
+    w = torch.randn(E, Cout, Cin, k, k, device="cuda") * 0.2
+    bias = torch.randn(E, Cout, device="cuda")
+    for act in ("softplus", "relu", None):
+        y32 = env["ops"].conv2d_chwn_bf16_forward(x, _pack_w(w), bias, (Cin, k, k), s, p, 1, act=act, out_f32=True)
+        y16 = env["ops"].conv2d_chwn_bf16_forward(x, _pack_w(w), bias, (Cin, k, k), s, p, 1, act=act, out_f32=False)
+        assert y16.dtype == torch.bfloat16 and y16.shape == y32.shape
+        assert torch.equal(y32.to(torch.bfloat16), y16), float((y32 - y16.float()).abs().max())
+
+
 def test_sampled_weights_bf16_are_the_rounded_fp32_samples(env):
     """Same Philox stream, same fp32 arithmetic, one nearest-even rounding; pad columns untouched (zero); biases fp32."""
     torch.manual_seed(0)
