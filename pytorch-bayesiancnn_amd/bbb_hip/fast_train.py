@@ -77,8 +77,6 @@ def _train_path_static(net, x):
                 (ph, pw), (dh, dw) = ops._pair(m.padding), ops._pair(m.dilation)
                 if dh * (m.kernel_size[0] - 1) < ph or dw * (m.kernel_size[1] - 1) < pw:
                     return None
-                if not first and m.in_channels % 4 != 0:
-                    return None
             elif m.in_features % 4 != 0:
                 return None              # (a first linear layer too: its weight gradient takes the 4-aligned channel path)
             first = False
@@ -190,15 +188,11 @@ class _MCForward(torch.autograd.Function):
                 g_pre = g
             gws[2 * li + 1] = g_pre.sum(dim=(2, 3, 4))                    # bias gradient [E, Cout]
             Cin = x_in.shape[1]
-            if Cin % 4 == 0:
+            if Cin % 4 == 0 or not rec["first"]:                         # (6-channel inputs etc.: padded to 8 inside)
                 gw = ops.conv2d_chwn_weight_grad(g_pre, x_in, tuple(w5.shape), stride, padding, dilation)
-            elif rec["first"]:
+            else:
                 # 3-channel first layer: its input is shared by all draws, so the draws stack into the GEMM's row dimension
                 gw = ops.conv2d_chwn_weight_grad_shared_input(g_pre, ctx.x_nchw, tuple(w5.shape), stride, padding, dilation)
-            else:
-                gy = g_pre.permute(0, 4, 1, 2, 3).contiguous()           # [E, B, Cout, Ho, Wo]
-                xn = x_in.permute(0, 4, 1, 2, 3).contiguous()
-                gw = ops.conv2d_weight_grad(gy, xn, tuple(w5.shape), stride, padding, dilation)
             gws[2 * li] = gw.reshape(ws_shape(rec))
             if not rec["first"]:
                 g = ops.conv2d_chwn_input_grad(g_pre, w5, (x_in.shape[2], x_in.shape[3]), padding, dilation)
@@ -311,7 +305,7 @@ class _MCForwardLRT(torch.autograd.Function):
             grads[4 * li + 2] = g_mu.sum(dim=(0, 2, 3, 4))
             grads[4 * li + 3] = g_var.sum(dim=(0, 2, 3, 4))
             wshape = (1,) + tuple(w_mu.shape)
-            if x_in.shape[1] % 4 == 0:
+            if x_in.shape[1] % 4 == 0 or not rec["first"]:
                 gw_mu = ops.conv2d_chwn_weight_grad(g_mu, x_in, wshape, stride, padding, dilation)
                 gw_var = ops.conv2d_chwn_weight_grad(g_var, x_in * x_in, wshape, stride, padding, dilation)
                 gw_mu = gw_mu[0] if gw_mu.shape[0] == 1 else gw_mu.sum(0)

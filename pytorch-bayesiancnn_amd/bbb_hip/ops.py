@@ -1070,14 +1070,19 @@ def conv2d_chwn_weight_grad(g_pre, x, w_shape, stride, padding, dilation):
     contraction channels, the layer's input channels the innermost ("image") axis, the output pixels the kernel taps:
         gw[e][n][tap][ci] = sum_{b, opix} g_pre'[e][n][b][opix] * x'[e][b][ipix(tap, opix)][ci]
     with x' = x as [E|1, B, H, W, Cin], g_pre' = g_pre as [E, Cout, B, Ho, Wo], stride <-> dilation swapped.  Padding taps
-    are skipped as in the forward.  Needs Cin % 4 == 0 (the innermost axis moves as 16-byte vectors); x may be shared by all
-    draws ([1, ...]).  A launch that would occupy fewer than 512 workgroups (one draw of a small model) splits the batch into
+    are skipped as in the forward.  The innermost axis moves as 16-byte vectors: an input with Cin % 4 != 0 is padded with zero
+    planes first.  x may be shared by all draws ([1, ...]).  A launch that would occupy fewer than 512 workgroups (one draw of a small model) splits the batch into
     S chunks that run as extra draws and are summed in a fixed order.  g_pre [E, Cout, Ho, Wo, B], x [E|1, Cin, H, W, B] ->
     [E, Cout, Cin, kh, kw]."""
     (sh, sw), (ph, pw), (dh, dw) = _pair(stride), _pair(padding), _pair(dilation)
     Ew, Cout, Cin, kh, kw = w_shape
     if Cin % 4 != 0:
-        raise _lib.BBBHipError("conv2d_chwn_weight_grad needs Cin % 4 == 0")
+        # the innermost axis of the role-swapped launch moves as 16-byte vectors: pad the input channels with zero planes
+        # (BayesianLeNet's 6-channel second conv) and drop their -- all-zero -- gradient columns
+        Cp = (Cin + 3) & ~3
+        xp = x.new_zeros((x.shape[0], Cp) + tuple(x.shape[2:]))
+        xp[:, :Cin] = x
+        return conv2d_chwn_weight_grad(g_pre, xp, (Ew, Cout, Cp, kh, kw), stride, padding, dilation)[:, :, :Cin].contiguous()
     E, B = g_pre.shape[0], g_pre.shape[4]
     xr = chwn_to_bhwc(x)                                                # [E|1, B, H, W, Cin]
     gr = chwn_grad_as_weights(g_pre)                                    # [E, Cout, B, Ho, Wo]

@@ -103,10 +103,11 @@ def test_chwn_wgrad_dgrad_vs_torch_float64(env, Cin, Cout, kk, pad, H):
 
 
 @pytest.mark.parametrize("net_type,cin,B,lt", [("alexnet", 3, 16, "bbb"), ("3conv3fc", 3, 8, "bbb"), ("alexnet", 3, 64, "bbb"),
-                                              ("alexnet", 3, 16, "lrt"), ("3conv3fc", 3, 8, "lrt")])
+                                              ("alexnet", 3, 16, "lrt"), ("3conv3fc", 3, 8, "lrt"),
+                                              ("lenet", 1, 8, "bbb"), ("lenet", 1, 16, "lrt")])
 def test_fast_autograd_matches_reference_layout_autograd(env, net_type, cin, B, lt):
     """Same noise, same loss: every parameter gradient of the fast path equals the reference-layout path's.
-    (BayesianLeNet's second conv has 6 input channels: not a multiple of 4, so it stays on the reference-layout path.)"""
+    (BayesianLeNet's second conv has 6 input channels: its weight gradient pads them to 8 zero-filled planes.)"""
     ens = env["ens"]
     torch.manual_seed(1)
     net = env["zoo"].getModel(net_type, cin, 10, P.CONFIG_PRIORS, lt, "softplus").cuda()
@@ -137,12 +138,16 @@ def test_fast_autograd_matches_reference_layout_autograd(env, net_type, cin, B, 
         assert err <= 2e-3, (n, err)
 
 
-def test_lenet_is_not_eligible_and_falls_back(env):
+def test_lenet_is_eligible_and_odd_batches_fall_back(env):
     torch.manual_seed(1)
     net = env["zoo"].getModel("lenet", 1, 10, P.CONFIG_PRIORS, "bbb", "softplus").cuda()
     x = torch.rand(8, 1, 32, 32, device="cuda")
-    assert not env["ft"].train_path_ok(net, x)
+    assert env["ft"].train_path_ok(net, x)
     lo, kl = env["ens"].mc_forward(net, x, 2, kl_mode="mean")
+    assert env["ens"].stats["path"] == "chwn-autograd" and lo.requires_grad
+    x6 = torch.rand(6, 1, 32, 32, device="cuda")                  # B % 4 != 0: the reference-layout path
+    assert not env["ft"].train_path_ok(net, x6)
+    lo, kl = env["ens"].mc_forward(net, x6, 2, kl_mode="mean")
     assert env["ens"].stats["path"] == "nchw" and lo.requires_grad
 
 
