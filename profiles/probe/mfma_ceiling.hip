@@ -33,11 +33,46 @@ __global__ __launch_bounds__(256) void mfma_loop_kernel(float* out, int iters, f
         clk[1] = wall_clock64() - w0;
     }
 }
+// The same loop on v_mfma_f32_32x32x16_f16 (the instruction a split-fp16 contraction would run on: DESIGN.md section 9, item 2).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void mfma_f16_loop_kernel(float* out, int iters, float a0, float b0, unsigned long long* clk) {
+    const unsigned long long c0 = __builtin_readcyclecounter(), w0 = wall_clock64();
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+    f16x8 a, b;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        a[j] = (_Float16)(a0 + threadIdx.x * 1e-3f + j * 0.01f);
+        b[j] = (_Float16)(b0 + threadIdx.x * 2e-3f - j * 0.01f);
+    }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[i], 0, 0, 0);
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[i][r];
+    out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && clk != nullptr) {
+        clk[0] = __builtin_readcyclecounter() - c0;
+        clk[1] = wall_clock64() - w0;
+    }
+}
 }  // namespace
 
 // tflops_out[0] = best of `reps` timed launches (HIP events on `stream`), in TFLOP/s; tflops_out[1] = the shader clock (GHz) the
 // kernel itself measured during that launch (0 if unavailable).  Returns a hipError_t.
-extern "C" int probe_mfma_f32_ceiling(double* tflops_out, int reps, void* stream) {
+static int probe_impl(double* tflops_out, int reps, void* stream, bool f16);
+extern "C" int probe_mfma_f32_ceiling(double* tflops_out, int reps, void* stream) { return probe_impl(tflops_out, reps, stream, false); }
+// the same for v_mfma_f32_32x32x16_f16 (32768 FLOP per instruction and wave)
+extern "C" int probe_mfma_f16_ceiling(double* tflops_out, int reps, void* stream) { return probe_impl(tflops_out, reps, stream, true); }
+
+static int probe_impl(double* tflops_out, int reps, void* stream, bool f16) {
     if (tflops_out == nullptr || reps <= 0) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
     int dev = 0, cus = 0;
@@ -56,13 +91,14 @@ extern "C" int probe_mfma_f32_ceiling(double* tflops_out, int reps, void* stream
     double best = 0.0;
     for (int r = 0; r < reps + 1; ++r) {                           // first launch is a warm-up
         (void)hipEventRecord(e0, st);
-        hipLaunchKernelGGL(mfma_loop_kernel, dim3(blocks), dim3(256), 0, st, out, iters, 1.0f, 0.5f, clk);
+        if (f16) hipLaunchKernelGGL(mfma_f16_loop_kernel, dim3(blocks), dim3(256), 0, st, out, iters, 1.0f, 0.5f, clk);
+        else     hipLaunchKernelGGL(mfma_loop_kernel, dim3(blocks), dim3(256), 0, st, out, iters, 1.0f, 0.5f, clk);
         (void)hipEventRecord(e1, st);
         er = hipEventSynchronize(e1);
         if (er != hipSuccess) break;
         float ms = 0.0f;
         (void)hipEventElapsedTime(&ms, e0, e1);
-        const double tf = (double)blocks * 4.0 * iters * 4.0 * 4096.0 / ((double)ms * 1e9);
+        const double tf = (double)blocks * 4.0 * iters * 4.0 * (f16 ? 32768.0 : 4096.0) / ((double)ms * 1e9);
         if (r > 0 && tf > best) {
             best = tf;
             unsigned long long h[2] = {0, 0};
