@@ -194,6 +194,11 @@ int bbb_lrt_conv2d_fwd(const bbb_conv_desc_t* d, const float* x, const float* w_
  */
 int bbb_conv2d_chwn_fwd(const bbb_conv_desc_t* d, const float* x, const float* w, const float* bias,
                         float* y, void* stream);
+/* The same launch with the contraction on the 16-bit matrix pipe at fp32 accuracy ("split fp16", ABI 7): every fp32 operand
+ * element is cut into hi = fp16(a), lo = fp16(a - hi) while its tile is staged and every product is hi*hi + hi*lo + lo*hi on
+ * v_mfma_f32_32x32x16_f16 with fp32 accumulation -- per-product error ~2^-22 (fp32: 2^-24), operands must stay below 65504 in
+ * magnitude.  Same tensors, layouts and descriptor as bbb_conv2d_chwn_fwd; not bit-identical to it.  Opt-in (ops.gemm_mode). */
+int bbb_conv2d_chwn_f16x2_fwd(const bbb_conv_desc_t* d, const float* x, const float* w, const float* bias, float* y, void* stream);
 int bbb_lrt_conv2d_chwn_fwd(const bbb_conv_desc_t* d, const float* x, const float* w_mu, const float* w_var,
                             const float* b_mu, const float* b_var, float* y,
                             float* act_mu_out, float* act_var_out, const float* eps_ext,

@@ -187,6 +187,9 @@ def lrt_conv2d_forward(x, w_mu, w_var, b_mu, b_var, seed, call0, stream_id, stri
     return y, am, av
 
 
+gemm_mode = "fp32"  # "fp16x2": the batch-innermost BBB GEMM launches (conv2d_chwn_forward) run their contraction on the 16-bit
+                    # matrix pipe at fp32 accuracy (bbb_conv2d_chwn_f16x2_fwd: operands split into two fp16 pieces, three products,
+                    # fp32 accumulation).  Opt-in: results agree with the fp32 kernel to rounding, not bit for bit.
 _split_plans = {}
 split_k = True     # small batch-innermost launches split their contraction over several workgroups per output tile
                    # (bbb_conv2d_chwn_splitk_fwd); False: never (tests that compare differently sized launches bit for bit)
@@ -261,6 +264,10 @@ def conv2d_chwn_forward(x, w, bias, stride=1, padding=0, dilation=1, act=None, o
             raise _lib.BBBHipError("out= must be a contiguous fp32 tensor of the output's size")
         y = out.view(shape)
     with on_device(x.device):
+        if gemm_mode == "fp16x2":
+            check(_lib.lib().bbb_conv2d_chwn_f16x2_fwd(ctypes.byref(d), x.data_ptr(), w.data_ptr(), ptr(bias), y.data_ptr(),
+                                                       cur_stream(x.device)), "bbb_conv2d_chwn_f16x2_fwd")
+            return y
         ks, scr = _split_scratch(d, False, x.device)
         if ks > 1:
             check(_lib.lib().bbb_conv2d_chwn_splitk_fwd(ctypes.byref(d), x.data_ptr(), w.data_ptr(), ptr(bias), y.data_ptr(), ks,

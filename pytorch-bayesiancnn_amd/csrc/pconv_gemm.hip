@@ -20,12 +20,14 @@
 // LRT variant: second accumulator set for sigma^2 * x^2, epilogue act_mu + sqrt(1e-16 + act_var) * eps with eps
 // indexed by the canonical NCHW element index (identical stream to the NCHW kernel and the oracle).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 
 #include "../../include/bbb_hip.h"
 #include "bbb_common.cuh"
 #include "pconv_args.h"
 #include "pconv_body.cuh"
+#include "pconv_f16x2.cuh"
 #ifdef PCONV_STAMPS
 static __device__ unsigned long long* g_census = nullptr;      // [grid][4]: start, end (100 MHz), hw id, xcc id
 extern "C" int bbb_census_set(unsigned long long* dev_buf) {
@@ -339,6 +341,33 @@ extern "C" int bbb_conv2d_chwn_fwd(const bbb_conv_desc_t* d, const float* x, con
     if ((((uintptr_t)x | (uintptr_t)y) & 15u) != 0 || (((uintptr_t)w | (uintptr_t)bias) & 3u) != 0) return BBB_EALIGN;
     a.x = x; a.w = w; a.bias = bias; a.y = y;
     return launch<false>(a, d->draws, (hipStream_t)stream);
+}
+
+// bbb_conv2d_chwn_fwd with the contraction on the 16-bit matrix pipe at fp32 accuracy (pconv_f16x2.cuh)
+extern "C" int bbb_conv2d_chwn_f16x2_fwd(const bbb_conv_desc_t* d, const float* x, const float* w, const float* bias, float* y,
+                                         void* stream) {
+    PConvArgs a = {};
+    const int rc = fill(d, a);
+    if (rc != 0) return rc;
+    if (x == nullptr || w == nullptr || y == nullptr) return BBB_EINVAL;
+    if ((((uintptr_t)x | (uintptr_t)y) & 15u) != 0 || (((uintptr_t)w | (uintptr_t)bias) & 3u) != 0) return BBB_EALIGN;
+    a.x = x; a.w = w; a.bias = bias; a.y = y;
+    a.Ntiles = (a.Cout + BN - 1) / BN;
+    a.G = a.Ntiles * d->draws;
+    const int64_t pixels = (int64_t)a.Ho * a.Wo;
+    // 256 images per workgroup (2 x 2 MFMA tiles per wave) unless that leaves fewer than two workgroups per CU
+    const int mt = pixels * ((a.B + 255) / 256) * a.G >= 512 ? 2 : 1;
+    a.nbt = (a.B + 128 * mt - 1) / (128 * mt);
+    const int64_t mtiles = pixels * a.nbt;
+    if (mtiles > 0x7fffffffLL) return BBB_ESHAPE;
+    a.Mtiles = (int)mtiles;
+    const int64_t per = ((int64_t)a.G * mtiles + 7) / 8;
+    if (8 * per > 0x7fffffffLL) return BBB_ESHAPE;
+    a.per_xcd = (int32_t)per;
+    const dim3 grid((unsigned)(8 * per)), block(kThreads);
+    if (mt == 2) hipLaunchKernelGGL((pconv_f16x2_kernel<2>), grid, block, 0, (hipStream_t)stream, a);
+    else         hipLaunchKernelGGL((pconv_f16x2_kernel<1>), grid, block, 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
 }
 
 extern "C" int bbb_lrt_conv2d_chwn_splitk_fwd(const bbb_conv_desc_t* d, const float* x, const float* w_mu, const float* w_var,

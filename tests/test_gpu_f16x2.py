@@ -1,0 +1,79 @@
+"""Split-fp16 contraction (bbb_conv2d_chwn_f16x2_fwd, ops.gemm_mode = "fp16x2"): fp32 operands cut into two fp16 pieces while
+staged, three products per fp32 product on the 16-bit matrix pipe, fp32 accumulation.  Held to the SAME bound as the fp32 kernel
+against the float64 oracle (tests/test_gpu_splitk.py: 4e-6 of sum_k |w||x|), and measured against it.  Run with -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+import bbb_numpy as O
+import ref_port_torch as P
+
+pytestmark = pytest.mark.gpu
+TOL = 4e-6
+
+
+@pytest.fixture(scope="module")
+def env():
+    import layers  # noqa: F401
+    from bbb_hip import ops, rng, ensemble, zoo
+    return dict(ops=ops, rng=rng, ens=ensemble, zoo=zoo)
+
+
+@pytest.fixture()
+def f16x2(env):
+    env["ops"].gemm_mode = "fp16x2"
+    yield
+    env["ops"].gemm_mode = "fp32"
+
+
+CASES = [
+    # B, Cin, H, W, Cout, k, stride, pad, dil, E, x_shared
+    (512, 3, 32, 32, 64, 11, 4, 5, 1, 2, True),      # AlexNet conv1
+    (256, 64, 4, 4, 192, 5, 1, 2, 1, 2, False),      # AlexNet conv2 shape: most taps of border pixels out of bounds
+    (132, 6, 9, 7, 70, 3, 1, 1, 1, 2, False),        # ragged image tile, ragged channel tile
+    (8, 16, 6, 6, 130, 3, 2, 1, 2, 3, False),        # stride + dilation
+    (40, 520, 1, 1, 10, 1, 1, 0, 1, 2, False),       # linear, K = 520 (three table chunks)
+    (64, 256, 2, 2, 256, 3, 1, 1, 1, 1, True),       # AlexNet conv4 shape, one draw: the 128-image tile
+]
+
+
+@pytest.mark.parametrize("B,Cin,H,W,Cout,k,s,p,d,E,xs", CASES)
+def test_f16x2_launch_vs_oracle_and_fp32_kernel(env, f16x2, B, Cin, H, W, Cout, k, s, p, d, E, xs):
+    ops = env["ops"]
+    torch.manual_seed(B + Cout)
+    x = torch.randn(1 if xs else E, Cin, H, W, B, device="cuda") * 3.0
+    w = torch.randn(E, Cout, Cin, k, k, device="cuda") * 0.2
+    bias = torch.randn(E, Cout, device="cuda")
+    y = ops.conv2d_chwn_forward(x, w, bias, s, p, d, act=None)
+    ops.gemm_mode = "fp32"
+    y32 = ops.conv2d_chwn_forward(x, w, bias, s, p, d, act=None)
+    worst = worst32 = 0.0
+    for e in range(E):
+        xe = x[0 if xs else e].permute(3, 0, 1, 2).double().cpu().numpy()            # [B, C, H, W]
+        we, be = w[e].double().cpu().numpy(), bias[e].double().cpu().numpy()
+        want = O.conv2d(xe, we, be, s, p, d)
+        mag = O.conv2d(np.abs(xe), np.abs(we), np.abs(be), s, p, d)
+        got = y[e].permute(3, 0, 1, 2).double().cpu().numpy()
+        got32 = y32[e].permute(3, 0, 1, 2).double().cpu().numpy()
+        worst = max(worst, float((np.abs(got - want) / mag).max()))
+        worst32 = max(worst32, float((np.abs(got32 - want) / mag).max()))
+    print(f"relative to sum|w||x|: split-fp16 {worst:.2e}, fp32 kernel {worst32:.2e}")
+    assert worst <= TOL, (worst, worst32)
+
+
+def test_f16x2_model_step_matches_fp32_step(env, f16x2):
+    """The whole 512 x 10 AlexNet step in both modes, same noise: log-probabilities agree to 1e-5 of their largest magnitude (the
+    fp32 path itself sits 2.4e-6 of max|logit| from the float64 oracle at this size), KL identical."""
+    ens, ops = env["ens"], env["ops"]
+    torch.manual_seed(0)
+    net = env["zoo"].getModel("alexnet", 3, 10, P.CONFIG_PRIORS, "bbb", "softplus").cuda()
+    env["rng"].assign_stream_ids(net)
+    x = torch.rand(512, 3, 32, 32, device="cuda")
+    with torch.no_grad():
+        env["rng"].manual_seed(3, call=0)
+        lo, kl = ens.mc_forward(net, x, 10)
+        ops.gemm_mode = "fp32"
+        env["rng"].manual_seed(3, call=0)
+        lo32, kl32 = ens.mc_forward(net, x, 10)
+    assert torch.equal(kl, kl32)
+    assert float((lo - lo32).abs().max()) <= 1e-5 * float(lo32.abs().max())
