@@ -516,6 +516,56 @@ def dropin_loop(dev, steps):
                     "uses the batched ensemble entry point (all draws per launch, one hipGraph) instead"}
 
 
+def split_fp16(dev, steps, pipeline):
+    """The metric step with the GEMM launches on the 16-bit matrix pipe at fp32 accuracy (ops.gemm_mode = "fp16x2",
+    bbb_conv2d_chwn_f16x2_fwd: operands split into two fp16 pieces while staged, three products per fp32 product, fp32
+    accumulation).  Opt-in mode, reported NEXT TO the fp32 headline, never as it: throughput, single-lane latency, per-launch
+    times, and the largest difference of the step's log-probabilities from the fp32 path under the same noise."""
+    from bbb_hip import ensemble, ops, rng
+    cfg = CONFIGS["metric"]
+    net, x = build_net(cfg, dev)
+    E = cfg["E"]
+    out = {}
+    try:
+        with torch.no_grad():
+            seed_call = rng.next_calls(0)
+            ref_lo = ensemble.mc_forward(net, x, E)[0].clone()
+            ops.gemm_mode = "fp16x2"
+            rng.rewind(seed_call)
+            lo = ensemble.mc_forward(net, x, E)[0]
+            out["max_abs_diff_of_log_probs_vs_fp32_path"] = float((lo - ref_lo).abs().max())
+            out["max_abs_log_prob"] = float(ref_lo.abs().max())
+            for name, depth in (("steps_in_flight_%d" % pipeline, pipeline), ("one_step_in_flight", 1)):
+                pipe = ensemble.GraphedPipeline(net, x, E, depth=depth)
+                for _ in range(20):
+                    pipe.step()
+                pipe.sync()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    pipe.step()
+                pipe.sync()
+                dt = (time.perf_counter() - t0) / steps
+                out[name] = {"ms_per_step": round(1e3 * dt, 4), "value": round(cfg["B"] * E / dt, 1)}
+                del pipe
+            rec = LaunchRecorder()
+            ensemble.mc_forward(net, x, E, timers=rec)
+            torch.cuda.synchronize(dev)
+            ing = rec.time_in_graphs(dev)
+            g = ing.get("conv_gemm")
+            if g:
+                tf = g["work"] / (g["ms"] * 1e-3) / 1e12
+                out["gemm_launches"] = {"per_launch_us": rec.per_launch_us, "fp32_equivalent_TFLOPs": round(tf, 1),
+                                        "f16_mfma_TFLOPs": round(3 * tf, 1), "frac_of_bf16_f16_peak": round(3 * tf / PEAK_BF16_MFMA_TFLOPS, 4),
+                                        "frac_of_fp32_matrix_peak": round(tf / PEAK_F32_MFMA_TFLOPS, 4)}
+        out["unit"] = "samples/s"
+        out["note"] = ("opt-in precision mode: fp32 tensors in HBM, every GEMM operand element split into hi = fp16(a), lo = fp16(a - hi) "
+                       "while its tile is staged, products hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16, fp32 accumulation; "
+                       "against the float64 oracle 1.2-2.4e-7 of sum|w||x| (the fp32 kernel: 0.8-3.9e-7), tests/test_gpu_f16x2.py")
+    finally:
+        ops.gemm_mode = "fp32"
+    return out
+
+
 def training_step(dev, steps):
     """N1 (training extension), not the metric: one iteration of train_model's batch loop (main_bayesian.py:40-58) at the metric
     shape -- 10 stochastic forwards of 512 images, KL, logmeanexp, ELBO, backward, Adam -- on the batch-innermost kernels with
@@ -729,6 +779,11 @@ def main():
                 out["dropin_loop"] = dropin_loop(dev, max(5, args.steps // 5))
             except Exception as exc:
                 out["dropin_loop"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:160])}
+            if cfg is CONFIGS["metric"]:
+                try:
+                    out["split_fp16"] = split_fp16(dev, max(20, args.steps // 2), max(1, args.pipeline))
+                except Exception as exc:
+                    out["split_fp16"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:160])}
             try:
                 out["training_step"] = training_step(dev, max(5, args.steps // 5))
             except Exception as exc:

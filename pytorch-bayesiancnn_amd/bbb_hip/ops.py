@@ -264,11 +264,12 @@ def conv2d_chwn_forward(x, w, bias, stride=1, padding=0, dilation=1, act=None, o
             raise _lib.BBBHipError("out= must be a contiguous fp32 tensor of the output's size")
         y = out.view(shape)
     with on_device(x.device):
-        if gemm_mode == "fp16x2":
+        ks, scr = _split_scratch(d, False, x.device)
+        if gemm_mode == "fp16x2" and ks == 1 and E * ho * wo * -(-w.shape[1] // 64) * -(-x.shape[4] // 128) >= 256:
+            # (launches below ~256 workgroups stay on the fp32 kernel and its split contraction: measured faster there)
             check(_lib.lib().bbb_conv2d_chwn_f16x2_fwd(ctypes.byref(d), x.data_ptr(), w.data_ptr(), ptr(bias), y.data_ptr(),
                                                        cur_stream(x.device)), "bbb_conv2d_chwn_f16x2_fwd")
             return y
-        ks, scr = _split_scratch(d, False, x.device)
         if ks > 1:
             check(_lib.lib().bbb_conv2d_chwn_splitk_fwd(ctypes.byref(d), x.data_ptr(), w.data_ptr(), ptr(bias), y.data_ptr(), ks,
                                                         scr.data_ptr(), scr.numel(), cur_stream(x.device)), "bbb_conv2d_chwn_splitk_fwd")

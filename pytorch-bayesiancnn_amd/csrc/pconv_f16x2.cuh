@@ -8,9 +8,10 @@
 // launch; results differ from the fp32 fmaf chain by rounding (measured against the float64 oracle: 1.2-2.4e-7 of sum |w||x|,
 // the fp32 kernel 0.8-3.9e-7 on the same cases), not bit for bit.
 // Same decomposition: workgroup = one output pixel, 64 channels, BM = 128 * MT images, in-bounds taps only, k tables in LDS.
-// With the matrix phase of a tile down to 384 / 768 cycles per wave everything else shows: staging moves 16-byte vectors on
-// the LDS side (a thread owns 8 adjacent channels of one k / 8 adjacent images of one row), two register stages keep two tiles
-// of loads in flight, and the epilogue goes through an LDS transpose to 16-byte stores.
+// With the matrix phase of a tile down to 384 cycles per wave everything else shows (ablation, profiles/r03_notes.md section 12:
+// loads, split + LDS writes, MFMAs, epilogue and the bare loop each cost 15-25 % of a launch): staging moves 16-byte vectors on
+// the LDS side (a thread owns 8 adjacent channels of one k / 8 adjacent images of one row), the epilogue goes through an LDS
+// transpose to 16-byte stores, and registers are kept low enough for 4 workgroups per CU.
 #pragma once
 #include "pconv_body.cuh"
 
@@ -87,10 +88,11 @@ __global__ __launch_bounds__(kThreads) void pconv_f16x2_kernel(const PConvArgs p
 #pragma unroll
     for (int i = 0; i < 8; ++i) wrow[i] = (uint32_t)(n0 + wng + i) * (uint32_t)p.Kp * 4u;
 
-    // TWO register stages (A, B) + one LDS stage: tile t multiplies from LDS while tile t+1 has landed / is landing in one
-    // register set and tile t+2 is being requested into the other.
-    float wregA[8], wregB[8];
-    f32x4 xregA[2 * XPASS], xregB[2 * XPASS];
+    // One register stage + one LDS stage, as pconv_body.cuh: loads for tile t+1 are issued before tile t's MFMAs and written to
+    // LDS after them.  (Measured: a second register stage -- two tiles of loads in flight -- costs a workgroup per CU in
+    // registers and is 10-15 % slower on every layer; occupancy hides the latency better.)
+    float wregA[8];
+    f32x4 xregA[2 * XPASS];
 
     const float inv_nrq = nrq > 0 ? 1.0f / (float)nrq : 0.0f;
     const float inv_nq = nq > 0 ? 1.0f / (float)nq : 0.0f;
@@ -211,22 +213,14 @@ __global__ __launch_bounds__(kThreads) void pconv_f16x2_kernel(const PConvArgs p
         if (KCH < Keff) fill_chunk(1);
         store_tile(wregA, xregA);
         __syncthreads();                                             // tile 0 in LDS, table chunk 1 visible
-        if (ntiles > 1) load_tile(1, wregB, xregB);
-        // tile t sits in LDS; tile t+1 is in register set (t odd ? A : B); tile t+2 is requested into the set tile t came from
         for (int t = 0; t < ntiles; ++t) {
-            // decode chunk c+1 early in chunk c (c >= 1; chunk 1 is decoded in the prologue): its buffer was last read by the
-            // loads of tile 8c - 1, issued at tile 8c - 3
-            if ((t % TPC) == 0 && t / TPC >= 1 && (t / TPC + 1) * KCH < Keff) fill_chunk(t / TPC + 1);
-            if (t + 2 < ntiles) {
-                if (t & 1) load_tile(t + 2, wregB, xregB);
-                else       load_tile(t + 2, wregA, xregA);
-            }
+            const bool more = (t + 1) < ntiles;
+            if (more) load_tile(t + 1, wregA, xregA);
+            // decode chunk c+1 early in chunk c (c >= 1; chunk 1 is decoded in the prologue)
+            if ((t % TPC) == 1 && t / TPC >= 1 && (t / TPC + 1) * KCH < Keff) fill_chunk(t / TPC + 1);
             mma_tile();
             __syncthreads();
-            if (t + 1 < ntiles) {
-                if (t & 1) store_tile(wregA, xregA);
-                else       store_tile(wregB, xregB);
-            }
+            if (more) store_tile(wregA, xregA);
             __syncthreads();
         }
     }
