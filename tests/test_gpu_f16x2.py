@@ -77,3 +77,24 @@ def test_f16x2_model_step_matches_fp32_step(env, f16x2):
         lo32, kl32 = ens.mc_forward(net, x, 10)
     assert torch.equal(kl, kl32)
     assert float((lo - lo32).abs().max()) <= 1e-5 * float(lo32.abs().max())
+
+
+def test_f16x2_work_units_match_the_whole_step(env, f16x2):
+    """A rank's (draw x batch-slice) work units in split-fp16 mode: each unit's logits equal the corresponding block of the
+    unsharded step (the shares' smaller launches may take the fp32 kernel -- launch-size policy in ops -- hence a tolerance)."""
+    ens = env["ens"]
+    torch.manual_seed(0)
+    net = env["zoo"].getModel("alexnet", 3, 10, P.CONFIG_PRIORS, "bbb", "softplus").cuda()
+    env["rng"].assign_stream_ids(net)
+    x = torch.rand(512, 3, 32, 32, device="cuda")
+    E, S = 10, 4
+    with torch.no_grad():
+        full, kl = ens._mc_logits_chwn(net, x, E, 7, 3)                          # [E, C, B]
+        for rank in (0, 3, 7):
+            lo, hi = ens.unit_range(E, S, rank, 8)
+            part, klp = ens._mc_logits_chwn(net, x, E, 7, 3, units=(S, lo, hi))  # [hi-lo, C, B/S]
+            assert torch.equal(klp, kl)
+            for i, u in enumerate(range(lo, hi)):
+                j, sl = divmod(u, S)
+                want = full[j, :, sl * 128:(sl + 1) * 128]
+                assert float((part[i] - want).abs().max()) <= 1e-5 * float(want.abs().max())

@@ -76,7 +76,17 @@ def assert_fast_path(env):
 
 
 # --------------------------------------------------------------------------------------------------------------------
-def test_metric_config_alexnet10_bbb_bs512_ens10_vs_oracle(env):
+@pytest.fixture(params=["fp32", "fp16x2"])
+def gemm_mode(request, env):
+    """Both contraction modes of the batch-innermost GEMM are held to the SAME bounds: the fp32 matrix instruction, and the
+    split-fp16 form (two fp16 pieces per operand, three products, fp32 accumulation: pconv_f16x2.cuh)."""
+    from bbb_hip import ops
+    ops.gemm_mode = request.param
+    yield request.param
+    ops.gemm_mode = "fp32"
+
+
+def test_metric_config_alexnet10_bbb_bs512_ens10_vs_oracle(env, gemm_mode):
     """BASELINE metric config.  Logits of draws 0 and 9 vs the float64 oracle and vs the reference's fp32 CPU ops; the whole
     step (10 draws -> log_softmax -> logmeanexp, KL summed over calls) vs ref_port_torch.mc_step's arithmetic with replayed
     noise; the hipGraph replay the bench times returns the eager step's bits."""
@@ -113,7 +123,7 @@ def test_metric_config_alexnet10_bbb_bs512_ens10_vs_oracle(env):
             assert abs(kl.item() - kl64) <= 2e-6 * kl64
         # every draw against the reference's own fp32 result
         assert float(np.abs(logits[j] - lt.numpy()).max()) <= 2e-5 * scale, j
-    report("metric alexnet10 bbb bs512", scale=scale, dev_vs_f64=worst_dev, cpu_ref_vs_f64=worst_ref)
+    report("metric alexnet10 bbb bs512 " + gemm_mode, scale=scale, dev_vs_f64=worst_dev, cpu_ref_vs_f64=worst_ref)
     assert worst_dev <= max(4.0 * worst_ref, 4e-6)          # not a worse approximation of the exact result than the CPU path (x4)
     want = P.logmeanexp(torch.stack(ls_ref, dim=2), 2).numpy()
     got = lo.cpu().numpy()
