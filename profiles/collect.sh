@@ -36,6 +36,7 @@ rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- $BENCH > /tmp/kt/log.txt 2>
     echo
   done; } > "$OUT/${TAG}_graph_kernel_stats.txt" 2>&1
 
+if [ "${SKIP_PMC:-0}" = "1" ]; then ls -la "$OUT" | tail -8; exit 0; fi     # kernel traces only (the PMC passes were taken earlier in the round)
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pm && mkdir -p /tmp/pm
   rocprofv3 --kernel-trace --pmc $C -d /tmp/pm -o pm -- $EAGER > /tmp/pm/log.txt 2>&1
