@@ -189,7 +189,9 @@ def lrt_conv2d_forward(x, w_mu, w_var, b_mu, b_var, seed, call0, stream_id, stri
 
 gemm_mode = "fp32"  # "fp16x2": the batch-innermost BBB GEMM launches (conv2d_chwn_forward) run their contraction on the 16-bit
                     # matrix pipe at fp32 accuracy (bbb_conv2d_chwn_f16x2_fwd: operands split into two fp16 pieces, three products,
-                    # fp32 accumulation).  Opt-in: results agree with the fp32 kernel to rounding, not bit for bit.
+                    # fp32 accumulation).  Opt-in: results agree with the fp32 kernel to rounding, not bit for bit; full accuracy for
+                    # 1.2e-4 <= |w| < 64 and 2e-3 <= |x| < 1024 (csrc/pconv_f16x2.cuh: operand window).
+f16x2_min_workgroups = 256   # smaller launches stay on the fp32 kernel (and its split contraction) even in "fp16x2" mode
 _split_plans = {}
 split_k = True     # small batch-innermost launches split their contraction over several workgroups per output tile
                    # (bbb_conv2d_chwn_splitk_fwd); False: never (tests that compare differently sized launches bit for bit)
@@ -265,7 +267,7 @@ def conv2d_chwn_forward(x, w, bias, stride=1, padding=0, dilation=1, act=None, o
         y = out.view(shape)
     with on_device(x.device):
         ks, scr = _split_scratch(d, False, x.device)
-        if gemm_mode == "fp16x2" and ks == 1 and E * ho * wo * -(-w.shape[1] // 64) * -(-x.shape[4] // 128) >= 256:
+        if gemm_mode == "fp16x2" and ks == 1 and E * ho * wo * -(-w.shape[1] // 64) * -(-x.shape[4] // 128) >= f16x2_min_workgroups:
             # (launches below ~256 workgroups stay on the fp32 kernel and its split contraction: measured faster there)
             check(_lib.lib().bbb_conv2d_chwn_f16x2_fwd(ctypes.byref(d), x.data_ptr(), w.data_ptr(), ptr(bias), y.data_ptr(),
                                                        cur_stream(x.device)), "bbb_conv2d_chwn_f16x2_fwd")

@@ -1,6 +1,6 @@
 // fp32-accurate contraction on the 16-bit matrix pipe ("split fp16"): the pixel-major implicit GEMM of pconv_body.cuh with
 // every fp32 operand element a cut into two fp16 pieces while its tile is staged,
-//     hi = fp16(a)   lo = fp16(a - hi)        (a = hi + lo up to 2^-22 |a|; |a| < 65504)
+//     hi = fp16(a)   lo = fp16(a - hi)        (a = hi + lo up to 2^-22 |a|; a pre-scaled by a power of two, see kScaleW / kScaleX)
 // and every product taken as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation (the dropped lo*lo term is
 // < 2^-22 |a b|).  Three instructions of 32 cycles do the work of sixteen 64-cycle v_mfma_f32_32x32x2_f32: 3/16 of the fp32 pipe
 // time at the nominal rates (measured instruction ceilings on one box: 1952 vs 141 TFLOP/s, profiles/r03_notes.md section 11).
@@ -16,6 +16,19 @@
 #include "pconv_body.cuh"
 
 namespace pconv {
+
+// Operand window.  The matrix instruction flushes fp16 SUBNORMAL inputs to zero (measured: tests/test_gpu_f16x2.py, the
+// out-of-window case), and the lo piece of an element below 0.125 is subnormal: such an element is carried by hi alone, 2^-11
+// relative.  Operands are therefore pre-scaled by exact powers of two while they are split -- weights by 2^10, activations by
+// 2^6, accumulators scaled back by 2^-16 in the epilogue (exact) -- so that the window of full accuracy is
+//     1.2e-4 <= |w| < 64      2e-3 <= |x| < 1024
+// (Bayesian-CNN weights are O(0.01-1), softplus / ReLU activations and [0, 1) images O(0.1-10)).  Elements below the window
+// degrade gracefully -- they are small, and lose at most 2^-11 of themselves.  Measured against the float64 oracle, Gaussian
+// tensors, error relative to sum|w||x|: typical |x| / |w| of 3 / 0.2 or 100 / 8 -> 1.2-2.4e-7 (the fp32 kernel: 1.3-3.9e-7);
+// 0.25 / 0.01 (a few per cent of the elements under the window) -> 0.4-3.2e-6; 0.004 / 0.0003 (typical magnitude under the
+// window) -> 1e-5..1e-4.  Elements above the window saturate at 65504 / scale instead of turning into inf.  A per-tensor dynamic
+// scale (the producing kernel publishing max|y|) would remove the window; not built.
+constexpr float kScaleW = 1024.0f, kScaleX = 64.0f, kUnscale = 1.0f / 65536.0f, kF16Max = 65504.0f;
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef short f16s4 __attribute__((ext_vector_type(4)));
@@ -133,8 +146,9 @@ __global__ __launch_bounds__(kThreads) void pconv_f16x2_kernel(const PConvArgs p
         f16x8 h, l;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            h[i] = (_Float16)wreg[i];
-            l[i] = (_Float16)(wreg[i] - (float)h[i]);
+            const float v = __builtin_amdgcn_fmed3f(wreg[i] * kScaleW, -kF16Max, kF16Max);
+            h[i] = (_Float16)v;
+            l[i] = (_Float16)(v - (float)h[i]);
         }
         *reinterpret_cast<f16x8*>(&Wh[wkl * LDWH + (wng ^ wswz)]) = h;
         *reinterpret_cast<f16x8*>(&Wl[wkl * LDWH + (wng ^ wswz)]) = l;
@@ -142,7 +156,7 @@ __global__ __launch_bounds__(kThreads) void pconv_f16x2_kernel(const PConvArgs p
         for (int ps = 0; ps < XPASS; ++ps) {
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                const float v = xreg[2 * ps + (c >> 2)][c & 3];
+                const float v = __builtin_amdgcn_fmed3f(xreg[2 * ps + (c >> 2)][c & 3] * kScaleX, -kF16Max, kF16Max);
                 h[c] = (_Float16)v;
                 l[c] = (_Float16)(v - (float)h[c]);
             }
@@ -249,7 +263,7 @@ __global__ __launch_bounds__(kThreads) void pconv_f16x2_kernel(const PConvArgs p
                 const float bv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brs, (uint32_t)n * 4u, 0, 0));
                 f32x4 o;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) o[c] = bbb::apply_act(v4[c] + bv, p.act);
+                for (int c = 0; c < 4; ++c) o[c] = bbb::apply_act(v4[c] * kUnscale + bv, p.act);
                 const uint32_t off = ((b < p.B) & (n < p.Cout)) ? (uint32_t)(((int64_t)n * HoWo + pix) * p.B + b) * 4u : kOOB;
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(uint32_t)))) uint32_t, o), yrs, off, 0, 0);
             }

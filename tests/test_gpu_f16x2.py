@@ -26,6 +26,18 @@ def f16x2(env):
     env["ops"].gemm_mode = "fp32"
 
 
+@pytest.fixture()
+def every_launch(env):
+    """No launch-size policy: also the small test shapes run on the split-fp16 kernel (and no fp32 split contraction)."""
+    ops = env["ops"]
+    keep = (ops.f16x2_min_workgroups, ops.split_k)
+    ops.f16x2_min_workgroups, ops.split_k = 0, False
+    ops._split_plans.clear()
+    yield
+    ops.f16x2_min_workgroups, ops.split_k = keep
+    ops._split_plans.clear()
+
+
 CASES = [
     # B, Cin, H, W, Cout, k, stride, pad, dil, E, x_shared
     (512, 3, 32, 32, 64, 11, 4, 5, 1, 2, True),      # AlexNet conv1
@@ -38,12 +50,17 @@ CASES = [
 
 
 @pytest.mark.parametrize("B,Cin,H,W,Cout,k,s,p,d,E,xs", CASES)
-def test_f16x2_launch_vs_oracle_and_fp32_kernel(env, f16x2, B, Cin, H, W, Cout, k, s, p, d, E, xs):
+@pytest.mark.parametrize("xscale,wscale,bound", [(3.0, 0.2, TOL), (0.25, 0.01, TOL), (100.0, 8.0, TOL), (0.004, 0.0003, 2e-4)])
+def test_f16x2_launch_vs_oracle_and_fp32_kernel(env, f16x2, every_launch, B, Cin, H, W, Cout, k, s, p, d, E, xs, xscale, wscale, bound):
+    """Inside the operand window (pconv_f16x2.cuh) the fp32 kernel's bound holds -- at its lower edge (Gaussian tensors of
+    typical size 0.25 / 0.01: a few per cent of their elements lose the lo piece) with 1e-6 instead of 2e-7; the last scale pair
+    lies BELOW the window (most lo pieces are fp16 subnormals, which the matrix instruction flushes): graceful, stated
+    degradation, no garbage."""
     ops = env["ops"]
     torch.manual_seed(B + Cout)
-    x = torch.randn(1 if xs else E, Cin, H, W, B, device="cuda") * 3.0
-    w = torch.randn(E, Cout, Cin, k, k, device="cuda") * 0.2
-    bias = torch.randn(E, Cout, device="cuda")
+    x = torch.randn(1 if xs else E, Cin, H, W, B, device="cuda") * xscale
+    w = torch.randn(E, Cout, Cin, k, k, device="cuda") * wscale
+    bias = torch.randn(E, Cout, device="cuda") * (xscale * wscale)
     y = ops.conv2d_chwn_forward(x, w, bias, s, p, d, act=None)
     ops.gemm_mode = "fp32"
     y32 = ops.conv2d_chwn_forward(x, w, bias, s, p, d, act=None)
@@ -58,7 +75,9 @@ def test_f16x2_launch_vs_oracle_and_fp32_kernel(env, f16x2, B, Cin, H, W, Cout, 
         worst = max(worst, float((np.abs(got - want) / mag).max()))
         worst32 = max(worst32, float((np.abs(got32 - want) / mag).max()))
     print(f"relative to sum|w||x|: split-fp16 {worst:.2e}, fp32 kernel {worst32:.2e}")
-    assert worst <= TOL, (worst, worst32)
+    assert worst <= bound, (worst, worst32)
+    if xscale >= 3.0:
+        assert worst <= 1.5 * worst32 + 1e-7          # operands of O(0.1-1) and larger: not a worse approximation than the fp32 kernel
 
 
 def test_f16x2_model_step_matches_fp32_step(env, f16x2):
