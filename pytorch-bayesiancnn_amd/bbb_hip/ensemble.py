@@ -403,11 +403,17 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
     n_out = getattr(children[last_bayes], "out_features", None) if tail_is_last else None
     logits_buf = torch.empty((E, n_out, B), dtype=torch.float32, device=x.device) if n_out is not None else None
 
+    # split-fp16 GEMM mode: the activation scale of every layer's split follows the data -- max|x| of the input here, then each
+    # GEMM launch publishes max|y| for the next one (bbb_conv2d_chwn_f16x2_fwd; device scalars, no host sync)
+    f16x2 = ops.gemm_mode == "fp16x2" and not bf16 and bool(bbb)
+    amax0 = x.detach().abs().amax().expand(ops.AMAX_SLOTS).contiguous() if f16x2 else None
+
     def run(e0, e1):
         """Layers for draws [e0, e1) on the current stream -> logits [e1-e0, C, B] (or None: fall back)."""
         nonlocal logits_buf
         B = xt.shape[-1]
         Es = e1 - e0
+        amax = amax0
         h = xt[e0:e1] if (per_draw_x and draws > 1) else xt
         boff = int(b_offset)           # global index of the first local "image" (rows multiply at a flatten that cuts images up)
         per_slice = bool(ukw)          # work units: until the first Bayesian layer, h is one block per batch slice
@@ -450,8 +456,10 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
                     fl = conv_flops(B, h5.shape[1], h5.shape[2], h5.shape[3], w.shape[1], w.shape[3], w.shape[4], *geom, Es) \
                         if timers is not None else None
                     dst = logits_buf[e0:e1] if (logits_buf is not None and i == last_bayes and not is_conv) else None
-                    y = _run(timers, "conv_gemm", fl, lambda h5=h5, w=w, b=b, geom=geom, act=act, dst=dst, ukw2=ukw2:
-                             ops.conv2d_chwn_forward(h5, w, b, *geom, act=act, out=dst, **ukw2))
+                    a_out = torch.zeros(ops.AMAX_SLOTS, dtype=torch.float32, device=x.device) if (f16x2 and i != last_bayes) else None
+                    y = _run(timers, "conv_gemm", fl, lambda h5=h5, w=w, b=b, geom=geom, act=act, dst=dst, ukw2=ukw2, a_in=amax, a_out=a_out:
+                             ops.conv2d_chwn_forward(h5, w, b, *geom, act=act, out=dst, amax_in=a_in, amax_out=a_out, **ukw2))
+                    amax = a_out                     # (max-pooling in between keeps it an upper bound)
                 else:
                     w_var, b_var = variances[mod]
                     w_mu = mod.W_mu

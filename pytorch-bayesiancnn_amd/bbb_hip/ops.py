@@ -191,6 +191,7 @@ gemm_mode = "fp32"  # "fp16x2": the batch-innermost BBB GEMM launches (conv2d_ch
                     # matrix pipe at fp32 accuracy (bbb_conv2d_chwn_f16x2_fwd: operands split into two fp16 pieces, three products,
                     # fp32 accumulation).  Opt-in: results agree with the fp32 kernel to rounding, not bit for bit; full accuracy for
                     # 1.2e-4 <= |w| < 64 and 2e-3 <= |x| < 1024 (csrc/pconv_f16x2.cuh: operand window).
+AMAX_SLOTS = 64              # BBB_AMAX_SLOTS: length of the max|x| / max|y| arrays of bbb_conv2d_chwn_f16x2_fwd
 f16x2_min_workgroups = 256   # smaller launches stay on the fp32 kernel (and its split contraction) even in "fp16x2" mode
 _split_plans = {}
 split_k = True     # small batch-innermost launches split their contraction over several workgroups per output tile
@@ -239,11 +240,13 @@ def _desc_chwn(x, w, stride, padding, dilation, draws, x_shared, w_shared, act):
 
 
 def conv2d_chwn_forward(x, w, bias, stride=1, padding=0, dilation=1, act=None, out=None, units=None, n_units=None,
-                        x_per_slice=False):
+                        x_per_slice=False, amax_in=None, amax_out=None):
     """Batch-innermost conv for the ensemble path.  x: [E|1, Cin, H, W, B] (B % 4 == 0); w: [E|1, Cout, Cin, kh, kw];
     bias [E|1, Cout] or None -> y [E, Cout, Ho, Wo, B].  Padding taps are skipped, not multiplied.
     Work units (ensemble sharding): units = (S, off), n_units = U output slabs; w / bias hold the weight sets of the draws
-    the units touch, x is [U, ...] or, for a layer whose input is the same for every draw, the per-slice [S, Cin, H, W, Bs]."""
+    the units touch, x is [U, ...] or, for a layer whose input is the same for every draw, the per-slice [S, Cin, H, W, Bs].
+    amax_in / amax_out (gemm_mode "fp16x2" only; AMAX_SLOTS device floats each): their maximum bounds max|x| and sets the
+    activation scale of the split; where this launch leaves max|y| (zeroed by the caller) -- see bbb_conv2d_chwn_f16x2_fwd."""
     require_device(x, w, bias)
     x, w = x.contiguous(), w.contiguous()
     bias = None if bias is None else bias.contiguous()
@@ -269,8 +272,12 @@ def conv2d_chwn_forward(x, w, bias, stride=1, padding=0, dilation=1, act=None, o
         ks, scr = _split_scratch(d, False, x.device)
         if gemm_mode == "fp16x2" and ks == 1 and E * ho * wo * -(-w.shape[1] // 64) * -(-x.shape[4] // 128) >= f16x2_min_workgroups:
             # (launches below ~256 workgroups stay on the fp32 kernel and its split contraction: measured faster there)
+            require_device(amax_in, amax_out)
+            for t in (amax_in, amax_out):
+                if t is not None and (t.numel() != AMAX_SLOTS or not t.is_contiguous()):
+                    raise _lib.BBBHipError("amax_in / amax_out must be contiguous tensors of %d floats" % AMAX_SLOTS)
             check(_lib.lib().bbb_conv2d_chwn_f16x2_fwd(ctypes.byref(d), x.data_ptr(), w.data_ptr(), ptr(bias), y.data_ptr(),
-                                                       cur_stream(x.device)), "bbb_conv2d_chwn_f16x2_fwd")
+                                                       ptr(amax_in), ptr(amax_out), cur_stream(x.device)), "bbb_conv2d_chwn_f16x2_fwd")
             return y
         if ks > 1:
             check(_lib.lib().bbb_conv2d_chwn_splitk_fwd(ctypes.byref(d), x.data_ptr(), w.data_ptr(), ptr(bias), y.data_ptr(), ks,

@@ -26,15 +26,20 @@ namespace pconv {
 // degrade gracefully -- they are small, and lose at most 2^-11 of themselves.  Measured against the float64 oracle, Gaussian
 // tensors, error relative to sum|w||x|: typical |x| / |w| of 3 / 0.2 or 100 / 8 -> 1.2-2.4e-7 (the fp32 kernel: 1.3-3.9e-7);
 // 0.25 / 0.01 (a few per cent of the elements under the window) -> 0.4-3.2e-6; 0.004 / 0.0003 (typical magnitude under the
-// window) -> 1e-5..1e-4.  Elements above the window saturate at 65504 / scale instead of turning into inf.  A per-tensor dynamic
-// scale (the producing kernel publishing max|y|) would remove the window; not built.
+// window) -> 1e-5..1e-4.  Elements above the window saturate at 65504 / scale instead of turning into inf.  The ACTIVATION scale
+// can follow the data (x_amax / y_amax below: every launch publishes max|y| for the next one); the weight scale is fixed.
 constexpr float kScaleW = 1024.0f, kScaleX = 64.0f, kUnscale = 1.0f / 65536.0f, kF16Max = 65504.0f;
+constexpr unsigned kAmaxSlots = 64;          // x_amax / y_amax are arrays of this many floats; their maximum is the bound
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef short f16s4 __attribute__((ext_vector_type(4)));
 
+// x_amax / y_amax (optional): 64 device floats whose maximum is an upper bound of max|x| -- the activation scale then becomes
+// the power of two that puts that bound just under 2^14 instead of the fixed 2^6 -- and 64 device floats into which this launch
+// max-reduces |y| (atomics on the bits of non-negative floats), i.e. the x_amax of the next layer: per-step, data-dependent,
+// deterministic.
 template <int MT>
-__global__ __launch_bounds__(kThreads) void pconv_f16x2_kernel(const PConvArgs p) {
+__global__ __launch_bounds__(kThreads) void pconv_f16x2_kernel(const PConvArgs p, const float* __restrict__ x_amax, float* __restrict__ y_amax) {
     constexpr int BM = 128 * MT;
     constexpr int LDXH = BM + 32;              // 16-bit elements per image row: 64 B mod 256 -> the 4 rows of a transpose read hit disjoint banks
     constexpr int LDWH = BN + 32;              // 192 B: rows at 0 / 192 / 128 / 64 mod 256
@@ -80,6 +85,18 @@ __global__ __launch_bounds__(kThreads) void pconv_f16x2_kernel(const PConvArgs p
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave * 32 * MT;                                   // 4 waves side by side along the images, 64 channels each
+
+    float sx = kScaleX, unscale = kUnscale;
+    if (x_amax != nullptr) {
+        const uint32_t mb = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(uint32_t, bbb::wave_max(x_amax[lane])));
+        const int ef = (int)((mb >> 23) & 0xffu);                    // biased exponent: max|x| < 2^(ef - 126)
+        if (ef > 0 && ef < 255) {
+            int sh = 14 - (ef - 126);                                // max|x| * 2^sh < 2^14
+            sh = sh < -60 ? -60 : (sh > 60 ? 60 : sh);
+            sx = __builtin_bit_cast(float, (uint32_t)(127 + sh) << 23);
+            unscale = __builtin_bit_cast(float, (uint32_t)(127 - sh - 10) << 23);     // 1 / (sx * kScaleW), exact
+        }
+    }
 
     constexpr uint32_t kOOB = 0xFFFFFFF0u;
     constexpr uint32_t kWInv = 0x7FFFFFF0u;
@@ -156,7 +173,7 @@ __global__ __launch_bounds__(kThreads) void pconv_f16x2_kernel(const PConvArgs p
         for (int ps = 0; ps < XPASS; ++ps) {
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                const float v = __builtin_amdgcn_fmed3f(xreg[2 * ps + (c >> 2)][c & 3] * kScaleX, -kF16Max, kF16Max);
+                const float v = __builtin_amdgcn_fmed3f(xreg[2 * ps + (c >> 2)][c & 3] * sx, -kF16Max, kF16Max);
                 h[c] = (_Float16)v;
                 l[c] = (_Float16)(v - (float)h[c]);
             }
@@ -248,6 +265,7 @@ __global__ __launch_bounds__(kThreads) void pconv_f16x2_kernel(const PConvArgs p
         p.y + (int64_t)e * p.y_ds, 0, (int)((int64_t)p.Cout * HoWo * p.B * 4), 0x00020000);
     static_assert(2 * BK * LDXH * 2 >= 4 * 32 * 36 * 4, "epilogue staging must fit in the image planes");
     float* const T = reinterpret_cast<float*>(Xp) + wave * (32 * 36);       // [32 channels][36] floats, wave-private
+    float ymax = 0.0f;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -263,12 +281,22 @@ __global__ __launch_bounds__(kThreads) void pconv_f16x2_kernel(const PConvArgs p
                 const float bv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brs, (uint32_t)n * 4u, 0, 0));
                 f32x4 o;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) o[c] = bbb::apply_act(v4[c] * kUnscale + bv, p.act);
+                for (int c = 0; c < 4; ++c) o[c] = bbb::apply_act(v4[c] * unscale + bv, p.act);
                 const uint32_t off = ((b < p.B) & (n < p.Cout)) ? (uint32_t)(((int64_t)n * HoWo + pix) * p.B + b) * 4u : kOOB;
+                if (off != kOOB) ymax = fmaxf(ymax, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(uint32_t)))) uint32_t, o), yrs, off, 0, 0);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the reads are done before the next tile overwrites T
         }
+    if (y_amax != nullptr) {
+        // thousands of waves max-reduce: into kAmaxSlots words, not one (10 k atomics on one address cost 56 us on conv1; spread
+        // over 64 they disappear).  Bits of non-negative floats order like unsigned integers (an inf / NaN output ends up as a
+        // huge bound: scale floor).
+        ymax = bbb::wave_max(ymax);
+        if (lane == 0 && ymax > 0.0f)
+            __hip_atomic_fetch_max(reinterpret_cast<unsigned int*>(y_amax) + ((blockIdx.x * 4u + (unsigned)wave) & (kAmaxSlots - 1)),
+                                   __builtin_bit_cast(unsigned int, ymax), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 }  // namespace pconv

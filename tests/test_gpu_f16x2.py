@@ -117,3 +117,49 @@ def test_f16x2_work_units_match_the_whole_step(env, f16x2):
                 j, sl = divmod(u, S)
                 want = full[j, :, sl * 128:(sl + 1) * 128]
                 assert float((part[i] - want).abs().max()) <= 1e-5 * float(want.abs().max())
+
+
+def test_f16x2_activation_scale_follows_the_data(env, f16x2, every_launch):
+    """Activations far below the fixed-scale window (typical 0.004): with the launch told max|x| (amax_in) the fp32 bound holds
+    again, and the launch publishes max|y| (amax_out) for the next layer."""
+    ops = env["ops"]
+    torch.manual_seed(5)
+    B, Cin, H, W, Cout, k = 256, 64, 4, 4, 192, 5
+    x = torch.randn(1, Cin, H, W, B, device="cuda") * 0.004
+    w = torch.randn(2, Cout, Cin, k, k, device="cuda") * 0.2
+    bias = torch.randn(2, Cout, device="cuda") * 1e-3
+    amax_in = torch.zeros(ops.AMAX_SLOTS, device="cuda")
+    amax_in[5] = x.abs().max()                                    # the bound is the maximum over the slots
+    amax_out = torch.zeros(ops.AMAX_SLOTS, device="cuda")
+    y_fix = ops.conv2d_chwn_forward(x, w, bias, 1, 2, 1, act=None)
+    y_dyn = ops.conv2d_chwn_forward(x, w, bias, 1, 2, 1, act=None, amax_in=amax_in, amax_out=amax_out)
+    assert float(amax_out.max()) == float(y_dyn.abs().max())
+    errs = {}
+    for name, y in (("fixed", y_fix), ("dynamic", y_dyn)):
+        worst = 0.0
+        for e in range(2):
+            xe = x[0].permute(3, 0, 1, 2).double().cpu().numpy()
+            we, be = w[e].double().cpu().numpy(), bias[e].double().cpu().numpy()
+            want = O.conv2d(xe, we, be, 1, 2, 1)
+            mag = O.conv2d(np.abs(xe), np.abs(we), np.abs(be), 1, 2, 1)
+            worst = max(worst, float((np.abs(y[e].permute(3, 0, 1, 2).double().cpu().numpy() - want) / mag).max()))
+        errs[name] = worst
+    print(errs)
+    assert errs["dynamic"] <= TOL and errs["fixed"] > errs["dynamic"]
+
+
+def test_f16x2_model_with_tiny_inputs(env, f16x2):
+    """The ensemble path feeds every layer the previous layer's max|y|: a 512 x 10 step on images scaled by 1e-3 (far below the
+    fixed activation window) still agrees with the fp32 path to 1e-5."""
+    ens, ops = env["ens"], env["ops"]
+    torch.manual_seed(0)
+    net = env["zoo"].getModel("alexnet", 3, 10, P.CONFIG_PRIORS, "bbb", "softplus").cuda()
+    env["rng"].assign_stream_ids(net)
+    x = torch.rand(512, 3, 32, 32, device="cuda") * 1e-3
+    with torch.no_grad():
+        env["rng"].manual_seed(3, call=0)
+        lo, kl = ens.mc_forward(net, x, 10)
+        ops.gemm_mode = "fp32"
+        env["rng"].manual_seed(3, call=0)
+        lo32, kl32 = ens.mc_forward(net, x, 10)
+    assert float((lo - lo32).abs().max()) <= 1e-5 * float(lo32.abs().max())
