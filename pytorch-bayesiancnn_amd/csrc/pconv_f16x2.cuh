@@ -226,6 +226,9 @@ __global__ __launch_bounds__(kThreads) void pconv_f16x2_kernel(const PConvArgs p
                 bh[mt] = tr8(Xh, xoff[kk][0] + mt * 32, xoff[kk][1] + mt * 32);
                 bl[mt] = tr8(Xl, xoff[kk][0] + mt * 32, xoff[kk][1] + mt * 32);
             }
+            // all twelve LDS reads of the step in flight before its first MFMA (left alone, hipcc feeds each MFMA just in time:
+            // eight exposed LDS round trips per tile)
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
