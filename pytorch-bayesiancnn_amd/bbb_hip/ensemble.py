@@ -458,7 +458,7 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
                     dst = logits_buf[e0:e1] if (logits_buf is not None and i == last_bayes and not is_conv) else None
                     a_out = torch.zeros(ops.AMAX_SLOTS, dtype=torch.float32, device=x.device) if (f16x2 and i != last_bayes) else None
                     y = _run(timers, "conv_gemm", fl, lambda h5=h5, w=w, b=b, geom=geom, act=act, dst=dst, ukw2=ukw2, a_in=amax, a_out=a_out:
-                             ops.conv2d_chwn_forward(h5, w, b, *geom, act=act, out=dst, amax_in=a_in, amax_out=a_out, **ukw2))
+                             ops.conv2d_chwn_forward(h5, w, b, *geom, act=act, out=dst, amax_in=a_in, amax_out=a_out, f16x2=f16x2, **ukw2))
                     amax = a_out                     # (max-pooling in between keeps it an upper bound)
                 else:
                     w_var, b_var = variances[mod]
@@ -738,7 +738,7 @@ def mc_logits(net, x, draws, seed, call0, fuse_act=True, timers=None, eps=None, 
 
 
 def _local_lse(net, x, draws, seed, call0, mean_over, fuse_act=True, timers=None, streams=1, precision="fp32", units=None, b_offset=0,
-               step_end=None, per_draw_x=False):
+               step_end=None, per_draw_x=False, param_alias=None):
     """(log-sum-exp over the local draws of the per-draw log_softmax [B, C], kl of one forward), staying in the
     batch-innermost layout end to end when the fast path applies.  units = (S, lo, hi): the local work is the unit range
     lo..hi-1 instead of `draws` whole draws (call0 = call index of draw 0); rows of slices without a local unit are -inf.
@@ -785,7 +785,7 @@ def _local_lse(net, x, draws, seed, call0, mean_over, fuse_act=True, timers=None
         from . import fast_train
         if fast_train.train_path_ok(net, x):
             # training on the batch-innermost kernels: one autograd node for the whole batched forward
-            logits_cb, kl1 = fast_train.mc_logits_autograd(net, x, draws, seed, call0)
+            logits_cb, kl1 = fast_train.mc_logits_autograd(net, x, draws, seed, call0, alias=param_alias)
             stats["path"] = "chwn-autograd"
             lse = torch.logsumexp(F.log_softmax(logits_cb.permute(0, 2, 1), dim=2), dim=0) \
                 - (math.log(mean_over) if mean_over > 0 else 0.0)

@@ -324,9 +324,14 @@ class _MCForwardLRT(torch.autograd.Function):
         return (None, None, *grads)
 
 
-def mc_logits_autograd(net, x, draws, seed, call0):
+def mc_logits_autograd(net, x, draws, seed, call0, alias=None):
     """Differentiable batched forward: -> (logits [E, C, B] batch-innermost, kl of one forward), gradients flow to every
-    layer's W_mu, W_rho, bias_mu, bias_rho.  Call only when train_path_ok(net, x)."""
+    layer's W_mu, W_rho, bias_mu, bias_rho.  Call only when train_path_ok(net, x).
+    alias: {id(parameter): leaf tensor sharing its storage} -- the autograd graph is then rooted at those leaves instead of the
+    parameters (train.GraphedTrainStep: fresh leaves have no gradient accumulator bound to another stream)."""
+    def A(t):
+        return t if alias is None else alias.get(id(t), t)
+
     from . import ensemble
     _lib.require_device(x)
     kind = train_path_ok(net, x)
@@ -335,19 +340,19 @@ def mc_logits_autograd(net, x, draws, seed, call0):
         mus, rhos = [], []
         for l in layers:
             m, r, _ = l._param_lists()
-            mus += m
-            rhos += r
+            mus += [A(t) for t in m]
+            rhos += [A(t) for t in r]
         kl, s2 = ops.kl_only(mus, rhos, layers[0].prior_mu, layers[0].prior_sigma, want_sigma=True, sigma_squared=True)
         flat = []
         for li, l in enumerate(layers):
-            flat += [l.W_mu, s2[2 * li], l.bias_mu, s2[2 * li + 1]]
+            flat += [A(l.W_mu), s2[2 * li], A(l.bias_mu), s2[2 * li + 1]]
         cfg = dict(net=net, draws=int(draws), seed=seed, call0=call0)
         logits = _MCForwardLRT.apply(cfg, x, *flat)
         logits.bbb_cfg = cfg
         return logits, kl
     params = []
     for l in ensemble.bayesian_layers(net):
-        params += [l.W_mu, l.W_rho, l.bias_mu, l.bias_rho]
+        params += [A(l.W_mu), A(l.W_rho), A(l.bias_mu), A(l.bias_rho)]
     cfg = dict(net=net, draws=int(draws), seed=seed, call0=call0)
     logits, kl = _MCForward.apply(cfg, x, *params)
     logits.bbb_cfg = cfg

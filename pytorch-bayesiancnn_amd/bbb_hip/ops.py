@@ -187,7 +187,7 @@ def lrt_conv2d_forward(x, w_mu, w_var, b_mu, b_var, seed, call0, stream_id, stri
     return y, am, av
 
 
-gemm_mode = "fp32"  # "fp16x2": the batch-innermost BBB GEMM launches (conv2d_chwn_forward) run their contraction on the 16-bit
+gemm_mode = "fp32"  # "fp16x2": the batch-innermost BBB GEMM launches of the INFERENCE ensemble path run their contraction on the 16-bit
                     # matrix pipe at fp32 accuracy (bbb_conv2d_chwn_f16x2_fwd: operands split into two fp16 pieces, three products,
                     # fp32 accumulation).  Opt-in: results agree with the fp32 kernel to rounding, not bit for bit; full accuracy for
                     # 1.2e-4 <= |w| < 64 and 2e-3 <= |x| < 1024 (csrc/pconv_f16x2.cuh: operand window).
@@ -240,12 +240,14 @@ def _desc_chwn(x, w, stride, padding, dilation, draws, x_shared, w_shared, act):
 
 
 def conv2d_chwn_forward(x, w, bias, stride=1, padding=0, dilation=1, act=None, out=None, units=None, n_units=None,
-                        x_per_slice=False, amax_in=None, amax_out=None):
+                        x_per_slice=False, amax_in=None, amax_out=None, f16x2=False):
     """Batch-innermost conv for the ensemble path.  x: [E|1, Cin, H, W, B] (B % 4 == 0); w: [E|1, Cout, Cin, kh, kw];
     bias [E|1, Cout] or None -> y [E, Cout, Ho, Wo, B].  Padding taps are skipped, not multiplied.
     Work units (ensemble sharding): units = (S, off), n_units = U output slabs; w / bias hold the weight sets of the draws
     the units touch, x is [U, ...] or, for a layer whose input is the same for every draw, the per-slice [S, Cin, H, W, Bs].
-    amax_in / amax_out (gemm_mode "fp16x2" only; AMAX_SLOTS device floats each): their maximum bounds max|x| and sets the
+    f16x2: this launch may run on the split-fp16 kernel when gemm_mode == "fp16x2" (the inference ensemble path passes True;
+    the role-swapped gradient launches of fast_train never do: their operands -- gradients of 1e-6 -- lie far below the operand
+    window of that kernel).  amax_in / amax_out (AMAX_SLOTS device floats each): their maximum bounds max|x| and sets the
     activation scale of the split; where this launch leaves max|y| (zeroed by the caller) -- see bbb_conv2d_chwn_f16x2_fwd."""
     require_device(x, w, bias)
     x, w = x.contiguous(), w.contiguous()
@@ -270,7 +272,7 @@ def conv2d_chwn_forward(x, w, bias, stride=1, padding=0, dilation=1, act=None, o
         y = out.view(shape)
     with on_device(x.device):
         ks, scr = _split_scratch(d, False, x.device)
-        if gemm_mode == "fp16x2" and ks == 1 and E * ho * wo * -(-w.shape[1] // 64) * -(-x.shape[4] // 128) >= f16x2_min_workgroups:
+        if f16x2 and gemm_mode == "fp16x2" and ks == 1 and E * ho * wo * -(-w.shape[1] // 64) * -(-x.shape[4] // 128) >= f16x2_min_workgroups:
             # (launches below ~256 workgroups stay on the fp32 kernel and its split contraction: measured faster there)
             require_device(amax_in, amax_out)
             for t in (amax_in, amax_out):

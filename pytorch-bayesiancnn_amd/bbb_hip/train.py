@@ -204,7 +204,10 @@ def train_step(net, optimizer, x, target, num_ens, beta, train_size, dp_group=No
         if st["streak"] > int(auto_graph["after"]) and not _python_hooks(net, optimizer):
             optimizer.make_capturable()
             g = GraphedTrainStep(net, optimizer, x, target, num_ens, beta, train_size, warmup=1)   # the warm-up IS this iteration
-            st["graphed"] = g
+            if g.graph is not None:
+                st["graphed"] = g
+            else:
+                st["streak"] = -(1 << 60)            # capture refused (stale gradient accumulators): launch by launch from here on
             return g.warm_loss.clone(), g.warm_log_outputs.clone(), g.warm_kl.clone()
     optimizer.zero_grad()
     log_outputs, kl = ensemble.mc_forward(net, x, num_ens, kl_mode="mean")
@@ -240,30 +243,60 @@ class GraphedTrainStep:
         self.seed, self.call0 = rng.next_calls(0)
         self.stream = torch.cuda.Stream(device=dev)
         self.stream.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(self.stream), rng.device_call_offset(self.counter):
-            for _ in range(max(1, int(warmup))):
-                self.opt.zero_grad(set_to_none=True)
-                self.warm_loss, self.warm_log_outputs, self.warm_kl = self._body()      # results of the last eager iteration
-                rng.next_calls(self.num_ens)
+        import warnings
+        with warnings.catch_warnings(record=True) as seen:
+            warnings.simplefilter("always")
+            with torch.cuda.stream(self.stream), rng.device_call_offset(self.counter):
+                for _ in range(max(1, int(warmup))):
+                    self.opt.zero_grad(set_to_none=True)
+                    self.warm_loss, self.warm_log_outputs, self.warm_kl = self._body()      # results of the last eager iteration
+                    rng.next_calls(self.num_ens)
         self._next_call = rng.next_calls(0)[1]
         torch.cuda.current_stream(dev).wait_stream(self.stream)
         torch.cuda.synchronize(dev)
+        # A parameter's gradient accumulator from an earlier backward on ANOTHER stream, kept alive by a still-referenced
+        # non-detached output of that forward, makes autograd synchronise with that stream -- fine in the warm-up iterations above
+        # (torch warns), fatal inside a capture (observed: a segmentation fault in capture_end).  Refuse to capture instead.
+        self.capture_refused = next((str(w.message).split(".")[0] for w in seen if "AccumulateGrad node's stream" in str(w.message)), None)
+        for w in seen:
+            if "AccumulateGrad node's stream" not in str(w.message):
+                warnings.warn_explicit(w.message, w.category, w.filename, w.lineno)
+        self.graph = None
+        self.replays = 0
+        if self.capture_refused:
+            return
         self.graph = torch.cuda.CUDAGraph()
         self.opt.zero_grad(set_to_none=True)
         with rng.device_call_offset(self.counter), torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="thread_local"):
             self.loss, self.log_outputs, self.kl = self._body()
-        self.replays = 0
 
     def _body(self):
-        log_outputs, kl = ensemble._local_lse(self.net, self.x, self.num_ens, self.seed, self.call0, self.num_ens)
+        from . import fast_train
+        params = [p for g in self.opt.param_groups for p in g["params"] if p.requires_grad]
+        # The autograd graph of a captured step is rooted at FRESH leaves that share the parameters' storage, and differentiated
+        # with torch.autograd.grad: the parameters' own gradient accumulators never take part.  (One that an earlier backward
+        # created on another stream -- kept alive by a still-referenced, non-detached output of that forward -- makes autograd
+        # synchronise with that stream: harmless eagerly, a segmentation fault inside a capture.)  The batch-innermost training
+        # path takes the leaves as arguments; on the reference-layout path the layers read their own parameters, and the
+        # warm-up iteration's stream-mismatch warning is the (best-effort) signal to refuse the capture.
+        alias = None
+        if ensemble.fast_autograd and fast_train.train_path_ok(self.net, self.x):
+            alias = {id(p): p.detach().requires_grad_(True) for p in params}
+        log_outputs, kl = ensemble._local_lse(self.net, self.x, self.num_ens, self.seed, self.call0, self.num_ens, param_alias=alias)
         loss = elbo(log_outputs, self.target, kl, self.beta, self.train_size)      # kl of one forward = kl / num_ens of the sum
-        loss.backward()
+        leaves = params if alias is None else [alias[id(p)] for p in params]
+        grads = torch.autograd.grad(loss, leaves, allow_unused=True)
+        for p, g in zip(params, grads):
+            p.grad = g                               # (captured: the tensor lives in the graph's pool; replays rewrite it in place)
         self.counter.add_(self.num_ens)              # after backward: it regenerates eps from the same counter value
         self.opt.step()
         return loss.detach(), log_outputs.detach(), kl.detach()
 
     def step(self, x=None, target=None, beta=None):
         from . import rng
+        if self.graph is None:
+            raise _lib.BBBHipError("this step was not captured: " + str(self.capture_refused) + " (drop the references to the "
+                                   "outputs of earlier non-detached forwards, then build the GraphedTrainStep again)")
         if x is not None:
             self.x.copy_(x, non_blocking=True)
         if target is not None:

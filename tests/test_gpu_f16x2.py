@@ -61,7 +61,7 @@ def test_f16x2_launch_vs_oracle_and_fp32_kernel(env, f16x2, every_launch, B, Cin
     x = torch.randn(1 if xs else E, Cin, H, W, B, device="cuda") * xscale
     w = torch.randn(E, Cout, Cin, k, k, device="cuda") * wscale
     bias = torch.randn(E, Cout, device="cuda") * (xscale * wscale)
-    y = ops.conv2d_chwn_forward(x, w, bias, s, p, d, act=None)
+    y = ops.conv2d_chwn_forward(x, w, bias, s, p, d, act=None, f16x2=True)
     ops.gemm_mode = "fp32"
     y32 = ops.conv2d_chwn_forward(x, w, bias, s, p, d, act=None)
     worst = worst32 = 0.0
@@ -131,8 +131,8 @@ def test_f16x2_activation_scale_follows_the_data(env, f16x2, every_launch):
     amax_in = torch.zeros(ops.AMAX_SLOTS, device="cuda")
     amax_in[5] = x.abs().max()                                    # the bound is the maximum over the slots
     amax_out = torch.zeros(ops.AMAX_SLOTS, device="cuda")
-    y_fix = ops.conv2d_chwn_forward(x, w, bias, 1, 2, 1, act=None)
-    y_dyn = ops.conv2d_chwn_forward(x, w, bias, 1, 2, 1, act=None, amax_in=amax_in, amax_out=amax_out)
+    y_fix = ops.conv2d_chwn_forward(x, w, bias, 1, 2, 1, act=None, f16x2=True)
+    y_dyn = ops.conv2d_chwn_forward(x, w, bias, 1, 2, 1, act=None, amax_in=amax_in, amax_out=amax_out, f16x2=True)
     assert float(amax_out.max()) == float(y_dyn.abs().max())
     errs = {}
     for name, y in (("fixed", y_fix), ("dynamic", y_dyn)):
@@ -163,3 +163,27 @@ def test_f16x2_model_with_tiny_inputs(env, f16x2):
         env["rng"].manual_seed(3, call=0)
         lo32, kl32 = ens.mc_forward(net, x, 10)
     assert float((lo - lo32).abs().max()) <= 1e-5 * float(lo32.abs().max())
+
+
+def test_f16x2_mode_leaves_training_on_the_fp32_kernel(env, f16x2):
+    """Gradients are 1e-6-sized operands, far below the split's operand window: the training path (forward and role-swapped
+    backward launches of fast_train) ignores the mode -- same gradients, bit for bit, as in fp32 mode."""
+    import torch.nn.functional as F
+    ens, ops = env["ens"], env["ops"]
+    torch.manual_seed(0)
+    net = env["zoo"].getModel("alexnet", 3, 10, P.CONFIG_PRIORS, "bbb", "softplus").cuda()
+    env["rng"].assign_stream_ids(net)
+    x = torch.rand(512, 3, 32, 32, device="cuda")
+    y = torch.randint(0, 10, (512,), device="cuda")
+    grads = {}
+    for mode in ("fp16x2", "fp32"):
+        ops.gemm_mode = mode
+        net.zero_grad(set_to_none=True)
+        env["rng"].manual_seed(5, call=0)
+        lo, kl = ens.mc_forward(net, x, 4, kl_mode="mean")
+        assert ens.stats["path"] == "chwn-autograd"
+        (F.nll_loss(lo, y) * 50000.0 + 0.1 * kl).backward()
+        grads[mode] = [p.grad.detach().clone() for p in net.parameters()]
+        del lo, kl
+    for a, b in zip(grads["fp16x2"], grads["fp32"]):
+        assert torch.equal(a, b)

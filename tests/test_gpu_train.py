@@ -223,3 +223,35 @@ def test_train_step_captures_itself_and_keeps_the_eager_sequence(env, layer_type
         T.train_step(net_g, opt_g, x, y, E, beta, n)
     assert T._auto[net_g]["graphed"] is None
     h.remove()
+
+
+def test_train_step_captures_despite_stale_gradient_accumulators(env):
+    """A non-detached output of an earlier forward + backward on the default stream is still referenced: its graph keeps the
+    parameters' gradient accumulators (bound to that stream) alive, and a capture on another stream that reached them would make
+    autograd synchronise with it (observed: a segmentation fault inside capture_end).  The captured step is rooted at fresh
+    leaves sharing the parameters' storage, so the capture goes through and reproduces the launch-by-launch sequence."""
+    import torch.nn.functional as F
+    T = env["train"]
+    x = torch.rand(32, 1, 32, 32, device="cuda")
+    y = torch.randint(0, 10, (32,), device="cuda")
+    keep = []
+
+    def run(graph):
+        torch.manual_seed(3)
+        net = env["zoo"].BBBLeNet(10, 1, P.CONFIG_PRIORS, "bbb", "softplus").cuda()
+        env["rng"].assign_stream_ids(net)
+        env["rng"].manual_seed(9, call=0)
+        lo, kl = env["ens"].mc_forward(net, x, 2, kl_mode="mean")
+        (F.nll_loss(lo, y) + 1e-3 * kl).backward()              # lo / kl stay referenced (keep)
+        keep.append((lo, kl))
+        opt = T.FusedAdam(net.parameters(), lr=1e-3)
+        losses = [T.train_step(net, opt, x, y, 2, 0.1, 1000.0, graph=graph)[0].item() for _ in range(8)]
+        return net, losses
+
+    net_e, eager = run(False)
+    net_g, auto = run(None)
+    assert T._auto[net_g]["graphed"] is not None
+    np.testing.assert_allclose(auto, eager, rtol=2e-5)
+    for a, b in zip(net_e.parameters(), net_g.parameters()):
+        np.testing.assert_allclose(b.detach().cpu().numpy(), a.detach().cpu().numpy(), rtol=2e-5, atol=1e-7)
+    assert all(lo.requires_grad for lo, _ in keep)
