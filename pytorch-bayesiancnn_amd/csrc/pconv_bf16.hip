@@ -586,6 +586,7 @@ int launch_shape(const PConvArgs& a, int shape, int kgs, bool ws, int64_t blocks
         return kgs == 2 ? launch_cfg<OUT_F32, 1, 4, 2, false>(a, blocks, st) : launch_cfg<OUT_F32, 1, 4, 1, false>(a, blocks, st);
     }
     if (ws) return launch_cfg<OUT_F32, 1, 2, 1, true>(a, blocks, st);
+    if (kgs == 4) return launch_cfg<OUT_F32, 1, 2, 4, false>(a, blocks, st);
     return kgs == 2 ? launch_cfg<OUT_F32, 1, 2, 2, false>(a, blocks, st) : launch_cfg<OUT_F32, 1, 2, 1, false>(a, blocks, st);
 }
 
@@ -712,6 +713,13 @@ extern "C" int bbb_conv2d_chwn_bf16_fwd(const bbb_conv_desc_t* d, const void* x,
     const double c14 = 288.0 * waste(a.Cout, 64) * waste(a.B, 256);
     const double c12 = 320.0 * waste(a.Cout, 64) * waste(a.B, 128);
     int shape = (c22 <= c14 && c22 <= c12) ? 22 : (c14 <= c12 ? 14 : 12);
+    // A handful of workgroups with a long row (a 1000 -> 10 classifier: ONE 64 x 256 tile per draw, 16 tiles of k) is nothing
+    // but the serial k loop: take the two-wave 64 x 128 shape, whose small stage leaves room for FOUR k-groups per workgroup
+    // (each with its own stage and loads in flight; 3Conv3FC fc3, four draws: 20.7 -> see profiles/r03_notes.md section 10).
+    const int t64_all = (int)((K + BK - 1) / BK);
+    const bool tiny = a.Cout <= 64 && t64_all >= 16 &&
+                      (int64_t)d->draws * ho * wo * ((a.Cout + 63) / 64) * ((a.B + 127) / 128) < 64;
+    if (tiny) shape = 12;
     const int bn = shape == 22 ? 128 : 64, bm = shape == 14 ? 256 : 128;
     a.Ntiles = (a.Cout + bn - 1) / bn;
     a.G = a.Ntiles * d->draws;
@@ -728,6 +736,7 @@ extern "C" int bbb_conv2d_chwn_bf16_fwd(const bbb_conv_desc_t* d, const void* x,
     // fill the chip with workgroups and the k loop is long: then per-tile latency, not LDS throughput, sets the pace
     const int t64 = (int)((K + BK - 1) / BK);
     int kgs = (items < 512 && t64 >= 8) ? 2 : 1;
+    if (tiny) kgs = 4;
     // wave specialisation pays when few workgroups are resident per CU (nothing else hides the staging phases); measured
     // on AlexNet bs=512 E=10: conv3 31.7 -> 23.2 us, conv4 46.5 -> 33.3, conv5 18.2 -> 16.8, but conv1 / conv2 (1280+
     // workgroups, or the 64x256 shape whose two stages leave one workgroup per CU) 20-30 % slower

@@ -51,6 +51,7 @@ CONV_CASES = [
     (8, 64, 4, 4, 64, 5, 1, 2, 1, 1, True),         # K = 1600: seven decode chunks
     (16, 24, 5, 7, 40, 3, 1, 1, 1, 2, False),       # cin = 24: 64-k tiles straddle taps in the tap-major order
     (264, 384, 2, 2, 256, 3, 1, 1, 1, 1, False),    # AlexNet conv4 shape: 4 of 9 taps in bounds
+    (136, 1040, 1, 1, 10, 1, 1, 0, 1, 2, False),    # a classifier with a long row: a handful of workgroups, FOUR k-groups each
 ]
 
 
