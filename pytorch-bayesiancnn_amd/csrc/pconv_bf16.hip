@@ -22,6 +22,7 @@
 // LDS pitches: image rows 320 B (= 64 B mod 256: the four rows of a transpose read and the two 16-column halves of a
 // 32-lane group land on disjoint banks), weight rows 144 B (conflict-free for the 16-byte reads).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 
 #include "../../include/bbb_hip.h"
@@ -713,12 +714,13 @@ extern "C" int bbb_conv2d_chwn_bf16_fwd(const bbb_conv_desc_t* d, const void* x,
     const double c14 = 288.0 * waste(a.Cout, 64) * waste(a.B, 256);
     const double c12 = 320.0 * waste(a.Cout, 64) * waste(a.B, 128);
     int shape = (c22 <= c14 && c22 <= c12) ? 22 : (c14 <= c12 ? 14 : 12);
-    // A handful of workgroups with a long row (a 1000 -> 10 classifier: ONE 64 x 256 tile per draw, 16 tiles of k) is nothing
-    // but the serial k loop: take the two-wave 64 x 128 shape, whose small stage leaves room for FOUR k-groups per workgroup
-    // (each with its own stage and loads in flight; 3Conv3FC fc3, four draws: 20.7 -> see profiles/r03_notes.md section 10).
+    // Few workgroups with long rows (a 1000 -> 10 classifier: ONE 64 x 256 tile per draw, 16 tiles of k; AlexNet's conv3-5 at one
+    // draw) are nothing but their serial k loops: take the two-wave 64 x 128 shape, whose small stage leaves room for FOUR
+    // k-groups per workgroup, each with its own stage and loads in flight (measured, profiles/r03_notes.md section 10: fc3 of
+    // 3Conv3FC 20.7 -> 16.5 us, fc2 15.7 -> 14.6, AlexNet one draw conv2 19.0 -> 15.6, conv4 20.3 -> 18.4, conv5 15.4 -> 14.2).
     const int t64_all = (int)((K + BK - 1) / BK);
-    const bool tiny = a.Cout <= 64 && t64_all >= 16 &&
-                      (int64_t)d->draws * ho * wo * ((a.Cout + 63) / 64) * ((a.B + 127) / 128) < 64;
+    const int64_t items12 = (int64_t)d->draws * ho * wo * ((a.Cout + 63) / 64) * ((a.B + 127) / 128);
+    const bool tiny = t64_all >= 16 && items12 < 256;
     if (tiny) shape = 12;
     const int bn = shape == 22 ? 128 : 64, bm = shape == 14 ? 256 : 128;
     a.Ntiles = (a.Cout + bn - 1) / bn;
