@@ -63,7 +63,13 @@ def test_unit_sharding_matches_single_device(env, net_type, lt, ncls, B, E, worl
             assert tuple(logits.shape) == (hi - lo, ncls, Bs)
             for e, u in enumerate(range(lo, hi)):                       # every unit = the matching slice of the matching draw
                 j, s = divmod(u, S)
-                assert torch.equal(logits[e], full[j][:, s * Bs:(s + 1) * Bs]), (r, u)
+                ref = full[j][:, s * Bs:(s + 1) * Bs]
+                if precision == "bf16":
+                    # the bf16 launcher picks tile shape and k-groups by launch size (a rank's share is a smaller launch): the
+                    # fp32 summation order differs, a hidden activation on a rounding boundary flips by one bf16 ulp
+                    assert float((logits[e] - ref).abs().max()) <= 2e-2 * float(ref.abs().max()), (r, u)
+                else:
+                    assert torch.equal(logits[e], ref), (r, u)
             covered += hi - lo
             assert kl1.item() == kl_full.item()
             lse, _ = ens._local_lse(net, x, E, seed, call0, 0, precision=precision, units=(S, lo, hi))
@@ -72,7 +78,10 @@ def test_unit_sharding_matches_single_device(env, net_type, lt, ncls, B, E, worl
         assert covered == E * S
         got = torch.logsumexp(torch.stack(blocks), 0) - math.log(E)
     # log-probabilities reach -150 here: 1 fp32 ulp = 1.5e-5; the only difference is the order of the log-sum-exp
-    np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=5e-7, atol=3e-6)
+    if precision == "bf16":
+        np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=0, atol=2e-2 * float(want.abs().max()))
+    else:
+        np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=5e-7, atol=3e-6)
     assert abs(kl_sum - E * kl_full.item()) <= 1e-6 * E * kl_full.item()
 
 
