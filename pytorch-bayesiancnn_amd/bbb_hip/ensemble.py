@@ -340,12 +340,14 @@ def _chwn_mods_ok(mods):
 
 
 def _check_precision(precision, net, x, fast_path_allowed):
-    """precision: "fp32" (the reference's arithmetic, default) or "bf16" (bf16 storage of sampled weights and
-    activations, fp32 accumulate; inference on the batch-innermost path only -- anything else fails loudly)."""
-    if precision == "fp32":
+    """precision: "fp32" (the reference's arithmetic, default); "fp16x2" (fp32 tensors and fp32 accuracy, the BBB GEMM launches of
+    the batch-innermost inference path on the 16-bit matrix pipe -- split-fp16, ops.gemm_mode -- everything else as fp32); or
+    "bf16" (bf16 storage of sampled weights and activations, fp32 accumulate; inference on the batch-innermost path only --
+    anything else fails loudly)."""
+    if precision in ("fp32", "fp16x2"):
         return
     if precision != "bf16":
-        raise _lib.BBBHipError(f"precision must be 'fp32' or 'bf16', got {precision!r}")
+        raise _lib.BBBHipError(f"precision must be 'fp32', 'fp16x2' or 'bf16', got {precision!r}")
     if not fast_path_allowed or not _chwn_ok(net, x):
         raise _lib.BBBHipError("bf16 runs on the batch-innermost inference path only (no autograd, no external eps, "
                                "4-d input with B % 8 == 0, BBB layers + ReLU/Softplus/MaxPool2d/FlattenLayer)")
@@ -405,7 +407,7 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
 
     # split-fp16 GEMM mode: the activation scale of every layer's split follows the data -- max|x| of the input here, then each
     # GEMM launch publishes max|y| for the next one (bbb_conv2d_chwn_f16x2_fwd; device scalars, no host sync)
-    f16x2 = ops.gemm_mode == "fp16x2" and not bf16 and bool(bbb)
+    f16x2 = (precision == "fp16x2" or ops.gemm_mode == "fp16x2") and not bf16 and bool(bbb)
     amax0 = x.detach().abs().amax().expand(ops.AMAX_SLOTS).contiguous() if f16x2 else None
 
     def run(e0, e1):
@@ -657,7 +659,7 @@ def mc_logits(net, x, draws, seed, call0, fuse_act=True, timers=None, eps=None, 
         out = _mc_logits_chwn(net, x, draws, seed, call0, timers, streams, precision)
         if out is not None:
             return out[0].permute(0, 2, 1).contiguous(), out[1]      # API layout [E, B, C]
-    if precision != "fp32":
+    if precision == "bf16":
         raise _lib.BBBHipError("this model / input does not fit the batch-innermost path, which is the only bf16 path")
     if flat_children(net) is None:
         return _loop_logits(net, x, draws, seed, call0, eps)
@@ -779,7 +781,7 @@ def _local_lse(net, x, draws, seed, call0, mean_over, fuse_act=True, timers=None
             return lse, out[1]
     if b_offset:
         raise _lib.BBBHipError("a batch offset needs the batch-innermost inference path (checked: this model / input does not fit it)")
-    if precision != "fp32":
+    if precision == "bf16":
         raise _lib.BBBHipError("this model / input does not fit the batch-innermost path, which is the only bf16 path")
     if fuse_act and fast_autograd and torch.is_grad_enabled() and timers is None:
         from . import fast_train

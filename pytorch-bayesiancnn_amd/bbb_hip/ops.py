@@ -245,7 +245,8 @@ def conv2d_chwn_forward(x, w, bias, stride=1, padding=0, dilation=1, act=None, o
     bias [E|1, Cout] or None -> y [E, Cout, Ho, Wo, B].  Padding taps are skipped, not multiplied.
     Work units (ensemble sharding): units = (S, off), n_units = U output slabs; w / bias hold the weight sets of the draws
     the units touch, x is [U, ...] or, for a layer whose input is the same for every draw, the per-slice [S, Cin, H, W, Bs].
-    f16x2: this launch may run on the split-fp16 kernel when gemm_mode == "fp16x2" (the inference ensemble path passes True;
+    f16x2: this launch may run on the split-fp16 kernel (the inference ensemble path passes True under precision="fp16x2" /
+    gemm_mode == "fp16x2";
     the role-swapped gradient launches of fast_train never do: their operands -- gradients of 1e-6 -- lie far below the operand
     window of that kernel).  amax_in / amax_out (AMAX_SLOTS device floats each): their maximum bounds max|x| and sets the
     activation scale of the split; where this launch leaves max|y| (zeroed by the caller) -- see bbb_conv2d_chwn_f16x2_fwd."""
@@ -272,7 +273,7 @@ def conv2d_chwn_forward(x, w, bias, stride=1, padding=0, dilation=1, act=None, o
         y = out.view(shape)
     with on_device(x.device):
         ks, scr = _split_scratch(d, False, x.device)
-        if f16x2 and gemm_mode == "fp16x2" and ks == 1 and E * ho * wo * -(-w.shape[1] // 64) * -(-x.shape[4] // 128) >= f16x2_min_workgroups:
+        if f16x2 and ks == 1 and E * ho * wo * -(-w.shape[1] // 64) * -(-x.shape[4] // 128) >= f16x2_min_workgroups:
             # (launches below ~256 workgroups stay on the fp32 kernel and its split contraction: measured faster there)
             require_device(amax_in, amax_out)
             for t in (amax_in, amax_out):

@@ -187,3 +187,28 @@ def test_f16x2_mode_leaves_training_on_the_fp32_kernel(env, f16x2):
         del lo, kl
     for a, b in zip(grads["fp16x2"], grads["fp32"]):
         assert torch.equal(a, b)
+
+
+def test_precision_argument_selects_the_mode(env):
+    """precision="fp16x2" on the ensemble entry points == ops.gemm_mode = "fp16x2" (same bits), graph replay included."""
+    ens, ops = env["ens"], env["ops"]
+    torch.manual_seed(0)
+    net = env["zoo"].getModel("alexnet", 3, 10, P.CONFIG_PRIORS, "bbb", "softplus").cuda()
+    env["rng"].assign_stream_ids(net)
+    x = torch.rand(512, 3, 32, 32, device="cuda")
+    with torch.no_grad():
+        env["rng"].manual_seed(3, call=0)
+        a, _ = ens.mc_forward(net, x, 10, precision="fp16x2")
+        env["rng"].manual_seed(3, call=0)
+        g = ens.GraphedMC(net, x, 10, precision="fp16x2")
+        b, _ = g.step()
+        torch.cuda.synchronize()
+        ops.gemm_mode = "fp16x2"
+        try:
+            env["rng"].manual_seed(3, call=0)
+            c, _ = ens.mc_forward(net, x, 10)
+        finally:
+            ops.gemm_mode = "fp32"
+        env["rng"].manual_seed(3, call=0)
+        d, _ = ens.mc_forward(net, x, 10)
+    assert torch.equal(a, b) and torch.equal(a, c) and not torch.equal(a, d)
