@@ -641,6 +641,9 @@ def main():
                     help="independent MC steps in flight (hipGraph lanes on separate streams); default 3, and 4 when N > 1 "
                          "(a rank's share of a step is a few small launches: measured 124 vs 140 us per step for the 8-rank share)")
     ap.add_argument("--config", default="metric", choices=list(CONFIGS), help="which BASELINE configuration is the reported value")
+    ap.add_argument("--gemm-mode", default="fp32", choices=["fp32", "fp16x2"],
+                    help="fp16x2: the opt-in split-fp16 GEMM mode for the WHOLE run (profiling it, or timing a sharded run with it); the "
+                         "default run reports it as the secondary object `split_fp16` next to the fp32 headline")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -683,8 +686,9 @@ def main():
             dist.init_process_group(backend)
         group = dist.group.WORLD
 
-    from bbb_hip import ensemble, _lib
+    from bbb_hip import ensemble, _lib, ops
     _lib.lib()   # fail loudly here if the HIP library is missing
+    ops.gemm_mode = args.gemm_mode
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.no_extras:
@@ -731,7 +735,9 @@ def main():
             "value": head["value"], "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "bf16" if cfg["precision"] == "bf16" else "f32", "data": "synthetic",
+            "dtype": "bf16" if cfg["precision"] == "bf16" else
+                     ("f32" if args.gemm_mode == "fp32" else "f32 tensors; GEMM products as 3 x f16 (hi/lo split), f32 accumulate"),
+            "data": "synthetic",
             "config": {"workload": cfg["what"] + ", forward only (main_bayesian.py:73-80)",
                        "global_batch": cfg["B"], "num_ens_total": cfg["E"],
                        "parallelism": ("mc-ensemble work units: %d batch slices per draw, %d (draw x slice) units of %d images, "
@@ -781,7 +787,8 @@ def main():
                 out["dropin_loop"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:160])}
             if cfg is CONFIGS["metric"]:
                 try:
-                    out["split_fp16"] = split_fp16(dev, max(20, args.steps // 2), max(1, args.pipeline))
+                    if args.gemm_mode == "fp32":
+                        out["split_fp16"] = split_fp16(dev, max(20, args.steps // 2), max(1, args.pipeline))
                 except Exception as exc:
                     out["split_fp16"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:160])}
             try:
