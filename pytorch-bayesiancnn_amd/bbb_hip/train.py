@@ -148,7 +148,39 @@ def elbo(log_outputs, target, kl, beta, train_size):
 
 
 auto_graph = {"enabled": True, "after": 3}      # train_step captures itself once this many identical calls in a row were seen
-_auto = weakref.WeakKeyDictionary()              # net -> {"key", "streak", "graphed"}
+
+
+
+class _AutoState(dict):
+    """Per-net self-capture state; copies and pickles of the net do not take it along (a captured graph belongs to one module)."""
+
+    def __deepcopy__(self, memo):
+        return _AutoState()
+
+    def __reduce__(self):
+        return (_AutoState, ())
+
+
+class _AutoStates:
+    """net -> {"key", "streak", "graphed"}, kept ON the module (net.__dict__): the captured step references its net, so a
+    WeakKeyDictionary entry would keep its own key alive for ever; a net -> state -> step -> net cycle is ordinary garbage."""
+
+    @staticmethod
+    def get(net, default=None):
+        return net.__dict__.get("_bbb_train_auto") or default        # (an empty state = a copied net's placeholder)
+
+    def __getitem__(self, net):
+        return net.__dict__["_bbb_train_auto"]
+
+    def __setitem__(self, net, st):
+        net.__dict__["_bbb_train_auto"] = _AutoState(st)
+
+    @staticmethod
+    def pop(net, default=None):
+        return net.__dict__.pop("_bbb_train_auto", default)
+
+
+_auto = _AutoStates()
 
 
 def _python_hooks(net, optimizer):
@@ -191,9 +223,9 @@ def train_step(net, optimizer, x, target, num_ens, beta, train_size, dp_group=No
     key = _auto_key(net, optimizer, x, target, num_ens, train_size) if (graph is not False and dp_group is None) else None
     st = _auto.get(net)
     if key is None or st is None or st["key"] != key:
-        st = {"key": key, "streak": 0, "graphed": None}
         if key is not None:
-            _auto[net] = st
+            _auto[net] = {"key": key, "streak": 0, "graphed": None}
+            st = _auto[net]
         else:
             _auto.pop(net, None)
     if key is not None:

@@ -92,6 +92,14 @@ class _Spec:
         self.last_streak = 0
         self.batches = 0
 
+    # the cache lives on the wrapper (wrapper.__dict__): copies / pickles of the model (copy.deepcopy, torch.save(net)) start with
+    # an empty one instead of dragging cached draws and a weak reference along
+    def __deepcopy__(self, memo):
+        return _Spec()
+
+    def __reduce__(self):
+        return (_Spec, ())
+
 
 def _hooks_present(wrapper, mods):
     import torch.nn.modules.module as _m

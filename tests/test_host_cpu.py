@@ -603,3 +603,39 @@ def test_fused_adam_state_dict_is_torch_adams():
     sd["param_groups"][0]["lr"] = 5e-4
     opt.load_state_dict(sd)
     assert opt.param_groups[0]["lr"] == 5e-4 and opt._lr_dev == {}
+
+
+def test_self_capture_state_does_not_travel_with_copies_of_the_net():
+    """train_step keeps its per-net capture state on the module; deepcopy / pickle of the net must not try to copy a hipGraph."""
+    import copy
+    import pickle
+    import torch
+    from bbb_hip import train
+    net = torch.nn.Linear(3, 2)
+    train._auto[net] = {"key": ("k",), "streak": 2, "graphed": object()}
+    assert train._auto.get(net)["streak"] == 2
+    twin = copy.deepcopy(net)
+    assert train._auto.get(twin) is None and train._auto.get(net)["streak"] == 2
+    back = pickle.loads(pickle.dumps(net))
+    assert train._auto.get(back) is None
+    train._auto.pop(net)
+    assert train._auto.get(net) is None
+
+
+def test_speculation_cache_does_not_travel_with_copies_of_the_net():
+    import copy
+    import pickle
+    import weakref
+    import torch
+    import layers  # noqa: F401
+    from layers import _fused
+    from bbb_hip import zoo
+    net = zoo.getModel("lenet", 1, 10, P.CONFIG_PRIORS, "bbb", "softplus")
+    sp = net.__dict__["_bbb_spec"] = _fused._Spec()
+    x = torch.zeros(2)
+    sp.xref, sp.logits, sp.streak = weakref.ref(x), torch.ones(3), 5
+    twin = copy.deepcopy(net)
+    assert twin.__dict__["_bbb_spec"].logits is None and twin.__dict__["_bbb_spec"].streak == 0
+    back = pickle.loads(pickle.dumps(net))                      # (a weak reference cannot be pickled)
+    assert back.__dict__["_bbb_spec"].xref is None
+    assert sp.streak == 5
