@@ -628,6 +628,7 @@ def test_speculation_cache_does_not_travel_with_copies_of_the_net():
     import weakref
     import torch
     import layers  # noqa: F401
+    import ref_port_torch as P
     from layers import _fused
     from bbb_hip import zoo
     net = zoo.getModel("lenet", 1, 10, P.CONFIG_PRIORS, "bbb", "softplus")
