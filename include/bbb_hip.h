@@ -201,11 +201,12 @@ int bbb_conv2d_chwn_fwd(const bbb_conv_desc_t* d, const float* x, const float* w
  * Operands are pre-scaled by powers of two while they are split (fp16 subnormal pieces are flushed by the matrix instruction):
  * weights by 2^10 (full accuracy for 1.2e-4 <= |w| < 64); activations by 2^6 (2e-3 <= |x| < 1024) or, when x_amax is given
  * (BBB_AMAX_SLOTS device floats whose maximum is an upper bound of max|x|; NULL / all zero = unknown), by the power of two that
- * puts that bound just under 2^14.  y_amax (BBB_AMAX_SLOTS device floats, NULL = skip; zero them before the launch): receive
- * max|y| of this launch, spread over the slots -- the next layer's x_amax. */
+ * puts that bound just under 2^14; w_amax: the same for the weights (for sampled weights max(|mu| + 6.66 sigma) is a bound that
+ * needs no pass over them).  y_amax (BBB_AMAX_SLOTS device floats, NULL = skip; zero them before the launch): receive max|y| of
+ * this launch, spread over the slots -- the next layer's x_amax. */
 #define BBB_AMAX_SLOTS 64
 int bbb_conv2d_chwn_f16x2_fwd(const bbb_conv_desc_t* d, const float* x, const float* w, const float* bias, float* y,
-                              const float* x_amax, float* y_amax, void* stream);
+                              const float* x_amax, const float* w_amax, float* y_amax, void* stream);
 int bbb_lrt_conv2d_chwn_fwd(const bbb_conv_desc_t* d, const float* x, const float* w_mu, const float* w_var,
                             const float* b_mu, const float* b_var, float* y,
                             float* act_mu_out, float* act_var_out, const float* eps_ext,

@@ -459,8 +459,10 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
                         if timers is not None else None
                     dst = logits_buf[e0:e1] if (logits_buf is not None and i == last_bayes and not is_conv) else None
                     a_out = torch.zeros(ops.AMAX_SLOTS, dtype=torch.float32, device=x.device) if (f16x2 and i != last_bayes) else None
-                    y = _run(timers, "conv_gemm", fl, lambda h5=h5, w=w, b=b, geom=geom, act=act, dst=dst, ukw2=ukw2, a_in=amax, a_out=a_out:
-                             ops.conv2d_chwn_forward(h5, w, b, *geom, act=act, out=dst, amax_in=a_in, amax_out=a_out, f16x2=f16x2, **ukw2))
+                    a_w = _weight_bound(mod) if f16x2 else None
+                    y = _run(timers, "conv_gemm", fl, lambda h5=h5, w=w, b=b, geom=geom, act=act, dst=dst, ukw2=ukw2, a_in=amax, a_out=a_out, a_w=a_w:
+                             ops.conv2d_chwn_forward(h5, w, b, *geom, act=act, out=dst, amax_in=a_in, amax_out=a_out, amax_w=a_w,
+                                                     f16x2=f16x2, **ukw2))
                     amax = a_out                     # (max-pooling in between keeps it an upper bound)
                 else:
                     w_var, b_var = variances[mod]
@@ -625,6 +627,23 @@ def _lane_streams(device, n):
             torch.zeros(1, device=device)
         pool.append(st)
     return pool[:n]
+
+
+def _weight_bound(layer):
+    """AMAX_SLOTS device floats bounding max|w| of every weight set the layer can sample: max(|W_mu| + 6.66 softplus(W_rho)) --
+    Box-Muller on 32-bit uniforms cannot exceed sqrt(-2 ln 2^-32) = 6.66 -- the split-fp16 GEMM's weight scale
+    (bbb_conv2d_chwn_f16x2_fwd).  ONE persistent buffer per layer, rewritten in place when the parameters' versions or storage
+    change: a captured step keeps reading the same address, and GraphedMC.step() calls this before every replay."""
+    mu, rho = layer.W_mu, layer.W_rho
+    key = (mu._version, rho._version, mu.data_ptr(), rho.data_ptr())
+    st = layer.__dict__.get("_bbb_w_bound")
+    if st is None or st[1].device != mu.device:
+        st = layer.__dict__["_bbb_w_bound"] = [None, torch.zeros(ops.AMAX_SLOTS, dtype=torch.float32, device=mu.device)]
+    if st[0] != key:
+        with torch.no_grad():
+            st[1].copy_((mu.detach().abs() + 6.66 * F.softplus(rho.detach())).amax().expand(ops.AMAX_SLOTS))
+        st[0] = key
+    return st[1]
 
 
 def _loop_logits(net, x, draws, seed, call0, eps=None):
@@ -925,6 +944,8 @@ class GraphedMC:
                  precision="fp32", steps=1):
         _lib.require_device(x)
         self.steps, self.slot = int(steps), 0
+        self.f16x2_layers = [l for l in bayesian_layers(net) if isinstance(l, _BBBLayer)] \
+            if (precision == "fp16x2" or ops.gemm_mode == "fp16x2") else []
         if self.steps > 1:
             if int(num_ens) != 1 or group is not None:
                 raise _lib.BBBHipError("steps > 1 batches ONE-draw steps of a single process (num_ens == 1, no group)")
@@ -1039,6 +1060,9 @@ class GraphedMC:
         producer = torch.cuda.current_stream(self.x.device) if (x is not None and self.own_stream) else None
         ctx = torch.cuda.stream(self.stream) if self.own_stream else _null_ctx()
         with ctx:
+            if self.f16x2_layers:
+                for l in self.f16x2_layers:          # split-fp16 weight scales follow the parameters (host-side version check)
+                    _weight_bound(l)
             if self.steps > 1:
                 g, B = self.slot, self.B
                 if x is not None:

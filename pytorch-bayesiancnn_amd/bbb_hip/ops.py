@@ -240,7 +240,7 @@ def _desc_chwn(x, w, stride, padding, dilation, draws, x_shared, w_shared, act):
 
 
 def conv2d_chwn_forward(x, w, bias, stride=1, padding=0, dilation=1, act=None, out=None, units=None, n_units=None,
-                        x_per_slice=False, amax_in=None, amax_out=None, f16x2=False):
+                        x_per_slice=False, amax_in=None, amax_out=None, f16x2=False, amax_w=None):
     """Batch-innermost conv for the ensemble path.  x: [E|1, Cin, H, W, B] (B % 4 == 0); w: [E|1, Cout, Cin, kh, kw];
     bias [E|1, Cout] or None -> y [E, Cout, Ho, Wo, B].  Padding taps are skipped, not multiplied.
     Work units (ensemble sharding): units = (S, off), n_units = U output slabs; w / bias hold the weight sets of the draws
@@ -248,8 +248,8 @@ def conv2d_chwn_forward(x, w, bias, stride=1, padding=0, dilation=1, act=None, o
     f16x2: this launch may run on the split-fp16 kernel (the inference ensemble path passes True under precision="fp16x2" /
     gemm_mode == "fp16x2";
     the role-swapped gradient launches of fast_train never do: their operands -- gradients of 1e-6 -- lie far below the operand
-    window of that kernel).  amax_in / amax_out (AMAX_SLOTS device floats each): their maximum bounds max|x| and sets the
-    activation scale of the split; where this launch leaves max|y| (zeroed by the caller) -- see bbb_conv2d_chwn_f16x2_fwd."""
+    window of that kernel).  amax_in / amax_w / amax_out (AMAX_SLOTS device floats each): bounds of max|x| / max|w| that set the
+    operand scales of the split; where this launch leaves max|y| (zeroed by the caller) -- see bbb_conv2d_chwn_f16x2_fwd."""
     require_device(x, w, bias)
     x, w = x.contiguous(), w.contiguous()
     bias = None if bias is None else bias.contiguous()
@@ -275,12 +275,13 @@ def conv2d_chwn_forward(x, w, bias, stride=1, padding=0, dilation=1, act=None, o
         ks, scr = _split_scratch(d, False, x.device)
         if f16x2 and ks == 1 and E * ho * wo * -(-w.shape[1] // 64) * -(-x.shape[4] // 128) >= f16x2_min_workgroups:
             # (launches below ~256 workgroups stay on the fp32 kernel and its split contraction: measured faster there)
-            require_device(amax_in, amax_out)
-            for t in (amax_in, amax_out):
+            require_device(amax_in, amax_out, amax_w)
+            for t in (amax_in, amax_out, amax_w):
                 if t is not None and (t.numel() != AMAX_SLOTS or not t.is_contiguous()):
                     raise _lib.BBBHipError("amax_in / amax_out must be contiguous tensors of %d floats" % AMAX_SLOTS)
             check(_lib.lib().bbb_conv2d_chwn_f16x2_fwd(ctypes.byref(d), x.data_ptr(), w.data_ptr(), ptr(bias), y.data_ptr(),
-                                                       ptr(amax_in), ptr(amax_out), cur_stream(x.device)), "bbb_conv2d_chwn_f16x2_fwd")
+                                                       ptr(amax_in), ptr(amax_w), ptr(amax_out), cur_stream(x.device)),
+                  "bbb_conv2d_chwn_f16x2_fwd")
             return y
         if ks > 1:
             check(_lib.lib().bbb_conv2d_chwn_splitk_fwd(ctypes.byref(d), x.data_ptr(), w.data_ptr(), ptr(bias), y.data_ptr(), ks,

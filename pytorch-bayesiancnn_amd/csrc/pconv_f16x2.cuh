@@ -26,20 +26,23 @@ namespace pconv {
 // degrade gracefully -- they are small, and lose at most 2^-11 of themselves.  Measured against the float64 oracle, Gaussian
 // tensors, error relative to sum|w||x|: typical |x| / |w| of 3 / 0.2 or 100 / 8 -> 1.2-2.4e-7 (the fp32 kernel: 1.3-3.9e-7);
 // 0.25 / 0.01 (a few per cent of the elements under the window) -> 0.4-3.2e-6; 0.004 / 0.0003 (typical magnitude under the
-// window) -> 1e-5..1e-4.  Elements above the window saturate at 65504 / scale instead of turning into inf.  The ACTIVATION scale
-// can follow the data (x_amax / y_amax below: every launch publishes max|y| for the next one); the weight scale is fixed.
-constexpr float kScaleW = 1024.0f, kScaleX = 64.0f, kUnscale = 1.0f / 65536.0f, kF16Max = 65504.0f;
+// window) -> 1e-5..1e-4.  Elements above the window saturate at 65504 / scale instead of turning into inf.  Both scales can follow
+// the data instead (x_amax / w_amax / y_amax below): every launch publishes max|y| for the next one, and sampled weights have an
+// analytic bound; the fixed scales are the fallback of callers that pass no bounds.
+constexpr float kF16Max = 65504.0f;          // (default scales: weights 2^10, activations 2^6 -- in the kernel)
 constexpr unsigned kAmaxSlots = 64;          // x_amax / y_amax are arrays of this many floats; their maximum is the bound
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef short f16s4 __attribute__((ext_vector_type(4)));
 
-// x_amax / y_amax (optional): 64 device floats whose maximum is an upper bound of max|x| -- the activation scale then becomes
-// the power of two that puts that bound just under 2^14 instead of the fixed 2^6 -- and 64 device floats into which this launch
-// max-reduces |y| (atomics on the bits of non-negative floats), i.e. the x_amax of the next layer: per-step, data-dependent,
-// deterministic.
+// x_amax / w_amax / y_amax (optional): 64 device floats whose maximum is an upper bound of max|x| (max|w|) -- that operand's scale
+// then becomes the power of two that puts the bound just under 2^14 instead of the fixed 2^6 (2^10) -- and 64 device floats into
+// which this launch max-reduces |y| (atomics on the bits of non-negative floats), i.e. the x_amax of the next layer: per-step,
+// data-dependent, deterministic.  (For sampled weights a bound that needs no pass over them: max(|mu| + 6.66 sigma) -- Box-Muller
+// on 32-bit uniforms cannot exceed sqrt(-2 ln 2^-32) = 6.66.)
 template <int MT>
-__global__ __launch_bounds__(kThreads) void pconv_f16x2_kernel(const PConvArgs p, const float* __restrict__ x_amax, float* __restrict__ y_amax) {
+__global__ __launch_bounds__(kThreads) void pconv_f16x2_kernel(const PConvArgs p, const float* __restrict__ x_amax,
+                                                               const float* __restrict__ w_amax, float* __restrict__ y_amax) {
     constexpr int BM = 128 * MT;
     constexpr int LDXH = BM + 32;              // 16-bit elements per image row: 64 B mod 256 -> the 4 rows of a transpose read hit disjoint banks
     constexpr int LDWH = BN + 32;              // 192 B: rows at 0 / 192 / 128 / 64 mod 256
@@ -86,17 +89,20 @@ __global__ __launch_bounds__(kThreads) void pconv_f16x2_kernel(const PConvArgs p
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave * 32 * MT;                                   // 4 waves side by side along the images, 64 channels each
 
-    float sx = kScaleX, unscale = kUnscale;
-    if (x_amax != nullptr) {
-        const uint32_t mb = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(uint32_t, bbb::wave_max(x_amax[lane])));
-        const int ef = (int)((mb >> 23) & 0xffu);                    // biased exponent: max|x| < 2^(ef - 126)
-        if (ef > 0 && ef < 255) {
-            int sh = 14 - (ef - 126);                                // max|x| * 2^sh < 2^14
-            sh = sh < -60 ? -60 : (sh > 60 ? 60 : sh);
-            sx = __builtin_bit_cast(float, (uint32_t)(127 + sh) << 23);
-            unscale = __builtin_bit_cast(float, (uint32_t)(127 - sh - 10) << 23);     // 1 / (sx * kScaleW), exact
-        }
-    }
+    // operand scales: fixed (2^6 / 2^10), or from a bound of the tensor's maximum: the power of two that puts it just under 2^14
+    int shx = 6, shw = 10;
+    auto shift_for = [&](const float* amax, int dflt) {
+        const uint32_t mb = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(uint32_t, bbb::wave_max(amax[lane])));
+        const int ef = (int)((mb >> 23) & 0xffu);                    // biased exponent: the maximum is < 2^(ef - 126)
+        if (ef == 0 || ef == 255) return dflt;                       // zero / inf / NaN: unknown
+        const int sh = 14 - (ef - 126);
+        return sh < -40 ? -40 : (sh > 40 ? 40 : sh);
+    };
+    if (x_amax != nullptr) shx = shift_for(x_amax, shx);
+    if (w_amax != nullptr) shw = shift_for(w_amax, shw);
+    const float sx = __builtin_bit_cast(float, (uint32_t)(127 + shx) << 23);
+    const float sw = __builtin_bit_cast(float, (uint32_t)(127 + shw) << 23);
+    const float unscale = __builtin_bit_cast(float, (uint32_t)(127 - shx - shw) << 23);      // 1 / (sx * sw), exact
 
     constexpr uint32_t kOOB = 0xFFFFFFF0u;
     constexpr uint32_t kWInv = 0x7FFFFFF0u;
@@ -163,7 +169,7 @@ __global__ __launch_bounds__(kThreads) void pconv_f16x2_kernel(const PConvArgs p
         f16x8 h, l;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const float v = __builtin_amdgcn_fmed3f(wreg[i] * kScaleW, -kF16Max, kF16Max);
+            const float v = __builtin_amdgcn_fmed3f(wreg[i] * sw, -kF16Max, kF16Max);
             h[i] = (_Float16)v;
             l[i] = (_Float16)(v - (float)h[i]);
         }

@@ -345,7 +345,7 @@ extern "C" int bbb_conv2d_chwn_fwd(const bbb_conv_desc_t* d, const float* x, con
 
 // bbb_conv2d_chwn_fwd with the contraction on the 16-bit matrix pipe at fp32 accuracy (pconv_f16x2.cuh)
 extern "C" int bbb_conv2d_chwn_f16x2_fwd(const bbb_conv_desc_t* d, const float* x, const float* w, const float* bias, float* y,
-                                         const float* x_amax, float* y_amax, void* stream) {
+                                         const float* x_amax, const float* w_amax, float* y_amax, void* stream) {
     PConvArgs a = {};
     const int rc = fill(d, a);
     if (rc != 0) return rc;
@@ -365,8 +365,8 @@ extern "C" int bbb_conv2d_chwn_f16x2_fwd(const bbb_conv_desc_t* d, const float* 
     if (8 * per > 0x7fffffffLL) return BBB_ESHAPE;
     a.per_xcd = (int32_t)per;
     const dim3 grid((unsigned)(8 * per)), block(kThreads);
-    if ((((uintptr_t)x_amax | (uintptr_t)y_amax) & 3u) != 0) return BBB_EALIGN;
-    hipLaunchKernelGGL((pconv_f16x2_kernel<1>), grid, block, 0, (hipStream_t)stream, a, x_amax, y_amax);
+    if ((((uintptr_t)x_amax | (uintptr_t)w_amax | (uintptr_t)y_amax) & 3u) != 0) return BBB_EALIGN;
+    hipLaunchKernelGGL((pconv_f16x2_kernel<1>), grid, block, 0, (hipStream_t)stream, a, x_amax, w_amax, y_amax);
     return (int)hipGetLastError();
 }
 

@@ -212,3 +212,41 @@ def test_precision_argument_selects_the_mode(env):
         env["rng"].manual_seed(3, call=0)
         d, _ = ens.mc_forward(net, x, 10)
     assert torch.equal(a, b) and torch.equal(a, c) and not torch.equal(a, d)
+
+
+def test_f16x2_weight_scale_follows_the_parameters(env, f16x2):
+    """Weights far below the fixed-scale window (posterior means of 1e-4): the layer's analytic bound max(|mu| + 6.66 sigma) sets
+    the weight scale, the step agrees with the fp32 path to 1e-5; after an in-place parameter update a captured step picks the new
+    bound up at its next replay."""
+    ens, ops = env["ens"], env["ops"]
+    torch.manual_seed(0)
+    net = env["zoo"].getModel("alexnet", 3, 10, P.CONFIG_PRIORS, "bbb", "softplus").cuda()
+    env["rng"].assign_stream_ids(net)
+    with torch.no_grad():
+        for l in ens.bayesian_layers(net):
+            l.W_mu.mul_(1e-3)
+            l.W_rho.fill_(-12.0)
+    x = torch.rand(512, 3, 32, 32, device="cuda")
+    with torch.no_grad():
+        env["rng"].manual_seed(3, call=0)
+        g = ens.GraphedMC(net, x, 10)
+        lo, _ = g.step()
+        torch.cuda.synchronize()
+        lo = lo.clone()
+        b0 = float(ens._weight_bound(ens.bayesian_layers(net)[0])[0])
+        ops.gemm_mode = "fp32"
+        env["rng"].manual_seed(3, call=0)
+        lo32, _ = ens.mc_forward(net, x, 10)
+        ops.gemm_mode = "fp16x2"
+        assert float((lo - lo32).abs().max()) <= 1e-5 * float(lo32.abs().max())
+        for l in ens.bayesian_layers(net):
+            l.W_mu.mul_(100.0)                                   # an optimizer step, exaggerated
+        env["rng"].manual_seed(3, call=10)
+        lo2, _ = g.step()
+        torch.cuda.synchronize()
+        b1 = float(ens._weight_bound(ens.bayesian_layers(net)[0])[0])
+        assert b1 > 50 * b0
+        ops.gemm_mode = "fp32"
+        env["rng"].manual_seed(3, call=10)
+        lo2_32, _ = ens.mc_forward(net, x, 10)
+        assert float((lo2 - lo2_32).abs().max()) <= 1e-5 * float(lo2_32.abs().max())
