@@ -282,7 +282,8 @@ class LaunchRecorder:
                 fn()
             torch.cuda.synchronize(dev)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            from bbb_hip import ops as _ops
+            with _ops.graph_capture(g):
                 for _ in range(self.reps):
                     fn()
             g.replay()
@@ -324,7 +325,8 @@ def reparam_probe(net, dev, n_params, E):
             fn()
         torch.cuda.synchronize(dev)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        from bbb_hip import ops as _ops
+        with _ops.graph_capture(g):
             for _ in range(reps):
                 fn()
         g.replay()

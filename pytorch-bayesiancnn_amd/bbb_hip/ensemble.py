@@ -992,7 +992,7 @@ class GraphedMC:
             torch.cuda.current_stream(dev).wait_stream(self.stream)
             torch.cuda.synchronize(dev)
             self.graph = torch.cuda.CUDAGraph()
-            with torch.no_grad(), rng.device_call_offset(self.counter), torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="thread_local"):
+            with torch.no_grad(), rng.device_call_offset(self.counter), ops.graph_capture(self.graph, self.stream):
                 self.lse, self.kl_local = self._step_body(streams)
         else:
             self.graph = None                        # more ranks than draws: this rank only joins the collective
@@ -1008,7 +1008,7 @@ class GraphedMC:
             torch.cuda.current_stream(dev).wait_stream(self.stream)
             torch.cuda.synchronize(dev)
             self.post = torch.cuda.CUDAGraph()
-            with torch.no_grad(), torch.cuda.graph(self.post, stream=self.stream, capture_error_mode="thread_local"):
+            with torch.no_grad(), ops.graph_capture(self.post, self.stream):
                 self._post_body()
 
     def _post_body(self):

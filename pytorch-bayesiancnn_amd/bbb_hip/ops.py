@@ -6,6 +6,7 @@ gradients run on the SAME fp32-MFMA implicit-GEMM kernel as the forward (wgrad =
 flipped-weight convolution of the stride-upsampled output gradient) -- no ATen / MIOpen / rocBLAS convolution or GEMM
 anywhere.  Activations, pooling and the loss tail use torch autograd (element-wise ops) in this mode.
 """
+import contextlib
 import ctypes
 
 import torch
@@ -185,6 +186,25 @@ def lrt_conv2d_forward(x, w_mu, w_var, b_mu, b_var, seed, call0, stream_id, stri
                                             cur_stream(x.device)),
               "bbb_lrt_conv2d_fwd")
     return y, am, av
+
+
+@contextlib.contextmanager
+def graph_capture(graph, stream=None):
+    """torch.cuda.graph(graph, stream, thread-local error mode) with the cyclic garbage collector out of the way: this torch no
+    longer collects before a capture, and a dead reference cycle that owns an older hipGraph (or any device memory) may be
+    collected at ANY allocation -- inside the capture, where destroying a graph is an illegal HIP call that surfaces as
+    `operation not permitted when stream is capturing` from a destructor, i.e. terminate().  Collect first, keep the collector off
+    until the capture has ended."""
+    import gc
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
+            yield
+    finally:
+        if was:
+            gc.enable()
 
 
 gemm_mode = "fp32"  # "fp16x2": the batch-innermost BBB GEMM launches of the INFERENCE ensemble path run their contraction on the 16-bit

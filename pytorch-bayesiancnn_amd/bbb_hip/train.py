@@ -10,7 +10,7 @@ import weakref
 import torch
 import torch.nn.functional as F
 
-from . import _lib, ensemble
+from . import _lib, ensemble, ops
 from ._lib import AdamSegment, check, cur_stream
 
 
@@ -235,7 +235,7 @@ def train_step(net, optimizer, x, target, num_ens, beta, train_size, dp_group=No
         st["streak"] += 1
         if st["streak"] > int(auto_graph["after"]) and not _python_hooks(net, optimizer):
             optimizer.make_capturable()
-            g = GraphedTrainStep(net, optimizer, x, target, num_ens, beta, train_size, warmup=1)   # the warm-up IS this iteration
+            g = GraphedTrainStep(net, optimizer, x, target, num_ens, beta, train_size, warmup=1, weak_net=True)   # the warm-up IS this iteration
             if g.graph is not None:
                 st["graphed"] = g
             else:
@@ -263,10 +263,13 @@ class GraphedTrainStep:
     `warmup` real training iterations run eagerly on the capture stream first.
     The optimizer must be FusedAdam(capturable=True) (or another capturable optimizer that keeps lr on the device)."""
 
-    def __init__(self, net, optimizer, x, target, num_ens, beta, train_size, warmup=3):
+    def __init__(self, net, optimizer, x, target, num_ens, beta, train_size, warmup=3, weak_net=False):
         from . import rng
         _lib.require_device(x)
-        self.net, self.opt, self.num_ens = net, optimizer, int(num_ens)
+        # weak_net (train_step's self-capture keeps this object ON the net): no net -> state -> step -> net cycle, so dropping the
+        # net frees the graph then and there instead of whenever the cyclic collector runs (possibly inside another capture)
+        self._net = weakref.ref(net) if weak_net else (lambda n=net: n)
+        self.opt, self.num_ens = optimizer, int(num_ens)
         self.train_size = float(train_size)
         self.x, self.target = x.clone(), target.clone()
         dev = x.device
@@ -299,8 +302,12 @@ class GraphedTrainStep:
             return
         self.graph = torch.cuda.CUDAGraph()
         self.opt.zero_grad(set_to_none=True)
-        with rng.device_call_offset(self.counter), torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="thread_local"):
+        with rng.device_call_offset(self.counter), ops.graph_capture(self.graph, self.stream):
             self.loss, self.log_outputs, self.kl = self._body()
+
+    @property
+    def net(self):
+        return self._net()
 
     def _body(self):
         from . import fast_train
