@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define BBB_ABI_VERSION 7
+#define BBB_ABI_VERSION 8
 #define BBB_MAX_SEGMENTS 16
 
 #define BBB_EINVAL (-1)   /* bad argument (null pointer, non-positive size, too many segments) */
@@ -234,44 +234,6 @@ int bbb_lrt_conv2d_chwn_splitk_fwd(const bbb_conv_desc_t* d, const float* x, con
                                    float* act_mu_out, float* act_var_out, const float* eps_ext,
                                    uint64_t seed, uint32_t call0, uint32_t stream_id, int sample,
                                    const uint32_t* call_dev, int k_split, void* scratch, int64_t scratch_bytes, void* stream);
-
-/*
- * One Monte-Carlo step's chain of layers in ONE persistent launch (ABI 6).  Replaces the per-layer sequence of
- * bbb_conv2d_chwn_fwd / bbb_maxpool_chwn calls that ModuleWrapper.forward (layers/misc.py:16-25) makes for a model such as
- * models/BayesianModels/BayesianAlexNet.py:35-53, for all num_ens draws of main_bayesian.py:73-80 at once: resident workgroups
- * claim (stage, slab, tile) work items ready-first -- slab e of a stage may start as soon as slab e of the stage it reads is
- * complete (one completion counter per (stage, slab)), and the deepest ready stage is preferred -- so the layers of different
- * draws overlap instead of meeting at a kernel boundary per layer.  Same results, bit for bit, as the per-layer entry points
- * (the GEMM items run the same instruction sequence).
- *   stages[i].kind  BBB_CHAIN_CONV: conv2d / linear exactly as bbb_conv2d_chwn_fwd(&conv, x, w, bias, y) (slabs = conv.draws;
- *                   work-unit fields allowed; w_row_pitch and b_offset must be 0).
- *                   BBB_CHAIN_MAXPOOL: bbb_maxpool_chwn(x, y, planes = conv.draws * conv.cin, conv.h, conv.w, conv.batch,
- *                   k = conv.kh, s = conv.stride_h); the other geometry fields are ignored.
- *   stages[i].dep   index (< i) of the stage whose output y IS this stage's x (same pointer, slab for slab), or -1 when x was
- *                   complete before the launch (the first layer: x may then be shared by all slabs, x_draw_stride = 0).
- *   flags           0, or BBB_CHAIN_SHALLOW_FIRST (prefer the shallowest ready stage: layer-major order; measurement aid).
- *   workspace       device int32 scratch of at least bbb_chain_workspace(nstages, slabs) words, 4-byte aligned; zeroed by
- *                   the call (a memset node under stream capture).  Word 8 is an error flag: non-zero after the launch means
- *                   the scheduler gave up waiting (results invalid); it never hangs.  One workspace per stream in flight.
- * Every conv.draws must be equal and <= 64; conv.batch % 32 == 0; x and y 128-byte aligned; every stage output slab a multiple
- * of 128 bytes (BBB_ESHAPE otherwise: use the per-layer entry points).  At most BBB_CHAIN_MAX_STAGES stages.
- */
-#define BBB_CHAIN_MAX_STAGES 12
-#define BBB_CHAIN_CONV    0
-#define BBB_CHAIN_MAXPOOL 1
-#define BBB_CHAIN_SHALLOW_FIRST 1u
-typedef struct bbb_chain_stage {
-    int32_t kind;
-    int32_t dep;
-    bbb_conv_desc_t conv;
-    const float* x;
-    const float* w;       /* BBB_CHAIN_CONV only */
-    const float* bias;    /* BBB_CHAIN_CONV only, may be NULL */
-    float* y;
-} bbb_chain_stage_t;
-int64_t bbb_chain_workspace(int nstages, int slabs);
-int bbb_chain_fwd(const bbb_chain_stage_t* stages, int nstages, uint32_t flags, int32_t* workspace, int64_t workspace_ints,
-                  void* stream);
 
 /* nn.MaxPool2d(kernel_size=k, stride=s) (no padding, floor mode; models/BayesianModels/BayesianAlexNet.py:37)
  * on batch-innermost planes: x [planes][h][w][B] -> y [planes][(h-k)/s+1][(w-k)/s+1][B]. */

@@ -1,4 +1,4 @@
-"""Race hunting for the cross-workgroup protocols (split-contraction tickets, chain counters): the same launches repeated many
+"""Race hunting for the cross-workgroup protocols (split-contraction tickets): the same launches repeated many
 times, alone and with three graph lanes keeping the chip under uneven load, every result compared bitwise with the first."""
 import json
 import os
@@ -35,24 +35,4 @@ for lt, classes in (("bbb", 10), ("lrt", 100)):
         torch.cuda.synchronize()
         out[f"splitk_{lt}"] = {"iterations": 400 * 3, "mismatches": bad, "seconds": round(time.time() - t0, 1)}
         del load
-# chain under load
-torch.manual_seed(0)
-net = zoo.getModel("alexnet", 3, 10, PRI, "bbb", "softplus").to(dev)
-rng.assign_stream_ids(net)
-x = torch.rand(512, 3, 32, 32, device=dev)
-with torch.no_grad():
-    ensemble.use_chain = False
-    want = ensemble._mc_logits_chwn(net, x, 10, 7, 3)[0].clone()
-    ops.split_k = False
-    ensemble.use_chain = True
-    side = torch.cuda.Stream()
-    bad = errs = 0
-    for it in range(200):
-        with torch.cuda.stream(side):
-            ensemble._mc_logits_chwn(net, x, 10, 9, 50 + it)            # a second chain launch in flight on another stream
-        got = ensemble._mc_logits_chwn(net, x, 10, 7, 3)[0]
-        bad += int(not torch.equal(got, want))
-    torch.cuda.synchronize()
-    errs = sum(int(b[8].item()) for k, b in ops._scratch.items() if k[1] == "chain")
-    out["chain_two_streams"] = {"iterations": 200, "mismatches": bad, "error_words": errs}
 print(json.dumps(out))

@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede CDLL: shares torch's HIP runtime)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BBB_HIP_LIB") or os.path.join(_HERE, "libbbb_hip.so")   # env override: experiments only
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 MAX_SEGMENTS = 16
 SIGMA_SQUARED = 1
 KL_TEXTBOOK = 2
@@ -38,15 +38,6 @@ class ConvDesc(ctypes.Structure):
                 ("w_draw_stride", c_i64), ("b_draw_stride", c_i64), ("act", c_i32),
                 ("unit_div", c_i32), ("unit_off", c_i32), ("x_unit_mod", c_i32), ("w_row_pitch", c_i32), ("b_offset", c_i32)]
 
-
-class ChainStage(ctypes.Structure):
-    _fields_ = [("kind", c_i32), ("dep", c_i32), ("conv", ConvDesc), ("x", c_void_p), ("w", c_void_p), ("bias", c_void_p),
-                ("y", c_void_p)]
-
-
-CHAIN_MAX_STAGES = 12
-CHAIN_CONV, CHAIN_MAXPOOL = 0, 1
-CHAIN_SHALLOW_FIRST = 1
 
 _SIGNATURES = {
     "bbb_reparam_kl_fwd": (c_int, [ctypes.POINTER(Segment), c_int, c_int, c_float, c_float, c_u64, c_u32, c_u32,
@@ -92,8 +83,6 @@ _SIGNATURES = {
     "bbb_lrt_conv2d_chwn_splitk_fwd": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                c_void_p, c_void_p, c_void_p, c_u64, c_u32, c_u32, c_int, c_void_p, c_int, c_void_p, c_i64,
                                                c_void_p]),
-    "bbb_chain_workspace": (c_i64, [c_int, c_int]),
-    "bbb_chain_fwd": (c_int, [ctypes.POINTER(ChainStage), c_int, c_u32, c_void_p, c_i64, c_void_p]),
     "bbb_abi_version": (c_int, []),
     "bbb_build_info": (ctypes.c_char_p, []),
 }

@@ -30,10 +30,6 @@ except ImportError as e:  # pragma: no cover
 
 
 fast_autograd = True      # False: training forwards take the reference-layout autograd path (tests compare the two)
-use_chain = False         # True: fp32 BBB inference steps run their conv / pool stages as ONE persistent launch
-                          # (ops.chain_forward / bbb_chain_fwd: same bits).  Off by default: measured SLOWER than one launch per
-                          # layer on every BASELINE shape (profiles/r03_notes.md section 1) -- kept as a tested alternative.
-chain_flags = 0           # bbb_chain_fwd flags (include/bbb_hip.h); bits 8..11: experiment cap on workgroups per CU
 stats = {"path": None, "launch": None}   # which layout the last mc_logits / mc_forward took: "chwn" (batch-innermost fast path) or "nchw"
 
 
@@ -530,49 +526,8 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
             return dst
         return h
 
-    def run_chain():
-        """All conv / linear / pool stages of the step as ONE persistent launch (bbb_chain_fwd), or None: not this shape."""
-        specs, i, pending_flat = [], 0, None
-        while i < len(children):
-            mod = children[i]
-            nxt = children[i + 1] if i + 1 < len(children) else None
-            if isinstance(mod, _BBBLayer):
-                is_conv = isinstance(mod, _BBBConv)
-                act = _act_name(nxt) if nxt is not None else None
-                w, b = sampled[mod]
-                if not is_conv:
-                    w = w.reshape(w.shape[0], mod.out_features, mod.in_features, 1, 1)
-                    if not specs:
-                        return None                              # a model that starts with a linear layer: per-layer path
-                geom = (mod.stride, mod.padding, mod.dilation) if is_conv else (1, 0, 1)
-                kw = dict(ukw, x_per_slice=not specs) if ukw else {}
-                dst = logits_buf if (logits_buf is not None and i == last_bayes and not is_conv) else None
-                specs.append(("conv", w, b, *geom, act, dst, kw))
-                if act is not None:
-                    i += 1
-            elif isinstance(mod, FlattenLayer):
-                specs.append(("flatten", mod.num_features))
-            elif isinstance(mod, nn.MaxPool2d):
-                specs.append(("pool", mod.kernel_size, mod.stride))
-            else:
-                return None                                      # a stand-alone activation etc.
-            i += 1
-        if not tail_is_last or logits_buf is None:
-            return None
-        y = ops.chain_forward(xt, specs, flags=chain_flags)
-        if y is None:
-            return None
-        return y.reshape(E, -1, xt.shape[-1])
-
     nsplit = max(1, min(int(streams), E))
-    out = None
-    if use_chain and timers is None and not bf16 and not lrt and bbb and xt.shape[-1] % 128 == 0 and not per_draw_x:
-        out = run_chain()
-        if out is not None:
-            stats["launch"] = "chain"
-    if out is not None:
-        pass
-    elif nsplit == 1 or timers is not None:
+    if nsplit == 1 or timers is not None:
         stats["launch"] = "layers"
         out = run(0, E)
         if out is None:

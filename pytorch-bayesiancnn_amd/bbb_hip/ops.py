@@ -15,17 +15,26 @@ from . import _lib, rng
 from ._lib import Segment, ConvDesc, check, ptr, require_device, cur_stream, on_device
 
 _scratch = {}
+_retired = []     # outgrown scratch buffers: a captured hipGraph may have their address baked in, so they are NEVER freed (a
+                  # second pipeline / a larger model captured on the same stream must not pull the first graph's tickets or KL
+                  # slots out from under it).  Sizes at least double, so a stream retires < its final size in total.
+
+
+def _grow(key, need, make):
+    buf = _scratch.get(key)
+    if buf is None or buf.numel() < need:
+        if buf is not None:
+            _retired.append(buf)
+            need = max(int(need), 2 * buf.numel())
+        buf = _scratch[key] = make(int(need))
+    return buf
 
 
 def _partials(device, n):
-    # one scratch buffer per (device, stream): launches on different streams (graph lanes, a second model) may overlap
-    key = (device.index, "kl", cur_stream(device))
-    buf = _scratch.get(key)
-    if buf is None or buf.numel() < n:
-        # every slot starts as "not published yet" (0xFF bytes); each launch re-arms the slots it consumed
-        buf = torch.full((max(n, 4096),), -1, dtype=torch.int64, device=device).view(torch.float64)
-        _scratch[key] = buf
-    return buf
+    # one scratch buffer per (device, stream): launches on different streams (graph lanes, a second model) may overlap.
+    # every slot starts as "not published yet" (0xFF bytes); each launch re-arms the slots it consumed
+    return _grow((device.index, "kl", cur_stream(device)), max(int(n), 4096),
+                 lambda m: torch.full((m,), -1, dtype=torch.int64, device=device).view(torch.float64))
 
 
 def _segments(mus, rhos, ws, sigmas, epss, stream_ids, draws):
@@ -232,11 +241,8 @@ def _split_scratch(d, lrt, device):
     ks_v, need = plan
     if ks_v <= 1 or need <= 0:
         return 1, None
-    key = (device.index, "splitk", cur_stream(device))
-    buf = _scratch.get(key)
-    if buf is None or buf.numel() < need:
-        buf = torch.zeros(max(int(need), 1 << 22), dtype=torch.uint8, device=device)
-        _scratch[key] = buf
+    buf = _grow((device.index, "splitk", cur_stream(device)), max(int(need), 1 << 22),
+                lambda m: torch.zeros(m, dtype=torch.uint8, device=device))
     return ks_v, buf
 
 
@@ -375,108 +381,6 @@ def maxpool_chwn(x, k, s):
         check(_lib.lib().bbb_maxpool_chwn(x.data_ptr(), y.data_ptr(), planes, H, W, B, int(k), int(s), cur_stream(x.device)),
               "bbb_maxpool_chwn")
     return y
-
-
-# ---- one persistent launch for a whole step's layers (bbb_chain_fwd) ------------------------------------------------
-
-def _chain_workspace(device, n):
-    # one workspace per (device, stream): steps in flight on different streams (graph lanes) must not share counters
-    key = (device.index, "chain", cur_stream(device))
-    buf = _scratch.get(key)
-    if buf is None or buf.numel() < n:
-        buf = torch.zeros(int(n), dtype=torch.int32, device=device)
-        _scratch[key] = buf
-    return buf
-
-
-def chain_error(device):
-    """Error word of the current stream's chain workspace (non-zero: a dependency wait timed out).  Synchronises."""
-    buf = _scratch.get((torch.device(device).index, "chain", cur_stream(torch.device(device))))
-    return 0 if buf is None else int(buf[8].item())
-
-
-def chain_forward(x, specs, flags=0):
-    """A chain of conv / linear / max-pool stages over `slabs` Monte-Carlo draws (or work units) as ONE persistent launch:
-    the same numbers, bit for bit, as conv2d_chwn_forward / maxpool_chwn called stage by stage (include/bbb_hip.h,
-    bbb_chain_fwd).  x: [E|1|S, Cin, H, W, B] input of the first stage (a conv).  specs, in order:
-        ("conv", w, bias, stride, padding, dilation, act, out, kw)   w [E|.., Cout, Cin, kh, kw]; kw = units keywords of conv2d_chwn_forward
-        ("pool", k, s)
-        ("flatten", features)        free view [E, C, H, W, B] -> [E, features, 1, 1, B]
-    Returns the last stage's output, or None when the geometry is outside what the chain kernel takes (caller falls back)."""
-    require_device(x)
-    cur = x.contiguous()
-    stages = []
-    keep = []
-    prev = -1
-    slabs = None
-    for sp in specs:
-        if sp[0] == "flatten":
-            if prev < 0 or cur.shape[1] * cur.shape[2] * cur.shape[3] != sp[1]:
-                return None
-            cur = cur.reshape(cur.shape[0], sp[1], 1, 1, cur.shape[4])
-            continue
-        st = _lib.ChainStage()
-        if sp[0] == "conv":
-            _, w, bias, stride, padding, dilation, act, out, kw = sp
-            require_device(w, bias)
-            w = w.contiguous()
-            bias = None if bias is None else bias.contiguous()
-            units, n_units, x_per_slice = kw.get("units"), kw.get("n_units"), kw.get("x_per_slice", False)
-            if units is not None and units[0] > 1:
-                E = int(n_units)
-                d, ho, wo = _desc_chwn(cur, w, stride, padding, dilation, E, False, False, act)
-                _apply_units(d, units, x_per_slice)
-            else:
-                E = max(cur.shape[0], w.shape[0])
-                if cur.shape[0] not in (1, E) or w.shape[0] not in (1, E):
-                    raise _lib.BBBHipError("leading (draw) dims of x and w must be 1 or equal")
-                d, ho, wo = _desc_chwn(cur, w, stride, padding, dilation, E, cur.shape[0] == 1 and E > 1, w.shape[0] == 1 and E > 1, act)
-            shape = (E, w.shape[1], ho, wo, cur.shape[4])
-            if out is None:
-                y = torch.empty(shape, dtype=torch.float32, device=cur.device)
-            else:
-                if out.numel() != E * w.shape[1] * ho * wo * cur.shape[4] or not out.is_contiguous() or out.dtype != torch.float32:
-                    raise _lib.BBBHipError("out= must be a contiguous fp32 tensor of the output's size")
-                y = out.view(shape)
-            st.kind, st.conv = _lib.CHAIN_CONV, d
-            st.w, st.bias = w.data_ptr(), ptr(bias)
-            keep += [w, bias]
-        else:
-            _, k, s_ = sp
-            if prev < 0:
-                return None                               # a pool on the raw input has no per-draw slabs
-            E, C, H, W, B = cur.shape
-            d = ConvDesc()
-            d.batch, d.cin, d.h, d.w, d.kh, d.stride_h, d.draws = B, C, H, W, int(k), int(s_), E
-            if H < k or W < k:
-                return None
-            y = torch.empty((E, C, (H - k) // s_ + 1, (W - k) // s_ + 1, B), dtype=torch.float32, device=cur.device)
-            st.kind, st.conv = _lib.CHAIN_MAXPOOL, d
-        if slabs is None:
-            slabs = E
-        elif E != slabs:
-            return None
-        st.dep = prev
-        st.x, st.y = cur.data_ptr(), y.data_ptr()
-        stages.append(st)
-        keep += [cur, y]
-        prev = len(stages) - 1
-        cur = y
-    if not stages or len(stages) > _lib.CHAIN_MAX_STAGES:
-        return None
-    arr = (_lib.ChainStage * len(stages))(*stages)
-    L = _lib.lib()
-    dev = cur.device
-    n = L.bbb_chain_workspace(len(stages), slabs)
-    if n <= 0:
-        return None                                       # more slabs than the chain kernel schedules: per-layer launches
-    with on_device(dev):
-        ws = _chain_workspace(dev, n)
-        rc = L.bbb_chain_fwd(arr, len(stages), int(flags), ws.data_ptr(), ws.numel(), cur_stream(dev))
-    if rc in (-2, -3):                                    # alignment / geometry outside the chain kernel: per-layer launches
-        return None
-    check(rc, "bbb_chain_fwd")
-    return cur
 
 
 # ---- bf16 storage path (BASELINE.json configs[1]) -------------------------------------------------------------------

@@ -43,6 +43,9 @@ class FusedAdam(torch.optim.Optimizer):
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
+        # new 'step' / 'exp_avg' / 'exp_avg_sq' tensors replaced the ones an earlier capture (train_step's self-capture,
+        # GraphedTrainStep) baked in: the generation is part of train_step's capture key, so such a graph is dropped
+        self._state_generation = getattr(self, "_state_generation", 0) + 1
         for rec in self._lr_dev.values():     # the captured step keeps reading OUR scalars: refresh them from the loaded lr
             rec[1] = None
         if self._lr_dev and not torch.cuda.is_current_stream_capturing():
@@ -64,7 +67,8 @@ class FusedAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         L = _lib.lib()
-        for group in self.param_groups:
+        touched = []
+        for gi, group in enumerate(self.param_groups):
             cap = group.get("capturable", False)
             by_step = {}
             for p in group["params"]:
@@ -92,7 +96,6 @@ class FusedAdam(torch.optim.Optimizer):
                 # the device-side learning rate lives in a private dict keyed by group index, NOT in param_groups: state_dict()
                 # stays interchangeable with torch.optim.Adam's, and load_state_dict / map_location cannot swap or move the
                 # scalar a captured step reads
-                gi = self.param_groups.index(group)
                 if gi not in self._lr_dev:
                     self._lr_dev[gi] = [torch.full((), float(group["lr"]), dtype=torch.float32, device=steps[0].device), float(group["lr"])]
                 elif not torch.cuda.is_current_stream_capturing():
@@ -112,7 +115,17 @@ class FusedAdam(torch.optim.Optimizer):
                                               float(group["betas"][1]), float(group["eps"]), step,
                                               part[0][1]["step"].data_ptr() if cap else 0, lr_dev, cur_stream(dev)),
                               "bbb_adam_step")
+                    touched += [p for p, _ in part]
+        _bump_versions(touched)
         return loss
+
+
+def _bump_versions(params):
+    """The HIP kernels write parameters through raw pointers: tell torch (Tensor._version) so that version-keyed caches --
+    the split-fp16 weight bound, the speculation cache of layers/_fused.py, fast_train's stale-parameter check -- see the
+    update.  Host-side bookkeeping only (legal inside a capture; replays are bumped by GraphedTrainStep.step)."""
+    if params:
+        torch.autograd.graph.increment_version(params)
 
 
 def allreduce_gradients(params, group=None, bucket_bytes=64 << 20):
@@ -200,10 +213,13 @@ def _auto_key(net, optimizer, x, target, num_ens, train_size):
     if not (auto_graph["enabled"] and isinstance(optimizer, FusedAdam) and torch.is_tensor(x) and x.is_cuda and target.is_cuda
             and torch.is_grad_enabled() and not x.requires_grad and not torch.cuda.is_current_stream_capturing()):
         return None
-    groups = tuple((tuple(g["betas"]), float(g["eps"]), tuple((id(p), p.requires_grad) for p in g["params"]))
+    # parameter STORAGE and optimizer-state identity are baked into a captured step too: net.to(...), `p.data = ...` or
+    # optimizer.load_state_dict(...) after the capture must drop it (the replay would read and write freed buffers)
+    groups = tuple((tuple(g["betas"]), float(g["eps"]), tuple((id(p), p.requires_grad, p.data_ptr()) for p in g["params"]))
                    for g in optimizer.param_groups)
     from . import rng
-    return (id(optimizer), tuple(x.shape), x.dtype, tuple(target.shape), target.dtype, int(num_ens), float(train_size), net.training,
+    return (id(optimizer), getattr(optimizer, "_state_generation", 0), tuple(x.shape), x.dtype, tuple(target.shape), target.dtype,
+            int(num_ens), float(train_size), net.training,
             ensemble._epoch[0], groups, rng.next_calls(0)[0])               # the noise seed is a constant of the captured kernels
 
 
@@ -350,6 +366,7 @@ class GraphedTrainStep:
             self.counter.fill_(d - (1 << 32) if d >= (1 << 31) else d)     # the kernels add it modulo 2^32
         self.graph.replay()
         self.replays += 1
+        _bump_versions([p for g in self.opt.param_groups for p in g["params"] if p.requires_grad])   # the replay rewrote them
         rng.next_calls(self.num_ens)                 # keep the host-side noise counter in step with the device's
         self._next_call = call + self.num_ens
         return self.loss, self.log_outputs, self.kl

@@ -1,16 +1,11 @@
-// The work-item body of the pixel-major fp32 implicit GEMM (see pconv_gemm.hip for the algorithm): shared by the
-// one-launch-per-layer kernel (pconv_gemm.hip) and the persistent chain kernel (pchain.hip), so that both run the SAME
-// instruction sequence per output tile and therefore produce the same bits.
+// The work-item body of the pixel-major fp32 implicit GEMM (see pconv_gemm.hip for the algorithm): one device function shared
+// by the plain and the split-contraction kernels, so that every form runs the SAME instruction sequence per output tile.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "bbb_common.cuh"
 #include "pconv_args.h"
-
-#ifdef PCONV_STAMPS
-static __device__ unsigned long long g_pconv_ts[8 * 4 * 8];   // experiment builds: per-phase cycle sums of sampled workgroups
-#endif
 
 namespace pconv {
 
@@ -25,22 +20,16 @@ constexpr int KCH = 256;                 // k_eff entries per decode chunk (one 
 constexpr int TPC = KCH / BK;            // tiles per chunk
 
 // One work item = one (draw, 64-channel tile, output pixel, BM-image tile) of a pixel-major GEMM: the whole body of
-// pconv_gemm_kernel, callable from a kernel that owns several items (pchain.hip).  `item` indexes the launch's items in
-// (draw, channel tile)-major order, as the XCD-aware block mapping of the launcher enumerates them.
-// PUB: the item's output will be read by OTHER workgroups of the SAME launch (persistent chain): output stores are
-// write-through (sc1) so that no release fence is needed before the completion counter, and the image-row loads bypass the
-// CU's L1 (sc1), which is never refreshed by other CUs' stores (MI355X: per-XCD L2s are not coherent either, but a line is
-// only ever read after its final value has been written through, so no L2 holds a stale copy).
+// pconv_gemm_kernel.  `item` indexes the launch's items in (draw, channel tile)-major order, as the XCD-aware block mapping of
+// the launcher enumerates them.
 // SPLIT: the item's contraction is cut into p.ksplit consecutive ranges of k tiles, one per workgroup (`ks` = this
 // workgroup's range) -- launches of a few dozen to a few hundred items cannot fill 256 CUs, and a lone workgroup is bounded by
 // its serial k loop (conv4 at one draw: 48 tiles on 128 of the 256 CUs).  Every workgroup writes its raw accumulator tile(s) to
 // scratch (write-through, 16 bytes per lane), takes a ticket, and the LAST arriver adds the ksplit partial tiles in range
 // order 0, 1, ... (whoever it is: the sum does not depend on timing), applies the epilogue and stores the output.  The
 // partial sums round differently from the unsplit fmaf chain: results agree with an unsplit launch to ~1e-7 relative.
-template <int BM, bool LRT, bool ILV, bool PUB, bool SPLIT = false>
+template <int BM, bool LRT, bool ILV, bool SPLIT = false>
 __device__ __forceinline__ void pconv_item(const PConvArgs& p, const int64_t item, const int ks = 0) {
-    static_assert(!(LRT && PUB), "the LRT epilogue has no write-through form yet");
-    static_assert(!(SPLIT && PUB), "split launches publish partial tiles, not outputs");
     constexpr int LDX = BM + 4;
     constexpr int NT = (BM >= 128) ? 2 : 1;              // 32-channel MFMA tiles per wave
     constexpr int MT = (BM == 256) ? 2 : 1;              // 32-image MFMA tiles per wave
@@ -48,8 +37,6 @@ __device__ __forceinline__ void pconv_item(const PConvArgs& p, const int64_t ite
     constexpr int XL = BM / 4;                 // lanes per X row (float4 each)
     constexpr int XRPP = kThreads / XL;        // X rows per pass
     constexpr int XPASS = BK / XRPP;
-    constexpr int AUX_X = PUB ? 16 : 0;        // buffer cache-policy bits: 16 = sc1
-    constexpr int AUX_Y = PUB ? 16 : 0;
 
     // ONE LDS stage per operand; the second stage of the pipeline is the register file (loads for tile t+1 are
     // issued before tile t's MFMAs and written to LDS after them, inside one loop iteration: no loop-carried
@@ -161,7 +148,7 @@ __device__ __forceinline__ void pconv_item(const PConvArgs& p, const int64_t ite
     };
     auto load_one = [&](int i, float (&wreg)[WSETS][8], f32x4 (&xreg)[XPASS]) {
         if (i < XPASS) {          // x rows first: they are the wider transfers
-            xreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, loff[8 + i], 0, AUX_X));
+            xreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, loff[8 + i], 0, 0));
         } else {
             const int ps = i - XPASS;
             wreg[0][ps] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrs, loff[ps], 0, 0));
@@ -250,52 +237,26 @@ __device__ __forceinline__ void pconv_item(const PConvArgs& p, const int64_t ite
         if ((c0 + 1) * KCH < Keff) fill_chunk(c0 + 1);
         store_tile(0, wregA, xregA);
         __syncthreads();
-#ifdef PCONV_STAMPS_TILE
-        unsigned long long ts_acc[5] = {0, 0, 0, 0, 0}, ts_first = __builtin_readcyclecounter();
-#define TS_MARK(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); ts_acc[i] += n_ - ts_last; ts_last = n_; } while (0)
-#else
-#define TS_MARK(i) do { } while (0)
-#endif
         for (int t = t0; t < t1; ++t) {
-#ifdef PCONV_STAMPS_TILE
-            unsigned long long ts_last = __builtin_readcyclecounter();
-#endif
             const bool more = (t + 1) < t1;
             if (more) {
                 if (ILV) load_addr(t + 1);                            // loads themselves are issued inside mma_tile()
                 else     load_tile(t + 1, wregA, xregA);              // all loads up front (large launches)
             }
-            TS_MARK(0);
             // decode chunk c+1 early in chunk c (c >= c0 + 1; chunk c0 + 1 is decoded in the prologue): its buffer was last
             // read by load_tile(TPC*c - 1), several barriers ago
             if ((t % TPC) == 1 && t / TPC >= c0 + 1 && (t / TPC + 1) * KCH < Keff) fill_chunk(t / TPC + 1);
             mma_tile(more);
-            TS_MARK(1);
             __syncthreads();                                          // every wave is done reading the LDS stage
-            TS_MARK(2);
             if (more) store_tile(0, wregA, xregA);
-            TS_MARK(3);
             __syncthreads();
-            TS_MARK(4);
         }
-#ifdef PCONV_STAMPS_TILE
-        {   // one sampled workgroup per XCD, from the middle of the launch
-            const int bid_ = blockIdx.x;
-            if ((bid_ >> 3) == p.per_xcd / 2 && lane == 0) {
-                unsigned long long* o = g_pconv_ts + ((bid_ & 7) * 4 + wave) * 8;
-                for (int i = 0; i < 5; ++i) o[i] = ts_acc[i];
-                o[5] = __builtin_readcyclecounter() - ts_first;
-                o[6] = (unsigned long long)(t1 - t0);
-                o[7] = 1;
-            }
-        }
-#endif
     }
 
     if constexpr (SPLIT) {
         // ---- split contraction: partial tile(s) -> scratch, ticket, last arriver combines ----
         constexpr int TILE = 64 * BM;                                 // elements of one accumulator set's tile
-        constexpr int TW = (BK * LDX) / 1024 >= 4 ? 4 : 2;            // wave tiles the X stage can hold (see the PUB epilogue)
+        constexpr int TW = (BK * LDX) / 1024 >= 4 ? 4 : 2;            // wave tiles the X stage can hold (see the epilogue)
         __shared__ int s_last;
         const int S = p.ksplit;
         const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
@@ -404,9 +365,8 @@ __device__ __forceinline__ void pconv_item(const PConvArgs& p, const int64_t ite
     if constexpr (!LRT) {
         // Every wave transposes its 32 x 32 accumulator tile(s) through LDS (the X stage is free after the k loop) so that a
         // lane ends up with FOUR consecutive images of one channel: 8 16-byte stores and 8 bias loads per lane instead of 32 +
-        // 32 four-byte ones (measured neutral for the per-layer kernel at 4 workgroups per CU -- profiles/r03_notes.md section 3 --
-        // and required for PUB, whose write-through (sc1) stores are one fabric write per lane: 4-byte ones cost ~6x the time per
-        // byte).  Same values, same bits as the MFMA-layout epilogue of rounds 1-2.
+        // 32 four-byte ones (measured neutral at 4 workgroups per CU -- profiles/r03_notes.md section 3; the split form's
+        // write-through partial stores need the 16-byte shape).  Same values, same bits as the MFMA-layout epilogue of rounds 1-2.
         // The stage holds TW wave tiles at a time (BM = 64: two passes).
         constexpr int TW = (BK * LDX) / 1024 >= 4 ? 4 : 2;               // wave tiles the X stage can hold
         float* const T = &Xs[0][(wave % TW) * 1024];
@@ -429,7 +389,7 @@ __device__ __forceinline__ void pconv_item(const PConvArgs& p, const int64_t ite
                             for (int c = 0; c < 4; ++c) v4[c] = bbb::apply_act(v4[c] + bn, p.act);
                             const uint32_t off = ((bb < p.B) & (n < p.Cout)) ? (uint32_t)(((int64_t)n * HoWo + pix) * p.B + bb) * 4u : kOOB;
                             __builtin_amdgcn_raw_buffer_store_b128(
-                                __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(uint32_t)))) uint32_t, v4), yrs, off, 0, AUX_Y);
+                                __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(uint32_t)))) uint32_t, v4), yrs, off, 0, 0);
                         }
                     }
                     if (TW < 4) __syncthreads();                         // the other pair of waves reuses the tiles

@@ -28,18 +28,6 @@
 #include "pconv_args.h"
 #include "pconv_body.cuh"
 #include "pconv_f16x2.cuh"
-#ifdef PCONV_STAMPS
-static __device__ unsigned long long* g_census = nullptr;      // [grid][4]: start, end (100 MHz), hw id, xcc id
-extern "C" int bbb_census_set(unsigned long long* dev_buf) {
-    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_census), &dev_buf, sizeof(dev_buf));
-}
-extern "C" int bbb_ts_read(unsigned long long* host_out) {
-    hipError_t e = hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_pconv_ts), sizeof(unsigned long long) * 256);
-    unsigned long long z[256] = {0};
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pconv_ts), z, sizeof(z));
-    return (int)e;
-}
-#endif
 
 namespace {
 
@@ -57,19 +45,7 @@ __global__ __launch_bounds__(kThreads) void pconv_gemm_kernel(const PConvArgs p)
     const int64_t item = (int64_t)xcd * p.per_xcd + (bid >> 3);
     const int64_t item_end = (int64_t)(xcd + 1) * p.per_xcd;
     if (item >= item_end || item >= (int64_t)p.G * p.Mtiles) return;
-#ifdef PCONV_STAMPS
-    const unsigned long long c_start = wall_clock64(), c_cyc = __builtin_readcyclecounter();
-#endif
-    pconv_item<BM, LRT, ILV, false>(p, item);
-#ifdef PCONV_STAMPS
-    if (g_census != nullptr && threadIdx.x == 0) {
-        uint32_t hw = 0, xcc = 0;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        unsigned long long* o = g_census + (size_t)bid * 4;
-        o[0] = c_start; o[1] = wall_clock64(); o[2] = hw; o[3] = (xcc & 7) | ((__builtin_readcyclecounter() - c_cyc) << 8);
-    }
-#endif
+    pconv_item<BM, LRT, ILV>(p, item);
 }
 
 // Split contraction (pconv_body.cuh, SPLIT): block -> (item, k range).  The ksplit blocks of an item are consecutive, so they
@@ -82,7 +58,7 @@ __global__ __launch_bounds__(kThreads) void pconv_gemm_splitk_kernel(const PConv
     const int64_t blk_end = (int64_t)(xcd + 1) * p.per_xcd;
     if (blk >= blk_end || blk >= (int64_t)p.G * p.Mtiles * p.ksplit) return;
     const int64_t item = blk / p.ksplit;
-    pconv_item<BM, LRT, ILV, false, true>(p, item, (int)(blk - item * p.ksplit));
+    pconv_item<BM, LRT, ILV, true>(p, item, (int)(blk - item * p.ksplit));
 }
 
 // maxpool over [planes][H][W][B] (planes = draws * channels), B innermost; 4 images per thread.

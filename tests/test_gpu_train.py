@@ -255,3 +255,97 @@ def test_train_step_captures_despite_stale_gradient_accumulators(env):
     for a, b in zip(net_e.parameters(), net_g.parameters()):
         np.testing.assert_allclose(b.detach().cpu().numpy(), a.detach().cpu().numpy(), rtol=2e-5, atol=1e-7)
     assert all(lo.requires_grad for lo, _ in keep)
+
+
+def test_two_param_groups_capturable_and_self_captured(env):
+    """The usual (mu-group, rho-group) split: two groups whose 'params' lists have equal length.  Capturable FusedAdam looks its
+    group up by INDEX (list.index compared the dicts by value: `tensor == tensor` raised, or picked the wrong group's lr), so
+    the per-group learning rates reach the kernel -- eagerly, with capturable=True, and through train_step's self-capture."""
+    T = env["train"]
+    x = torch.rand(32, 1, 32, 32, device="cuda")
+    y = torch.randint(0, 10, (32,), device="cuda")
+
+    def run(mode):
+        torch.manual_seed(5)
+        net = env["zoo"].BBBLeNet(10, 1, P.CONFIG_PRIORS, "bbb", "softplus").cuda()
+        env["rng"].assign_stream_ids(net)
+        env["rng"].manual_seed(21, call=0)
+        mus = [p for n, p in net.named_parameters() if n.endswith("_mu")]
+        rhos = [p for n, p in net.named_parameters() if n.endswith("_rho")]
+        assert len(mus) == len(rhos)
+        opt = T.FusedAdam([{"params": mus, "lr": 1e-3}, {"params": rhos, "lr": 3e-2}], capturable=(mode == "capturable"))
+        losses = [T.train_step(net, opt, x, y, 2, 0.1, 1000.0, graph=(None if mode == "auto" else False))[0].item() for _ in range(7)]
+        return net, losses
+
+    net_e, eager = run("eager")
+    net_c, cap = run("capturable")
+    net_a, auto = run("auto")
+    assert T._auto[net_a]["graphed"] is not None
+    np.testing.assert_allclose(cap, eager, rtol=2e-5)
+    np.testing.assert_allclose(auto, eager, rtol=2e-5)
+    for (n, a), b, c in zip(net_e.named_parameters(), net_c.parameters(), net_a.parameters()):
+        np.testing.assert_allclose(b.detach().cpu().numpy(), a.detach().cpu().numpy(), rtol=2e-5, atol=1e-7, err_msg=n)
+        np.testing.assert_allclose(c.detach().cpu().numpy(), a.detach().cpu().numpy(), rtol=2e-5, atol=1e-7, err_msg=n)
+    # the rho group really moved 30x faster than the mu group would have
+    d_rho = (net_e.conv1.W_rho.detach() - (-5.0)).abs().mean().item()
+    assert d_rho > 0.05
+
+
+def test_loaded_optimizer_state_and_moved_storage_drop_the_capture(env):
+    """optimizer.load_state_dict() replaces exp_avg / exp_avg_sq / step with new tensors, `p.data = ...` moves a parameter's
+    storage: a step captured before either would keep reading and writing the OLD buffers.  Both are part of train_step's
+    capture key: the graph is dropped and later steps follow the loaded state / the new storage."""
+    T = env["train"]
+    x = torch.rand(32, 1, 32, 32, device="cuda")
+    y = torch.randint(0, 10, (32,), device="cuda")
+    torch.manual_seed(5)
+    net = env["zoo"].BBBLeNet(10, 1, P.CONFIG_PRIORS, "bbb", "softplus").cuda()
+    env["rng"].assign_stream_ids(net)
+    env["rng"].manual_seed(21, call=0)
+    opt = T.FusedAdam(net.parameters(), lr=1e-3)
+    for _ in range(5):
+        T.train_step(net, opt, x, y, 2, 0.1, 1000.0)
+    assert T._auto[net]["graphed"] is not None
+    import copy
+    sd = copy.deepcopy(opt.state_dict())
+    for st in sd["state"].values():
+        st["exp_avg"].zero_()
+        st["exp_avg_sq"].fill_(1.0)
+    opt.load_state_dict(sd)
+    p0 = net.conv1.W_mu
+    before = p0.detach().clone()
+    T.train_step(net, opt, x, y, 2, 0.1, 1000.0)
+    st = T._auto.get(net)
+    assert st is None or st["graphed"] is None                         # key changed: launch by launch again
+    # with exp_avg = 0 and exp_avg_sq = 1 loaded, one Adam step moves every element by far less than lr
+    assert (p0.detach() - before).abs().max().item() < 1e-3
+    assert opt.state[p0]["exp_avg_sq"].mean().item() > 0.9            # the LOADED moments were updated, not the old ones
+    for _ in range(5):
+        T.train_step(net, opt, x, y, 2, 0.1, 1000.0)
+    assert T._auto[net]["graphed"] is not None
+    p0.data = p0.data.clone()                                          # new storage for one parameter
+    T.train_step(net, opt, x, y, 2, 0.1, 1000.0)
+    st = T._auto.get(net)
+    assert st is None or st["graphed"] is None
+
+
+def test_parameter_versions_follow_the_hip_updates(env):
+    """bbb_adam_step writes parameters through raw pointers; FusedAdam.step and every replay of a captured training step bump
+    Tensor._version, so the version-keyed caches (split-fp16 weight bound, speculation cache, stale-backward check) see it."""
+    T = env["train"]
+    x = torch.rand(32, 1, 32, 32, device="cuda")
+    y = torch.randint(0, 10, (32,), device="cuda")
+    torch.manual_seed(5)
+    net = env["zoo"].BBBLeNet(10, 1, P.CONFIG_PRIORS, "bbb", "softplus").cuda()
+    env["rng"].assign_stream_ids(net)
+    opt = T.FusedAdam(net.parameters(), lr=1e-3)
+    seen = []
+    for _ in range(7):
+        T.train_step(net, opt, x, y, 1, 0.1, 1000.0)
+        seen.append(net.conv1.W_mu._version)
+    assert T._auto[net]["graphed"] is not None
+    assert all(b > a for a, b in zip(seen, seen[1:])), seen
+    bound0 = env["ens"]._weight_bound(net.conv1).clone()
+    for _ in range(3):
+        T.train_step(net, opt, x, y, 1, 0.1, 1000.0)
+    assert not torch.equal(env["ens"]._weight_bound(net.conv1), bound0)

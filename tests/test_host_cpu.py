@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol(built):
     h = _lib.lib()                      # CDLL + argtypes for every symbol; raises if one is missing
     for name in decl:
         assert hasattr(h, name)
-    assert h.bbb_abi_version() == 7
+    assert h.bbb_abi_version() == 8
     assert b"gfx950" in h.bbb_build_info()
 
 
@@ -49,8 +49,6 @@ int main(void) {
   printf("%zu %zu %zu %zu %zu\n", sizeof(bbb_segment_t), offsetof(bbb_segment_t, n), offsetof(bbb_segment_t, stream_id),
          sizeof(bbb_conv_desc_t), offsetof(bbb_conv_desc_t, x_draw_stride));
   printf("%zu %zu\n", offsetof(bbb_conv_desc_t, act), offsetof(bbb_conv_desc_t, draws));
-  printf("%zu %zu %zu %zu\n", sizeof(bbb_chain_stage_t), offsetof(bbb_chain_stage_t, conv), offsetof(bbb_chain_stage_t, x),
-         offsetof(bbb_chain_stage_t, y));
   return 0; }
 '''
     import tempfile
@@ -61,9 +59,9 @@ int main(void) {
         subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe], check=True)
         out = subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()
     got = [int(v) for v in out]
-    S, C, K = _lib.Segment, _lib.ConvDesc, _lib.ChainStage
+    S, C = _lib.Segment, _lib.ConvDesc
     assert got == [ctypes.sizeof(S), S.n.offset, S.stream_id.offset, ctypes.sizeof(C), C.x_draw_stride.offset,
-                   C.act.offset, C.draws.offset, ctypes.sizeof(K), K.conv.offset, K.x.offset, K.y.offset]
+                   C.act.offset, C.draws.offset]
 
 
 def test_argument_errors_without_a_gpu(built):
@@ -86,16 +84,6 @@ def test_argument_errors_without_a_gpu(built):
     assert h.bbb_mc_tail(None, 1, 1, 1, 0, None, None) == -1
     assert h.bbb_eps_dump(None, 4, 0, 0, 0, 0, None) == -1
     assert h.bbb_maxpool_chwn(None, None, 1, 4, 4, 4, 2, 2, None) == -1
-    # the persistent chain launch validates its stage table on the host
-    st = (_lib.ChainStage * 2)()
-    assert h.bbb_chain_fwd(st, 0, 0, None, 0, None) == -1                                          # no stages / no workspace
-    assert h.bbb_chain_fwd(st, 13, 0, None, 0, None) == -1                                         # > BBB_CHAIN_MAX_STAGES
-    assert h.bbb_chain_workspace(2, 10) > 0 and h.bbb_chain_workspace(2, 65) == 0 and h.bbb_chain_workspace(13, 1) == 0
-    ws = (ctypes.c_int32 * int(h.bbb_chain_workspace(2, 2)))()
-    st[0].conv.draws = 2
-    assert h.bbb_chain_fwd(st, 1, 0, ws, len(ws), None) == -1                                      # stage 0: null x / y
-    st[0].conv.draws = 70
-    assert h.bbb_chain_fwd(st, 1, 0, ws, len(ws), None) == -3                                      # more slabs than it schedules
 
 
 def test_product_path_refuses_cpu_tensors(built):
@@ -640,3 +628,25 @@ def test_speculation_cache_does_not_travel_with_copies_of_the_net():
     back = pickle.loads(pickle.dumps(net))                      # (a weak reference cannot be pickled)
     assert back.__dict__["_bbb_spec"].xref is None
     assert sp.streak == 5
+
+
+def test_outgrown_scratch_buffers_are_retired_not_freed():
+    """ops._grow: a scratch buffer (split-contraction tickets / partial tiles, KL partial slots) that a later, larger launch
+    outgrows stays alive -- a hipGraph captured earlier on the same stream has its address baked in."""
+    from bbb_hip import ops
+    key = ("test", "grow", 0)
+    made = []
+
+    def make(n):
+        made.append(n)
+        return torch.zeros(n, dtype=torch.uint8)
+
+    n_ret = len(ops._retired)
+    a = ops._grow(key, 100, make)
+    assert ops._grow(key, 50, make) is a and ops._grow(key, 100, make) is a
+    b = ops._grow(key, 101, make)
+    assert b is not a and b.numel() >= 200 and ops._retired[n_ret] is a       # doubled, the old one kept
+    assert ops._grow(key, 150, make) is b
+    assert made == [100, 200]
+    ops._scratch.pop(key)
+    del ops._retired[n_ret:]
