@@ -452,8 +452,8 @@ def run_config(cfg, steps, warmup, pipeline, dev, group=None, world=1, want_roof
                 xg = x.repeat(steps_per_launch, 1, 1, 1)
 
                 def one_pass(t):
-                    seed, call0 = rng.next_calls(steps_per_launch)
-                    ensemble._local_lse(net, xg, steps_per_launch, seed, call0, 1, timers=t, precision=prec, per_draw_x=True)
+                    seed, call0 = rng.next_calls(steps_per_launch * E)
+                    ensemble._local_lse(net, xg, E, seed, call0, E, timers=t, precision=prec, groups=steps_per_launch)
             else:
                 def one_pass(t):
                     ensemble.mc_forward(net, x, E, timers=t, precision=prec)

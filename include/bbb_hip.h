@@ -158,6 +158,10 @@ typedef struct bbb_conv_desc {
                              cin*kh*kw).  Lets a launch contract over a K-slice of a wider matrix in place (split-K over draws). */
     int32_t b_offset;     /* LRT noise only: global index of local image 0 (batch-parallel shards), added to the image index
                              that keys the activation noise; a unit's slice adds slice * batch on top */
+    int32_t x_unit_div;   /* batch-innermost entry points (ABI 8).  D > 1: output slab e reads INPUT slab e / D (x holds draws / D
+                             slabs at x_draw_stride) -- several Monte-Carlo steps in one launch: slab e = step e / D, draw e % D,
+                             the first layer's input being the same for all D draws of a step.  Weight / bias set: e, as usual.
+                             0 / 1: input slab e.  Not combined with work units (unit_div > 1). */
 } bbb_conv_desc_t;
 
 /*
@@ -338,6 +342,14 @@ int bbb_mc_tail_units(const float* logits, int units, int slices, int unit_off, 
 int bbb_mc_tail_units_step(const float* logits, int units, int slices, int unit_off, int batch_slice, int classes, int mean_over,
                            float* lse_out, const float* kl_in, float kl_scale, float* kl_out, uint32_t* counter,
                            uint32_t counter_add, void* stream);
+
+/* Several Monte-Carlo steps in one set of launches (ABI 8): logits [groups * draws][C][batch] hold `groups` consecutive steps of
+ * `draws` forwards each, step g on its own batch (slab g * draws + j = draw j of step g; main_bayesian.py:73-80 run `groups`
+ * times) -> lse_out [groups * batch][C], block g = the log-sum-exp over step g's draws (minus log(mean_over) when > 0).
+ * kl_in / kl_scale / kl_out / counter / counter_add as in bbb_mc_tail_units_step (all NULL / 0 = plain tail). */
+int bbb_mc_tail_groups_step(const float* logits, int groups, int draws, int batch, int classes, int mean_over,
+                            float* lse_out, const float* kl_in, float kl_scale, float* kl_out, uint32_t* counter,
+                            uint32_t counter_add, void* stream);
 
 /*
  * Uncertainty decomposition over `draws` stochastic forwards (uncertainty_estimation.py:37-58 per image, :61-102 per

@@ -16,7 +16,7 @@ def per_launch(net, x, E, per_draw=False):
     rec = bench.LaunchRecorder()
     with torch.no_grad():
         if per_draw:          # E one-draw steps on E batches in one set of launches (GraphedPipeline steps_per_launch)
-            ensemble._mc_logits_chwn(net, x.repeat(E, 1, 1, 1), E, 7, 3, timers=rec, precision="bf16", per_draw_x=True)
+            ensemble._mc_logits_chwn(net, x.repeat(E, 1, 1, 1), 1, 7, 3, timers=rec, precision="bf16", groups=E)
         else:
             ensemble._mc_logits_chwn(net, x, E, 7, 3, timers=rec, precision="bf16")
     torch.cuda.synchronize()

@@ -349,14 +349,15 @@ def _check_precision(precision, net, x, fast_path_allowed):
                                "4-d input with B % 8 == 0, BBB layers + ReLU/Softplus/MaxPool2d/FlattenLayer)")
 
 
-def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precision="fp32", units=None, b_offset=0, per_draw_x=False):
+def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precision="fp32", units=None, b_offset=0, groups=1):
     """Inference path of mc_logits in the batch-innermost layout ([E, C, H, W, B]): pixel-major GEMMs that
     skip padding taps, activation fused into the GEMM epilogue, pooling on contiguous image vectors.
     units = (S, lo, hi): instead of `draws` whole draws starting at call0, run the work units lo..hi-1 of the draw-major
     (draw, batch slice) grid with S slices per draw (call0 = the call index of draw 0); returns logits [hi-lo, C, B/S].
     b_offset: global index of x's first image (batch-parallel shards): LRT activation noise is keyed by the global image.
-    per_draw_x: x holds `draws` batches back to back ([draws * B, C, H, W]) and draw e runs on batch e -- several one-draw steps
-    in one set of launches (GraphedMC steps > 1); returns logits [draws, C, B]."""
+    groups = G > 1: x holds G batches back to back ([G * B, C, H, W]) and the launches run G consecutive Monte-Carlo steps of
+    `draws` forwards each -- slab g * draws + j = draw j of step g, on batch g, under noise call call0 + g * draws + j, i.e.
+    exactly what G separate steps would compute (GraphedMC steps > 1); returns logits [G * draws, C, B]."""
     layers = bayesian_layers(net)
     bbb = [l for l in layers if isinstance(l, _BBBLayer)]
     lrt = [l for l in layers if isinstance(l, _LRTLayer)]
@@ -364,12 +365,15 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
     bf16 = precision == "bf16"
     E, B = draws, x.shape[0]
     ukw = {}
-    if per_draw_x:
+    G = int(groups)
+    if G > 1:
         if units is not None and units[0] > 1:
-            raise _lib.BBBHipError("per-draw inputs and work units do not combine")
-        if B % draws or (B // draws) % (8 if bf16 else 4):
-            raise _lib.BBBHipError("per-draw inputs: every batch must hold a multiple of 4 (bf16: 8) images")
-        B = B // draws
+            raise _lib.BBBHipError("several steps per launch and work units do not combine")
+        if B % G or (B // G) % (8 if bf16 else 4):
+            raise _lib.BBBHipError("several steps per launch: every batch must hold a multiple of 4 (bf16: 8) images")
+        B = B // G
+        E = G * draws
+        streams = 1
     if units is not None and units[0] > 1:
         S, lo, hi = units
         if B % S or (B // S) % (8 if bf16 else 4):
@@ -381,7 +385,7 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
         ukw = dict(units=(S, lo % S), n_units=E)
         streams = 1
     else:
-        S, n_draws = 1, draws
+        S, n_draws = 1, E
     if bf16 and (lrt or B % 8 != 0):
         raise _lib.BBBHipError("the bf16 path covers BBB (non-LRT) layers and batch sizes that are multiples of 8")
     if bbb:
@@ -390,8 +394,8 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
         variances, k2 = _variances_all(lrt, timers)
         kl = k2 if kl is None else kl + k2
     to_cb = ops.to_batch_innermost_bf16 if bf16 else ops.to_batch_innermost
-    if S > 1 or (per_draw_x and draws > 1):                     # [S, C, H, W, B/S]: one batch-innermost block per slice / per draw
-        nblk = S if S > 1 else draws
+    if S > 1 or G > 1:                                          # [S, C, H, W, B/S]: one batch-innermost block per slice / per step
+        nblk = S if S > 1 else G
         xt = ops.to_batch_innermost_bf16_slices(x, nblk) if bf16 else ops.to_batch_innermost_slices(x, nblk)
     else:
         xt = to_cb(x).unsqueeze(0)                              # [1, C, H, W, B], shared by all draws
@@ -412,9 +416,10 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
         B = xt.shape[-1]
         Es = e1 - e0
         amax = amax0
-        h = xt[e0:e1] if (per_draw_x and draws > 1) else xt
+        h = xt
         boff = int(b_offset)           # global index of the first local "image" (rows multiply at a flatten that cuts images up)
         per_slice = bool(ukw)          # work units: until the first Bayesian layer, h is one block per batch slice
+        x_div = draws if (G > 1 and draws > 1) else 1   # several steps per launch: the first layer's slab e reads batch e // draws
         i = 0
         while i < len(children):
             mod = children[i]
@@ -426,8 +431,9 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
                 h5 = h if is_conv else h.reshape(h.shape[0], mod.in_features, 1, 1, -1)
                 if h5.dim() != 5 or h5.shape[-1] != B:
                     return None                                  # flatten quirk etc.: caller falls back
-                ukw2 = dict(ukw, x_per_slice=per_slice) if ukw else {}
+                ukw2 = dict(ukw, x_per_slice=per_slice) if ukw else ({"x_div": x_div} if x_div > 1 else {})
                 per_slice = False
+                x_div = 1
                 if isinstance(mod, _BBBLayer) and bf16:
                     w, b = sampled[mod]
                     if not ukw:
@@ -466,7 +472,7 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
                     if not is_conv:
                         shp = (mod.out_features, mod.in_features, 1, 1)
                         w_mu, w_var = w_mu.reshape(shp), w_var.reshape(shp)
-                    shared_in = h5.shape[0] == 1 and Es > 1 and not ukw
+                    shared_in = h5.shape[0] == 1 and Es > 1 and not ukw and G == 1
                     fl = conv_flops(B, h5.shape[1], h5.shape[2], h5.shape[3], w_mu.shape[0], w_mu.shape[2], w_mu.shape[3],
                                     *geom, 1 if shared_in else Es, 2) if timers is not None else None
                     if shared_in:
@@ -714,25 +720,26 @@ def mc_logits(net, x, draws, seed, call0, fuse_act=True, timers=None, eps=None, 
 
 
 def _local_lse(net, x, draws, seed, call0, mean_over, fuse_act=True, timers=None, streams=1, precision="fp32", units=None, b_offset=0,
-               step_end=None, per_draw_x=False, param_alias=None):
+               step_end=None, groups=1, param_alias=None):
     """(log-sum-exp over the local draws of the per-draw log_softmax [B, C], kl of one forward), staying in the
     batch-innermost layout end to end when the fast path applies.  units = (S, lo, hi): the local work is the unit range
     lo..hi-1 instead of `draws` whole draws (call0 = call index of draw 0); rows of slices without a local unit are -inf.
     step_end = (scale, counter, counter_add) (a captured step, GraphedMC): the tail launch also writes kl * scale and advances the
     device-side call counter; then the second return value is the SCALED kl, and step_end[3] is set to True -- on the paths without
-    the fused tail the caller does both itself."""
+    the fused tail the caller does both itself.
+    groups = G > 1: x holds G batches and the launches run G consecutive steps of `draws` forwards each (_mc_logits_chwn);
+    -> [G * B, C], block g = step g's result."""
     _check_precision(precision, net, x, fuse_act)
-    if per_draw_x:
-        # `draws` one-draw steps on `draws` batches in one set of launches: -> [draws * B, C], block g = log_softmax of step g
-        # (its log-mean-exp over one draw), through the work-unit tail with one "slice" per step
-        out = _mc_logits_chwn(net, x, draws, seed, call0, timers, 1, precision, per_draw_x=True)
+    if int(groups) > 1:
+        out = _mc_logits_chwn(net, x, draws, seed, call0, timers, 1, precision, groups=groups)
         if out is None:
             raise _lib.BBBHipError("several steps per launch need the batch-innermost path")
         if step_end is not None and timers is None:
-            lse, klf = ops.mc_tail_units(out[0], draws, 0, mean_over=1, step_end=(out[1], step_end[0], step_end[1], step_end[2]))
+            lse, klf = ops.mc_tail_groups(out[0], groups, draws, mean_over=mean_over,
+                                          step_end=(out[1], step_end[0], step_end[1], step_end[2]))
             step_end[3] = True
             return lse, klf
-        lse = _run(timers, "mc_tail", 0, lambda: ops.mc_tail_units(out[0], draws, 0, mean_over=1))
+        lse = _run(timers, "mc_tail", 0, lambda: ops.mc_tail_groups(out[0], groups, draws, mean_over=mean_over))
         return lse, out[1]
     if units is not None and units[0] > 1:
         out = _mc_logits_chwn(net, x, draws, seed, call0, timers, 1, precision, units=units)
@@ -888,10 +895,11 @@ class GraphedMC:
     outside the graphs) and replays a second small graph that reduces the gathered blocks over ranks -- three host calls per
     step (replay, all_gather, replay), which matters when 8 ranks leave each GPU only ~0.1 ms of work per step.
     step() returns (log_outputs [B, C], kl): buffers overwritten by the lane's next replay.
-    steps > 1 (num_ens == 1, single process, batch-innermost path): the graph holds `steps` consecutive one-draw steps -- `steps`
-    batches, each with its own weight draw and its own noise calls, exactly what `steps` separate replays would compute -- as ONE
-    set of launches (a one-draw step of a small model is a chain of ~10 launch-latency-bound kernels; `steps` of them per launch
-    fill the same chain with `steps` times the work).  step(x) then only stores the batch in the next slot and replays when the
+    steps > 1 (single process, batch-innermost path): the graph holds `steps` consecutive steps -- `steps` batches, each with
+    its own num_ens weight draws and its own noise calls (step g, draw j = call g * num_ens + j), exactly what `steps` separate
+    replays would compute -- as ONE set of launches of steps * num_ens slabs (a one-draw step of a small model is a chain of ~10
+    launch-latency-bound kernels; and the 10-draw launches of the metric step are one or two rounds of workgroups whose ramp and
+    tail cost ~13 % of the GEMM and ~10 us of fixed cost in the parameter pass: `steps` of them per launch amortise both).  step(x) then only stores the batch in the next slot and replays when the
     last slot is filled (flush() replays a partly filled group); the (log_outputs, kl) it returns are that slot's views of the
     graph's output, valid once the group has been replayed and the lane's stream synchronised."""
 
@@ -902,8 +910,8 @@ class GraphedMC:
         self.f16x2_layers = [l for l in bayesian_layers(net) if isinstance(l, _BBBLayer)] \
             if (precision == "fp16x2" or ops.gemm_mode == "fp16x2") else []
         if self.steps > 1:
-            if int(num_ens) != 1 or group is not None:
-                raise _lib.BBBHipError("steps > 1 batches ONE-draw steps of a single process (num_ens == 1, no group)")
+            if group is not None:
+                raise _lib.BBBHipError("steps > 1 batches the steps of a single process (no group)")
             with torch.no_grad():
                 if not units_ok(net, x):
                     raise _lib.BBBHipError("steps > 1 needs the batch-innermost path (model / input shape not covered)")
@@ -984,8 +992,8 @@ class GraphedMC:
         # the tail launch of the fast path also scales the KL and advances the noise counter (two element-wise launches less)
         end = [scale, self.counter, self.stride, False]
         if self.steps > 1:
-            lse, kl = _local_lse(self.net, self.x, self.steps, self.seed, self.call0, 1, precision=self.precision, step_end=end,
-                                 per_draw_x=True)
+            lse, kl = _local_lse(self.net, self.x, self.num_ens, self.seed, self.call0, self.num_ens, precision=self.precision,
+                                 step_end=end, groups=self.steps)
         elif self.S > 1:
             lse, kl = _local_lse(self.net, self.x, self.num_ens, self.seed, self.call0, 0, precision=self.precision,
                                  units=(self.S, self.lo, self.hi), step_end=end)
@@ -1007,7 +1015,7 @@ class GraphedMC:
             with ctx:
                 self.graph.replay()
             self.replays += 1
-            rng.next_calls(self.steps - self.slot)   # the graph consumed the calls of the empty slots too
+            rng.next_calls((self.steps - self.slot) * self.num_ens)   # the graph consumed the calls of the empty slots too
             self.slot = 0
 
     def step(self, x=None):
@@ -1025,7 +1033,7 @@ class GraphedMC:
                         self.stream.wait_stream(producer)
                     self.x[g * B:(g + 1) * B].copy_(x, non_blocking=True)
                 self.slot += 1
-                rng.next_calls(1)
+                rng.next_calls(self.num_ens)
                 if self.slot == self.steps:
                     self.graph.replay()
                     self.replays += 1
@@ -1062,7 +1070,7 @@ class GraphedPipeline:
     work with its own noise (lane l, replay r = noise calls of step r*depth + l).
     step() returns the (log_outputs, kl) buffers of the lane just enqueued; call sync() (or synchronize the device)
     before reading them.
-    steps_per_launch = G > 1 (num_ens == 1): every lane's graph holds G consecutive steps (GraphedMC steps=G): step i goes to
+    steps_per_launch = G > 1: every lane's graph holds G consecutive steps (GraphedMC steps=G): step i goes to
     slot i % G of lane (i // G) % depth and the lane replays when its G slots are filled -- same noise calls per step as G = 1;
     sync() replays partly filled groups first."""
 

@@ -266,11 +266,13 @@ def _desc_chwn(x, w, stride, padding, dilation, draws, x_shared, w_shared, act):
 
 
 def conv2d_chwn_forward(x, w, bias, stride=1, padding=0, dilation=1, act=None, out=None, units=None, n_units=None,
-                        x_per_slice=False, amax_in=None, amax_out=None, f16x2=False, amax_w=None):
+                        x_per_slice=False, amax_in=None, amax_out=None, f16x2=False, amax_w=None, x_div=1):
     """Batch-innermost conv for the ensemble path.  x: [E|1, Cin, H, W, B] (B % 4 == 0); w: [E|1, Cout, Cin, kh, kw];
     bias [E|1, Cout] or None -> y [E, Cout, Ho, Wo, B].  Padding taps are skipped, not multiplied.
     Work units (ensemble sharding): units = (S, off), n_units = U output slabs; w / bias hold the weight sets of the draws
     the units touch, x is [U, ...] or, for a layer whose input is the same for every draw, the per-slice [S, Cin, H, W, Bs].
+    x_div = D > 1 (several Monte-Carlo steps per launch): x holds E / D input slabs and output slab e reads slab e // D
+    (bbb_conv_desc_t::x_unit_div) -- the first layer of G steps x D draws, each step on its own batch.
     f16x2: this launch may run on the split-fp16 kernel (the inference ensemble path passes True under precision="fp16x2" /
     gemm_mode == "fp16x2";
     the role-swapped gradient launches of fast_train never do: their operands -- gradients of 1e-6 -- lie far below the operand
@@ -285,6 +287,12 @@ def conv2d_chwn_forward(x, w, bias, stride=1, padding=0, dilation=1, act=None, o
             raise _lib.BBBHipError("work units: x must hold one slab per unit, or one per batch slice with x_per_slice")
         d, ho, wo = _desc_chwn(x, w, stride, padding, dilation, E, False, False, act)
         _apply_units(d, units, x_per_slice)
+    elif int(x_div) > 1:
+        E = w.shape[0]
+        if E % int(x_div) or x.shape[0] * int(x_div) != E:
+            raise _lib.BBBHipError("x_div: x must hold E / x_div input slabs for the E weight sets")
+        d, ho, wo = _desc_chwn(x, w, stride, padding, dilation, E, False, False, act)
+        d.x_unit_div = int(x_div)
     else:
         E = max(x.shape[0], w.shape[0])
         if x.shape[0] not in (1, E) or w.shape[0] not in (1, E):
@@ -320,7 +328,7 @@ def conv2d_chwn_forward(x, w, bias, stride=1, padding=0, dilation=1, act=None, o
 
 def lrt_conv2d_chwn_forward(x, w_mu, w_var, b_mu, b_var, seed, call0, stream_id, stride=1, padding=0, dilation=1,
                             sample=True, eps=None, want_moments=False, act=None, units=None, n_units=None, b_offset=0,
-                            x_per_slice=False):
+                            x_per_slice=False, x_div=1):
     """LRT layer, batch-innermost.  x: [E, Cin, H, W, B] -> (y, act_mu|None, act_var|None) [E, Cout, Ho, Wo, B].
     Work units as in conv2d_chwn_forward (call0 = the call index of the first unit's draw; the noise of unit u is keyed by
     its draw and by the GLOBAL image index slice*B + b).  b_offset: global index of local image 0 (batch-parallel shards)."""
@@ -329,10 +337,12 @@ def lrt_conv2d_chwn_forward(x, w_mu, w_var, b_mu, b_var, seed, call0, stream_id,
     w_mu, w_var = w_mu.contiguous(), w_var.contiguous()
     b_mu = None if b_mu is None else b_mu.contiguous()
     b_var = None if b_var is None else b_var.contiguous()
-    E = x.shape[0] if (units is None or units[0] <= 1) else int(n_units)
+    E = x.shape[0] * int(x_div) if (units is None or units[0] <= 1) else int(n_units)
     d, ho, wo = _desc_chwn(x, w_mu.unsqueeze(0), stride, padding, dilation, E, False, True, act)
     if units is not None and units[0] > 1:
         _apply_units(d, units, x_per_slice)
+    elif int(x_div) > 1:
+        d.x_unit_div = int(x_div)                 # several steps per launch: slab e = step e // x_div on that step's batch
     d.b_offset = int(b_offset)
     d.w_draw_stride = 0
     d.b_draw_stride = 0
@@ -461,7 +471,7 @@ def to_batch_innermost_bf16_slices(x, slices):
 
 
 def conv2d_chwn_bf16_forward(x, w, bias, cin_khkw, stride=1, padding=0, dilation=1, act=None, out_f32=False, out=None,
-                             tap_major=False, units=None, n_units=None, x_per_slice=False):
+                             tap_major=False, units=None, n_units=None, x_per_slice=False, x_div=1):
     """bf16 batch-innermost conv.  x: [E|1, Cin, H, W, B] bf16 (B % 8 == 0); w: [E|1, Cout, Kp] bf16 as written by
     sample_weights_bf16 (tap_major = its column order, see bf16_tap_major); cin_khkw = (Cin, kh, kw); bias [E|1, Cout]
     fp32 or None -> y [E, Cout, Ho, Wo, B] bf16 (fp32 when out_f32)."""
@@ -471,8 +481,11 @@ def conv2d_chwn_bf16_forward(x, w, bias, cin_khkw, stride=1, padding=0, dilation
     bias = None if bias is None else bias.contiguous()
     cin, kh, kw = cin_khkw
     sharded = units is not None and units[0] > 1
+    grouped = not sharded and int(x_div) > 1
     E = int(n_units) if sharded else max(x.shape[0], w.shape[0])
-    if not sharded and (x.shape[0] not in (1, E) or w.shape[0] not in (1, E)):
+    if grouped and (E % int(x_div) or x.shape[0] * int(x_div) != E):
+        raise _lib.BBBHipError("x_div: x must hold E / x_div input slabs for the E weight sets")
+    if not sharded and not grouped and (x.shape[0] not in (1, E) or w.shape[0] not in (1, E)):
         raise _lib.BBBHipError("leading (draw) dims of x and w must be 1 or equal")
     Ex, Cin, H, W, B = x.shape
     if Cin != cin or w.shape[2] != bf16_row_pitch(cin * kh * kw):
@@ -482,7 +495,9 @@ def conv2d_chwn_bf16_forward(x, w, bias, cin_khkw, stride=1, padding=0, dilation
     d.batch, d.cin, d.h, d.w, d.cout, d.kh, d.kw = B, Cin, H, W, w.shape[1], kh, kw
     d.stride_h, d.stride_w, d.pad_h, d.pad_w, d.dil_h, d.dil_w = sh, sw, ph, pw, dh, dw
     d.draws = E
-    d.x_draw_stride = 0 if (Ex == 1 and E > 1 and not sharded) else Cin * H * W * B
+    d.x_draw_stride = 0 if (Ex == 1 and E > 1 and not sharded and not grouped) else Cin * H * W * B
+    if grouped:
+        d.x_unit_div = int(x_div)
     d.w_draw_stride = 0 if (w.shape[0] == 1 and E > 1 and not sharded) else w.shape[1] * w.shape[2]
     d.b_draw_stride = 0 if (bias is None or (bias.shape[0] == 1 and E > 1 and not sharded)) else w.shape[1]
     d.act = {None: 0, "relu": 1, "softplus": 2}[act]
@@ -552,6 +567,28 @@ def mc_tail_units(logits, slices, unit_off, mean_over=0, step_end=None):
                                        out.data_ptr(), kl_in.data_ptr(), float(scale), kl_out.data_ptr(), ptr(counter),
                                        int(add) & 0xFFFFFFFF, cur_stream(logits.device)), "bbb_mc_tail_units_step")
     return out, kl_out
+
+
+def mc_tail_groups(logits, groups, draws, mean_over=0, step_end=None):
+    """Tail of `groups` Monte-Carlo steps that share one set of launches: logits [groups * draws, C, B] (slab g * draws + j =
+    draw j of step g) -> [groups * B, C], block g = log-sum-exp over step g's draws of the per-draw log_softmax, minus
+    log(mean_over) when > 0.  step_end as in mc_tail_units."""
+    require_device(logits)
+    logits = logits.contiguous()
+    U, C, B = logits.shape
+    if U != int(groups) * int(draws) or U > 4096:
+        raise _lib.BBBHipError("mc_tail_groups: logits must hold groups * draws <= 4096 slabs")
+    out = torch.empty((int(groups) * B, C), dtype=torch.float32, device=logits.device)
+    kl_in, scale, counter, add = step_end if step_end is not None else (None, 0.0, None, 0)
+    require_device(kl_in)
+    kl_out = torch.empty((), dtype=torch.float32, device=logits.device) if step_end is not None else None
+    if counter is not None and (counter.dtype != torch.int32 or not counter.is_cuda):
+        raise _lib.BBBHipError("the call counter must be an int32 device tensor")
+    with on_device(logits.device):
+        check(_lib.lib().bbb_mc_tail_groups_step(logits.data_ptr(), int(groups), int(draws), B, C, int(mean_over), out.data_ptr(),
+                                                 ptr(kl_in), float(scale), ptr(kl_out), ptr(counter), int(add) & 0xFFFFFFFF,
+                                                 cur_stream(logits.device)), "bbb_mc_tail_groups_step")
+    return out if step_end is None else (out, kl_out)
 
 
 def uncertainty(logits, normalized=False):

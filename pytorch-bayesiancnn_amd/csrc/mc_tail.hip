@@ -67,6 +67,8 @@ constexpr int kCbRows = 16;
 // Work units (ensemble sharding, include/bbb_hip.h): the E slabs are units u = off + e of the draw-major (draw, batch slice)
 // grid with S slices of Bs images; image b = s*Bs + bl reduces over the local units of ITS slice, e = e0, e0 + S, ...
 // (e0 = (s - off) mod S), and gets -inf when the rank holds none.  S = 1, off = 0 is the plain [E][C][B] case.
+// Groups (grp > 0; several Monte-Carlo steps per launch): the E = S * grp slabs are S consecutive steps of grp draws each on
+// S different batches; image b of step s = b / Bs reduces over slabs s*grp .. s*grp + grp - 1 (e = e0 + k, stride 1).
 // Step epilogue riding on the tail launch (a captured Monte-Carlo step otherwise spends two more element-wise launches on
 // them): kl_out = kl_in * kl_scale (the KL of ONE forward times the number of forwards this rank ran, main_bayesian.py:76-77)
 // and counter += counter_add (the device-side noise call counter of include/bbb_hip.h `call_dev`: every kernel that reads it
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(kCbThreads * kCbRows) void mc_tail_cb_kernel(const 
                                                                           int off, int C, float sub, float* __restrict__ out,
                                                                           const float* __restrict__ kl_in, float kl_scale,
                                                                           float* __restrict__ kl_out, uint32_t* counter,
-                                                                          uint32_t counter_add) {
+                                                                          uint32_t counter_add, int grp) {
     extern __shared__ float lz[];                       // [ceil(E/S)][64]
     const int tx = threadIdx.x, ty = threadIdx.y, ny = blockDim.y;
     if (blockIdx.x == 0 && tx == 0 && ty == 0) {
@@ -87,10 +89,11 @@ __global__ __launch_bounds__(kCbThreads * kCbRows) void mc_tail_cb_kernel(const 
     const bool ok = b < B;
     const int bb = ok ? b : B - 1;
     const int sl = bb / Bs, bl = bb - sl * Bs;
-    const int e0 = (sl - off % S + S) % S;
-    const int ne = e0 < E ? (E - e0 + S - 1) / S : 0;
+    const int es = grp > 0 ? 1 : S;                     // slab stride between the draws an image reduces over
+    const int e0 = grp > 0 ? sl * grp : (sl - off % S + S) % S;
+    const int ne = grp > 0 ? grp : (e0 < E ? (E - e0 + S - 1) / S : 0);
     for (int k = ty; k < ne; k += ny) {
-        const float* p = logits + (int64_t)(e0 + k * S) * C * Bs + bl;
+        const float* p = logits + (int64_t)(e0 + k * es) * C * Bs + bl;
         float mx = -INFINITY;
         for (int c = 0; c < C; ++c) mx = fmaxf(mx, p[(int64_t)c * Bs]);
         float se = 0.0f;
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(kCbThreads * kCbRows) void mc_tail_cb_kernel(const 
     for (int c = ty; c < C; c += ny) {
         float m = -INFINITY, s = 0.0f;
         for (int k = 0; k < ne; ++k) {
-            const float ls = logits[((int64_t)(e0 + k * S) * C + c) * Bs + bl] - lz[k * kCbThreads + tx];
+            const float ls = logits[((int64_t)(e0 + k * es) * C + c) * Bs + bl] - lz[k * kCbThreads + tx];
             const float nm = fmaxf(m, ls);
             s = s * expf(m - nm) + expf(ls - nm);
             m = nm;
@@ -304,12 +307,12 @@ __global__ __launch_bounds__(256) void lrt_sample_nchw_kernel(const float* __res
 
 }  // namespace
 
-extern "C" int bbb_mc_tail_units_step(const float* logits, int units, int slices, int unit_off, int batch_slice, int classes,
-                                      int mean_over, float* lse_out, const float* kl_in, float kl_scale, float* kl_out,
-                                      uint32_t* counter, uint32_t counter_add, void* stream) {
+namespace {
+int mc_tail_launch(const float* logits, int units, int slices, int unit_off, int batch_slice, int classes, int mean_over, float* lse_out,
+                   const float* kl_in, float kl_scale, float* kl_out, uint32_t* counter, uint32_t counter_add, int grp, void* stream) {
     if ((kl_out != nullptr && kl_in == nullptr) || (((uintptr_t)kl_in | (uintptr_t)kl_out | (uintptr_t)counter) & 3u) != 0) return BBB_EINVAL;
     if (logits == nullptr || lse_out == nullptr || units <= 0 || slices <= 0 || unit_off < 0 || batch_slice <= 0 || classes <= 0 ||
-        mean_over < 0 || units > 4096)
+        mean_over < 0 || units > 4096 || grp < 0 || (grp > 0 && (int64_t)grp * slices != units))
         return BBB_EINVAL;
     if ((((uintptr_t)logits | (uintptr_t)lse_out) & 3u) != 0) return BBB_EALIGN;
     const float sub = mean_over > 0 ? logf((float)mean_over) : 0.0f;
@@ -321,8 +324,24 @@ extern "C" int bbb_mc_tail_units_step(const float* logits, int units, int slices
     const int ny = mx < kCbRows ? mx : kCbRows;
     hipLaunchKernelGGL(mc_tail_cb_kernel, dim3(blocks), dim3(kCbThreads, ny), (size_t)per_slice * kCbThreads * sizeof(float),
                        (hipStream_t)stream, logits, units, batch_slice, slices, unit_off, classes, sub, lse_out, kl_in, kl_scale, kl_out,
-                       counter, counter_add);
+                       counter, counter_add, grp);
     return (int)hipGetLastError();
+}
+}  // namespace
+
+extern "C" int bbb_mc_tail_units_step(const float* logits, int units, int slices, int unit_off, int batch_slice, int classes,
+                                      int mean_over, float* lse_out, const float* kl_in, float kl_scale, float* kl_out,
+                                      uint32_t* counter, uint32_t counter_add, void* stream) {
+    return mc_tail_launch(logits, units, slices, unit_off, batch_slice, classes, mean_over, lse_out, kl_in, kl_scale, kl_out, counter,
+                          counter_add, 0, stream);
+}
+
+extern "C" int bbb_mc_tail_groups_step(const float* logits, int groups, int draws, int batch, int classes, int mean_over,
+                                       float* lse_out, const float* kl_in, float kl_scale, float* kl_out, uint32_t* counter,
+                                       uint32_t counter_add, void* stream) {
+    if (groups <= 0 || draws <= 0 || (int64_t)groups * draws > 4096) return BBB_EINVAL;
+    return mc_tail_launch(logits, groups * draws, groups, 0, batch, classes, mean_over, lse_out, kl_in, kl_scale, kl_out, counter,
+                          counter_add, draws, stream);
 }
 
 extern "C" int bbb_mc_tail_units(const float* logits, int units, int slices, int unit_off, int batch_slice, int classes, int mean_over,

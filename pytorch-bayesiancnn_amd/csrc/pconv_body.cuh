@@ -55,7 +55,7 @@ __device__ __forceinline__ void pconv_item(const PConvArgs& p, const int64_t ite
     // work units (ensemble sharding): slab e is unit u = unit_off + e -> weight set u / S, input slab e (or u % S)
     const int ue = p.unit_off + e;
     const int ew = p.unit_div > 1 ? ue / p.unit_div : e;
-    const int ex = p.x_mod > 0 ? ue % p.x_mod : e;
+    const int ex = p.x_div > 1 ? e / p.x_div : (p.x_mod > 0 ? ue % p.x_mod : e);
     const int n0 = (g - e * p.Ntiles) * BN;
     const int pix = j / p.nbt;
     const int b0 = (j - pix * p.nbt) * BM;

@@ -1,6 +1,7 @@
-"""Several one-draw Monte-Carlo steps per launch (GraphedPipeline steps_per_launch, GraphedMC steps): every step must be what
-the one-step-per-replay pipeline computes for the same batch and the same noise calls -- bit for bit on the fp32 BBB / LRT kernels
-(split contraction off: it is planned per launch size), to bf16 storage rounding on the bf16 path.  Run with -m gpu."""
+"""Several Monte-Carlo steps per launch (GraphedPipeline steps_per_launch, GraphedMC steps; one-draw steps since round 3, any
+num_ens since round 4: G steps x E draws = G * E slabs per launch, bbb_conv_desc_t::x_unit_div + bbb_mc_tail_groups_step): every
+step must be what the one-step-per-replay pipeline computes for the same batch and the same noise calls -- bit for bit on the
+fp32 BBB / LRT kernels, to bf16 storage rounding on the bf16 path.  Run with -m gpu."""
 import pytest
 import torch
 
@@ -23,10 +24,10 @@ def _net(env, kind, layer_type, classes=10):
     return net
 
 
-def _run(env, net, batches, G, depth, precision):
+def _run(env, net, batches, G, depth, precision, E=1):
     env["rng"].manual_seed(21, call=0)
     with torch.no_grad():
-        pipe = env["ens"].GraphedPipeline(net, batches[0], 1, depth=depth, precision=precision, steps_per_launch=G)
+        pipe = env["ens"].GraphedPipeline(net, batches[0], E, depth=depth, precision=precision, steps_per_launch=G)
         outs, views = [], []
         for i, xb in enumerate(batches):
             views.append(pipe.step(xb))
@@ -57,6 +58,51 @@ def test_grouped_steps_equal_single_steps(env, kind, layer_type, precision, B):
     assert not torch.equal(got[0][0], got[1][0])
 
 
+@pytest.mark.parametrize("kind,layer_type,precision,B,E,G", [("alexnet", "bbb", "fp32", 128, 3, 2), ("alexnet", "bbb", "fp32", 64, 10, 4),
+                                                             ("alexnet", "lrt", "fp32", 64, 2, 3), ("lenet", "bbb", "fp32", 32, 4, 2),
+                                                             ("3conv3fc", "bbb", "bf16", 64, 2, 2)])
+def test_grouped_multi_draw_steps_equal_single_steps(env, kind, layer_type, precision, B, E, G):
+    """G steps x E draws per launch: slab g * E + j = draw j of step g (call g * E + j) on batch g; every step's log_outputs and
+    KL equal the one-step-per-launch pipeline's, and the host call counter advances E per step (flushed slots included)."""
+    torch.manual_seed(4)
+    cin = 1 if kind == "lenet" else 3
+    net = env["zoo"].getModel(kind, cin, 10, P.CONFIG_PRIORS, layer_type, "softplus").cuda()
+    env["rng"].assign_stream_ids(net)
+    torch.manual_seed(9)
+    n = 2 * 2 * G + 1                                                    # two full rounds of two lanes + one step in a flushed group
+    batches = [torch.rand(B, cin, 32, 32, device="cuda") for _ in range(n)]
+    ref, calls1 = _run(env, net, batches, 1, 2, precision, E)
+    got, callsG = _run(env, net, batches, G, 2, precision, E)
+    assert calls1 == n * E and callsG == (n + G - 1) * E
+    for i, ((lo_r, kl_r), (lo_g, kl_g)) in enumerate(zip(ref, got)):
+        assert lo_g.shape == lo_r.shape == (B, 10)
+        assert torch.equal(kl_g, kl_r)
+        if precision == "fp32":
+            assert torch.equal(lo_g, lo_r), f"step {i}: max diff {float((lo_g - lo_r).abs().max()):.3e}"
+        else:
+            assert float((lo_g - lo_r).abs().max()) <= 2e-2 * float(lo_r.abs().max())
+    assert not torch.equal(got[0][0], got[1][0])
+
+
+def test_grouped_tail_kernel_against_torch(env):
+    """bbb_mc_tail_groups_step on its own: [G * E, C, B] -> block g = logmeanexp over step g's draws of log_softmax."""
+    from bbb_hip import ops
+    torch.manual_seed(2)
+    G, E, C, B = 3, 5, 10, 72
+    logits = torch.randn(G * E, C, B, device="cuda") * 3
+    kl = torch.tensor(2.5, device="cuda")
+    counter = torch.tensor([7], dtype=torch.int32, device="cuda")
+    out, klo = ops.mc_tail_groups(logits, G, E, mean_over=E, step_end=(kl, 4.0, counter, 11))
+    want = torch.logsumexp(torch.log_softmax(logits.view(G, E, C, B), dim=2), dim=1) - torch.log(torch.tensor(float(E)))
+    want = want.permute(0, 2, 1).reshape(G * B, C)
+    torch.testing.assert_close(out, want, rtol=1e-5, atol=1e-5)
+    assert klo.item() == 10.0 and counter.item() == 18
+    plain = ops.mc_tail_groups(logits, G, E, mean_over=E)
+    assert torch.equal(plain, out)
+    for g in range(G):                                                   # block g = the ordinary tail of step g's slabs
+        assert torch.equal(out[g * B:(g + 1) * B], ops.mc_tail_cb(logits[g * E:(g + 1) * E], mean_over=E))
+
+
 def test_grouped_steps_keep_going_after_a_flush(env):
     """sync() in the middle of a group, then more steps: still the single-step sequence (call indices realigned to group starts)."""
     net = _net(env, "alexnet", "bbb")
@@ -84,4 +130,4 @@ def test_grouped_steps_refuse_what_they_do_not_cover(env):
     net = _net(env, "alexnet", "bbb")
     x = torch.rand(64, 3, 32, 32, device="cuda")
     with torch.no_grad(), pytest.raises(BBBHipError):
-        env["ens"].GraphedPipeline(net, x, 2, depth=2, steps_per_launch=4)          # num_ens > 1
+        env["ens"].GraphedPipeline(net, x[:6], 2, depth=2, steps_per_launch=4)      # B % 4 != 0: no batch-innermost path
