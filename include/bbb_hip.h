@@ -218,16 +218,24 @@ int bbb_lrt_conv2d_chwn_fwd(const bbb_conv_desc_t* d, const float* x, const floa
                             const uint32_t* call_dev, void* stream);
 
 /*
- * Split-contraction forms of the two batch-innermost entry points above (ABI 6), for SMALL launches: a single draw of a late
- * AlexNet layer is a few dozen workgroups, each bounded by its serial k loop (conv4: 48 tiles of 32 k on 128 of the 256 CUs).
- * With k_split = S > 1 every (pixel, 64 channels, 64 images) item is computed by S workgroups over consecutive k ranges; each
- * writes its partial accumulator tile to `scratch`, and the last to arrive adds the S tiles in range order (a fixed order: the
- * result does not depend on timing), applies bias / activation / the LRT sampling step and stores y.  Same contraction as the
- * unsplit entry points with the partial sums rounded separately: results agree to ~1e-7 relative, bitwise run to run.
- *   bbb_conv2d_chwn_splitk_scratch: the library's plan for this geometry -> *k_split (1 = do not split: call the plain entry
- *     point) and the scratch bytes the split launch needs.  lrt != 0: plan for the LRT entry point (two accumulator sets).
+ * Split-contraction forms of the two batch-innermost entry points above (ABI 6; a property of the LAYER since ABI 8).
+ * A draw of a late AlexNet layer is a few dozen workgroups, each bounded by its serial k loop (conv4: 48 tiles of 32 k on 128 of
+ * the 256 CUs).  For such layers -- at most 16 (output pixel, 64-channel tile) groups and at least 16 k tiles; the plan depends on
+ * the layer's GEOMETRY only, never on batch, draws or work units -- the contraction of every output tile is cut into k_split = 2..4
+ * consecutive k ranges whose partial sums are added in range order: ((p0 + p1) + p2) + p3.  Two executions of that one
+ * definition, chosen by launch size, same bits:
+ *   - across workgroups (launches of <= 384 items of 64 images, when scratch is given): each range is its own workgroup, partial
+ *     accumulator tiles go to `scratch`, the last arriver adds them in range order, applies bias / activation / the LRT sampling
+ *     step and stores y;
+ *   - inside one workgroup (any other launch; no scratch needed): the k loop restarts its accumulator at every range boundary.
+ * So one draw computed alone, the same draw inside a 10-draw launch, as a work unit of a sharded step or as one of several steps
+ * per launch is the same number, bit for bit.  Against the UNSPLIT chain of bbb_conv2d_chwn_fwd the partial sums round
+ * separately: ~1e-7 relative, 1-2e-6 of max|logit| through a model.
+ *   bbb_conv2d_chwn_splitk_scratch: the layer's plan -> *k_split (1 = no split: same as the plain entry point) and the scratch
+ *     bytes THIS launch (d->draws, d->batch) needs for the cross-workgroup form (0: it runs the in-workgroup form).
+ *     lrt != 0: sizes for the LRT entry point (two accumulator sets).
  *   scratch: device memory, 256-byte aligned, ZERO-FILLED before its first use (arrival tickets live at its start and every
- *     launch leaves them zero again); one scratch buffer per stream in flight.
+ *     launch leaves them zero again); one scratch buffer per stream in flight; NULL = always the in-workgroup form.
  * k_split must be the planned value (BBB_EINVAL otherwise); k_split <= 1 behaves exactly like the plain entry point.
  */
 int64_t bbb_conv2d_chwn_splitk_scratch(const bbb_conv_desc_t* d, int lrt, int32_t* k_split);

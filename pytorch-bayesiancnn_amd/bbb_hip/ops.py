@@ -223,24 +223,31 @@ gemm_mode = "fp32"  # "fp16x2": the batch-innermost BBB GEMM launches of the INF
 AMAX_SLOTS = 64              # BBB_AMAX_SLOTS: length of the max|x| / max|y| arrays of bbb_conv2d_chwn_f16x2_fwd
 f16x2_min_workgroups = 256   # smaller launches stay on the fp32 kernel (and its split contraction) even in "fp16x2" mode
 _split_plans = {}
-split_k = True     # small batch-innermost launches split their contraction over several workgroups per output tile
-                   # (bbb_conv2d_chwn_splitk_fwd); False: never (tests that compare differently sized launches bit for bit)
+split_k = True     # layers with few (pixel, channel-tile) groups and a long contraction (AlexNet conv4 / conv5) add their k ranges'
+                   # partial sums in range order (bbb_conv2d_chwn_splitk_fwd): a property of the LAYER, identical for every launch
+                   # size and partition.  False: the plain fmaf chain everywhere (bit-identical to the reference-layout kernel).
 
 
 def _split_scratch(d, lrt, device):
-    """(k_split, scratch tensor | None) for this launch: the library's plan + a zero-initialised per-(device, stream) buffer
-    (arrival tickets at its start stay zero from launch to launch)."""
+    """(k_split, scratch tensor | None) for this launch.  k_split is the LAYER's plan (a function of its geometry only:
+    bbb_conv2d_chwn_splitk_scratch), applied to every launch of the layer whatever its size, so that a draw computed alone, in
+    a 10-draw launch, as a work unit or as one of several steps per launch is the same number bit for bit; the scratch (a
+    zero-initialised per-(device, stream) buffer whose arrival tickets stay zero from launch to launch) is only there when
+    this launch is small enough for the cross-workgroup form -- larger launches run the same summation order inside one
+    workgroup per tile."""
     if not split_k:
         return 1, None
-    pkey = (bytes(d), bool(lrt))                       # the plan depends on the geometry only: asked once per shape
+    pkey = (bytes(d), bool(lrt))
     plan = _split_plans.get(pkey)
     if plan is None:
         ks = ctypes.c_int32(1)
         need = _lib.lib().bbb_conv2d_chwn_splitk_scratch(ctypes.byref(d), 1 if lrt else 0, ctypes.byref(ks))
         plan = _split_plans[pkey] = (ks.value, int(need))
     ks_v, need = plan
-    if ks_v <= 1 or need <= 0:
+    if ks_v <= 1:
         return 1, None
+    if need <= 0:
+        return ks_v, None
     buf = _grow((device.index, "splitk", cur_stream(device)), max(int(need), 1 << 22),
                 lambda m: torch.zeros(m, dtype=torch.uint8, device=device))
     return ks_v, buf
@@ -307,7 +314,7 @@ def conv2d_chwn_forward(x, w, bias, stride=1, padding=0, dilation=1, act=None, o
         y = out.view(shape)
     with on_device(x.device):
         ks, scr = _split_scratch(d, False, x.device)
-        if f16x2 and ks == 1 and E * ho * wo * -(-w.shape[1] // 64) * -(-x.shape[4] // 128) >= f16x2_min_workgroups:
+        if f16x2 and E * ho * wo * -(-w.shape[1] // 64) * -(-x.shape[4] // 128) >= f16x2_min_workgroups:
             # (launches below ~256 workgroups stay on the fp32 kernel and its split contraction: measured faster there)
             require_device(amax_in, amax_out, amax_w)
             for t in (amax_in, amax_out, amax_w):
@@ -319,7 +326,8 @@ def conv2d_chwn_forward(x, w, bias, stride=1, padding=0, dilation=1, act=None, o
             return y
         if ks > 1:
             check(_lib.lib().bbb_conv2d_chwn_splitk_fwd(ctypes.byref(d), x.data_ptr(), w.data_ptr(), ptr(bias), y.data_ptr(), ks,
-                                                        scr.data_ptr(), scr.numel(), cur_stream(x.device)), "bbb_conv2d_chwn_splitk_fwd")
+                                                        ptr(scr), 0 if scr is None else scr.numel(), cur_stream(x.device)),
+                  "bbb_conv2d_chwn_splitk_fwd")
         else:
             check(_lib.lib().bbb_conv2d_chwn_fwd(ctypes.byref(d), x.data_ptr(), w.data_ptr(), ptr(bias), y.data_ptr(),
                                                  cur_stream(x.device)), "bbb_conv2d_chwn_fwd")

@@ -28,8 +28,27 @@ constexpr int TPC = KCH / BK;            // tiles per chunk
 // scratch (write-through, 16 bytes per lane), takes a ticket, and the LAST arriver adds the ksplit partial tiles in range
 // order 0, 1, ... (whoever it is: the sum does not depend on timing), applies the epilogue and stores the output.  The
 // partial sums round differently from the unsplit fmaf chain: results agree with an unsplit launch to ~1e-7 relative.
-template <int BM, bool LRT, bool ILV, bool SPLIT = false>
+// SEQ (MODE 2): the SAME summation order computed by ONE workgroup -- it walks the p.ksplit ranges one after the other with a
+// fresh accumulator per range (the k loop itself does not change: at a range boundary the accumulator is added to a running
+// total and zeroed), total = ((p0 + p1) + p2) + ... in range order: bit for bit what the SPLIT form's last arriver computes,
+// without scratch, tickets or partial-tile traffic.  This is what makes the split a property of the LAYER (the plan depends on
+// its geometry only): launches too large to profit from a cross-workgroup split run SEQ, small ones SPLIT, same bits -- a draw
+// computed alone, inside a 10-draw launch, as a work unit of a sharded step or as one of G steps per launch is the same number.
+constexpr int kPlain = 0, kSplit = 1, kSeq = 2;
+
+// SEQ keeps its running totals in ACCUMULATION registers through inline asm: they are touched three times per item, and left to
+// the register allocator they became 28-55 extra VGPRs (one resident workgroup less per CU: +5-8 % per launch, measured);
+// gfx950's register file is unified, so 16 AGPRs are just 16 registers the k loop never looks at.
+__device__ __forceinline__ float agpr_read(float a) {
+    float v;
+    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a));
+    return v;
+}
+__device__ __forceinline__ void agpr_write(float& a, float v) { asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(v)); }
+template <int BM, bool LRT, bool ILV, int MODE = kPlain>
 __device__ __forceinline__ void pconv_item(const PConvArgs& p, const int64_t item, const int ks = 0) {
+    constexpr bool SPLIT = MODE == kSplit;
+    constexpr bool SEQ = MODE == kSeq;
     constexpr int LDX = BM + 4;
     constexpr int NT = (BM >= 128) ? 2 : 1;              // 32-channel MFMA tiles per wave
     constexpr int MT = (BM == 256) ? 2 : 1;              // 32-image MFMA tiles per wave
@@ -174,12 +193,17 @@ __device__ __forceinline__ void pconv_item(const PConvArgs& p, const int64_t ite
 
     f32x16 acc[NT][MT];
     f32x16 accv[NT][MT];
+    float tot[SEQ ? NT : 1][SEQ ? MT : 1][16];           // SEQ: running total of the finished ranges' partial sums (AGPRs)
+    float totv[(SEQ && LRT) ? NT : 1][(SEQ && LRT) ? MT : 1][16];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int u = 0; u < MT; ++u)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[t][u][r] = 0.0f; accv[t][u][r] = 0.0f; }
+            for (int r = 0; r < 16; ++r) {
+                acc[t][u][r] = 0.0f; accv[t][u][r] = 0.0f;
+                if constexpr (SEQ) { agpr_write(tot[t][u][r], 0.0f); if constexpr (LRT) agpr_write(totv[t][u][r], 0.0f); }
+            }
 
     const int lrow = lane & 31, lk = lane >> 5;
 
@@ -237,7 +261,30 @@ __device__ __forceinline__ void pconv_item(const PConvArgs& p, const int64_t ite
         if ((c0 + 1) * KCH < Keff) fill_chunk(c0 + 1);
         store_tile(0, wregA, xregA);
         __syncthreads();
+        int seq_r = 1;                                                // SEQ: next range boundary = tile index seq_r * ntiles / ksplit
+        int seq_next = SEQ ? (int)((int64_t)seq_r * ntiles / p.ksplit) : 0;
         for (int t = t0; t < t1; ++t) {
+            if constexpr (SEQ) {
+                // ranges [r * ntiles / S, (r + 1) * ntiles / S): tile t opens range(s) seq_r.. when it reaches their first tile
+                // (an empty range contributes a zero partial, exactly as its SPLIT workgroup would)
+                while (seq_r < p.ksplit && t == seq_next) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                agpr_write(tot[nt][mt][r], agpr_read(tot[nt][mt][r]) + acc[nt][mt][r]);   // (0 + p0 = p0)
+                                acc[nt][mt][r] = 0.0f;
+                                if constexpr (LRT) {
+                                    agpr_write(totv[nt][mt][r], agpr_read(totv[nt][mt][r]) + accv[nt][mt][r]);
+                                    accv[nt][mt][r] = 0.0f;
+                                }
+                            }
+                    ++seq_r;
+                    seq_next = (int)((int64_t)seq_r * ntiles / p.ksplit);
+                }
+            }
             const bool more = (t + 1) < t1;
             if (more) {
                 if (ILV) load_addr(t + 1);                            // loads themselves are issued inside mma_tile()
@@ -250,6 +297,18 @@ __device__ __forceinline__ void pconv_item(const PConvArgs& p, const int64_t ite
             __syncthreads();                                          // every wave is done reading the LDS stage
             if (more) store_tile(0, wregA, xregA);
             __syncthreads();
+        }
+        if constexpr (SEQ) {
+            // the last range's partial sum is added last (ntiles > 0 here, so every boundary 1 .. ksplit-1 was passed above)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        acc[nt][mt][r] = agpr_read(tot[nt][mt][r]) + acc[nt][mt][r];
+                        if constexpr (LRT) accv[nt][mt][r] = agpr_read(totv[nt][mt][r]) + accv[nt][mt][r];
+                    }
         }
     }
 

@@ -33,7 +33,7 @@ namespace {
 
 using namespace pconv;
 
-template <int BM, bool LRT, bool ILV>
+template <int BM, bool LRT, bool ILV, bool SEQ = false>
 __global__ __launch_bounds__(kThreads) void pconv_gemm_kernel(const PConvArgs p) {
     // ---- block -> work item; weight-tile sharers on one XCD ----
     // Work items (group g = (draw, channel tile), m-tile j) in g-major order are cut into 8 equal contiguous chunks,
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(kThreads) void pconv_gemm_kernel(const PConvArgs p)
     const int64_t item = (int64_t)xcd * p.per_xcd + (bid >> 3);
     const int64_t item_end = (int64_t)(xcd + 1) * p.per_xcd;
     if (item >= item_end || item >= (int64_t)p.G * p.Mtiles) return;
-    pconv_item<BM, LRT, ILV>(p, item);
+    pconv_item<BM, LRT, ILV, SEQ ? kSeq : kPlain>(p, item);
 }
 
 // Split contraction (pconv_body.cuh, SPLIT): block -> (item, k range).  The ksplit blocks of an item are consecutive, so they
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(kThreads) void pconv_gemm_splitk_kernel(const PConv
     const int64_t blk_end = (int64_t)(xcd + 1) * p.per_xcd;
     if (blk >= blk_end || blk >= (int64_t)p.G * p.Mtiles * p.ksplit) return;
     const int64_t item = blk / p.ksplit;
-    pconv_item<BM, LRT, ILV, true>(p, item, (int)(blk - item * p.ksplit));
+    pconv_item<BM, LRT, ILV, kSplit>(p, item, (int)(blk - item * p.ksplit));
 }
 
 // maxpool over [planes][H][W][B] (planes = draws * channels), B innermost; 4 images per thread.
@@ -197,6 +197,11 @@ int fill(const bbb_conv_desc_t* d, PConvArgs& a) {
     return 0;
 }
 
+// launches of more 64-image items than this run the in-workgroup form of a layer's split (measured, profiles/r03_notes.md
+// section 2 and r04_notes.md: above ~400 items the cross-workgroup form only adds partial-tile traffic; LRT items carry two
+// accumulator sets and their in-workgroup form runs at 3 waves per SIMD, so the crossover sits higher)
+constexpr int64_t split_max_items(bool lrt) { return lrt ? 512 : 384; }
+
 template <bool LRT>
 int launch(PConvArgs& a, int draws, hipStream_t st) {
     a.Ntiles = (a.Cout + BN - 1) / BN;
@@ -208,14 +213,17 @@ int launch(PConvArgs& a, int draws, hipStream_t st) {
     // LRT stages two weight tiles and keeps two accumulator sets: 64-wide only.
     const int64_t nb128 = pixels * ((a.B + 127) / 128) * a.G;
     int bm = (LRT || nb128 < 768) ? 64 : 128;        // (round 3 re-measured 600 / 300: conv4 +10 %, conv5 +25 % slower with 128)
+    const int64_t items64 = pixels * ((a.B + 63) / 64) * a.G;
+    const bool cross = a.ksplit > 1 && a.part != nullptr && items64 <= split_max_items(LRT);
+    if (cross) bm = 64;
     a.nbt = (a.B + bm - 1) / bm;
     const int64_t mt = pixels * a.nbt;
     if (mt > 0x7fffffffLL) return BBB_ESHAPE;
     a.Mtiles = (int)mt;
     const int64_t items = (int64_t)a.G * mt;
-    if (a.ksplit > 1) {
-        // split contraction: only planned for launches that took the 64-image tile (split_plan below)
-        if (bm != 64 || items * a.ksplit > 0x7fffffffLL) return BBB_EINVAL;
+    if (cross) {
+        // the layer's split contraction ACROSS workgroups: a launch this small cannot fill the chip otherwise
+        if (items * a.ksplit > 0x7fffffffLL) return BBB_EINVAL;
         const int64_t perb = (items * a.ksplit + 7) / 8;
         a.per_xcd = (int32_t)perb;
         hipLaunchKernelGGL((pconv_gemm_splitk_kernel<64, LRT, true>), dim3((unsigned)(8 * perb)), dim3(kThreads), 0, st, a);
@@ -229,6 +237,20 @@ int launch(PConvArgs& a, int draws, hipStream_t st) {
     // round 3 on the current kernel (profiles/r03_notes.md section 3) it is a 1-2 % gain up to ~12k items, one or three steps in flight
     const bool ilv = items <= 12000;
     const dim3 grid((unsigned)blocks), block(kThreads);
+    if (a.ksplit > 1) {
+        // the same summation order inside ONE workgroup per item (pconv_body.cuh, SEQ): no scratch, no extra traffic
+        if constexpr (!LRT) {
+            if (bm == 128) {
+                if (ilv) hipLaunchKernelGGL((pconv_gemm_kernel<128, false, true, true>), grid, block, 0, st, a);
+                else     hipLaunchKernelGGL((pconv_gemm_kernel<128, false, false, true>), grid, block, 0, st, a);
+                return (int)hipGetLastError();
+            }
+        }
+        const bool ilv_seq = ilv && !LRT;        // LRT: the interleaved form needs 172 registers (2 waves per SIMD), the plain one 161 (3)
+        if (ilv_seq) hipLaunchKernelGGL((pconv_gemm_kernel<64, LRT, true, true>), grid, block, 0, st, a);
+        else         hipLaunchKernelGGL((pconv_gemm_kernel<64, LRT, false, true>), grid, block, 0, st, a);
+        return (int)hipGetLastError();
+    }
     if constexpr (!LRT) {
         if (bm == 128) {
             if (ilv) hipLaunchKernelGGL((pconv_gemm_kernel<128, false, true>), grid, block, 0, st, a);
@@ -244,46 +266,50 @@ int launch(PConvArgs& a, int draws, hipStream_t st) {
 }  // namespace
 
 namespace {
-// How a small launch is split along the contraction: -> k ranges per item (1 = not split), scratch bytes, item count.
-// Depends on the launch's size (few items), hence results of differently sized launches agree to rounding, not bitwise.
 constexpr int64_t kTicketBytes = 4096;          // 512 items x 4 bytes, rounded up
 
-int split_plan(const PConvArgs& a, int draws, bool lrt, int64_t& bytes, int64_t& items_out) {
-    bytes = 0;
+// The split of a LAYER's contraction: a function of the layer's geometry ONLY (not of the batch, the number of draws or how a
+// step is partitioned), so that every launch that computes an output element of this layer -- one draw alone, a 10-draw
+// launch, a work unit of a sharded step, one of G steps per launch, a batch-parallel shard -- adds the same partial sums in the
+// same order (cross-workgroup SPLIT form for small launches, in-workgroup SEQ form otherwise: same bits).
+// Which layers: few (pixel, 64-channel tile) groups and a long contraction -- a draw of such a layer is a handful of workgroups
+// each walking a long serial k loop (AlexNet conv4: 4 pixels x 4 tiles, 48 k tiles; conv5: 4 x 2, 32 tiles; measured one draw,
+// bs 512: 42 -> 28 us and 28 -> 17 us with four ranges, profiles/r03_notes.md section 2).  Layers with more groups (conv2: 48, conv3:
+// 24) fill the chip from a few hundred images on and keep the plain chain.
+int canonical_ksplit(const PConvArgs& a) {
     const int ntl = (a.Cout + BN - 1) / BN;
-    const int64_t pixels = (int64_t)a.Ho * a.Wo;
-    const int64_t nb128 = pixels * ((a.B + 127) / 128) * ntl * draws;
-    if (!lrt && nb128 >= 768) return 1;                                  // the launcher takes 128-image tiles: large enough
-    const int64_t items = pixels * ((a.B + 63) / 64) * ntl * draws;
-    items_out = items;
-    // Measured (profiles/r03_notes.md section 2, AlexNet bs 512, one draw): conv4 42 -> 28 us and conv5 28 -> 17 us with four
-    // ranges, conv2 43 -> 35 us with two; three ranges of 8 tiles on conv3's 192 items lose 2 us; from ~400 items up a split
-    // only adds partial-tile traffic (and costs 15-20 % when several steps are in flight).
-    if (items > 384) return 1;
+    const int64_t groups = (int64_t)a.Ho * a.Wo * ntl;
+    if (groups > 16) return 1;
     // longest contraction of any pixel, in 32-k tiles (taps that can fall inside the image)
     const int nr = a.kh < (a.H - 1) / a.dh + 1 ? a.kh : (a.H - 1) / a.dh + 1;
     const int nq = a.kw < (a.W - 1) / a.dw + 1 ? a.kw : (a.W - 1) / a.dw + 1;
     const int tiles = (a.Cin * nr * nq + BK - 1) / BK;
-    int s = 4;
-    const int min_tiles = items <= 128 ? 8 : 12;                         // tiles per range
-    if (tiles / min_tiles < s) s = tiles / min_tiles;
-    const int64_t want = (768 + items - 1) / items;                      // ~3 workgroups per CU are enough
-    if (want < s) s = (int)want;
-    if (s < 2) return 1;
+    if (tiles < 16) return 1;
+    const int s = tiles / 8;                                             // >= 8 tiles per range
+    return s > 4 ? 4 : s;
+}
+
+// Scratch bytes the cross-workgroup form of this launch needs (0: the launch is too large for it and runs the SEQ form).
+int64_t split_scratch_bytes(const PConvArgs& a, int draws, bool lrt, int s) {
+    if (s <= 1) return 0;
+    const int ntl = (a.Cout + BN - 1) / BN;
+    const int64_t items = (int64_t)a.Ho * a.Wo * ((a.B + 63) / 64) * ntl * draws;
+    if (items > split_max_items(lrt)) return 0;
     // tickets live in a FIXED region at the start of the scratch (split launches have < 512 items), so that launches of
     // different sizes sharing one scratch buffer never put partial tiles where another launch expects zeroed tickets
-    bytes = kTicketBytes + items * s * (lrt ? 2 : 1) * 64 * 64 * 4;
-    return s;
+    return kTicketBytes + items * s * (lrt ? 2 : 1) * 64 * 64 * 4;
 }
 
 int split_setup(PConvArgs& a, int draws, bool lrt, int k_split, void* scratch, int64_t scratch_bytes) {
     if (k_split <= 1) return 0;
-    int64_t need = 0, items = 0;
-    const int s = split_plan(a, draws, lrt, need, items);
-    if (k_split != s || scratch == nullptr || scratch_bytes < need || (((uintptr_t)scratch) & 255u) != 0) return BBB_EINVAL;
+    if (k_split != canonical_ksplit(a)) return BBB_EINVAL;               // the split is the layer's, not the caller's choice
     a.ksplit = k_split;
-    a.tickets = static_cast<int32_t*>(scratch);
-    a.part = reinterpret_cast<float*>(static_cast<char*>(scratch) + kTicketBytes);
+    const int64_t need = split_scratch_bytes(a, draws, lrt, k_split);
+    if (need > 0 && scratch != nullptr) {
+        if (scratch_bytes < need || (((uintptr_t)scratch) & 255u) != 0) return BBB_EINVAL;
+        a.tickets = static_cast<int32_t*>(scratch);
+        a.part = reinterpret_cast<float*>(static_cast<char*>(scratch) + kTicketBytes);
+    }
     return 0;
 }
 }  // namespace
@@ -292,10 +318,9 @@ extern "C" int64_t bbb_conv2d_chwn_splitk_scratch(const bbb_conv_desc_t* d, int 
     PConvArgs a = {};
     if (k_split) *k_split = 1;
     if (fill(d, a) != 0) return 0;
-    int64_t need = 0, items = 0;
-    const int s = split_plan(a, d->draws, lrt != 0, need, items);
+    const int s = canonical_ksplit(a);
     if (k_split) *k_split = s;
-    return s > 1 ? need : 0;
+    return split_scratch_bytes(a, d->draws, lrt != 0, s);
 }
 
 extern "C" int bbb_conv2d_chwn_splitk_fwd(const bbb_conv_desc_t* d, const float* x, const float* w, const float* bias, float* y,

@@ -35,17 +35,3 @@ def golden():
 def golden_driver():
     import numpy as np
     return np.load(os.path.join(GOLDEN, "driver.npz"))
-
-
-@pytest.fixture
-def unsplit():
-    """Run the test with the split contraction of small launches switched off (ops.split_k): launches of different sizes
-    then run the identical fmaf chain per output, which is what the tests that compare them BIT FOR BIT assert.  With the
-    default (split on) such launches agree to rounding; tests/test_gpu_splitk.py holds that bound."""
-    from bbb_hip import ops
-    saved = ops.split_k
-    ops.split_k = False
-    try:
-        yield
-    finally:
-        ops.split_k = saved

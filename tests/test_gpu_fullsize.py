@@ -25,7 +25,6 @@ def build(env, net_type, lt, ncls, cin=3, seed=0):
     return net
 
 
-@pytest.mark.usefixtures("unsplit")
 def test_metric_config_alexnet_bs512_ens10(env):
     """BayesianAlexNet CIFAR-10 bs=512 num_ens=10 (the headline): the batch-innermost fast path, the NCHW batched
     path and the reference-style Python loop agree; KL is the sum of the layers' kl_loss(); reruns are bitwise equal."""
@@ -62,7 +61,6 @@ def test_metric_config_alexnet_bs512_ens10(env):
     assert abs(klsum.item() - E * kl_f.item()) <= 2e-6 * E * kl_f.item()
 
 
-@pytest.mark.usefixtures("unsplit")
 def test_config4_ens25_sharded_over_8_ranks_simulated(env):
     """num_ens=25 over 8 ranks: every rank's block equals the matching slice of the single-device ensemble and the
     rank-order log-sum-exp equals the unsharded result."""

@@ -166,7 +166,6 @@ def test_mc_step_vs_reference(env, golden):
 @pytest.mark.parametrize("net_type,lt,B,hw,cin", [("lenet", "bbb", 8, 32, 1), ("alexnet", "bbb", 16, 32, 3),
                                                    ("3conv3fc", "bbb", 4, 32, 3), ("alexnet", "lrt", 8, 32, 3),
                                                    ("lenet", "lrt", 4, 32, 1)])
-@pytest.mark.usefixtures("unsplit")
 def test_batched_ensemble_equals_loop(env, net_type, lt, B, hw, cin):
     torch.manual_seed(3)
     net = env["zoo"].getModel(net_type, cin, 10, P.CONFIG_PRIORS, lt, "softplus").cuda()
@@ -199,7 +198,6 @@ def test_batched_ensemble_equals_loop(env, net_type, lt, B, hw, cin):
     assert env["rng"].get_state()[1] == 10 + E
 
 
-@pytest.mark.usefixtures("unsplit")
 def test_simulated_rank_sharding_matches_single_device(env):
     """Draw-sharding without a second GPU: compute each rank's block on this device and combine as
     combine_ranks does; must equal the unsharded step."""
@@ -265,7 +263,6 @@ def test_train_step_runs_and_learns(env):
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
 
 
-@pytest.mark.usefixtures("unsplit")
 def test_graphed_step_replays_draw_fresh_noise_and_match_eager(env):
     """hipGraph replay r of GraphedMC == eager mc_forward at noise calls call0 + r*E (device-side call counter)."""
     torch.manual_seed(2)

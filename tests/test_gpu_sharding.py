@@ -12,7 +12,7 @@ import torch.nn as nn
 
 import ref_port_torch as P
 
-pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("unsplit")]   # bitwise comparisons across launch sizes
+pytestmark = pytest.mark.gpu          # bitwise comparisons across launch sizes, at the SHIPPED defaults (ops.split_k on)
 
 
 @pytest.fixture(scope="module")

@@ -6,7 +6,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("unsplit")]   # bitwise comparisons across launch sizes
+pytestmark = pytest.mark.gpu          # bitwise comparisons across launch sizes, at the SHIPPED defaults (ops.split_k on)
 PRI = {"prior_mu": 0, "prior_sigma": 0.1, "posterior_mu_initial": (0, 0.1), "posterior_rho_initial": (-5, 0.1)}
 
 

@@ -7,7 +7,7 @@ import torch
 
 import ref_port_torch as P
 
-pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("unsplit")]
+pytestmark = pytest.mark.gpu          # bitwise comparisons across launch sizes, at the SHIPPED defaults (ops.split_k on)
 
 
 @pytest.fixture(scope="module")
