@@ -9,10 +9,13 @@ OUT=$R/gpurun_out
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $R/bench.py --steps 50 --warmup 10 --no-cpu-baseline"
-# eager single-stream step, nothing else in the process: 2 warm-up + 5 timed steps = 7 MC steps
-EAGER="python $R/bench.py --steps 5 --warmup 2 --no-graph"
-EAGER16="python $R/bench.py --steps 5 --warmup 2 --no-graph --config configs[1]"
-NSTEPS=7
+# eager single-stream passes of the timed region's launches, nothing else in the process.  Round 4: a launch carries 4 steps
+# (bench.py --steps-per-launch 4, the default), so 4 warm-up + 8 timed steps = 3 passes = 12 MC steps; the bf16 configs[1] pass and
+# the one-step-per-launch comparison (EAGER1) keep 2 + 5 = 7 steps.
+EAGER="python $R/bench.py --steps 8 --warmup 4 --no-graph"
+EAGER1="python $R/bench.py --steps 5 --warmup 2 --no-graph --steps-per-launch 1"
+EAGER16="python $R/bench.py --steps 5 --warmup 2 --no-graph --config configs[1] --steps-per-launch 1"
+NSTEPS=12
 
 rm -rf /tmp/kt && mkdir -p /tmp/kt
 rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- $BENCH > /tmp/kt/log.txt 2>&1
@@ -29,10 +32,10 @@ rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- $BENCH > /tmp/kt/log.txt 2>
 # so their durations add up to more than the wall time; the single-lane table is the per-kernel in-graph duration.
 { for P in 1 3; do
     rm -rf /tmp/kg && mkdir -p /tmp/kg
-    rocprofv3 --kernel-trace -d /tmp/kg -o kg -- python $R/bench.py --steps 50 --warmup 10 --pipeline $P --no-extras --no-roofline > /tmp/kg/log.txt 2>&1
-    echo "# rocprofv3 --kernel-trace -- python bench.py --steps 50 --warmup 10 --pipeline $P --no-extras --no-roofline   ($TAG; the last 50 steps = the timed region's graph replays)"
+    rocprofv3 --kernel-trace -d /tmp/kg -o kg -- python $R/bench.py --steps 48 --warmup 8 --pipeline $P --no-extras --no-roofline --no-cpu-baseline --preheat-ms 0 > /tmp/kg/log.txt 2>&1
+    echo "# rocprofv3 --kernel-trace -- python bench.py --steps 48 --warmup 8 --pipeline $P --no-extras --no-roofline --preheat-ms 0   ($TAG; the last 12 launches per layer = the timed region's graph replays, 4 steps each)"
     grep '^{' /tmp/kg/log.txt | cut -c1-400
-    python $R/profiles/summarize_rocpd.py $(find /tmp/kg -name '*.db' | head -1) --last-steps 50 --by-grid
+    python $R/profiles/summarize_rocpd.py $(find /tmp/kg -name '*.db' | head -1) --last-steps 12 --by-grid
     echo
   done; } > "$OUT/${TAG}_graph_kernel_stats.txt" 2>&1
 
@@ -40,8 +43,13 @@ if [ "${SKIP_PMC:-0}" = "1" ]; then ls -la "$OUT" | tail -8; exit 0; fi     # ke
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pm && mkdir -p /tmp/pm
   rocprofv3 --kernel-trace --pmc $C -d /tmp/pm -o pm -- $EAGER > /tmp/pm/log.txt 2>&1
-  { echo "# rocprofv3 --kernel-trace --pmc $C -- python bench.py --steps 5 --warmup 2 --no-graph   (KB per launch; gfx950: FETCH_SIZE counts 1/2 of wide coalesced reads; STEP_TOTAL = per MC step, $NSTEPS steps)"
-    python $R/profiles/summarize_pmc.py $(find /tmp/pm -name '*.db' | head -1) --steps $NSTEPS; } > "$OUT/${TAG}_pmc_${C}.txt" 2>&1
+  { echo "# rocprofv3 --kernel-trace --pmc $C -- python bench.py --steps 8 --warmup 4 --no-graph   (KB per launch, 4 steps per launch; gfx950: FETCH_SIZE counts 1/2 of wide coalesced reads; STEP_TOTAL = per MC step, $NSTEPS steps)"
+    python $R/profiles/summarize_pmc.py $(find /tmp/pm -name '*.db' | head -1) --steps $NSTEPS
+    rm -rf /tmp/pm/*
+    rocprofv3 --kernel-trace --pmc $C -d /tmp/pm -o pm -- $EAGER1 > /tmp/pm/log.txt 2>&1
+    echo
+    echo "## the same with ONE step per launch (python bench.py --steps 5 --warmup 2 --no-graph --steps-per-launch 1; 7 steps): rows prefixed G1_"
+    python $R/profiles/summarize_pmc.py $(find /tmp/pm -name '*.db' | head -1) --steps 7 | sed 's/^STEP_TOTAL/G1_STEP_TOTAL/'; } > "$OUT/${TAG}_pmc_${C}.txt" 2>&1
 done
 rm -rf /tmp/pm && mkdir -p /tmp/pm
 { echo "# rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_WAIT_INST_ANY -- (fp32 eager step, then the bf16 configs[1] eager step)"

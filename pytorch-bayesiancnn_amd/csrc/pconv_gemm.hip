@@ -200,7 +200,10 @@ int fill(const bbb_conv_desc_t* d, PConvArgs& a) {
 // launches of more 64-image items than this run the in-workgroup form of a layer's split (measured, profiles/r03_notes.md
 // section 2 and r04_notes.md: above ~400 items the cross-workgroup form only adds partial-tile traffic; LRT items carry two
 // accumulator sets and their in-workgroup form runs at 3 waves per SIMD, so the crossover sits higher)
-constexpr int64_t split_max_items(bool lrt) { return lrt ? 512 : 384; }
+#ifndef PCONV_SPLIT_MAX
+#define PCONV_SPLIT_MAX 384
+#endif
+constexpr int64_t split_max_items(bool lrt) { return lrt ? 512 : PCONV_SPLIT_MAX; }
 
 template <bool LRT>
 int launch(PConvArgs& a, int draws, hipStream_t st) {
@@ -266,7 +269,7 @@ int launch(PConvArgs& a, int draws, hipStream_t st) {
 }  // namespace
 
 namespace {
-constexpr int64_t kTicketBytes = 4096;          // 512 items x 4 bytes, rounded up
+constexpr int64_t kTicketBytes = 16384;         // arrival counters of up to 4096 items
 
 // The split of a LAYER's contraction: a function of the layer's geometry ONLY (not of the batch, the number of draws or how a
 // step is partitioned), so that every launch that computes an output element of this layer -- one draw alone, a 10-draw
