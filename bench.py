@@ -811,7 +811,7 @@ def main():
     G = args.steps_per_launch
     head, net, x = run_config(cfg, args.steps, args.warmup, args.pipeline, dev, group, world, want_roofline=not args.no_roofline,
                               stat_blocks=5 if extras else 0, timer_steps=min(args.steps, 10), steps_per_launch=G,
-                              preheat_s=args.preheat_ms * 1e-3, cold_block=True, rank=rank)
+                              preheat_s=args.preheat_ms * 1e-3, cold_block=True, rank=rank, single_lane=extras)
     n_params = sum(p.numel() for n, p in net.named_parameters() if n.endswith("_mu"))
 
     weak = None

@@ -1054,6 +1054,50 @@ class GraphedMC:
             return self.out_lo, self.out_kl
 
 
+class GraphedLogits:
+    """K stochastic forwards of `net` on one batch as a captured hipGraph -> logits [K, B', C] (contiguous, API layout): what
+    the drop-in `net(x)` serves a speculated K-draw batch from (layers/_fused.py) -- ~30 launches through ctypes become one graph
+    launch.  The captured kernels read a device-side call offset, so run(x, call) computes draws call .. call + K - 1 of the
+    noise stream (seed fixed at capture), bit for bit what _mc_logits_chwn(net, x, K, seed, call) launches eagerly.  The output
+    buffer belongs to the graph and is overwritten by the next run(): callers clone what they keep."""
+
+    def __init__(self, net, x, K, precision="fp32"):
+        _lib.require_device(x)
+        self.K, self.precision = int(K), precision
+        self.x = x.detach().clone()
+        self.seed, self.call0 = rng.next_calls(0)
+        dev = x.device
+        self.counter = torch.zeros((1,), dtype=torch.int32, device=dev)
+        self.graph = None
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.no_grad(), torch.cuda.stream(side), rng.device_call_offset(self.counter):
+            for _ in range(2):                       # warm-up on a side stream (allocator, lazy module state, scratch growth)
+                if self._body(net) is None:
+                    return                           # this model / input does not fit the batch-innermost path
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.no_grad(), rng.device_call_offset(self.counter), ops.graph_capture(g, side):
+            self.logits, self.kl = self._body(net)
+        self.graph = g
+
+    def _body(self, net):
+        out = _mc_logits_chwn(net, self.x, self.K, self.seed, self.call0, precision=self.precision)
+        if out is None:
+            return None
+        return out[0].permute(0, 2, 1).contiguous(), out[1]
+
+    def run(self, x, call):
+        """Draws call .. call + K - 1 on batch x (enqueued on the current stream) -> (logits [K, B', C], kl): graph-owned buffers."""
+        if x.data_ptr() != self.x.data_ptr():
+            self.x.copy_(x, non_blocking=True)
+        d = (int(call) - self.call0) & 0xFFFFFFFF
+        self.counter.fill_(d - (1 << 32) if d >= (1 << 31) else d)     # the kernels add it modulo 2^32
+        self.graph.replay()
+        return self.logits, self.kl
+
+
 class _null_ctx:
     def __enter__(self):
         return self

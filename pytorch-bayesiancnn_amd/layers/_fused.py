@@ -71,7 +71,33 @@ def leave(scope):
             l._presampled = None
 
 
-speculation = {"enabled": True, "max_draws": 32}
+speculation = {"enabled": True, "max_draws": 32,
+               # a speculated K-draw batch under no_grad is served from a captured hipGraph (ensemble.GraphedLogits) once the same
+               # (input shape, K, noise seed, parameter storage, kernel modes) was seen `graph_after` times: one graph launch instead of
+               # ~30 launches through ctypes.  At most `graphs` graphs per model (least recently used goes first).
+               "graph_after": 2, "graphs": 4}
+
+
+def _logit_graph(wrapper, st, x, K, seed, pver):
+    """The cached GraphedLogits for this (model, input shape, K, seed, parameter storage, kernel modes), building it on the
+    `graph_after`-th sighting; None = run eagerly (not seen often enough yet, capture not possible, or the path does not apply)."""
+    from bbb_hip import ensemble, ops
+    if not speculation.get("graph_after"):
+        return None
+    cache = st.setdefault("logit_graphs", {})
+    key = (tuple(x.shape), x.dtype, x.device.index, int(K), int(seed), tuple(p[1] for p in pver[1:]), ops.split_k, ops.gemm_mode)
+    ent = cache.get(key)
+    if ent is None:
+        ent = cache[key] = [0, None]
+        while len(cache) > int(speculation["graphs"]):
+            cache.pop(next(iter(cache)))                       # dicts keep insertion order: the oldest entry goes
+    else:
+        cache[key] = cache.pop(key)                            # most recently used last
+    ent[0] += 1
+    if ent[1] is None and ent[0] >= int(speculation["graph_after"]):
+        g = ensemble.GraphedLogits(wrapper, x, K)
+        ent[1] = g if g.graph is not None else False
+    return ent[1] or None
 
 
 class _Spec:
@@ -166,8 +192,7 @@ def fast_forward(wrapper, x):
         sp.streak += 1
         for l in layers:
             l._kl = None
-        out = sp.logits[j].t()
-        return (out if grad else out.contiguous()), sp.kl
+        return (sp.logits[j].t() if grad else sp.logits[j]), sp.kl
     if same_x:
         sp.streak += 1
     else:
@@ -187,11 +212,16 @@ def fast_forward(wrapper, x):
         from bbb_hip import fast_train
         logits, kl = fast_train.mc_logits_autograd(wrapper, x, K, seed, call)
     else:
-        out = ensemble._mc_logits_chwn(wrapper, x, K, seed, call)
-        if out is None:
-            rng.rewind((seed, call))                  # nothing was launched: give the call index back
-            return None
-        logits, kl = out                              # [K, C, B']
+        g = _logit_graph(wrapper, st, x, K, seed, pver) if K > 1 else None
+        if g is not None:
+            logits, kl = g.run(x, call)               # one graph launch; the buffers are the graph's: keep our own copy
+            logits, kl = logits.clone(), kl.clone()
+        else:
+            out = ensemble._mc_logits_chwn(wrapper, x, K, seed, call)
+            if out is None:
+                rng.rewind((seed, call))              # nothing was launched: give the call index back
+                return None
+            logits, kl = out[0].permute(0, 2, 1).contiguous(), out[1]   # [K, B', C]: ONE transpose per batch of draws, not one per call
     for l in layers:
         l._kl = None
     import weakref
@@ -201,5 +231,4 @@ def fast_forward(wrapper, x):
         sp.batches += 1
     else:
         sp.logits = None
-    out0 = logits[0].t()
-    return (out0 if grad else out0.contiguous()), kl
+    return (logits[0].t() if grad else logits[0]), kl

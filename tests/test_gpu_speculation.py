@@ -152,3 +152,49 @@ def test_hooks_and_input_gradients_take_the_reference_layout_path():
     out2, _ = net(xg2)
     out2.sum().backward()
     assert xg2.grad is not None and float(xg2.grad.abs().max()) > 0
+
+
+def test_speculated_batches_served_from_a_cached_graph_are_the_loop_bit_for_bit():
+    """From the second batch of a shape on, a K-draw batch under no_grad is ONE hipGraph replay (ensemble.GraphedLogits): same
+    bits as the loop of single calls, same generator offsets, results owned by the caller (not the graph's buffers), a
+    parameter update between batches is seen (the graph reads the live parameters), new parameter storage drops the graph."""
+    from layers import _fused
+    from bbb_hip import ensemble
+    net, x = _net()
+    xs = [x] + [torch.rand_like(x) for _ in range(5)]
+    with torch.no_grad():
+        ref, off_ref = _loops(net, xs, 10, False)
+        net.__dict__.pop("_bbb_structure", None)
+        got, off_got = _loops(net, xs, 10, True)
+    assert _same(ref, got) and off_ref == off_got
+    graphs = [e[1] for e in ensemble._structure(net)["logit_graphs"].values() if e[1]]
+    assert len(graphs) == 1 and graphs[0].K == 10                       # batches 3..6 were replays of one graph
+    # outputs handed out earlier are the caller's: later replays did not overwrite them
+    assert torch.equal(got[25][0], ref[25][0]) and got[25][0].is_contiguous()
+    # a parameter moves between batches (optimizer step): the replay reads the live value
+    def mutate(li, j, xx, nn_):
+        if li == 3 and j == 0:
+            with torch.no_grad():
+                nn_.conv1.W_mu.add_(0.01)
+    with torch.no_grad():
+        net_a, _ = _net()
+        ref2, _ = _loops(net_a, [t.clone() for t in xs], 10, False, mutate=mutate)
+        net_b, _ = _net()
+        got2, _ = _loops(net_b, [t.clone() for t in xs], 10, True, mutate=mutate)
+    assert _same(ref2, got2)
+    # new storage for a parameter: a different key -> the old graph is not used for it
+    with torch.no_grad():
+        net_b.conv1.W_mu.data = net_b.conv1.W_mu.data.clone()
+        net_a.conv1.W_mu.data = net_a.conv1.W_mu.data.clone()
+        r3, _ = _loops(net_a, [xs[0].clone(), xs[1].clone()], 10, False, seed=9)
+        g3, _ = _loops(net_b, [xs[0].clone(), xs[1].clone()], 10, True, seed=9)
+    assert _same(r3, g3)
+    saved = _fused.speculation["graph_after"]
+    _fused.speculation["graph_after"] = 0                                # switch: speculation without graphs
+    try:
+        with torch.no_grad():
+            net_c, _ = _net()
+            got4, off4 = _loops(net_c, xs, 10, True)
+        assert _same(ref, got4) and off4 == off_ref and "logit_graphs" not in ensemble._structure(net_c)
+    finally:
+        _fused.speculation["graph_after"] = saved
