@@ -880,6 +880,69 @@ def _all_gather(recv, send, group):
     torch.distributed.all_gather_into_tensor(recv, send, group=group)
 
 
+capture_collectives = True     # a sharded GraphedMC step records its ONE all_gather inside the step's hipGraph when the backend allows
+                               # it (RCCL does; probed once per process group): one host call per step instead of three
+_capture_probe = {}
+_lane_groups = {}
+
+
+def lane_group(group, lane):
+    """The communicator lane `lane` of a pipeline records into its graphs.  Lane 0 uses `group` itself; every further lane gets
+    its OWN communicator over the same ranks (created collectively, once, cached): graphs of different lanes replay on different
+    streams, and two collectives of ONE communicator must never run concurrently or in different orders on different ranks --
+    eager process-group calls are serialised by torch, recorded ones are not."""
+    import torch.distributed as dist
+    if lane == 0 or group is None:
+        return group
+    key = (id(group), int(lane))
+    if key not in _lane_groups:
+        _lane_groups[key] = dist.new_group(ranks=dist.get_process_group_ranks(group), backend="nccl")
+    return _lane_groups[key]
+
+
+def collective_capture_ok(group, device):
+    """Can this process group's all_gather_into_tensor be recorded into a hipGraph?  Probed ONCE per group with a 4-float
+    gather on a side stream (capture, two replays, result checked), and agreed on by all ranks (all_reduce MIN) so that every
+    rank takes the same protocol.  Only the "nccl" (= RCCL) backend is tried: gloo collectives run on the host."""
+    import torch.distributed as dist
+    key = id(group)
+    if key in _capture_probe:
+        return _capture_probe[key]
+    ok = False
+    try:
+        if capture_collectives and dist.get_backend(group) == "nccl" and torch.device(device).type == "cuda":
+            world, rank = dist.get_world_size(group), dist.get_rank(group)
+            send = torch.full((4,), float(rank + 1), device=device)
+            recv = torch.zeros((4 * world,), device=device)
+            dist.all_gather_into_tensor(recv, send, group=group)          # the communicator exists before anything is captured
+            torch.cuda.synchronize(device)
+            side = torch.cuda.Stream(device=device)
+            g = torch.cuda.CUDAGraph()
+            try:
+                with ops.graph_capture(g, side):
+                    dist.all_gather_into_tensor(recv, send, group=group)
+                local = True
+            except Exception:                                             # a backend that refuses capture: fall back, do not fail
+                local = False
+            if local:
+                for v in (5.0, 9.0):
+                    send.fill_(v + rank)
+                    recv.zero_()
+                    torch.cuda.synchronize(device)
+                    with torch.cuda.stream(side):
+                        g.replay()
+                    side.synchronize()
+                    want = torch.arange(world, device=device, dtype=torch.float32).repeat_interleave(4) + v
+                    local = local and bool(torch.equal(recv, want))
+            flag = torch.tensor([1.0 if local else 0.0], device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            ok = bool(flag.item() > 0.5)
+    except Exception:
+        ok = False
+    _capture_probe[key] = ok
+    return ok
+
+
 class GraphedMC:
     """One Monte-Carlo step captured as a hipGraph (launch-bound inner loop -> one graph launch per step).
 
@@ -891,9 +954,11 @@ class GraphedMC:
     starts at lane*num_ens and advances by lanes*num_ens.
     With a process group the graph holds this rank's work units (shard_plan: (draw x batch-slice) units, or whole draws when
     the fast path does not apply) and ends by packing its [B, C] log-sum-exp block and its share of the KL sum into a
-    preallocated send buffer; step() then issues the ONE all_gather of the step eagerly on the lane's stream (collectives stay
-    outside the graphs) and replays a second small graph that reduces the gathered blocks over ranks -- three host calls per
-    step (replay, all_gather, replay), which matters when 8 ranks leave each GPU only ~0.1 ms of work per step.
+    preallocated send buffer.  When the backend's collectives can be recorded into a hipGraph (RCCL: collective_capture_ok,
+    probed once per group and agreed on by all ranks) the ONE all_gather of the step and the reduction over ranks are part of
+    the same graph: one host call per step.  Otherwise (gloo; a refused capture) step() issues the all_gather eagerly on the
+    lane's stream and replays a second small graph for the reduction -- three host calls per step, which matters when 8 ranks
+    leave each GPU only ~0.1 ms of work per step.
     step() returns (log_outputs [B, C], kl): buffers overwritten by the lane's next replay.
     steps > 1 (single process, batch-innermost path): the graph holds `steps` consecutive steps -- `steps` batches, each with
     its own num_ens weight draws and its own noise calls (step g, draw j = call g * num_ens + j), exactly what `steps` separate
@@ -938,6 +1003,7 @@ class GraphedMC:
         self.lse = self.kl_local = None
         self.shape = (output_rows(net, tuple(x.shape)) // self.steps, getattr(net, "num_classes", None))
         self.multi = self.world > 1 or self._force_combine
+        self.fused = False                           # the collective and the reduction over ranks live inside the step's graph
         if self.multi:
             if self.shape[1] is None:
                 raise _lib.BBBHipError("a sharded GraphedMC needs net.num_classes")
@@ -946,25 +1012,39 @@ class GraphedMC:
             self.send = torch.full((n,), -float("inf"), dtype=torch.float32, device=dev)     # a rank without work sends -inf / 0
             self.send[-1] = 0.0
             self.recv = torch.empty((self.world * n,), dtype=torch.float32, device=dev)
-        if self.hi > self.lo:
+        if self.multi:
+            self.out_lo = torch.empty(self.shape, dtype=torch.float32, device=dev)
+            self.out_kl = torch.empty((), dtype=torch.float32, device=dev)
+            self.recv.zero_()
+        can_fuse = self.multi and collective_capture_ok(group, dev)
+        if can_fuse and int(lanes) > 1:
+            self.group = lane_group(group, int(lane))            # (every rank builds the same lanes in the same order)
+        if self.hi > self.lo or can_fuse:
             self.stream.wait_stream(torch.cuda.current_stream(dev))
             with torch.no_grad(), torch.cuda.stream(self.stream), rng.device_call_offset(self.counter):
                 for _ in range(2):                   # warm-up on the capture stream (allocator, lazy module state)
-                    self._step_body(streams)
+                    if self.hi > self.lo:
+                        self._step_body(streams)
+                    if can_fuse:
+                        _all_gather(self.recv, self.send, self.group)
+                        self._post_body()
                 self.counter.fill_(self.start)
             torch.cuda.current_stream(dev).wait_stream(self.stream)
             torch.cuda.synchronize(dev)
             self.graph = torch.cuda.CUDAGraph()
             with torch.no_grad(), rng.device_call_offset(self.counter), ops.graph_capture(self.graph, self.stream):
-                self.lse, self.kl_local = self._step_body(streams)
+                if self.hi > self.lo:
+                    self.lse, self.kl_local = self._step_body(streams)
+                if can_fuse:
+                    # ONE graph = this rank's units + the step's one collective + the reduction over ranks: one host call per step
+                    _all_gather(self.recv, self.send, self.group)
+                    self._post_body()
+            self.fused = can_fuse
         else:
             self.graph = None                        # more ranks than draws: this rank only joins the collective
         self.replays = 0
-        if self.multi:
+        if self.multi and not self.fused:
             # the reduction over ranks as its own small graph: gathered [world, B*C + 1] -> log_outputs, kl
-            self.out_lo = torch.empty(self.shape, dtype=torch.float32, device=dev)
-            self.out_kl = torch.empty((), dtype=torch.float32, device=dev)
-            self.recv.zero_()
             self.stream.wait_stream(torch.cuda.current_stream(dev))
             with torch.no_grad(), torch.cuda.stream(self.stream):
                 self._post_body()
@@ -1049,8 +1129,9 @@ class GraphedMC:
             rng.next_calls(self.num_ens)             # keep the host-side counter in step with the device's
             if not self.multi:
                 return self.lse, self.kl_local
-            _all_gather(self.recv, self.send, self.group)          # ONE collective per MC step (RCCL on GPUs)
-            self.post.replay()
+            if not self.fused:
+                _all_gather(self.recv, self.send, self.group)      # ONE collective per MC step (RCCL on GPUs)
+                self.post.replay()
             return self.out_lo, self.out_kl
 
 

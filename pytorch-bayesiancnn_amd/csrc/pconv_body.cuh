@@ -68,8 +68,23 @@ __device__ __forceinline__ void pconv_item(const PConvArgs& p, const int64_t ite
     // (static LDS arrays, one set per instantiation: a kernel should call ONE instantiation of this function)
 
     // ---- item -> (draw, channel tile, pixel, batch tile) ----
-    const int g = (int)(item / p.Mtiles);
-    const int j = (int)(item - (int64_t)g * p.Mtiles);
+    // Default order: (draw, channel tile) major, (pixel, batch tile) minor -- neighbours on an XCD share a WEIGHT tile.  A layer
+    // whose input is shared by the draws of a step (the first layer: x_ds == 0, or x_div draws per input slab) is enumerated
+    // (step, pixel, batch tile) major and (draw, channel tile) minor instead: co-resident workgroups then read the SAME image rows
+    // -- AlexNet's 6.3 MB input does not fit a 4 MB XCD L2, so in draw-major order every draw re-fetched it from the fabric (78 MB
+    // per step for 7 MB of operands, profiles/r03_pmc_FETCH_SIZE.txt), while all draws' weights of such a layer (0.9 MB) do fit.
+    int g, j;
+    if (p.x_ds == 0 || p.x_div > 1) {
+        const int gs = p.x_div > 1 ? p.x_div * p.Ntiles : p.G;       // (draw, channel tile) groups per step
+        const int64_t per_step = (int64_t)p.Mtiles * gs;
+        const int step = (int)(item / per_step);
+        const int64_t r = item - (int64_t)step * per_step;
+        j = (int)(r / gs);
+        g = step * gs + (int)(r - (int64_t)j * gs);
+    } else {
+        g = (int)(item / p.Mtiles);
+        j = (int)(item - (int64_t)g * p.Mtiles);
+    }
     const int e = g / p.Ntiles;
     // work units (ensemble sharding): slab e is unit u = unit_off + e -> weight set u / S, input slab e (or u % S)
     const int ue = p.unit_off + e;
