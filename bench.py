@@ -45,6 +45,7 @@ import sys
 import time
 
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # before HIP initialises: one hardware queue per lane (bbb_hip/__init__.py)
+os.environ.setdefault("TORCH_NCCL_CUDA_EVENT_CACHE", "0")   # before the process group exists: recorded collectives (ensemble.collective_capture_ok)
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "pytorch-bayesiancnn_amd"))
 sys.dont_write_bytecode = True

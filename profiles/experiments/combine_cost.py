@@ -6,6 +6,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, os.path.join(ROOT, "pytorch-bayesiancnn_amd"))
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
 os.environ["BBB_FORCE_COMBINE"] = "1"
+if len(sys.argv) > 1 and sys.argv[1] == "cache":          # reproduces the watchdog abort (hipErrorCapturedEvent) of r04_notes.md
+    os.environ["TORCH_NCCL_CUDA_EVENT_CACHE"] = "1"
 import torch, torch.distributed as dist
 from bbb_hip import ensemble, zoo, rng
 dev = torch.device("cuda:0"); torch.cuda.set_device(0)

@@ -19,6 +19,11 @@ import os as _os
 # same 4-lane pipeline 0.087 or 0.115 ms per step).  8 queues keep every lane on its own.  Read by the HIP runtime when it
 # initialises (the first device call), so this must run before that; a value the user exported wins.
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# A sharded step records its one all_gather into the step's hipGraph (ensemble.collective_capture_ok).  torch's NCCL event cache
+# makes that unsafe: the watchdog thread may query an event it still holds for a finished eager collective after the cache gave
+# the same event to a collective under capture -> hipErrorCapturedEvent -> terminate().  Read when a process group is created, so
+# it must be set before that; if it was not "0" then, ensemble keeps collectives outside its graphs.  A value the user exported wins.
+_os.environ.setdefault("TORCH_NCCL_CUDA_EVENT_CACHE", "0")
 
 from . import _lib, rng, ops  # noqa: E402,F401
 from ._lib import BBBHipError, LIB_PATH  # noqa: E402,F401

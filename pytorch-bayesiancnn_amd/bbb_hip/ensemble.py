@@ -880,6 +880,19 @@ def _all_gather(recv, send, group):
     torch.distributed.all_gather_into_tensor(recv, send, group=group)
 
 
+def _eager_gather(recv, send, group, lane_stream, comm_stream):
+    """An EAGER collective between two graph replays of a lane, issued on the lane's own communication stream (ordered with the
+    lane stream through events), never on the lane stream itself: torch's NCCL watchdog thread keeps querying the completion
+    event of an eager collective for up to its polling interval after the call, and this HIP runtime refuses such a query
+    (hipErrorCapturedEvent -> the watchdog terminates the process) once the stream the event was recorded on is being
+    CAPTURED -- which a later GraphedMC on the same pooled lane stream would do.  Streams that get captured never carry eager
+    collectives."""
+    comm_stream.wait_stream(lane_stream)
+    with torch.cuda.stream(comm_stream):
+        torch.distributed.all_gather_into_tensor(recv, send, group=group)
+    lane_stream.wait_stream(comm_stream)
+
+
 capture_collectives = True     # a sharded GraphedMC step records its ONE all_gather inside the step's hipGraph when the backend allows
                                # it (RCCL does; probed once per process group): one host call per step instead of three
 _capture_probe = {}
@@ -896,7 +909,13 @@ def lane_group(group, lane):
         return group
     key = (id(group), int(lane))
     if key not in _lane_groups:
-        _lane_groups[key] = dist.new_group(ranks=dist.get_process_group_ranks(group), backend="nccl")
+        g = _lane_groups[key] = dist.new_group(ranks=dist.get_process_group_ranks(group), backend="nccl")
+        # the communicator must exist before a collective of it is recorded: one eager call, on the CURRENT stream -- never on a
+        # stream that will be captured (see _eager_gather)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        t = torch.zeros((4,), device=dev)
+        dist.all_gather_into_tensor(torch.empty((4 * dist.get_world_size(g),), device=dev), t, group=g)
+        torch.cuda.synchronize(dev)
     return _lane_groups[key]
 
 
@@ -910,12 +929,18 @@ def collective_capture_ok(group, device):
         return _capture_probe[key]
     ok = False
     try:
-        if capture_collectives and dist.get_backend(group) == "nccl" and torch.device(device).type == "cuda":
+        # torch's NCCL event cache hands an event that a finished eager collective's Work still references to the next collective;
+        # when that one is being CAPTURED the watchdog's query of the old Work throws hipErrorCapturedEvent and terminates the
+        # process (reproduced: profiles/r04_notes.md).  bbb_hip/__init__.py and bench.py switch the cache off before a process
+        # group exists; without that (a group created before this package was imported) collectives stay outside the graphs.
+        import os as _os
+        if capture_collectives and _os.environ.get("TORCH_NCCL_CUDA_EVENT_CACHE") == "0" and dist.get_backend(group) == "nccl" \
+                and torch.device(device).type == "cuda":
             world, rank = dist.get_world_size(group), dist.get_rank(group)
             send = torch.full((4,), float(rank + 1), device=device)
             recv = torch.zeros((4 * world,), device=device)
             dist.all_gather_into_tensor(recv, send, group=group)          # the communicator exists before anything is captured
-            torch.cuda.synchronize(device)
+            torch.cuda.synchronize(device)                                # (eager, on the current stream; the capture uses a fresh one)
             side = torch.cuda.Stream(device=device)
             g = torch.cuda.CUDAGraph()
             try:
@@ -1026,8 +1051,7 @@ class GraphedMC:
                     if self.hi > self.lo:
                         self._step_body(streams)
                     if can_fuse:
-                        _all_gather(self.recv, self.send, self.group)
-                        self._post_body()
+                        self._post_body()            # (no eager collective here: see _eager_gather; the communicator exists)
                 self.counter.fill_(self.start)
             torch.cuda.current_stream(dev).wait_stream(self.stream)
             torch.cuda.synchronize(dev)
@@ -1044,6 +1068,7 @@ class GraphedMC:
             self.graph = None                        # more ranks than draws: this rank only joins the collective
         self.replays = 0
         if self.multi and not self.fused:
+            self.comm_stream = torch.cuda.Stream(device=dev)     # the eager all_gather of every step runs here (_eager_gather)
             # the reduction over ranks as its own small graph: gathered [world, B*C + 1] -> log_outputs, kl
             self.stream.wait_stream(torch.cuda.current_stream(dev))
             with torch.no_grad(), torch.cuda.stream(self.stream):
@@ -1130,7 +1155,8 @@ class GraphedMC:
             if not self.multi:
                 return self.lse, self.kl_local
             if not self.fused:
-                _all_gather(self.recv, self.send, self.group)      # ONE collective per MC step (RCCL on GPUs)
+                # ONE collective per MC step (RCCL on GPUs), eager, on the lane's communication stream
+                _eager_gather(self.recv, self.send, self.group, torch.cuda.current_stream(self.x.device), self.comm_stream)
                 self.post.replay()
             return self.out_lo, self.out_kl
 
