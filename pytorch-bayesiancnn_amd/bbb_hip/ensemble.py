@@ -889,7 +889,7 @@ def _eager_gather(recv, send, group, lane_stream, comm_stream):
     collectives."""
     comm_stream.wait_stream(lane_stream)
     with torch.cuda.stream(comm_stream):
-        torch.distributed.all_gather_into_tensor(recv, send, group=group)
+        _all_gather(recv, send, group)
     lane_stream.wait_stream(comm_stream)
 
 
