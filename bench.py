@@ -576,11 +576,11 @@ def dropin_loop(dev, steps):
                     "previous call's input is answered from one speculatively batched K-draw launch (layers/_fused.py), 0.25 s pre-heat"}
 
 
-def split_fp16(dev, steps, pipeline):
-    """The metric step with the GEMM launches on the 16-bit matrix pipe at fp32 accuracy (ops.gemm_mode = "fp16x2",
-    bbb_conv2d_chwn_f16x2_fwd: operands split into two fp16 pieces while staged, three products per fp32 product, fp32
-    accumulation).  Opt-in mode, reported NEXT TO the fp32 headline, never as it: throughput, single-lane latency, per-launch
-    times, and the largest difference of the step's log-probabilities from the fp32 path under the same noise."""
+def split_bf16(dev, steps, pipeline):
+    """The metric step with the GEMM launches on the 16-bit matrix pipe at fp32 accuracy, range-free (ops.gemm_mode = "bf16x3",
+    bbb_conv2d_chwn_bf16x3_fwd: every operand element split into three bf16 pieces while staged, six products per fp32 product,
+    fp32 accumulation).  Opt-in mode, reported NEXT TO the fp32 headline, never as it: throughput, single-lane latency, per-launch
+    times, the largest difference of the step's log-probabilities from the fp32 path under the same noise, and the training step."""
     from bbb_hip import ensemble, ops, rng
     cfg = CONFIGS["metric"]
     net, x = build_net(cfg, dev)
@@ -590,15 +590,14 @@ def split_fp16(dev, steps, pipeline):
         with torch.no_grad():
             seed_call = rng.next_calls(0)
             ref_lo = ensemble.mc_forward(net, x, E)[0].clone()
-            ops.gemm_mode = "fp16x2"
+            ops.gemm_mode = "bf16x3"
             rng.rewind(seed_call)
             lo = ensemble.mc_forward(net, x, E)[0]
             out["max_abs_diff_of_log_probs_vs_fp32_path"] = float((lo - ref_lo).abs().max())
             out["max_abs_log_prob"] = float(ref_lo.abs().max())
             for name, depth in (("steps_in_flight_%d" % pipeline, pipeline), ("one_step_in_flight", 1)):
                 pipe = ensemble.GraphedPipeline(net, x, E, depth=depth)
-                for _ in range(20):
-                    pipe.step()
+                preheat(pipe.step, 0.2, dev)
                 pipe.sync()
                 t0 = time.perf_counter()
                 for _ in range(steps):
@@ -615,12 +614,13 @@ def split_fp16(dev, steps, pipeline):
             if g:
                 tf = g["work"] / (g["ms"] * 1e-3) / 1e12
                 out["gemm_launches"] = {"per_launch_us": rec.per_launch_us, "fp32_equivalent_TFLOPs": round(tf, 1),
-                                        "f16_mfma_TFLOPs": round(3 * tf, 1), "frac_of_bf16_f16_peak": round(3 * tf / PEAK_BF16_MFMA_TFLOPS, 4),
+                                        "bf16_mfma_TFLOPs": round(6 * tf, 1), "frac_of_bf16_peak": round(6 * tf / PEAK_BF16_MFMA_TFLOPS, 4),
                                         "frac_of_fp32_matrix_peak": round(tf / PEAK_F32_MFMA_TFLOPS, 4)}
         out["unit"] = "samples/s"
-        out["note"] = ("opt-in precision mode: fp32 tensors in HBM, every GEMM operand element split into hi = fp16(a), lo = fp16(a - hi) "
-                       "while its tile is staged, products hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16, fp32 accumulation; "
-                       "against the float64 oracle 1.2-2.4e-7 of sum|w||x| (the fp32 kernel: 0.8-3.9e-7), tests/test_gpu_f16x2.py")
+        out["note"] = ("opt-in precision mode, range-free: fp32 tensors in HBM, every GEMM operand element split into hi = bf16(a), "
+                       "mid = bf16(a - hi), lo = bf16(a - hi - mid) while its tile is staged (exact), six products on "
+                       "v_mfma_f32_32x32x16_bf16, fp32 accumulation; against the float64 oracle 2.5-3.2e-7 of sum|w||x| on every operand "
+                       "scale (the fp32 kernel: 2.8-3.7e-7), tests/test_gpu_bf16x3.py")
     finally:
         ops.gemm_mode = "fp32"
     return out
@@ -718,9 +718,9 @@ def main():
                          "against 0.650 for one step per launch x 3 lanes (profiles/r04_steps_per_launch_sweep.txt)")
     ap.add_argument("--preheat-ms", type=float, default=400.0, help="untimed replays of the timed graphs before the warm-up steps")
     ap.add_argument("--config", default="metric", choices=list(CONFIGS), help="which BASELINE configuration is the reported value")
-    ap.add_argument("--gemm-mode", default="fp32", choices=["fp32", "fp16x2"],
-                    help="fp16x2: the opt-in split-fp16 GEMM mode for the WHOLE run (profiling it, or timing a sharded run with it); the "
-                         "default run reports it as the secondary object `split_fp16` next to the fp32 headline")
+    ap.add_argument("--gemm-mode", default="fp32", choices=["fp32", "bf16x3"],
+                    help="bf16x3: the opt-in range-free split-bf16 GEMM mode for the WHOLE run (profiling it, or timing a sharded run with "
+                         "it); the default run reports it as the secondary object `split_bf16` next to the fp32 headline")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -831,7 +831,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "bf16" if cfg["precision"] == "bf16" else
-                     ("f32" if args.gemm_mode == "fp32" else "f32 tensors; GEMM products as 3 x f16 (hi/lo split), f32 accumulate"),
+                     ("f32" if args.gemm_mode == "fp32" else "f32 tensors; GEMM products as 6 x bf16 (hi/mid/lo split), f32 accumulate"),
             "data": "synthetic",
             "config": {"workload": cfg["what"] + ", forward only",
                        "global_batch": cfg["B"], "num_ens_total": cfg["E"],
@@ -917,9 +917,11 @@ def main():
             if cfg is CONFIGS["metric"]:
                 try:
                     if args.gemm_mode == "fp32":
-                        second["split_fp16"] = split_fp16(dev, max(20, args.steps // 2), 3)
+                        second["split_bf16"] = split_bf16(dev, max(20, args.steps // 2), 3)
+                        if out["roofline"] is not None and "steps_in_flight_3" in second["split_bf16"]:
+                            out["roofline"]["split_bf16_value"] = second["split_bf16"]["steps_in_flight_3"]["value"]
                 except Exception as exc:
-                    second["split_fp16"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:160])}
+                    second["split_bf16"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:160])}
             try:
                 second["training_step"] = training_step(dev, max(5, args.steps // 5))
             except Exception as exc:

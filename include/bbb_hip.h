@@ -198,19 +198,13 @@ int bbb_lrt_conv2d_fwd(const bbb_conv_desc_t* d, const float* x, const float* w_
  */
 int bbb_conv2d_chwn_fwd(const bbb_conv_desc_t* d, const float* x, const float* w, const float* bias,
                         float* y, void* stream);
-/* The same launch with the contraction on the 16-bit matrix pipe at fp32 accuracy ("split fp16", ABI 7): every fp32 operand
- * element is cut into hi = fp16(a), lo = fp16(a - hi) while its tile is staged and every product is hi*hi + hi*lo + lo*hi on
- * v_mfma_f32_32x32x16_f16 with fp32 accumulation -- per-product error ~2^-22 (fp32: 2^-24), operands must stay below 65504 in
- * magnitude.  Same tensors, layouts and descriptor as bbb_conv2d_chwn_fwd; not bit-identical to it.  Opt-in (ops.gemm_mode).
- * Operands are pre-scaled by powers of two while they are split (fp16 subnormal pieces are flushed by the matrix instruction):
- * weights by 2^10 (full accuracy for 1.2e-4 <= |w| < 64); activations by 2^6 (2e-3 <= |x| < 1024) or, when x_amax is given
- * (BBB_AMAX_SLOTS device floats whose maximum is an upper bound of max|x|; NULL / all zero = unknown), by the power of two that
- * puts that bound just under 2^14; w_amax: the same for the weights (for sampled weights max(|mu| + 6.66 sigma) is a bound that
- * needs no pass over them).  y_amax (BBB_AMAX_SLOTS device floats, NULL = skip; zero them before the launch): receive max|y| of
- * this launch, spread over the slots -- the next layer's x_amax. */
-#define BBB_AMAX_SLOTS 64
-int bbb_conv2d_chwn_f16x2_fwd(const bbb_conv_desc_t* d, const float* x, const float* w, const float* bias, float* y,
-                              const float* x_amax, const float* w_amax, float* y_amax, void* stream);
+/* The same launch with the contraction on the 16-bit matrix pipe at fp32 accuracy, RANGE-FREE ("split bf16", ABI 8): every fp32
+ * operand element is cut into hi = bf16(a), mid = bf16(a - hi), lo = bf16(a - hi - mid) while its tile is staged (a = hi + mid + lo
+ * exactly; bf16 has fp32's exponent range: no operand scales, windows or saturation) and every product is
+ * lo*hi + hi*lo + mid*mid + mid*hi + hi*mid + hi*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- the dropped terms are
+ * < 2^-23 |a b|.  Same tensors, layouts and descriptor as bbb_conv2d_chwn_fwd (work units, x_unit_div, w_row_pitch included); not
+ * bit-identical to it.  Opt-in (ops.gemm_mode = "bf16x3").  Operands must be finite. */
+int bbb_conv2d_chwn_bf16x3_fwd(const bbb_conv_desc_t* d, const float* x, const float* w, const float* bias, float* y, void* stream);
 int bbb_lrt_conv2d_chwn_fwd(const bbb_conv_desc_t* d, const float* x, const float* w_mu, const float* w_var,
                             const float* b_mu, const float* b_var, float* y,
                             float* act_mu_out, float* act_var_out, const float* eps_ext,

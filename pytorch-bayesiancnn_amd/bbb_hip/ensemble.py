@@ -336,14 +336,14 @@ def _chwn_mods_ok(mods):
 
 
 def _check_precision(precision, net, x, fast_path_allowed):
-    """precision: "fp32" (the reference's arithmetic, default); "fp16x2" (fp32 tensors and fp32 accuracy, the BBB GEMM launches of
-    the batch-innermost inference path on the 16-bit matrix pipe -- split-fp16, ops.gemm_mode -- everything else as fp32); or
+    """precision: "fp32" (the reference's arithmetic, default); "bf16x3" (fp32 tensors and fp32 accuracy, the BBB GEMM launches of
+    the batch-innermost path on the 16-bit matrix pipe -- range-free split bf16, ops.gemm_mode -- everything else as fp32); or
     "bf16" (bf16 storage of sampled weights and activations, fp32 accumulate; inference on the batch-innermost path only --
     anything else fails loudly)."""
-    if precision in ("fp32", "fp16x2"):
+    if precision in ("fp32", "bf16x3"):
         return
     if precision != "bf16":
-        raise _lib.BBBHipError(f"precision must be 'fp32', 'fp16x2' or 'bf16', got {precision!r}")
+        raise _lib.BBBHipError(f"precision must be 'fp32', 'bf16x3' or 'bf16', got {precision!r}")
     if not fast_path_allowed or not _chwn_ok(net, x):
         raise _lib.BBBHipError("bf16 runs on the batch-innermost inference path only (no autograd, no external eps, "
                                "4-d input with B % 8 == 0, BBB layers + ReLU/Softplus/MaxPool2d/FlattenLayer)")
@@ -405,17 +405,13 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
     n_out = getattr(children[last_bayes], "out_features", None) if tail_is_last else None
     logits_buf = torch.empty((E, n_out, B), dtype=torch.float32, device=x.device) if n_out is not None else None
 
-    # split-fp16 GEMM mode: the activation scale of every layer's split follows the data -- max|x| of the input here, then each
-    # GEMM launch publishes max|y| for the next one (bbb_conv2d_chwn_f16x2_fwd; device scalars, no host sync)
-    f16x2 = (precision == "fp16x2" or ops.gemm_mode == "fp16x2") and not bf16 and bool(bbb)
-    amax0 = x.detach().abs().amax().expand(ops.AMAX_SLOTS).contiguous() if f16x2 else None
+    bf16x3 = True if precision == "bf16x3" else None        # None: ops.gemm_mode decides
 
     def run(e0, e1):
         """Layers for draws [e0, e1) on the current stream -> logits [e1-e0, C, B] (or None: fall back)."""
         nonlocal logits_buf
         B = xt.shape[-1]
         Es = e1 - e0
-        amax = amax0
         h = xt
         boff = int(b_offset)           # global index of the first local "image" (rows multiply at a flatten that cuts images up)
         per_slice = bool(ukw)          # work units: until the first Bayesian layer, h is one block per batch slice
@@ -460,12 +456,8 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
                     fl = conv_flops(B, h5.shape[1], h5.shape[2], h5.shape[3], w.shape[1], w.shape[3], w.shape[4], *geom, Es) \
                         if timers is not None else None
                     dst = logits_buf[e0:e1] if (logits_buf is not None and i == last_bayes and not is_conv) else None
-                    a_out = torch.zeros(ops.AMAX_SLOTS, dtype=torch.float32, device=x.device) if (f16x2 and i != last_bayes) else None
-                    a_w = _weight_bound(mod) if f16x2 else None
-                    y = _run(timers, "conv_gemm", fl, lambda h5=h5, w=w, b=b, geom=geom, act=act, dst=dst, ukw2=ukw2, a_in=amax, a_out=a_out, a_w=a_w:
-                             ops.conv2d_chwn_forward(h5, w, b, *geom, act=act, out=dst, amax_in=a_in, amax_out=a_out, amax_w=a_w,
-                                                     f16x2=f16x2, **ukw2))
-                    amax = a_out                     # (max-pooling in between keeps it an upper bound)
+                    y = _run(timers, "conv_gemm", fl, lambda h5=h5, w=w, b=b, geom=geom, act=act, dst=dst, ukw2=ukw2:
+                             ops.conv2d_chwn_forward(h5, w, b, *geom, act=act, out=dst, bf16x3=bf16x3, **ukw2))
                 else:
                     w_var, b_var = variances[mod]
                     w_mu = mod.W_mu
@@ -588,23 +580,6 @@ def _lane_streams(device, n):
             torch.zeros(1, device=device)
         pool.append(st)
     return pool[:n]
-
-
-def _weight_bound(layer):
-    """AMAX_SLOTS device floats bounding max|w| of every weight set the layer can sample: max(|W_mu| + 6.66 softplus(W_rho)) --
-    Box-Muller on 32-bit uniforms cannot exceed sqrt(-2 ln 2^-32) = 6.66 -- the split-fp16 GEMM's weight scale
-    (bbb_conv2d_chwn_f16x2_fwd).  ONE persistent buffer per layer, rewritten in place when the parameters' versions or storage
-    change: a captured step keeps reading the same address, and GraphedMC.step() calls this before every replay."""
-    mu, rho = layer.W_mu, layer.W_rho
-    key = (mu._version, rho._version, mu.data_ptr(), rho.data_ptr())
-    st = layer.__dict__.get("_bbb_w_bound")
-    if st is None or st[1].device != mu.device:
-        st = layer.__dict__["_bbb_w_bound"] = [None, torch.zeros(ops.AMAX_SLOTS, dtype=torch.float32, device=mu.device)]
-    if st[0] != key:
-        with torch.no_grad():
-            st[1].copy_((mu.detach().abs() + 6.66 * F.softplus(rho.detach())).amax().expand(ops.AMAX_SLOTS))
-        st[0] = key
-    return st[1]
 
 
 def _loop_logits(net, x, draws, seed, call0, eps=None):
@@ -997,8 +972,6 @@ class GraphedMC:
                  precision="fp32", steps=1):
         _lib.require_device(x)
         self.steps, self.slot = int(steps), 0
-        self.f16x2_layers = [l for l in bayesian_layers(net) if isinstance(l, _BBBLayer)] \
-            if (precision == "fp16x2" or ops.gemm_mode == "fp16x2") else []
         if self.steps > 1:
             if group is not None:
                 raise _lib.BBBHipError("steps > 1 batches the steps of a single process (no group)")
@@ -1128,9 +1101,6 @@ class GraphedMC:
         producer = torch.cuda.current_stream(self.x.device) if (x is not None and self.own_stream) else None
         ctx = torch.cuda.stream(self.stream) if self.own_stream else _null_ctx()
         with ctx:
-            if self.f16x2_layers:
-                for l in self.f16x2_layers:          # split-fp16 weight scales follow the parameters (host-side version check)
-                    _weight_bound(l)
             if self.steps > 1:
                 g, B = self.slot, self.B
                 if x is not None:

@@ -216,12 +216,13 @@ def graph_capture(graph, stream=None):
             gc.enable()
 
 
-gemm_mode = "fp32"  # "fp16x2": the batch-innermost BBB GEMM launches of the INFERENCE ensemble path run their contraction on the 16-bit
-                    # matrix pipe at fp32 accuracy (bbb_conv2d_chwn_f16x2_fwd: operands split into two fp16 pieces, three products,
-                    # fp32 accumulation).  Opt-in: results agree with the fp32 kernel to rounding, not bit for bit; full accuracy for
-                    # 1.2e-4 <= |w| < 64 and 2e-3 <= |x| < 1024 (csrc/pconv_f16x2.cuh: operand window).
-AMAX_SLOTS = 64              # BBB_AMAX_SLOTS: length of the max|x| / max|y| arrays of bbb_conv2d_chwn_f16x2_fwd
-f16x2_min_workgroups = 256   # smaller launches stay on the fp32 kernel (and its split contraction) even in "fp16x2" mode
+gemm_mode = "fp32"  # "bf16x3": the batch-innermost BBB GEMM launches (inference AND the role-swapped gradient launches of the
+                    # training path) run their contraction on the 16-bit matrix pipe at fp32 accuracy (bbb_conv2d_chwn_bf16x3_fwd:
+                    # every operand element split into three bf16 pieces while staged, six products, fp32 accumulation).  Range-free
+                    # (bf16 has fp32's exponent range: no operand windows or scales).  Opt-in: results agree with the fp32 kernel
+                    # to rounding, not bit for bit.  LRT layers keep the fused fp32 kernel (one staged x tile feeds both of its
+                    # contractions; a split form would need twelve operand planes in LDS).
+bf16x3_min_workgroups = 256  # smaller launches stay on the fp32 kernel (and the layer's split contraction): measured faster there
 _split_plans = {}
 split_k = True     # layers with few (pixel, channel-tile) groups and a long contraction (AlexNet conv4 / conv5) add their k ranges'
                    # partial sums in range order (bbb_conv2d_chwn_splitk_fwd): a property of the LAYER, identical for every launch
@@ -273,18 +274,14 @@ def _desc_chwn(x, w, stride, padding, dilation, draws, x_shared, w_shared, act):
 
 
 def conv2d_chwn_forward(x, w, bias, stride=1, padding=0, dilation=1, act=None, out=None, units=None, n_units=None,
-                        x_per_slice=False, amax_in=None, amax_out=None, f16x2=False, amax_w=None, x_div=1):
+                        x_per_slice=False, x_div=1, bf16x3=None):
     """Batch-innermost conv for the ensemble path.  x: [E|1, Cin, H, W, B] (B % 4 == 0); w: [E|1, Cout, Cin, kh, kw];
     bias [E|1, Cout] or None -> y [E, Cout, Ho, Wo, B].  Padding taps are skipped, not multiplied.
     Work units (ensemble sharding): units = (S, off), n_units = U output slabs; w / bias hold the weight sets of the draws
     the units touch, x is [U, ...] or, for a layer whose input is the same for every draw, the per-slice [S, Cin, H, W, Bs].
     x_div = D > 1 (several Monte-Carlo steps per launch): x holds E / D input slabs and output slab e reads slab e // D
     (bbb_conv_desc_t::x_unit_div) -- the first layer of G steps x D draws, each step on its own batch.
-    f16x2: this launch may run on the split-fp16 kernel (the inference ensemble path passes True under precision="fp16x2" /
-    gemm_mode == "fp16x2";
-    the role-swapped gradient launches of fast_train never do: their operands -- gradients of 1e-6 -- lie far below the operand
-    window of that kernel).  amax_in / amax_w / amax_out (AMAX_SLOTS device floats each): bounds of max|x| / max|w| that set the
-    operand scales of the split; where this launch leaves max|y| (zeroed by the caller) -- see bbb_conv2d_chwn_f16x2_fwd."""
+    bf16x3: True / False = run this launch on the split-bf16 kernel or not; None (default) = ops.gemm_mode decides."""
     require_device(x, w, bias)
     x, w = x.contiguous(), w.contiguous()
     bias = None if bias is None else bias.contiguous()
@@ -313,17 +310,11 @@ def conv2d_chwn_forward(x, w, bias, stride=1, padding=0, dilation=1, act=None, o
             raise _lib.BBBHipError("out= must be a contiguous fp32 tensor of the output's size")
         y = out.view(shape)
     with on_device(x.device):
-        ks, scr = _split_scratch(d, False, x.device)
-        if f16x2 and E * ho * wo * -(-w.shape[1] // 64) * -(-x.shape[4] // 128) >= f16x2_min_workgroups:
-            # (launches below ~256 workgroups stay on the fp32 kernel and its split contraction: measured faster there)
-            require_device(amax_in, amax_out, amax_w)
-            for t in (amax_in, amax_out, amax_w):
-                if t is not None and (t.numel() != AMAX_SLOTS or not t.is_contiguous()):
-                    raise _lib.BBBHipError("amax_in / amax_out must be contiguous tensors of %d floats" % AMAX_SLOTS)
-            check(_lib.lib().bbb_conv2d_chwn_f16x2_fwd(ctypes.byref(d), x.data_ptr(), w.data_ptr(), ptr(bias), y.data_ptr(),
-                                                       ptr(amax_in), ptr(amax_w), ptr(amax_out), cur_stream(x.device)),
-                  "bbb_conv2d_chwn_f16x2_fwd")
+        if (bf16x3 if bf16x3 is not None else gemm_mode == "bf16x3") and E * ho * wo * -(-w.shape[1] // 64) * -(-x.shape[4] // 128) >= bf16x3_min_workgroups:
+            check(_lib.lib().bbb_conv2d_chwn_bf16x3_fwd(ctypes.byref(d), x.data_ptr(), w.data_ptr(), ptr(bias), y.data_ptr(),
+                                                        cur_stream(x.device)), "bbb_conv2d_chwn_bf16x3_fwd")
             return y
+        ks, scr = _split_scratch(d, False, x.device)
         if ks > 1:
             check(_lib.lib().bbb_conv2d_chwn_splitk_fwd(ctypes.byref(d), x.data_ptr(), w.data_ptr(), ptr(bias), y.data_ptr(), ks,
                                                         ptr(scr), 0 if scr is None else scr.numel(), cur_stream(x.device)),

@@ -27,7 +27,7 @@
 #include "bbb_common.cuh"
 #include "pconv_args.h"
 #include "pconv_body.cuh"
-#include "pconv_f16x2.cuh"
+#include "pconv_bf16x3.cuh"
 
 namespace {
 
@@ -349,9 +349,9 @@ extern "C" int bbb_conv2d_chwn_fwd(const bbb_conv_desc_t* d, const float* x, con
     return launch<false>(a, d->draws, (hipStream_t)stream);
 }
 
-// bbb_conv2d_chwn_fwd with the contraction on the 16-bit matrix pipe at fp32 accuracy (pconv_f16x2.cuh)
-extern "C" int bbb_conv2d_chwn_f16x2_fwd(const bbb_conv_desc_t* d, const float* x, const float* w, const float* bias, float* y,
-                                         const float* x_amax, const float* w_amax, float* y_amax, void* stream) {
+// bbb_conv2d_chwn_fwd with the contraction on the 16-bit matrix pipe at fp32 accuracy, range-free (pconv_bf16x3.cuh)
+extern "C" int bbb_conv2d_chwn_bf16x3_fwd(const bbb_conv_desc_t* d, const float* x, const float* w, const float* bias, float* y,
+                                          void* stream) {
     PConvArgs a = {};
     const int rc = fill(d, a);
     if (rc != 0) return rc;
@@ -361,18 +361,14 @@ extern "C" int bbb_conv2d_chwn_f16x2_fwd(const bbb_conv_desc_t* d, const float* 
     a.Ntiles = (a.Cout + BN - 1) / BN;
     a.G = a.Ntiles * d->draws;
     const int64_t pixels = (int64_t)a.Ho * a.Wo;
-    // 128 images per workgroup (measured: the 256-image form, one workgroup less per CU, is within +-5 % on every AlexNet layer)
-    const int mt = 1;
-    a.nbt = (a.B + 128 * mt - 1) / (128 * mt);
+    a.nbt = (a.B + 127) / 128;
     const int64_t mtiles = pixels * a.nbt;
     if (mtiles > 0x7fffffffLL) return BBB_ESHAPE;
     a.Mtiles = (int)mtiles;
     const int64_t per = ((int64_t)a.G * mtiles + 7) / 8;
     if (8 * per > 0x7fffffffLL) return BBB_ESHAPE;
     a.per_xcd = (int32_t)per;
-    const dim3 grid((unsigned)(8 * per)), block(kThreads);
-    if ((((uintptr_t)x_amax | (uintptr_t)w_amax | (uintptr_t)y_amax) & 3u) != 0) return BBB_EALIGN;
-    hipLaunchKernelGGL((pconv_f16x2_kernel<1>), grid, block, 0, (hipStream_t)stream, a, x_amax, w_amax, y_amax);
+    hipLaunchKernelGGL((pconv_bf16x3_kernel<1>), dim3((unsigned)(8 * per)), dim3(kThreads), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
 

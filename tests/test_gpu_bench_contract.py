@@ -59,7 +59,7 @@ def test_bench_json_contract_default():
     assert abs(r["reparam_frac"] - r["reparam_bytes"] / (r["reparam_avg_us"] * 1e-6) / 8e12) < 2e-3
     # the secondary line: the objects of rounds 1-3, unabridged
     for k in ("roofline_detail", "roofline_reparam", "stats", "one_step_in_flight", "one_step_per_launch", "dropin_loop", "configs",
-              "training_step", "split_fp16"):
+              "training_step", "split_bf16"):
         assert k in sec, k
     rr = sec["roofline_reparam"]
     assert rr["bound"] == "hbm" and rr["peak"] == 8000.0 and abs(rr["frac"] - rr["achieved"] / rr["peak"]) < 1e-3

@@ -76,10 +76,12 @@ def assert_fast_path(env):
 
 
 # --------------------------------------------------------------------------------------------------------------------
-@pytest.fixture(params=["fp32", "fp16x2"])
+@pytest.fixture(params=["fp32", "bf16x3"])
 def gemm_mode(request, env):
-    """Both contraction modes of the batch-innermost GEMM are held to the SAME bounds: the fp32 matrix instruction, and the
-    split-fp16 form (two fp16 pieces per operand, three products, fp32 accumulation: pconv_f16x2.cuh)."""
+    """Both contraction modes of the batch-innermost GEMM are held to the SAME bounds, on EVERY full-size configuration: the fp32
+    matrix instruction, and the range-free split-bf16 form (three bf16 pieces per operand, six products, fp32 accumulation:
+    pconv_bf16x3.cuh; LRT layers keep their fused fp32 kernel in that mode -- the LRT tests then check that the mode leaves them
+    intact)."""
     from bbb_hip import ops
     ops.gemm_mode = request.param
     yield request.param
@@ -160,7 +162,7 @@ def test_config1_3conv3fc_bs256_bf16_vs_oracle(env):
         assert abs(kl16.item() - klw) <= 2e-6 * klw
 
 
-def test_config2_alexnet100_lrt_bs512_vs_oracle(env):
+def test_config2_alexnet100_lrt_bs512_vs_oracle(env, gemm_mode):
     """configs[2]: BayesianAlexNet CIFAR-100, BBB_LRT layers, batch 512: act_mu + sqrt(act_var) * eps with eps replayed by
     canonical NCHW element index of each layer's output."""
     net, params, sid = build(env, "alexnet", "lrt", 100)
@@ -189,7 +191,7 @@ def test_config2_alexnet100_lrt_bs512_vs_oracle(env):
     assert abs(klsum.item() - E * kl64) <= 2e-6 * E * kl64
 
 
-def test_config3_alexnet10_ens25_vs_oracle(env):
+def test_config3_alexnet10_ens25_vs_oracle(env, gemm_mode):
     """configs[3] on one device: num_ens = 25.  All 25 draws against the reference's CPU ops with replayed noise, then the
     25-way logmeanexp and the KL sum."""
     net, params, sid = build(env, "alexnet", "bbb", 10, seed=1)
@@ -216,7 +218,7 @@ def test_config3_alexnet10_ens25_vs_oracle(env):
     assert abs(klsum.item() - klr) <= 5e-6 * klr
 
 
-def test_config4_alexnet_224_bs64_vs_oracle(env):
+def test_config4_alexnet_224_bs64_vs_oracle(env, gemm_mode):
     """configs[4] shape (3x224x224, the MFMA-bound regime), 64 images of the 512-per-GPU shard: one draw vs the reference's CPU
     ops, including the view(-1, 128) flatten quirk ([B,128,7,7] -> [B*49,128], layers/misc.py:35)."""
     net, params, sid = build(env, "alexnet", "bbb", 10, seed=2)
@@ -235,7 +237,7 @@ def test_config4_alexnet_224_bs64_vs_oracle(env):
     assert abs(kl.item() - float(klt)) <= 5e-6 * float(klt)
 
 
-def test_config4_alexnet_224_bs512_shard_vs_oracle(env):
+def test_config4_alexnet_224_bs512_shard_vs_oracle(env, gemm_mode):
     """configs[4] at the size bench.py times: the 512-image shard one GPU holds of the batch-4096 run (3x224x224), one draw vs
     the reference's CPU ops on all 512 x 49 output rows."""
     net, params, sid = build(env, "alexnet", "bbb", 10, seed=2)
@@ -255,7 +257,7 @@ def test_config4_alexnet_224_bs512_shard_vs_oracle(env):
     assert abs(kl.item() - float(klt)) <= 5e-6 * float(klt)
 
 
-def test_alexnet_224_lrt_vs_oracle(env):
+def test_alexnet_224_lrt_vs_oracle(env, gemm_mode):
     """The 224x224 shape through the LOCAL-REPARAMETERISATION layers (the reference's default layer type,
     config_bayesian.py:1-18): activation noise replayed on the CPU from the device's stream, keyed by the canonical NCHW
     element index -- through the flatten quirk, where the classifier's noise rows are the 49 cuts of each image."""
