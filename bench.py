@@ -616,6 +616,29 @@ def split_bf16(dev, steps, pipeline):
                 out["gemm_launches"] = {"per_launch_us": rec.per_launch_us, "fp32_equivalent_TFLOPs": round(tf, 1),
                                         "bf16_mfma_TFLOPs": round(6 * tf, 1), "frac_of_bf16_peak": round(6 * tf / PEAK_BF16_MFMA_TFLOPS, 4),
                                         "frac_of_fp32_matrix_peak": round(tf / PEAK_F32_MFMA_TFLOPS, 4)}
+        # the mode also covers the role-swapped gradient GEMMs of the training step (range-free: 1e-6-sized operands are fine)
+        try:
+            from bbb_hip import train
+            y = torch.randint(0, cfg["classes"], (cfg["B"],), device=dev)
+            res = {}
+            for mode in ("fp32", "bf16x3"):
+                ops.gemm_mode = mode
+                net_t, _ = build_net(cfg, dev)
+                opt = train.FusedAdam(net_t.parameters(), lr=1e-3)
+                for _ in range(4):
+                    train.train_step(net_t, opt, x, y, E, 0.1, 50000.0, graph=False)
+                torch.cuda.synchronize(dev)
+                n = max(5, steps // 8)
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    train.train_step(net_t, opt, x, y, E, 0.1, 50000.0, graph=False)
+                torch.cuda.synchronize(dev)
+                res[mode] = round(1e3 * (time.perf_counter() - t0) / n, 4)
+                del net_t, opt
+            out["training_step_ms"] = {"bf16x3": res["bf16x3"], "fp32": res["fp32"],
+                                       "what": "forward + backward + Adam, bs=512 num_ens=10, launch by launch; forward, wgrad and dgrad GEMMs in the mode"}
+        except Exception as exc:
+            out["training_step_ms"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:160])}
         out["unit"] = "samples/s"
         out["note"] = ("opt-in precision mode, range-free: fp32 tensors in HBM, every GEMM operand element split into hi = bf16(a), "
                        "mid = bf16(a - hi), lo = bf16(a - hi - mid) while its tile is staged (exact), six products on "

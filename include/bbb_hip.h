@@ -199,12 +199,26 @@ int bbb_lrt_conv2d_fwd(const bbb_conv_desc_t* d, const float* x, const float* w_
 int bbb_conv2d_chwn_fwd(const bbb_conv_desc_t* d, const float* x, const float* w, const float* bias,
                         float* y, void* stream);
 /* The same launch with the contraction on the 16-bit matrix pipe at fp32 accuracy, RANGE-FREE ("split bf16", ABI 8): every fp32
- * operand element is cut into hi = bf16(a), mid = bf16(a - hi), lo = bf16(a - hi - mid) while its tile is staged (a = hi + mid + lo
- * exactly; bf16 has fp32's exponent range: no operand scales, windows or saturation) and every product is
+ * operand element is cut into hi = bf16(a), mid = bf16(a - hi), lo = bf16(a - hi - mid) (a = hi + mid + lo exactly; bf16 has
+ * fp32's exponent range: no operand scales, windows or saturation) and every product is
  * lo*hi + hi*lo + mid*mid + mid*hi + hi*mid + hi*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- the dropped terms are
- * < 2^-23 |a b|.  Same tensors, layouts and descriptor as bbb_conv2d_chwn_fwd (work units, x_unit_div, w_row_pitch included); not
- * bit-identical to it.  Opt-in (ops.gemm_mode = "bf16x3").  Operands must be finite. */
-int bbb_conv2d_chwn_bf16x3_fwd(const bbb_conv_desc_t* d, const float* x, const float* w, const float* bias, float* y, void* stream);
+ * < 2^-23 |a b|.  Same descriptor as bbb_conv2d_chwn_fwd (work units, x_unit_div, w_row_pitch included); not bit-identical to it.
+ * Opt-in (ops.gemm_mode = "bf16x3").  Operands must be finite.
+ * flags = 0: x and y are the fp32 tensors of bbb_conv2d_chwn_fwd (operands are cut while their tiles are staged).
+ * BBB_S3_IN / BBB_S3_OUT: x / y travel in the split ACTIVATION format "S3" -- three bf16 planes per slab,
+ * [draws|1][3][C][H][W][B] (batch % 8 == 0, 16-byte aligned; d->x_draw_stride then counts bf16 elements, 3*C*H*W*B per slab or
+ * 0 = shared) -- the exact fp32 values stored as their three pieces, written once by the producing launch and staged by the
+ * consumer without arithmetic (the kernel is bound by the VALU work of the split otherwise).  bbb_maxpool_chwn_s3 pools S3
+ * tensors; bbb_s3_convert converts fp32 <-> S3 (both exact). */
+#define BBB_S3_IN  1u
+#define BBB_S3_OUT 2u
+int bbb_conv2d_chwn_bf16x3_fwd(const bbb_conv_desc_t* d, const void* x, const float* w, const float* bias, void* y, uint32_t flags,
+                               void* stream);
+/* nn.MaxPool2d(k, s) on an S3 tensor [slabs][3][channels][h][w][batch] -> [slabs][3][channels][ho][wo][batch]: the S3 form of what
+ * bbb_maxpool_chwn computes on the fp32 values. */
+int bbb_maxpool_chwn_s3(const void* x, void* y, int64_t slabs, int channels, int h, int w, int batch, int k, int s, void* stream);
+/* fp32 [slabs][n] -> S3 [slabs][3][n] (to_s3 != 0) or back (to_s3 == 0); n % 8 == 0; exact in both directions. */
+int bbb_s3_convert(const void* src, void* dst, int64_t slabs, int64_t n, int to_s3, void* stream);
 int bbb_lrt_conv2d_chwn_fwd(const bbb_conv_desc_t* d, const float* x, const float* w_mu, const float* w_var,
                             const float* b_mu, const float* b_var, float* y,
                             float* act_mu_out, float* act_var_out, const float* eps_ext,

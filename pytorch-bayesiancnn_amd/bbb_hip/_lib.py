@@ -53,7 +53,9 @@ _SIGNATURES = {
     "bbb_lrt_conv2d_fwd": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_u64, c_u32, c_u32, c_int, c_void_p, c_void_p]),
     "bbb_conv2d_chwn_fwd": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "bbb_conv2d_chwn_bf16x3_fwd": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "bbb_conv2d_chwn_bf16x3_fwd": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_u32, c_void_p]),
+    "bbb_maxpool_chwn_s3": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "bbb_s3_convert": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_int, c_void_p]),
     "bbb_lrt_conv2d_chwn_fwd": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_u64, c_u32, c_u32, c_int, c_void_p, c_void_p]),
     "bbb_lrt_sample_chwn": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_u64, c_u32, c_u32, c_void_p,

@@ -406,6 +406,11 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
     logits_buf = torch.empty((E, n_out, B), dtype=torch.float32, device=x.device) if n_out is not None else None
 
     bf16x3 = True if precision == "bf16x3" else None        # None: ops.gemm_mode decides
+    # split-bf16 mode, steps large enough that every conv launch takes that kernel: the activations between the layers travel in
+    # the split format S3 (three bf16 planes holding the exact fp32 values; ops.conv2d_chwn_forward x_s3 / out_s3) -- each
+    # element is cut into its pieces ONCE, by the launch that produces it, instead of by every workgroup that stages it
+    s3_chain = ((precision == "bf16x3" or ops.gemm_mode == "bf16x3") and not bf16 and not lrt and bool(bbb) and B % 8 == 0
+                and E * B >= ops.s3_min_images and tail_is_last)
 
     def run(e0, e1):
         """Layers for draws [e0, e1) on the current stream -> logits [e1-e0, C, B] (or None: fall back)."""
@@ -413,6 +418,7 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
         B = xt.shape[-1]
         Es = e1 - e0
         h = xt
+        s3 = False                     # h is an S3 tensor [E, 3, C, H, W, B] (split-bf16 chain)
         boff = int(b_offset)           # global index of the first local "image" (rows multiply at a flatten that cuts images up)
         per_slice = bool(ukw)          # work units: until the first Bayesian layer, h is one block per batch slice
         x_div = draws if (G > 1 and draws > 1) else 1   # several steps per launch: the first layer's slab e reads batch e // draws
@@ -424,8 +430,11 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
             if isinstance(mod, (_BBBLayer, _LRTLayer)):
                 is_conv = isinstance(mod, (_BBBConv, _LRTConv))
                 geom = (mod.stride, mod.padding, mod.dilation) if is_conv else (1, 0, 1)
-                h5 = h if is_conv else h.reshape(h.shape[0], mod.in_features, 1, 1, -1)
-                if h5.dim() != 5 or h5.shape[-1] != B:
+                if s3:
+                    h5 = h if is_conv else h.reshape(h.shape[0], 3, mod.in_features, 1, 1, -1)
+                else:
+                    h5 = h if is_conv else h.reshape(h.shape[0], mod.in_features, 1, 1, -1)
+                if h5.dim() != (6 if s3 else 5) or h5.shape[-1] != B:
                     return None                                  # flatten quirk etc.: caller falls back
                 ukw2 = dict(ukw, x_per_slice=per_slice) if ukw else ({"x_div": x_div} if x_div > 1 else {})
                 per_slice = False
@@ -453,11 +462,12 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
                         b = None if b is None else b[e0:e1]
                     if not is_conv:
                         w = w.reshape(w.shape[0], mod.out_features, mod.in_features, 1, 1)
-                    fl = conv_flops(B, h5.shape[1], h5.shape[2], h5.shape[3], w.shape[1], w.shape[3], w.shape[4], *geom, Es) \
-                        if timers is not None else None
+                    fl = conv_flops(B, *h5.shape[-4:-1], w.shape[1], w.shape[3], w.shape[4], *geom, Es) if timers is not None else None
                     dst = logits_buf[e0:e1] if (logits_buf is not None and i == last_bayes and not is_conv) else None
-                    y = _run(timers, "conv_gemm", fl, lambda h5=h5, w=w, b=b, geom=geom, act=act, dst=dst, ukw2=ukw2:
-                             ops.conv2d_chwn_forward(h5, w, b, *geom, act=act, out=dst, bf16x3=bf16x3, **ukw2))
+                    o_s3 = s3_chain and i != last_bayes          # intermediate layers hand their output on already split
+                    y = _run(timers, "conv_gemm", fl, lambda h5=h5, w=w, b=b, geom=geom, act=act, dst=dst, ukw2=ukw2, s3=s3, o_s3=o_s3:
+                             ops.conv2d_chwn_forward(h5, w, b, *geom, act=act, out=dst, bf16x3=bf16x3, x_s3=s3, out_s3=o_s3, **ukw2))
+                    s3 = o_s3
                 else:
                     w_var, b_var = variances[mod]
                     w_mu = mod.W_mu
@@ -487,10 +497,14 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
                 if act is not None:
                     i += 1
             elif isinstance(mod, FlattenLayer):
-                if h.dim() != 5:
+                if s3 and h.shape[2] * h.shape[3] * h.shape[4] != mod.num_features:
+                    h, s3 = ops.s3_to_f32(h), False              # the flatten quirk below works on the fp32 tensor
+                if h.dim() != (6 if s3 else 5):
                     return None
-                chw = h.shape[1] * h.shape[2] * h.shape[3]
-                if chw == mod.num_features:
+                chw = h.shape[-4] * h.shape[-3] * h.shape[-2]
+                if s3:
+                    h = h.reshape(h.shape[0], 3, mod.num_features, 1, 1, B)
+                elif chw == mod.num_features:
                     h = h.reshape(h.shape[0], mod.num_features, 1, 1, B)
                 else:
                     # the reference's view(-1, num_features) on a larger map (AlexNet on 224x224: [B,128,7,7] -> [B*49,128])
@@ -507,13 +521,19 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
                     if logits_buf is not None and logits_buf.shape[2] != B:
                         logits_buf = torch.empty((E, n_out, B), dtype=torch.float32, device=x.device)
             elif isinstance(mod, nn.MaxPool2d):
-                pool = ops.maxpool_chwn_bf16 if bf16 else ops.maxpool_chwn
+                pool = ops.maxpool_chwn_s3 if s3 else (ops.maxpool_chwn_bf16 if bf16 else ops.maxpool_chwn)
                 h = _run(timers, "maxpool", None, lambda: pool(h, mod.kernel_size, mod.stride))
             elif isinstance(mod, nn.ReLU):
+                if s3:
+                    h, s3 = ops.s3_to_f32(h), False
                 h = torch.relu(h)
             else:
+                if s3:
+                    h, s3 = ops.s3_to_f32(h), False
                 h = F.softplus(h)
             i += 1
+        if s3:
+            h, s3 = ops.s3_to_f32(h), False
         if h.shape[0] == 1 and Es > 1:
             h = h.expand(Es, *h.shape[1:])
         h = h.reshape(Es, -1, B)

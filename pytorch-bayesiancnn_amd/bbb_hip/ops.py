@@ -223,6 +223,8 @@ gemm_mode = "fp32"  # "bf16x3": the batch-innermost BBB GEMM launches (inference
                     # to rounding, not bit for bit.  LRT layers keep the fused fp32 kernel (one staged x tile feeds both of its
                     # contractions; a split form would need twelve operand planes in LDS).
 bf16x3_min_workgroups = 256  # smaller launches stay on the fp32 kernel (and the layer's split contraction): measured faster there
+s3_min_images = 2048         # split-bf16 mode: steps of at least this many (draw x image) rows keep their activations in the split
+                             # format S3 between layers (ensemble._mc_logits_chwn); smaller steps split while staging, per launch
 _split_plans = {}
 split_k = True     # layers with few (pixel, channel-tile) groups and a long contraction (AlexNet conv4 / conv5) add their k ranges'
                    # partial sums in range order (bbb_conv2d_chwn_splitk_fwd): a property of the LAYER, identical for every launch
@@ -274,45 +276,62 @@ def _desc_chwn(x, w, stride, padding, dilation, draws, x_shared, w_shared, act):
 
 
 def conv2d_chwn_forward(x, w, bias, stride=1, padding=0, dilation=1, act=None, out=None, units=None, n_units=None,
-                        x_per_slice=False, x_div=1, bf16x3=None):
+                        x_per_slice=False, x_div=1, bf16x3=None, x_s3=False, out_s3=False):
     """Batch-innermost conv for the ensemble path.  x: [E|1, Cin, H, W, B] (B % 4 == 0); w: [E|1, Cout, Cin, kh, kw];
     bias [E|1, Cout] or None -> y [E, Cout, Ho, Wo, B].  Padding taps are skipped, not multiplied.
     Work units (ensemble sharding): units = (S, off), n_units = U output slabs; w / bias hold the weight sets of the draws
     the units touch, x is [U, ...] or, for a layer whose input is the same for every draw, the per-slice [S, Cin, H, W, Bs].
     x_div = D > 1 (several Monte-Carlo steps per launch): x holds E / D input slabs and output slab e reads slab e // D
     (bbb_conv_desc_t::x_unit_div) -- the first layer of G steps x D draws, each step on its own batch.
-    bf16x3: True / False = run this launch on the split-bf16 kernel or not; None (default) = ops.gemm_mode decides."""
-    require_device(x, w, bias)
+    bf16x3: True / False = run this launch on the split-bf16 kernel or not; None (default) = ops.gemm_mode decides.
+    x_s3 / out_s3 (split-bf16 kernel only, B % 8 == 0): the input / output travels in the split activation format S3 -- a bf16
+    tensor [E|1, 3, C, H, W, B] holding the hi / mid / lo pieces of the same fp32 values (s3_from_f32 / s3_to_f32)."""
+    require_device(w, bias)
+    require_device(x, dtype=torch.bfloat16 if x_s3 else torch.float32)
     x, w = x.contiguous(), w.contiguous()
     bias = None if bias is None else bias.contiguous()
+    if x_s3:
+        if x.dim() != 6 or x.shape[1] != 3 or x.shape[5] % 8:
+            raise _lib.BBBHipError("an S3 input is a bf16 tensor [E|1, 3, C, H, W, B] with B % 8 == 0")
+        x5 = x.new_empty((x.shape[0],) + tuple(x.shape[2:]), dtype=torch.float32, device="meta")
+    else:
+        x5 = x
     if units is not None and units[0] > 1:
         E = int(n_units)
-        if x.shape[0] != (units[0] if x_per_slice else E):
+        if x5.shape[0] != (units[0] if x_per_slice else E):
             raise _lib.BBBHipError("work units: x must hold one slab per unit, or one per batch slice with x_per_slice")
-        d, ho, wo = _desc_chwn(x, w, stride, padding, dilation, E, False, False, act)
+        d, ho, wo = _desc_chwn(x5, w, stride, padding, dilation, E, False, False, act)
         _apply_units(d, units, x_per_slice)
     elif int(x_div) > 1:
         E = w.shape[0]
-        if E % int(x_div) or x.shape[0] * int(x_div) != E:
+        if E % int(x_div) or x5.shape[0] * int(x_div) != E:
             raise _lib.BBBHipError("x_div: x must hold E / x_div input slabs for the E weight sets")
-        d, ho, wo = _desc_chwn(x, w, stride, padding, dilation, E, False, False, act)
+        d, ho, wo = _desc_chwn(x5, w, stride, padding, dilation, E, False, False, act)
         d.x_unit_div = int(x_div)
     else:
-        E = max(x.shape[0], w.shape[0])
-        if x.shape[0] not in (1, E) or w.shape[0] not in (1, E):
+        E = max(x5.shape[0], w.shape[0])
+        if x5.shape[0] not in (1, E) or w.shape[0] not in (1, E):
             raise _lib.BBBHipError("leading (draw) dims of x and w must be 1 or equal")
-        d, ho, wo = _desc_chwn(x, w, stride, padding, dilation, E, x.shape[0] == 1 and E > 1, w.shape[0] == 1 and E > 1, act)
-    shape = (E, w.shape[1], ho, wo, x.shape[4])
+        d, ho, wo = _desc_chwn(x5, w, stride, padding, dilation, E, x5.shape[0] == 1 and E > 1, w.shape[0] == 1 and E > 1, act)
+    if x_s3:
+        d.x_draw_stride *= 3                                   # bf16 elements per S3 slab
+    B = x5.shape[4]
+    shape = (E, 3, w.shape[1], ho, wo, B) if out_s3 else (E, w.shape[1], ho, wo, B)
+    odt = torch.bfloat16 if out_s3 else torch.float32
+    if out_s3 and B % 8:
+        raise _lib.BBBHipError("an S3 output needs B % 8 == 0")
     if out is None:
-        y = torch.empty(shape, dtype=torch.float32, device=x.device)
+        y = torch.empty(shape, dtype=odt, device=x.device)
     else:
-        if out.numel() != E * w.shape[1] * ho * wo * x.shape[4] or not out.is_contiguous() or out.dtype != torch.float32:
-            raise _lib.BBBHipError("out= must be a contiguous fp32 tensor of the output's size")
+        if out.numel() != E * (3 if out_s3 else 1) * w.shape[1] * ho * wo * B or not out.is_contiguous() or out.dtype != odt:
+            raise _lib.BBBHipError("out= must be a contiguous tensor of the output's size and dtype")
         y = out.view(shape)
     with on_device(x.device):
-        if (bf16x3 if bf16x3 is not None else gemm_mode == "bf16x3") and E * ho * wo * -(-w.shape[1] // 64) * -(-x.shape[4] // 128) >= bf16x3_min_workgroups:
+        if x_s3 or out_s3 or ((bf16x3 if bf16x3 is not None else gemm_mode == "bf16x3")
+                              and E * ho * wo * -(-w.shape[1] // 64) * -(-B // 128) >= bf16x3_min_workgroups):
             check(_lib.lib().bbb_conv2d_chwn_bf16x3_fwd(ctypes.byref(d), x.data_ptr(), w.data_ptr(), ptr(bias), y.data_ptr(),
-                                                        cur_stream(x.device)), "bbb_conv2d_chwn_bf16x3_fwd")
+                                                        (1 if x_s3 else 0) | (2 if out_s3 else 0), cur_stream(x.device)),
+                  "bbb_conv2d_chwn_bf16x3_fwd")
             return y
         ks, scr = _split_scratch(d, False, x.device)
         if ks > 1:
@@ -322,6 +341,42 @@ def conv2d_chwn_forward(x, w, bias, stride=1, padding=0, dilation=1, act=None, o
         else:
             check(_lib.lib().bbb_conv2d_chwn_fwd(ctypes.byref(d), x.data_ptr(), w.data_ptr(), ptr(bias), y.data_ptr(),
                                                  cur_stream(x.device)), "bbb_conv2d_chwn_fwd")
+    return y
+
+
+def s3_from_f32(x):
+    """fp32 [E, ...] -> its split activation form S3: bf16 [E, 3, ...] (hi, mid, lo pieces; exact).  The trailing dims must hold
+    a multiple of 8 elements."""
+    require_device(x)
+    x = x.contiguous()
+    n = x.numel() // x.shape[0]
+    y = torch.empty((x.shape[0], 3) + tuple(x.shape[1:]), dtype=torch.bfloat16, device=x.device)
+    with on_device(x.device):
+        check(_lib.lib().bbb_s3_convert(x.data_ptr(), y.data_ptr(), x.shape[0], n, 1, cur_stream(x.device)), "bbb_s3_convert")
+    return y
+
+
+def s3_to_f32(x):
+    """S3 bf16 [E, 3, ...] -> the fp32 tensor [E, ...] it stores (hi + mid + lo, exact)."""
+    require_device(x, dtype=torch.bfloat16)
+    x = x.contiguous()
+    n = x.numel() // (3 * x.shape[0])
+    y = torch.empty((x.shape[0],) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+    with on_device(x.device):
+        check(_lib.lib().bbb_s3_convert(x.data_ptr(), y.data_ptr(), x.shape[0], n, 0, cur_stream(x.device)), "bbb_s3_convert")
+    return y
+
+
+def maxpool_chwn_s3(x, k, s):
+    """MaxPool2d(k, s) on an S3 tensor [E, 3, C, H, W, B] (B % 8 == 0) -> [E, 3, C, Ho, Wo, B]."""
+    require_device(x, dtype=torch.bfloat16)
+    x = x.contiguous()
+    E, three, C, H, W, B = x.shape
+    ho, wo = (H - k) // s + 1, (W - k) // s + 1
+    y = torch.empty((E, 3, C, ho, wo, B), dtype=torch.bfloat16, device=x.device)
+    with on_device(x.device):
+        check(_lib.lib().bbb_maxpool_chwn_s3(x.data_ptr(), y.data_ptr(), E, C, H, W, B, int(k), int(s), cur_stream(x.device)),
+              "bbb_maxpool_chwn_s3")
     return y
 
 

@@ -11,6 +11,12 @@
 // Inputs, weights, bias and outputs stay fp32 in HBM in the layouts of bbb_conv2d_chwn_fwd: the kernel is a drop-in for that
 // launch (same descriptor, work units and x_unit_div included); results differ from the fp32 fmaf chain by rounding, not bit
 // for bit, which is why it is a mode (ops.gemm_mode = "bf16x3") and not the silent default.
+// Split ACTIVATION format ("S3", template flags XPRE / OSPLIT): the kernel is VALU-bound on the split itself -- every image row
+// element is cut into pieces again by every channel-tile workgroup that stages it (24 elements per thread and tile against 768
+// cycles of matrix work per wave).  So between the layers of a step activations may travel already split: three bf16 planes per
+// slab, [draw][3][C][H][W][B], written ONCE by the producing launch's epilogue (OSPLIT), pooled plane-wise
+// (bbb_maxpool_chwn_s3), and staged by the consumer with plain 16-byte loads and no arithmetic (XPRE).  hi + mid + lo is still
+// the exact fp32 value, so the numbers do not change: S3 is a storage format of the same fp32 activations (6 bytes per element).
 // Same decomposition: workgroup = one output pixel, 64 channels, 128 images, in-bounds taps only, k tables in LDS; staging
 // moves 16-byte vectors on the LDS side (a thread owns 8 adjacent channels of one k / 8 adjacent images of one row), both MFMA
 // operands come from ds_read_b64_tr_b16, the epilogue goes through an LDS transpose to 16-byte stores.
@@ -21,20 +27,26 @@ namespace pconv {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short f16s4 __attribute__((ext_vector_type(4)));
-typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 
-// a -> (hi, mid, lo) bf16 bit patterns (v_cvt_pk_bf16_f32 rounds to nearest even; bf16 -> fp32 is a 16-bit shift)
-__device__ __forceinline__ void split3(float a, unsigned short& h, unsigned short& m, unsigned short& l) {
-    const __bf16 hb = (__bf16)a;
-    const float r1 = a - (float)hb;
-    const __bf16 mb = (__bf16)r1;
-    const float r2 = r1 - (float)mb;
-    h = __builtin_bit_cast(unsigned short, hb);
-    m = __builtin_bit_cast(unsigned short, mb);
-    l = __builtin_bit_cast(unsigned short, (__bf16)r2);
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// (a0, a1) -> packed (hi, mid, lo) bf16 PAIRS, element 0 in the low half of each word.  Written on pairs so that it compiles to
+// 3 v_cvt_pk_bf16_f32 (round to nearest even) + 2 shifts + 2 ands (bf16 -> fp32 is a 16-bit shift) + 2 v_pk_add_f32: 4.5 VALU
+// instructions per element -- the kernel is VALU-bound on exactly this work (left to the scalar form hipcc spent 8 per element).
+__device__ __forceinline__ void split3_pair(f32x2 a, uint32_t& h, uint32_t& m, uint32_t& l) {
+    h = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, bf16x2));
+    const f32x2 hf = {__builtin_bit_cast(float, h << 16), __builtin_bit_cast(float, h & 0xFFFF0000u)};
+    const f32x2 r1 = a - hf;                                     // exact
+    m = __builtin_bit_cast(uint32_t, __builtin_convertvector(r1, bf16x2));
+    const f32x2 mf = {__builtin_bit_cast(float, m << 16), __builtin_bit_cast(float, m & 0xFFFF0000u)};
+    const f32x2 r2 = r1 - mf;                                    // exact
+    l = __builtin_bit_cast(uint32_t, __builtin_convertvector(r2, bf16x2));
 }
 
-template <int MT>
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <int MT, bool XPRE, bool OSPLIT>
 __global__ __launch_bounds__(kThreads) void pconv_bf16x3_kernel(const PConvArgs p) {
     constexpr int BM = 128 * MT;
     constexpr int LDXH = BM + 32;              // 16-bit elements per image row: 64 B mod 256 -> the 4 rows of a transpose read hit disjoint banks
@@ -87,8 +99,16 @@ __global__ __launch_bounds__(kThreads) void pconv_bf16x3_kernel(const PConvArgs 
     constexpr uint32_t kOOB = 0xFFFFFFF0u;
     constexpr uint32_t kWInv = 0x7FFFFFF0u;
     const uint32_t kXInv = p.x_inv;
+    // XPRE: p.x is a bf16 S3 tensor (x_ds / x_ps count bf16 elements); one descriptor per plane, sized like one plane, so that
+    // the invalid-row marker (half the fp32 one: offsets are in 2-byte elements here) stays out of range
+    const unsigned short* const xb16 = reinterpret_cast<const unsigned short*>(p.x) + (XPRE ? (int64_t)ex * p.x_ds : 0);
+    const int x_bytes = (int)((int64_t)p.Cin * p.H * p.W * p.B * (XPRE ? 2 : 4));
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.x + (int64_t)ex * p.x_ds), 0, (int)((int64_t)p.Cin * p.H * p.W * p.B * 4), 0x00020000);
+        XPRE ? (void*)const_cast<unsigned short*>(xb16) : (void*)const_cast<float*>(p.x + (int64_t)ex * p.x_ds), 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrs1 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned short*>(xb16 + (XPRE ? p.x_ps : 0)), 0, XPRE ? x_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrs2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned short*>(xb16 + (XPRE ? 2 * p.x_ps : 0)), 0, XPRE ? x_bytes : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.w + (int64_t)ew * p.w_ds), 0, (int)((int64_t)p.Cout * p.Kp * 4), 0x00020000);
 
@@ -99,15 +119,16 @@ __global__ __launch_bounds__(kThreads) void pconv_bf16x3_kernel(const PConvArgs 
     const int wkl = tid & 31, wng = (tid >> 5) * 8;
     const int wswz = ((wkl >> 2) & 7) << 3;
     const int xb8 = (tid % XL) * 8, xkr = tid / XL;
-    const uint32_t xcol = (uint32_t)(b0 + xb8) * 4u;
+    const uint32_t xcol = (uint32_t)(b0 + xb8) * (XPRE ? 2u : 4u);
     uint32_t wrow[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) wrow[i] = (uint32_t)(n0 + wng + i) * (uint32_t)p.Kp * 4u;
 
     // One register stage + one LDS stage, as pconv_body.cuh: loads for tile t+1 are issued before tile t's MFMAs and written to
     // LDS after them.
+    constexpr int XV = (XPRE ? 3 : 2) * XPASS;           // 16-byte vectors of image data per thread and tile
     float wregA[8];
-    f32x4 xregA[2 * XPASS];
+    u32x4 xregA[XV];
 
     const float inv_nrq = nrq > 0 ? 1.0f / (float)nrq : 0.0f;
     const float inv_nq = nq > 0 ? 1.0f / (float)nq : 0.0f;
@@ -128,44 +149,56 @@ __global__ __launch_bounds__(kThreads) void pconv_bf16x3_kernel(const PConvArgs 
         kt_w[chunk & 1][tid] = (int32_t)wo;
         kt_x[chunk & 1][tid] = (int32_t)xo;
     };
-    auto load_tile = [&](int tile, float (&wreg)[8], f32x4 (&xreg)[2 * XPASS]) {
+    auto load_tile = [&](int tile, float (&wreg)[8], u32x4 (&xreg)[XV]) {
         const int buf = (tile / TPC) & 1;
         const int kb = (tile % TPC) * BK;
         const uint32_t wob = (uint32_t)kt_w[buf][kb + wkl];
         uint32_t xo[XPASS];
 #pragma unroll
-        for (int ps = 0; ps < XPASS; ++ps) xo[ps] = (uint32_t)kt_x[buf][kb + xkr + ps * XRPP] + xcol;
+        for (int ps = 0; ps < XPASS; ++ps)       // (the table holds fp32 byte offsets of a row: half of that in a bf16 plane)
+            xo[ps] = (XPRE ? ((uint32_t)kt_x[buf][kb + xkr + ps * XRPP] >> 1) : (uint32_t)kt_x[buf][kb + xkr + ps * XRPP]) + xcol;
 #pragma unroll
         for (int ps = 0; ps < XPASS; ++ps) {
-            xreg[2 * ps] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xo[ps], 0, 0));
-            xreg[2 * ps + 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xo[ps] + 16u, 0, 0));
+            if constexpr (XPRE) {
+                xreg[3 * ps] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xo[ps], 0, 0));
+                xreg[3 * ps + 1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs1, xo[ps], 0, 0));
+                xreg[3 * ps + 2] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs2, xo[ps], 0, 0));
+            } else {
+                xreg[2 * ps] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xo[ps], 0, 0));
+                xreg[2 * ps + 1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xo[ps] + 16u, 0, 0));
+            }
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) wreg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrs, wrow[i] + wob, 0, 0));
     };
     // the split: the three pieces of every staged element go to LDS, [k][n] / [k][b] planes of 16-bit elements, 16 bytes per write
-    auto store_tile = [&](float (&wreg)[8], f32x4 (&xreg)[2 * XPASS]) {
-        u16x8 h, m, l;
+    auto store_tile = [&](float (&wreg)[8], u32x4 (&xreg)[XV]) {
+        u32x4 h, m, l;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            unsigned short a0, a1, a2;
-            split3(wreg[i], a0, a1, a2);
+        for (int i = 0; i < 4; ++i) {
+            uint32_t a0, a1, a2;
+            split3_pair(f32x2{wreg[2 * i], wreg[2 * i + 1]}, a0, a1, a2);
             h[i] = a0; m[i] = a1; l[i] = a2;
         }
-        *reinterpret_cast<u16x8*>(&Wh[wkl * LDWH + (wng ^ wswz)]) = h;
-        *reinterpret_cast<u16x8*>(&Wm[wkl * LDWH + (wng ^ wswz)]) = m;
-        *reinterpret_cast<u16x8*>(&Wl[wkl * LDWH + (wng ^ wswz)]) = l;
+        *reinterpret_cast<u32x4*>(&Wh[wkl * LDWH + (wng ^ wswz)]) = h;
+        *reinterpret_cast<u32x4*>(&Wm[wkl * LDWH + (wng ^ wswz)]) = m;
+        *reinterpret_cast<u32x4*>(&Wl[wkl * LDWH + (wng ^ wswz)]) = l;
 #pragma unroll
         for (int ps = 0; ps < XPASS; ++ps) {
+            if constexpr (XPRE) {                    // already split by the producer: straight to the planes
+                h = xreg[3 * ps]; m = xreg[3 * ps + 1]; l = xreg[3 * ps + 2];
+            } else {
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                unsigned short a0, a1, a2;
-                split3(xreg[2 * ps + (c >> 2)][c & 3], a0, a1, a2);
-                h[c] = a0; m[c] = a1; l[c] = a2;
+                for (int c = 0; c < 4; ++c) {
+                    uint32_t a0, a1, a2;
+                    const f32x4 v = __builtin_bit_cast(f32x4, xreg[2 * ps + (c >> 1)]);
+                    split3_pair((c & 1) ? f32x2{v[2], v[3]} : f32x2{v[0], v[1]}, a0, a1, a2);
+                    h[c] = a0; m[c] = a1; l[c] = a2;
+                }
             }
-            *reinterpret_cast<u16x8*>(&Xh[(xkr + ps * XRPP) * LDXH + xb8]) = h;
-            *reinterpret_cast<u16x8*>(&Xm[(xkr + ps * XRPP) * LDXH + xb8]) = m;
-            *reinterpret_cast<u16x8*>(&Xl[(xkr + ps * XRPP) * LDXH + xb8]) = l;
+            *reinterpret_cast<u32x4*>(&Xh[(xkr + ps * XRPP) * LDXH + xb8]) = h;
+            *reinterpret_cast<u32x4*>(&Xm[(xkr + ps * XRPP) * LDXH + xb8]) = m;
+            *reinterpret_cast<u32x4*>(&Xl[(xkr + ps * XRPP) * LDXH + xb8]) = l;
         }
     };
 
@@ -255,8 +288,13 @@ __global__ __launch_bounds__(kThreads) void pconv_bf16x3_kernel(const PConvArgs 
     const int HoWo = p.Ho * p.Wo;
     const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.bias ? p.bias + (int64_t)ew * p.b_ds : p.w), 0, p.bias ? p.Cout * 4 : 0, 0x00020000);
+    // OSPLIT: y is a bf16 S3 tensor [draw][3][Cout][Ho][Wo][B] (y_ds / y_ps count bf16 elements): one descriptor per plane
+    unsigned short* const yb16 = reinterpret_cast<unsigned short*>(p.y) + (OSPLIT ? (int64_t)e * p.y_ds : 0);
+    const int y_bytes = (int)((int64_t)p.Cout * HoWo * p.B * (OSPLIT ? 2 : 4));
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
-        p.y + (int64_t)e * p.y_ds, 0, (int)((int64_t)p.Cout * HoWo * p.B * 4), 0x00020000);
+        OSPLIT ? (void*)yb16 : (void*)(p.y + (int64_t)e * p.y_ds), 0, y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrs1 = __builtin_amdgcn_make_buffer_rsrc(yb16 + (OSPLIT ? p.y_ps : 0), 0, OSPLIT ? y_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrs2 = __builtin_amdgcn_make_buffer_rsrc(yb16 + (OSPLIT ? 2 * p.y_ps : 0), 0, OSPLIT ? y_bytes : 0, 0x00020000);
     static_assert(3 * BK * LDXH * 2 >= 4 * 32 * 36 * 4, "epilogue staging must fit in the image planes");
     float* const T = reinterpret_cast<float*>(Xp) + wave * (32 * 36);       // [32 channels][36] floats, wave-private
 #pragma unroll
@@ -275,8 +313,21 @@ __global__ __launch_bounds__(kThreads) void pconv_bf16x3_kernel(const PConvArgs 
                 f32x4 o;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) o[c] = bbb::apply_act(v4[c] + bv, p.act);
-                const uint32_t off = ((b < p.B) & (n < p.Cout)) ? (uint32_t)(((int64_t)n * HoWo + pix) * p.B + b) * 4u : kOOB;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(uint32_t)))) uint32_t, o), yrs, off, 0, 0);
+                const uint32_t off = ((b < p.B) & (n < p.Cout)) ? (uint32_t)(((int64_t)n * HoWo + pix) * p.B + b) * (OSPLIT ? 2u : 4u) : kOOB;
+                if constexpr (OSPLIT) {              // the next layer's operand pieces, written once here instead of per staging
+                    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                    u32x2 h2, m2, l2;
+                    uint32_t a0, a1, a2;
+                    split3_pair(f32x2{o[0], o[1]}, a0, a1, a2);
+                    h2[0] = a0; m2[0] = a1; l2[0] = a2;
+                    split3_pair(f32x2{o[2], o[3]}, a0, a1, a2);
+                    h2[1] = a0; m2[1] = a1; l2[1] = a2;
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((__vector_size__(2 * sizeof(uint32_t)))) uint32_t, h2), yrs, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((__vector_size__(2 * sizeof(uint32_t)))) uint32_t, m2), yrs1, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((__vector_size__(2 * sizeof(uint32_t)))) uint32_t, l2), yrs2, off, 0, 0);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(uint32_t)))) uint32_t, o), yrs, off, 0, 0);
+                }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the reads are done before the next tile overwrites T
         }

@@ -350,25 +350,145 @@ extern "C" int bbb_conv2d_chwn_fwd(const bbb_conv_desc_t* d, const float* x, con
 }
 
 // bbb_conv2d_chwn_fwd with the contraction on the 16-bit matrix pipe at fp32 accuracy, range-free (pconv_bf16x3.cuh)
-extern "C" int bbb_conv2d_chwn_bf16x3_fwd(const bbb_conv_desc_t* d, const float* x, const float* w, const float* bias, float* y,
-                                          void* stream) {
+extern "C" int bbb_conv2d_chwn_bf16x3_fwd(const bbb_conv_desc_t* d, const void* x, const float* w, const float* bias, void* y,
+                                          uint32_t flags, void* stream) {
     PConvArgs a = {};
     const int rc = fill(d, a);
     if (rc != 0) return rc;
-    if (x == nullptr || w == nullptr || y == nullptr) return BBB_EINVAL;
+    if (x == nullptr || w == nullptr || y == nullptr || (flags & ~3u) != 0) return BBB_EINVAL;
     if ((((uintptr_t)x | (uintptr_t)y) & 15u) != 0 || (((uintptr_t)w | (uintptr_t)bias) & 3u) != 0) return BBB_EALIGN;
-    a.x = x; a.w = w; a.bias = bias; a.y = y;
+    const bool xs3 = (flags & BBB_S3_IN) != 0, ys3 = (flags & BBB_S3_OUT) != 0;
+    if ((xs3 || ys3) && d->batch % 8 != 0) return BBB_ESHAPE;           // S3 rows move as 16-byte vectors of 8 bf16
+    a.x = static_cast<const float*>(x); a.w = w; a.bias = bias; a.y = static_cast<float*>(y);
+    a.x_ps = (int64_t)a.Cin * a.H * a.W * a.B;
+    a.y_ps = (int64_t)a.Cout * a.Ho * a.Wo * a.B;
+    if (ys3) a.y_ds = 3 * a.y_ps;
+    if (xs3 && (d->x_draw_stride != 0 && d->x_draw_stride < 3 * a.x_ps)) return BBB_EINVAL;
     a.Ntiles = (a.Cout + BN - 1) / BN;
     a.G = a.Ntiles * d->draws;
     const int64_t pixels = (int64_t)a.Ho * a.Wo;
-    a.nbt = (a.B + 127) / 128;
+    // 128 images per workgroup (measured: the 256-image form -- 2 workgroups per CU, half the workgroups -- is slower on four of
+    // the six launches of the metric step, profiles/r04_notes.md)
+    constexpr int kMT = 1;
+    a.nbt = (a.B + 128 * kMT - 1) / (128 * kMT);
     const int64_t mtiles = pixels * a.nbt;
     if (mtiles > 0x7fffffffLL) return BBB_ESHAPE;
     a.Mtiles = (int)mtiles;
     const int64_t per = ((int64_t)a.G * mtiles + 7) / 8;
     if (8 * per > 0x7fffffffLL) return BBB_ESHAPE;
     a.per_xcd = (int32_t)per;
-    hipLaunchKernelGGL((pconv_bf16x3_kernel<1>), dim3((unsigned)(8 * per)), dim3(kThreads), 0, (hipStream_t)stream, a);
+    const dim3 grid((unsigned)(8 * per)), block(kThreads);
+    hipStream_t st = (hipStream_t)stream;
+    if (xs3 && ys3)      hipLaunchKernelGGL((pconv_bf16x3_kernel<kMT, true, true>), grid, block, 0, st, a);
+    else if (xs3)        hipLaunchKernelGGL((pconv_bf16x3_kernel<kMT, true, false>), grid, block, 0, st, a);
+    else if (ys3)        hipLaunchKernelGGL((pconv_bf16x3_kernel<kMT, false, true>), grid, block, 0, st, a);
+    else                 hipLaunchKernelGGL((pconv_bf16x3_kernel<kMT, false, false>), grid, block, 0, st, a);
+    return (int)hipGetLastError();
+}
+
+namespace {
+// S3 helpers: 8 images (16 bytes per plane) per thread
+typedef uint32_t s3_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void s3_join(const s3_u32x4 h, const s3_u32x4 m, const s3_u32x4 l, float (&v)[8]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {        // hi + mid is exact (16 significant bits), + lo gives back the fp32 value exactly
+        v[2 * c] = (__builtin_bit_cast(float, h[c] << 16) + __builtin_bit_cast(float, m[c] << 16)) + __builtin_bit_cast(float, l[c] << 16);
+        v[2 * c + 1] = (__builtin_bit_cast(float, h[c] & 0xFFFF0000u) + __builtin_bit_cast(float, m[c] & 0xFFFF0000u)) +
+                       __builtin_bit_cast(float, l[c] & 0xFFFF0000u);
+    }
+}
+
+__device__ __forceinline__ void s3_cut(const float (&v)[8], s3_u32x4& h, s3_u32x4& m, s3_u32x4& l) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        uint32_t a0, a1, a2;
+        split3_pair(f32x2{v[2 * c], v[2 * c + 1]}, a0, a1, a2);
+        h[c] = a0; m[c] = a1; l[c] = a2;
+    }
+}
+
+// MaxPool2d(k, s) on S3 planes: x [slabs][3][C][H][W][B] -> y [slabs][3][C][Ho][Wo][B]; values are joined (exact), compared as
+// fp32 and cut again (exact), so the result is the S3 form of what maxpool_chwn_kernel computes on the fp32 tensor.
+__global__ __launch_bounds__(256) void maxpool_s3_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ y,
+                                                         int64_t total8, int C, int H, int W, int Ho, int Wo, int B8, int k, int s) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total8) return;
+    const int b8 = (int)(i % B8);
+    int64_t t = i / B8;
+    const int ow = (int)(t % Wo);
+    t /= Wo;
+    const int oh = (int)(t % Ho);
+    t /= Ho;
+    const int c = (int)(t % C);
+    const int64_t slab = t / C;
+    const int64_t xps = (int64_t)C * H * W * B8, yps = (int64_t)C * Ho * Wo * B8;     // plane strides in 16-byte units
+    const s3_u32x4* xp = reinterpret_cast<const s3_u32x4*>(x) + slab * 3 * xps + (((int64_t)c * H + (int64_t)oh * s) * W + (int64_t)ow * s) * B8 + b8;
+    float best[8];
+    for (int a = 0; a < k; ++a)
+        for (int q = 0; q < k; ++q) {
+            const int64_t o = ((int64_t)a * W + q) * B8;
+            float v[8];
+            s3_join(xp[o], xp[o + xps], xp[o + 2 * xps], v);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) best[u] = (a == 0 && q == 0) ? v[u] : fmaxf(best[u], v[u]);
+        }
+    s3_u32x4 h, m, l;
+    s3_cut(best, h, m, l);
+    s3_u32x4* yp = reinterpret_cast<s3_u32x4*>(y) + slab * 3 * yps + (((int64_t)c * Ho + oh) * Wo + ow) * B8 + b8;
+    yp[0] = h; yp[yps] = m; yp[2 * yps] = l;
+}
+
+// fp32 [slabs][n] <-> S3 [slabs][3][n] (n % 8 == 0): test / boundary helpers
+__global__ __launch_bounds__(256) void s3_from_f32_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, int64_t n8, int64_t slabs) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8 * slabs) return;
+    const int64_t slab = i / n8, j = i - slab * n8;
+    const f32x4* xp = reinterpret_cast<const f32x4*>(x) + (slab * n8 + j) * 2;
+    const f32x4 a = xp[0], b = xp[1];
+    const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    s3_u32x4 h, m, l;
+    s3_cut(v, h, m, l);
+    s3_u32x4* yp = reinterpret_cast<s3_u32x4*>(y) + slab * 3 * n8 + j;
+    yp[0] = h; yp[n8] = m; yp[2 * n8] = l;
+}
+
+__global__ __launch_bounds__(256) void s3_to_f32_kernel(const unsigned short* __restrict__ x, float* __restrict__ y, int64_t n8, int64_t slabs) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8 * slabs) return;
+    const int64_t slab = i / n8, j = i - slab * n8;
+    const s3_u32x4* xp = reinterpret_cast<const s3_u32x4*>(x) + slab * 3 * n8 + j;
+    float v[8];
+    s3_join(xp[0], xp[n8], xp[2 * n8], v);
+    f32x4* yp = reinterpret_cast<f32x4*>(y) + (slab * n8 + j) * 2;
+    yp[0] = f32x4{v[0], v[1], v[2], v[3]};
+    yp[1] = f32x4{v[4], v[5], v[6], v[7]};
+}
+}  // namespace
+
+extern "C" int bbb_maxpool_chwn_s3(const void* x, void* y, int64_t slabs, int channels, int h, int w, int batch, int k, int s, void* stream) {
+    if (x == nullptr || y == nullptr || slabs <= 0 || channels <= 0 || h <= 0 || w <= 0 || batch <= 0 || k <= 0 || s <= 0) return BBB_EINVAL;
+    if (batch % 8 != 0 || h < k || w < k) return BBB_ESHAPE;
+    if ((((uintptr_t)x | (uintptr_t)y) & 15u) != 0) return BBB_EALIGN;
+    const int ho = (h - k) / s + 1, wo = (w - k) / s + 1;
+    const int64_t total8 = slabs * channels * ho * wo * (batch / 8);
+    const int64_t blocks = (total8 + 255) / 256;
+    if (blocks > 0x7fffffffLL) return BBB_ESHAPE;
+    hipLaunchKernelGGL(maxpool_s3_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, static_cast<const unsigned short*>(x),
+                       static_cast<unsigned short*>(y), total8, channels, h, w, ho, wo, batch / 8, k, s);
+    return (int)hipGetLastError();
+}
+
+extern "C" int bbb_s3_convert(const void* src, void* dst, int64_t slabs, int64_t n, int to_s3, void* stream) {
+    if (src == nullptr || dst == nullptr || slabs <= 0 || n <= 0) return BBB_EINVAL;
+    if (n % 8 != 0) return BBB_ESHAPE;
+    if ((((uintptr_t)src | (uintptr_t)dst) & 15u) != 0) return BBB_EALIGN;
+    const int64_t blocks = (slabs * (n / 8) + 255) / 256;
+    if (blocks > 0x7fffffffLL) return BBB_ESHAPE;
+    if (to_s3) hipLaunchKernelGGL(s3_from_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, static_cast<const float*>(src),
+                                  static_cast<unsigned short*>(dst), n / 8, slabs);
+    else       hipLaunchKernelGGL(s3_to_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                                  static_cast<const unsigned short*>(src), static_cast<float*>(dst), n / 8, slabs);
     return (int)hipGetLastError();
 }
 

@@ -171,3 +171,52 @@ def test_bf16x3_mode_covers_the_training_gemms(env, bf16x3, lt):
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()), n
         differ += int(not torch.equal(a, b))
     assert differ > 0
+
+
+def test_s3_format_is_exact_and_transparent(env):
+    """The split activation format S3 (three bf16 planes = the hi / mid / lo pieces of the same fp32 values): conversion is exact
+    both ways; a launch that reads S3 and writes S3 computes, piece for piece, what the launch on the fp32 tensors computes (the
+    in-kernel split IS the same function), so its result is bitwise the S3 form of that launch's fp32 output; pooling S3 planes
+    is bitwise pooling the fp32 tensor."""
+    ops = env["ops"]
+    torch.manual_seed(4)
+    E, Cin, H, W, B, Cout, k = 3, 64, 4, 4, 256, 192, 5
+    x = torch.randn(E, Cin, H, W, B, device="cuda") * torch.logspace(-6, 6, Cin, device="cuda").view(1, Cin, 1, 1, 1)
+    xs = ops.s3_from_f32(x)
+    assert xs.shape == (E, 3, Cin, H, W, B) and xs.dtype == torch.bfloat16
+    assert torch.equal(ops.s3_to_f32(xs), x)
+    assert torch.equal(xs[:, 0].float() + xs[:, 1].float() + xs[:, 2].float(), x)
+    w = torch.randn(E, Cout, Cin, k, k, device="cuda") * 0.05
+    b = torch.randn(E, Cout, device="cuda")
+    y = ops.conv2d_chwn_forward(x, w, b, 1, 2, 1, act="softplus", bf16x3=True)
+    for xin, x_s3 in ((x, False), (xs, True)):
+        for out_s3 in (False, True):
+            got = ops.conv2d_chwn_forward(xin, w, b, 1, 2, 1, act="softplus", bf16x3=True, x_s3=x_s3, out_s3=out_s3)
+            assert torch.equal(ops.s3_to_f32(got) if out_s3 else got, y), (x_s3, out_s3)
+    # a shared input slab (first layer of an ensemble) and the x_div form
+    y1 = ops.conv2d_chwn_forward(x[:1], w, b, 1, 2, 1, act=None, bf16x3=True)
+    assert torch.equal(ops.conv2d_chwn_forward(xs[:1], w, b, 1, 2, 1, act=None, x_s3=True), y1)
+    # pooling
+    ys = ops.s3_from_f32(y)
+    assert torch.equal(ops.s3_to_f32(ops.maxpool_chwn_s3(ys, 2, 2)), ops.maxpool_chwn(y, 2, 2))
+    assert torch.equal(ops.s3_to_f32(ops.maxpool_chwn_s3(ys, 3, 1)), ops.maxpool_chwn(y, 3, 1))
+
+
+@pytest.mark.parametrize("net_type,B,E", [("alexnet", 512, 10), ("3conv3fc", 256, 8), ("lenet", 64, 32)])
+def test_s3_chain_equals_per_launch_splitting(env, bf16x3, every_launch, net_type, B, E):
+    """A whole step in split-bf16 mode with the activations travelling as S3 between the layers (the default for steps of >=
+    ops.s3_min_images rows) against the same step with every launch splitting its fp32 operands itself: same bits."""
+    ens, ops = env["ens"], env["ops"]
+    torch.manual_seed(0)
+    cin = 1 if net_type == "lenet" else 3
+    net = env["zoo"].getModel(net_type, cin, 10, P.CONFIG_PRIORS, "bbb", "softplus").cuda()
+    env["rng"].assign_stream_ids(net)
+    x = torch.rand(B, cin, 32, 32, device="cuda")
+    with torch.no_grad():
+        chain, kl = ens._mc_logits_chwn(net, x, E, 7, 3)
+        keep, ops.s3_min_images = ops.s3_min_images, 1 << 40
+        try:
+            plain, kl2 = ens._mc_logits_chwn(net, x, E, 7, 3)
+        finally:
+            ops.s3_min_images = keep
+    assert torch.equal(kl, kl2) and torch.equal(chain, plain)
