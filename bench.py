@@ -781,6 +781,11 @@ def main():
     backend = os.environ.get("BBB_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    # the reference's CPU path first, on rank 0, BEFORE the process group exists: the other ranks then
+    # wait in the rendezvous (sleeping on a socket), not in a collective (spinning on the cores the baseline is being timed on)
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline and not args.no_extras and not args.no_graph:
+        cpu = cpu_baseline(20.0 if world == 1 else 10.0)
     group = None
     if world > 1:
         import torch.distributed as dist
@@ -794,10 +799,6 @@ def main():
     from bbb_hip import ensemble, _lib, ops
     _lib.lib()   # fail loudly here if the HIP library is missing
     ops.gemm_mode = args.gemm_mode
-
-    cpu = None
-    if rank == 0 and not args.no_cpu_baseline and not args.no_extras:
-        cpu = cpu_baseline(20.0 if world == 1 else 8.0)     # N > 1: a shorter sample, the other ranks wait at the first barrier
 
     if args.no_graph:
         # profiling mode (rocprofv3 --pmc per launch): the timed region's launches issued eagerly on one stream, nothing else.
