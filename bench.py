@@ -390,7 +390,7 @@ def reparam_probe(net, dev, n_params, E, hbm_probe=True):
 
 
 def run_config(cfg, steps, warmup, pipeline, dev, group=None, world=1, want_roofline=True, stat_blocks=0, timer_steps=5,
-               total_ens=None, steps_per_launch=1, preheat_s=0.4, cold_block=False, single_lane=True, rank=0):
+               total_ens=None, steps_per_launch=1, preheat_s=0.4, cold_block=False, single_lane=True, rank=0, multi=None):
     """Throughput of one configuration: hipGraph lanes, K timed steps between device syncs (max over ranks) -> dict.
     steps_per_launch = G > 1: every lane's graph holds G consecutive steps (GraphedPipeline).  cold_block: the K steps are also
     timed once BEFORE the pre-heat (reported as cold_first_block, never the value)."""
@@ -399,9 +399,11 @@ def run_config(cfg, steps, warmup, pipeline, dev, group=None, world=1, want_roof
     E = cfg["E"] if total_ens is None else total_ens
     prec = cfg["precision"]
     G = int(steps_per_launch)
+    if multi is None:
+        multi = world > 1                                # the process-group flow (also rehearsed at world size 1: BBB_BENCH_SELF_GROUP)
 
     def barrier():
-        if world > 1:
+        if multi:
             torch.distributed.barrier(group=group)
         torch.cuda.synchronize(dev)
 
@@ -429,7 +431,7 @@ def run_config(cfg, steps, warmup, pipeline, dev, group=None, world=1, want_roof
 
         if cold_block:
             dt, _ = timed_block(steps)
-            if world > 1:
+            if multi:
                 t = torch.tensor([dt], device=dev, dtype=torch.float64)
                 torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=group)
                 dt = t.item()
@@ -437,7 +439,7 @@ def run_config(cfg, steps, warmup, pipeline, dev, group=None, world=1, want_roof
         # pre-heat: the same replays, untimed (every rank runs the same number of collectives: a fixed step count from rank 0's clock)
         t0 = time.perf_counter()
         if preheat_s > 0:
-            if world > 1:
+            if multi:
                 n_heat = torch.tensor([0], device=dev, dtype=torch.int64)
                 if rank == 0:
                     dt1, _ = timed_block(max(8, steps))
@@ -463,7 +465,7 @@ def run_config(cfg, steps, warmup, pipeline, dev, group=None, world=1, want_roof
         lo, kl = lo.clone(), kl.clone()
         torch.cuda.synchronize(dev)
         assert torch.isfinite(lo).all() and torch.isfinite(kl).all()
-        if world > 1:
+        if multi:
             t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=group)
             elapsed = t.item()
@@ -471,7 +473,7 @@ def run_config(cfg, steps, warmup, pipeline, dev, group=None, world=1, want_roof
         out["ms_per_step"] = round(1e3 * elapsed / steps, 4)
         out["value"] = round(cfg["B"] * E / (elapsed / steps), 1)
         out["rows_out"] = rows
-        if stat_blocks and world == 1:
+        if stat_blocks and not multi:
             # block statistics: `stat_blocks` blocks of `steps` steps, each between device syncs
             vals = []
             for _ in range(stat_blocks):
@@ -480,7 +482,7 @@ def run_config(cfg, steps, warmup, pipeline, dev, group=None, world=1, want_roof
             out["stats"] = {"blocks": stat_blocks, "steps_per_block": steps, "median": round(statistics.median(vals), 1),
                             "p10": round(pctl(vals, 0.1), 1), "p90": round(pctl(vals, 0.9), 1), "unit": "samples/s"}
         del gstep, step, flush
-        if world == 1 and single_lane and (pipeline > 1 or G > 1):
+        if not multi and single_lane and (pipeline > 1 or G > 1):
             g1 = ensemble.GraphedMC(net, x, E, precision=prec)
             preheat(g1.step, 0.1, dev)
             n1 = max(steps, 10)
@@ -505,7 +507,7 @@ def run_config(cfg, steps, warmup, pipeline, dev, group=None, world=1, want_roof
                 def one_pass(t):
                     seed, call0 = rng.next_calls(G * E)
                     ensemble._local_lse(net, xg, E, seed, call0, E, timers=t, precision=prec, groups=G)
-            elif world > 1:                              # rank 0's share of the sharded step
+            elif multi:                                  # rank 0's share of the sharded step
                 def one_pass(t):
                     seed, call0 = rng.next_calls(E)
                     if S > 1:
@@ -518,22 +520,22 @@ def run_config(cfg, steps, warmup, pipeline, dev, group=None, world=1, want_roof
             for _ in range(timer_steps):
                 one_pass(timers)
             torch.cuda.synchronize(dev)
-            per = G if world == 1 else 1
-            eager = gemm_roofline(timers.summary(), timer_steps * per, prec, cfg is CONFIGS["metric"] and world == 1)
+            per = G if not multi else 1
+            eager = gemm_roofline(timers.summary(), timer_steps * per, prec, cfg is CONFIGS["metric"] and not multi)
             # the same launches in the timed region's launch mode: every GEMM launch of the step replayed 20x back to back
             # inside its own hipGraph (no host, no event packets between kernels), pre-heated, HIP events around 3 replays
             rec = LaunchRecorder()
             one_pass(rec)
             torch.cuda.synchronize(dev)
             ing = rec.time_in_graphs(dev)
-            roof = gemm_roofline(ing, per, prec, cfg is CONFIGS["metric"] and world == 1) if ing else None
+            roof = gemm_roofline(ing, per, prec, cfg is CONFIGS["metric"] and not multi) if ing else None
             if roof is not None and eager is not None:
                 roof["timed_by"] = ("per launch: hipGraph of %d back-to-back replays, pre-heated, HIP events around 3 graph replays, median of 3; "
                                     "summed over the %d conv/linear launches" % (rec.reps, roof["launches"]))
                 roof["eager_event_brackets"] = {"achieved": eager["achieved"], "frac": eager["frac"], "avg_us": eager["avg_us"],
                                                 "launches": eager["launches"], "timed_by": eager["timed_by"]}
                 roof["per_launch_us"] = rec.per_launch_us
-                roof["slabs_per_launch"] = (G * E) if world == 1 else (hi_u - lo_u)
+                roof["slabs_per_launch"] = (G * E) if not multi else (hi_u - lo_u)
             out["roofline"] = roof if roof is not None else eager
     return out, net, x
 
@@ -747,13 +749,17 @@ def main():
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # test hook (never set by the driver): run the N > 1 FLOW -- RCCL process group, sharded lanes with the recorded collective, barriers,
+    # max-over-ranks timing -- with ONE rank on one GPU, so that the code a multi-GPU box would execute runs in every suite run
+    self_group = os.environ.get("BBB_BENCH_SELF_GROUP") == "1" and "WORLD_SIZE" not in os.environ and args.gpus == 1
+    multi = world > 1 or self_group
     cfg = CONFIGS[args.config]
     if args.steps_per_launch is None:
-        args.steps_per_launch = 4 if (world == 1 and args.gpus == 1 and cfg["hw"] == 32 and cfg["E"] <= 10) else 1
-    if world > 1 or args.gpus > 1:
+        args.steps_per_launch = 4 if (not multi and args.gpus == 1 and cfg["hw"] == 32 and cfg["E"] <= 10) else 1
+    if multi or args.gpus > 1:
         args.steps_per_launch = 1                        # a sharded step ends in a collective: one step per launch
     if args.pipeline is None:
-        args.pipeline = 4 if (world > 1 or args.gpus > 1) else (2 if args.steps_per_launch > 1 else 3)
+        args.pipeline = 4 if (multi or args.gpus > 1) else (2 if args.steps_per_launch > 1 else 3)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -787,10 +793,17 @@ def main():
     if rank == 0 and not args.no_cpu_baseline and not args.no_extras and not args.no_graph:
         cpu = cpu_baseline(20.0 if world == 1 else 10.0)
     group = None
-    if world > 1:
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
+        if self_group:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+            os.environ["BBB_FORCE_COMBINE"] = "1"        # ensemble: the sharded code path although one rank holds every unit
+            dist.init_process_group(backend, rank=0, world_size=1, **({"device_id": dev} if backend == "nccl" else {}))
+        elif backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
@@ -805,7 +818,7 @@ def main():
         # With G steps per launch a pass is G steps; --warmup / --steps are rounded up to whole passes.
         from bbb_hip import rng
         net, x = build_net(cfg, dev)
-        G = args.steps_per_launch if world == 1 else 1
+        G = args.steps_per_launch if not multi else 1
         xg = x.repeat(G, 1, 1, 1) if G > 1 else x
 
         def one_pass():
@@ -828,23 +841,24 @@ def main():
             print(json.dumps({"metric": "eager single-stream step (profiling mode)", "value": round(cfg["B"] * cfg["E"] / dt, 1),
                               "unit": "samples/s", "ms_per_step": round(1e3 * dt, 4), "n_gpus": world, "steps": nt * G,
                               "warmup": nw * G, "steps_per_launch": G, "mc_steps_total": (nw + nt) * G}), flush=True)
-        if world > 1:
+        if multi:
             torch.distributed.destroy_process_group()
         return
 
-    extras = rank == 0 and world == 1 and not args.no_extras
+    extras = rank == 0 and not multi and not args.no_extras
     G = args.steps_per_launch
     head, net, x = run_config(cfg, args.steps, args.warmup, args.pipeline, dev, group, world, want_roofline=not args.no_roofline,
                               stat_blocks=5 if extras else 0, timer_steps=min(args.steps, 10), steps_per_launch=G,
-                              preheat_s=args.preheat_ms * 1e-3, cold_block=True, rank=rank, single_lane=extras)
+                              preheat_s=args.preheat_ms * 1e-3, cold_block=True, rank=rank, single_lane=extras, multi=multi)
     n_params = sum(p.numel() for n, p in net.named_parameters() if n.endswith("_mu"))
 
     weak = None
-    if world > 1 and not args.no_extras:
+    if multi and not args.no_extras:
         w, _, _ = run_config(cfg, max(5, args.steps // 2), 3, args.pipeline, dev, group, world, want_roofline=False,
-                             total_ens=cfg["E"] * world, preheat_s=0.1, rank=rank)
+                             total_ens=cfg["E"] * max(world, 2 if self_group else 1), preheat_s=0.1, rank=rank, multi=multi)
         weak = {"value": w["value"], "unit": "samples/s", "ms_per_step": w["ms_per_step"], "num_ens_total": cfg["E"] * world}  # 10 draws per GPU
 
+    final_lines = []
     if rank == 0:
         with torch.no_grad():
             S, lo, hi = ensemble.shard_plan(net, x, cfg["E"], 0, world, True, cfg["precision"])
@@ -861,13 +875,13 @@ def main():
                        "global_batch": cfg["B"], "num_ens_total": cfg["E"],
                        "parallelism": ("work units: %d slices/draw, %d units of %d images, <= %d per GPU, one all_gather per step"
                                        % (S, cfg["E"] * S, cfg["B"] // S, hi - lo))
-                       if world > 1 else "single",
+                       if multi else "single",
                        "launch": launch},
             "preheat_ms": head.get("preheat_ms"),
         }
         if "cold_first_block" in head:
             out["cold_first_block"] = head["cold_first_block"]
-        if world > 1:
+        if multi:
             out["config"]["ranks_seen"] = torch.distributed.get_world_size(group)
             out["config"]["units_per_rank"] = [(lambda r: r[1] - r[0])(ensemble.unit_range(cfg["E"], S, r, world)) for r in range(world)]
             out["config"]["backend"] = backend
@@ -890,7 +904,7 @@ def main():
             if roof.get("traffic") and fps and cfg is CONFIGS["metric"]:
                 tr = profile_traffic("pconv_gemm")
                 r["traffic_ratio"] = round(roof["traffic"] / ALGORITHMIC_GEMM_BYTES, 3) if tr else None
-            if cfg["precision"] != "bf16" and world == 1:
+            if cfg["precision"] != "bf16" and not multi:
                 ceil = mfma_loop_ceiling()
                 if ceil:
                     r["mfma_loop_TFLOPs"] = ceil[0]
@@ -986,13 +1000,28 @@ def main():
                                    "p10": cpu["p10"], "p90": cpu["p90"], "cpu_model": cpu["cpu_model"],
                                    "autograd_value": cpu["autograd_enabled"]["value"]}
             out["speedup_vs_cpu"] = round(out["value"] / cpu["value"], 1)
-        if second:
-            print("SECONDARY " + json.dumps(second), flush=True)
-        line = json.dumps(compact(out))
-        print(line, flush=True)
-    if world > 1:
+        final_lines = (["SECONDARY " + json.dumps(second)] if second else []) + [json.dumps(compact(out))]
+    def flush_c_stdio():
+        # RCCL writes a version banner through C stdio, which sits in libc's buffer until exit when stdout is a pipe -- it would
+        # land AFTER a line printed from Python and become the "last line" of the run.  Flush it out first: the JSON stays last.
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+
+    if multi:
+        flush_c_stdio()                                  # every rank, while the ranks can still be ordered
         torch.distributed.barrier(group=group)
         torch.distributed.destroy_process_group()
+        flush_c_stdio()
+        if rank == 0 and world > 1:
+            time.sleep(1.0)                              # the other ranks have nothing left to do but exit: let them (and their stdio) go first
+    if rank == 0:
+        flush_c_stdio()
+        for ln in final_lines:
+            print(ln, flush=True)
 
 
 # algorithmic operand + output bytes of the six GEMM launches of one metric step: 185.0 MB read + 209.9 MB written

@@ -126,3 +126,22 @@ def test_bench_gpus_2_as_typed_launches_its_own_ranks():
     j, _ = _split(p.stdout)
     assert j["n_gpus"] == 2 and j["steps"] == 4 and j["warmup"] == 2 and j["scaling"] == "strong" and j["value"] > 0
     assert j["config"]["ranks_seen"] == 2 and sum(j["config"]["units_per_rank"]) == 10 and j["config"]["backend"] == "gloo"
+
+
+def test_bench_multi_rank_flow_over_rccl_with_one_rank():
+    """The code path a multi-GPU box executes -- RCCL process group, the probe for recordable collectives, per-lane communicators,
+    sharded lanes whose graphs hold the step's one all_gather, barriers, broadcast pre-heat, max-over-ranks timing, weak-scaling
+    leg, rank 0's share roofline -- run through the REAL backend ("nccl") with a single rank (bench.py's BBB_BENCH_SELF_GROUP hook;
+    the gloo rehearsals above cover two processes, this covers RCCL itself)."""
+    env = dict(os.environ, BBB_BENCH_SELF_GROUP="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "BBB_BENCH_BACKEND", "BBB_BENCH_DEVICE"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "8", "--warmup", "2", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    j, _ = _split(p.stdout)
+    assert j["n_gpus"] == 1 and j["config"]["ranks_seen"] == 1 and j["config"]["backend"] == "nccl"
+    assert j["config"]["units_per_rank"] == [10] and "4 lane" in j["config"]["launch"]
+    assert j["value"] > 0 and j["weak_scaling"]["value"] > 0
+    _check_roofline(j["roofline"], 157.3)
+    assert j["roofline"]["slabs_per_launch"] == 10
