@@ -392,6 +392,18 @@ int bbb_flip_transpose_w(const float* w, float* out, int64_t draws, int cout, in
  * weight-gradient GEMM (see bbb_hip/ops.py: conv2d_chwn_weight_grad_shared_input). */
 int bbb_im2col_pbj(const float* x, float* out, const bbb_conv_desc_t* d, void* stream);
 
+/* Training extension, the small steps between the gradient GEMMs (ABI 8; deterministic, no atomics):
+ * bbb_plane_sum: out[r] = sum over o < outer, j < cols of x[o*outer_stride + r*row_pitch + j] -- bias gradients (the gradient w.r.t.
+ *   a layer's pre-activation summed over pixels and images per (draw, channel) plane; outer > 1 also sums over draws: LRT biases).
+ * bbb_sum_leading: out[i] = sum over o < outer of x[o*n + i], added in index order -- the draws of a first LRT layer share
+ *   one pair of moments, and shared-weight gradients are summed over draws.
+ * bbb_lrt_glue: mode 0: out = x*x (the variance contraction's operand, layers/BBB_LRT/BBBConv.py:73); mode 1: out[i] = a[i] +
+ *   2*x[i % x_n]*b[i] -- the LRT input gradient dgrad(g_mu, mu) + 2 x dgrad(g_var, sigma^2) with x one slab or one per draw. */
+int bbb_plane_sum(const float* x, float* out, int64_t outer, int64_t rows, int64_t cols, int64_t row_pitch, int64_t outer_stride,
+                  void* stream);
+int bbb_sum_leading(const float* x, float* out, int64_t outer, int64_t n, void* stream);
+int bbb_lrt_glue(const float* a, const float* x, const float* b, float* out, int64_t n, int64_t x_n, int mode, void* stream);
+
 /* Library / device introspection (host-only). */
 int bbb_abi_version(void);
 const char* bbb_build_info(void);

@@ -87,6 +87,9 @@ _SIGNATURES = {
     "bbb_lrt_conv2d_chwn_splitk_fwd": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                c_void_p, c_void_p, c_void_p, c_u64, c_u32, c_u32, c_int, c_void_p, c_int, c_void_p, c_i64,
                                                c_void_p]),
+    "bbb_plane_sum": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_void_p]),
+    "bbb_sum_leading": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_void_p]),
+    "bbb_lrt_glue": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_int, c_void_p]),
     "bbb_abi_version": (c_int, []),
     "bbb_build_info": (ctypes.c_char_p, []),
 }

@@ -186,7 +186,7 @@ class _MCForward(torch.autograd.Function):
                 g_pre = ops.pool_act_backward_chwn(g, y, 0, 1, act, pad_planes=pad)
             else:
                 g_pre = g
-            gws[2 * li + 1] = g_pre.sum(dim=(2, 3, 4))                    # bias gradient [E, Cout]
+            gws[2 * li + 1] = ops.plane_sums(g_pre)                       # bias gradient [E, Cout]
             Cin = x_in.shape[1]
             if Cin % 4 == 0 or not rec["first"]:                         # (6-channel inputs etc.: padded to 8 inside)
                 gw = ops.conv2d_chwn_weight_grad(g_pre, x_in, tuple(w5.shape), stride, padding, dilation)
@@ -301,26 +301,25 @@ class _MCForwardLRT(torch.autograd.Function):
             pad = rec["first"] and x_in.shape[1] % 4 != 0                # feeds conv2d_chwn_weight_grad_shared_input
             g_mu, g_var = ops.lrt_pool_act_backward_chwn(g, y, am, av, k, s, act, pad_planes=pad)
             if am.shape[0] == 1 and g_mu.shape[0] > 1:      # first layer: one pair of moments feeds every draw
-                g_mu, g_var = g_mu.sum(0, keepdim=True), g_var.sum(0, keepdim=True)
-            grads[4 * li + 2] = g_mu.sum(dim=(0, 2, 3, 4))
-            grads[4 * li + 3] = g_var.sum(dim=(0, 2, 3, 4))
+                g_mu, g_var = ops.sum_over_draws(g_mu, keepdim=True), ops.sum_over_draws(g_var, keepdim=True)
+            grads[4 * li + 2] = ops.plane_sums(g_mu, over_draws=True)
+            grads[4 * li + 3] = ops.plane_sums(g_var, over_draws=True)
             wshape = (1,) + tuple(w_mu.shape)
             if x_in.shape[1] % 4 == 0 or not rec["first"]:
                 gw_mu = ops.conv2d_chwn_weight_grad(g_mu, x_in, wshape, stride, padding, dilation)
-                gw_var = ops.conv2d_chwn_weight_grad(g_var, x_in * x_in, wshape, stride, padding, dilation)
-                gw_mu = gw_mu[0] if gw_mu.shape[0] == 1 else gw_mu.sum(0)
-                gw_var = gw_var[0] if gw_var.shape[0] == 1 else gw_var.sum(0)
+                gw_var = ops.conv2d_chwn_weight_grad(g_var, ops.square(x_in), wshape, stride, padding, dilation)
+                gw_mu, gw_var = ops.sum_over_draws(gw_mu), ops.sum_over_draws(gw_var)
             else:
                 xn = ctx.x_nchw
                 gw_mu = ops.conv2d_chwn_weight_grad_shared_input(g_mu, xn, wshape, stride, padding, dilation)[0]
-                gw_var = ops.conv2d_chwn_weight_grad_shared_input(g_var, xn * xn, wshape, stride, padding, dilation)[0]
+                gw_var = ops.conv2d_chwn_weight_grad_shared_input(g_var, ops.square(xn), wshape, stride, padding, dilation)[0]
             m = rec["layer"]
             grads[4 * li] = gw_mu.reshape(m.W_mu.shape)
             grads[4 * li + 1] = gw_var.reshape(m.W_mu.shape)
             if not rec["first"]:
                 hw = (x_in.shape[2], x_in.shape[3])
-                g = torch.addcmul(ops.conv2d_chwn_input_grad(g_mu, w_mu.unsqueeze(0), hw, padding, dilation), x_in,
-                                  ops.conv2d_chwn_input_grad(g_var, w_var.unsqueeze(0), hw, padding, dilation), value=2.0)
+                g = ops.lrt_input_grad_combine(ops.conv2d_chwn_input_grad(g_mu, w_mu.unsqueeze(0), hw, padding, dilation), x_in,
+                                               ops.conv2d_chwn_input_grad(g_var, w_var.unsqueeze(0), hw, padding, dilation))
         return (None, None, *grads)
 
 

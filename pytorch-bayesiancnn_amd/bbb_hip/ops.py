@@ -1020,6 +1020,59 @@ def pool_act_backward_chwn(g_out, y, k, s, act, pad_planes=False):
     return g_pre
 
 
+def plane_sums(g, over_draws=False):
+    """Bias gradient from the gradient w.r.t. a layer's pre-activation g [E, C, H, W, B] (possibly a padded-pitch view as
+    pool_act_backward_chwn returns it): -> [E, C] (sum over pixels and images), or [C] with over_draws (bbb_plane_sum)."""
+    require_device(g)
+    E, C, H, W, B = g.shape
+    cols = H * W * B
+    if g.stride(4) != 1 or g.stride(3) != B or g.stride(2) != W * B or g.stride(0) != C * g.stride(1):
+        g = g.contiguous()
+    pitch = g.stride(1)
+    out = torch.empty((C,) if over_draws else (E, C), dtype=torch.float32, device=g.device)
+    with on_device(g.device):
+        if over_draws:
+            check(_lib.lib().bbb_plane_sum(g.data_ptr(), out.data_ptr(), E, C, cols, pitch, C * pitch, cur_stream(g.device)), "bbb_plane_sum")
+        else:
+            check(_lib.lib().bbb_plane_sum(g.data_ptr(), out.data_ptr(), 1, E * C, cols, pitch, 0, cur_stream(g.device)), "bbb_plane_sum")
+    return out
+
+
+def sum_over_draws(x, keepdim=False):
+    """x [E, ...] -> the sum over the leading (draw) axis, added in draw order (bbb_sum_leading); trailing size % 4 == 0."""
+    require_device(x)
+    x = x.contiguous()
+    E = x.shape[0]
+    if E == 1:
+        return x if keepdim else x[0]
+    n = x.numel() // E
+    out = torch.empty(((1,) if keepdim else ()) + tuple(x.shape[1:]), dtype=torch.float32, device=x.device)
+    with on_device(x.device):
+        check(_lib.lib().bbb_sum_leading(x.data_ptr(), out.data_ptr(), E, n, cur_stream(x.device)), "bbb_sum_leading")
+    return out
+
+
+def square(x):
+    """x * x (bbb_lrt_glue mode 0): the operand of the LRT variance contraction's weight gradient."""
+    require_device(x)
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    with on_device(x.device):
+        check(_lib.lib().bbb_lrt_glue(0, x.data_ptr(), 0, out.data_ptr(), x.numel(), 0, 0, cur_stream(x.device)), "bbb_lrt_glue")
+    return out
+
+
+def lrt_input_grad_combine(g1, x, g2):
+    """g1 + 2 * x * g2 with x [1|E, ...] broadcast over the draws of g1 / g2 [E, ...] (bbb_lrt_glue mode 1)."""
+    require_device(g1, x, g2)
+    g1, x, g2 = g1.contiguous(), x.contiguous(), g2.contiguous()
+    out = torch.empty_like(g1)
+    with on_device(g1.device):
+        check(_lib.lib().bbb_lrt_glue(g1.data_ptr(), x.data_ptr(), g2.data_ptr(), out.data_ptr(), g1.numel(), x.numel(), 1,
+                                      cur_stream(g1.device)), "bbb_lrt_glue")
+    return out
+
+
 def lrt_pool_act_backward_chwn(g_out, y, act_mu, act_var, k, s, act, pad_planes=False):
     """pool_act_backward_chwn for a local-reparameterisation layer: -> (g_mu, g_var), the gradients w.r.t. act_mu and act_var
     (bbb_lrt_pool_act_bwd_chwn).  act_mu / act_var: y's shape, or one draw's worth ([1, C, H, W, B]) when every draw was sampled

@@ -228,3 +228,35 @@ def test_alexnet_training_iterations_vs_cpu_port(env, lt):
             # after 3 Adam steps each element has moved by <= 3 * lr; the two runs may disagree where |g| ~ 1e-8 (sign flips)
             assert float((a - b).abs().max()) <= 6.1e-3, (n, k)
             assert float((a - b).abs().mean()) <= 2e-5, (n, k, float((a - b).abs().mean()))
+
+
+def test_training_glue_kernels_vs_torch():
+    """bbb_plane_sum / bbb_sum_leading / bbb_lrt_glue (the bias gradients and LRT glue of the training backward, ATen kernels until
+    round 4) against torch in float64: 1e-6 of the reduction's scale; bitwise run to run."""
+    import torch
+    from bbb_hip import ops
+    torch.manual_seed(1)
+    E, C, H, W, B = 3, 70, 5, 3, 36
+    g = torch.randn(E, C, H, W, B, device="cuda")
+    want = g.double().sum(dim=(2, 3, 4))
+    got = ops.plane_sums(g)
+    assert got.shape == (E, C) and torch.equal(got, ops.plane_sums(g))
+    assert float((got.double() - want).abs().max()) <= 1e-6 * float(g.abs().sum(dim=(2, 3, 4)).max())
+    assert float((ops.plane_sums(g, over_draws=True).double() - want.sum(0)).abs().max()) <= 1e-6 * float(g.abs().sum(dim=(0, 2, 3, 4)).max())
+    # a padded-pitch view, as pool_act_backward_chwn(pad_planes=True) returns it
+    K = H * W * B
+    buf = torch.randn(E * C, ops.padded_plane_pitch(K) + 4, device="cuda")
+    view = buf[:, :K].view(E, C, H, W, B)
+    assert float((ops.plane_sums(view).double() - view.double().sum(dim=(2, 3, 4))).abs().max()) <= 1e-6 * K
+    for shape in ((4, 6, 1, 5, 5), (5, 64, 32, 3, 3), (1, 8, 8)):            # 150 elements per draw: not a multiple of 4
+        x = torch.randn(*shape, device="cuda")
+        s0 = ops.sum_over_draws(x)
+        assert s0.shape == tuple(shape[1:]) and float((s0.double() - x.double().sum(0)).abs().max()) <= 1e-6 * shape[0] * 4
+        assert ops.sum_over_draws(x, keepdim=True).shape == (1,) + tuple(shape[1:])
+    x = torch.randn(1, 16, 4, 4, 64, device="cuda")
+    a, b = torch.randn(5, 16, 4, 4, 64, device="cuda"), torch.randn(5, 16, 4, 4, 64, device="cuda")
+    assert torch.equal(ops.square(x), x * x)
+    got = ops.lrt_input_grad_combine(a, x, b)
+    want = a.double() + 2.0 * x.double() * b.double()
+    assert float((got.double() - want).abs().max()) <= 1e-6 * float(want.abs().max())
+    assert float((ops.lrt_input_grad_combine(a, a, b) - torch.addcmul(a, a, b, value=2.0)).abs().max()) <= 1e-5
