@@ -501,7 +501,14 @@ def run_config(cfg, steps, warmup, pipeline, dev, group=None, world=1, want_roof
             # the event brackets then hold kernel time only, not host launch latency
             torch.cuda._sleep(int(1.0e8))
             from bbb_hip import rng
-            if G > 1:                                    # the launches of the timed region: G batches x E draws per launch
+            if G > 1 and multi:                          # rank 0's share of a group of G steps: whole draws on whole batches
+                lo_u, hi_u, _g0, n_gl, g_off = ensemble.group_share(E, G, 0, world)
+                xg = x.repeat(n_gl, 1, 1, 1)
+
+                def one_pass(t):
+                    seed, call0 = rng.next_calls(G * E)
+                    ensemble._local_lse(net, xg, hi_u - lo_u, seed, call0 + lo_u, 0, timers=t, precision=prec, share=(E, g_off))
+            elif G > 1:                                  # the launches of the timed region: G batches x E draws per launch
                 xg = x.repeat(G, 1, 1, 1)
 
                 def one_pass(t):
@@ -520,7 +527,7 @@ def run_config(cfg, steps, warmup, pipeline, dev, group=None, world=1, want_roof
             for _ in range(timer_steps):
                 one_pass(timers)
             torch.cuda.synchronize(dev)
-            per = G if not multi else 1
+            per = G                                      # the recorded launches cover (this rank's share of) G steps
             eager = gemm_roofline(timers.summary(), timer_steps * per, prec, cfg is CONFIGS["metric"] and not multi)
             # the same launches in the timed region's launch mode: every GEMM launch of the step replayed 20x back to back
             # inside its own hipGraph (no host, no event packets between kernels), pre-heated, HIP events around 3 replays
@@ -755,11 +762,12 @@ def main():
     multi = world > 1 or self_group
     cfg = CONFIGS[args.config]
     if args.steps_per_launch is None:
-        args.steps_per_launch = 4 if (not multi and args.gpus == 1 and cfg["hw"] == 32 and cfg["E"] <= 10) else 1
-    if multi or args.gpus > 1:
-        args.steps_per_launch = 1                        # a sharded step ends in a collective: one step per launch
+        args.steps_per_launch = 4 if (cfg["hw"] == 32 and cfg["E"] <= 10) else 1
     if args.pipeline is None:
-        args.pipeline = 4 if (multi or args.gpus > 1) else (2 if args.steps_per_launch > 1 else 3)
+        # lanes by the draws one launch of one rank holds (profiles/r03_notes.md section 7, r04 section 2): large launches fill the
+        # chip themselves, small ones need more of them in flight
+        local = -(-args.steps_per_launch * cfg["E"] // max(1, args.gpus))
+        args.pipeline = 2 if local >= 30 else (3 if local >= 10 else 4)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -818,7 +826,7 @@ def main():
         # With G steps per launch a pass is G steps; --warmup / --steps are rounded up to whole passes.
         from bbb_hip import rng
         net, x = build_net(cfg, dev)
-        G = args.steps_per_launch if not multi else 1
+        G = args.steps_per_launch if not multi else 1     # (the eager profiling pass of a sharded run: one step, work units)
         xg = x.repeat(G, 1, 1, 1) if G > 1 else x
 
         def one_pass():
@@ -873,8 +881,11 @@ def main():
             "data": "synthetic",
             "config": {"workload": cfg["what"] + ", forward only",
                        "global_batch": cfg["B"], "num_ens_total": cfg["E"],
-                       "parallelism": ("work units: %d slices/draw, %d units of %d images, <= %d per GPU, one all_gather per step"
-                                       % (S, cfg["E"] * S, cfg["B"] // S, hi - lo))
+                       "parallelism": (("groups of %d steps: the %d draws of a group in %d contiguous ranges (whole draws on whole batches, "
+                                        "<= %d per GPU), one all_gather per group"
+                                        % (G, G * cfg["E"], world, -(-G * cfg["E"] // world))) if G > 1 else
+                                       ("work units: %d slices/draw, %d units of %d images, <= %d per GPU, one all_gather per step"
+                                        % (S, cfg["E"] * S, cfg["B"] // S, hi - lo)))
                        if multi else "single",
                        "launch": launch},
             "preheat_ms": head.get("preheat_ms"),
@@ -883,7 +894,10 @@ def main():
             out["cold_first_block"] = head["cold_first_block"]
         if multi:
             out["config"]["ranks_seen"] = torch.distributed.get_world_size(group)
-            out["config"]["units_per_rank"] = [(lambda r: r[1] - r[0])(ensemble.unit_range(cfg["E"], S, r, world)) for r in range(world)]
+            if G > 1:
+                out["config"]["draws_per_rank"] = [(lambda r: r[1] - r[0])(ensemble.group_share(cfg["E"], G, r, world)) for r in range(world)]
+            else:
+                out["config"]["units_per_rank"] = [(lambda r: r[1] - r[0])(ensemble.unit_range(cfg["E"], S, r, world)) for r in range(world)]
             out["config"]["backend"] = backend
         if args.config != "metric":
             out["metric"] = "MC-forward samples/sec, " + cfg["what"]

@@ -162,6 +162,9 @@ typedef struct bbb_conv_desc {
                              slabs at x_draw_stride) -- several Monte-Carlo steps in one launch: slab e = step e / D, draw e % D,
                              the first layer's input being the same for all D draws of a step.  Weight / bias set: e, as usual.
                              0 / 1: input slab e.  Not combined with work units (unit_div > 1). */
+    int32_t x_unit_off;   /* with x_unit_div = D > 1: output slab e reads input slab (e + x_unit_off) / D, 0 <= x_unit_off < D -- a
+                             rank's share of a GROUP of steps starts in the middle of a step (draws x_unit_off .. D-1 of its first
+                             step); x then holds ceil((draws + x_unit_off) / D) slabs and draws need not be a multiple of D. */
 } bbb_conv_desc_t;
 
 /*
@@ -366,6 +369,14 @@ int bbb_mc_tail_units_step(const float* logits, int units, int slices, int unit_
 int bbb_mc_tail_groups_step(const float* logits, int groups, int draws, int batch, int classes, int mean_over,
                             float* lse_out, const float* kl_in, float kl_scale, float* kl_out, uint32_t* counter,
                             uint32_t counter_add, void* stream);
+
+/* A RANK'S SHARE of a group of steps (ABI 8): the `slabs` local draws are draws first_off, first_off + 1, ... of the draw-major
+ * enumeration (step g, draw j) -> g * draws + j of `steps` consecutive local steps (the share may start and end in the middle of a
+ * step): lse_out [steps * batch][C], block k = the log-sum-exp over the LOCAL draws of local step k (no mean; -inf where it holds none);
+ * the ranks' blocks are combined by one more log-sum-exp.  kl / counter arguments as in bbb_mc_tail_units_step. */
+int bbb_mc_tail_share_step(const float* logits, int slabs, int steps, int draws, int first_off, int batch, int classes,
+                           float* lse_out, const float* kl_in, float kl_scale, float* kl_out, uint32_t* counter,
+                           uint32_t counter_add, void* stream);
 
 /*
  * Uncertainty decomposition over `draws` stochastic forwards (uncertainty_estimation.py:37-58 per image, :61-102 per

@@ -1,4 +1,6 @@
-"""Per-rank GPU time of the strong-scaling step, measured on ONE GPU: rank r of N runs its work units (no collective)."""
+"""Per-rank GPU time of the strong-scaling step, measured on ONE GPU: rank r of N runs its work units (no collective).
+`python rank_sim.py groups [G]`: the same for GROUPS of G steps per launch (default 4) dealt to the ranks as contiguous draw ranges
+(ensemble.group_share) -- ms per STEP of the busiest rank."""
 import os, sys, time, json
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "pytorch-bayesiancnn_amd"))
@@ -33,6 +35,40 @@ class Lane:
     def step(self):
         with torch.cuda.stream(self.stream):
             self.g.replay()
+class GroupLane(Lane):
+    def __init__(self, G, rank, world, lane, lanes):
+        self.G = G
+        self.lo, self.hi, g_lo, self.n_gl, self.off = ensemble.group_share(E, G, rank, world)
+        self.xg = x.repeat(self.n_gl, 1, 1, 1)
+        Lane.__init__(self, 1, self.lo, self.hi, lane, lanes)
+        self.stride = lanes * E * G
+    def body(self):
+        lse, kl = ensemble._local_lse(net, self.xg, self.hi - self.lo, 1, self.lo, 0, share=(E, self.off))
+        self.counter.add_(lanes_stride[0])
+        return lse, kl
+lanes_stride = [0]
+if len(sys.argv) > 1 and sys.argv[1] == "groups":
+    G = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+    for world in (1, 2, 4, 8):
+        for depth in (1, 2, 3, 4):
+            worst = 0
+            lanes_stride[0] = depth * E * G
+            for rank in sorted({0, world // 2, world - 1}):
+                lanes = [GroupLane(G, rank, world, l, depth) for l in range(depth)]
+                for i in range(12): lanes[i % depth].step()
+                torch.cuda.synchronize()
+                t_end = time.perf_counter() + 0.3
+                while time.perf_counter() < t_end:
+                    for i in range(depth): lanes[i].step()
+                    torch.cuda.synchronize()
+                t0 = time.perf_counter(); n = 120
+                for i in range(n): lanes[i % depth].step()
+                torch.cuda.synchronize()
+                worst = max(worst, (time.perf_counter() - t0) / (n * G))
+                del lanes
+            print(json.dumps({"world": world, "steps_per_launch": G, "draws_per_rank": -(-G * E // world), "lanes": depth,
+                              "ms_per_step_busiest_rank": round(worst * 1e3, 4), "projected_samples_per_s": round(5120 / worst, 0)}), flush=True)
+    sys.exit(0)
 for world in (1, 2, 4, 8):
     S = ensemble.plan_slices(E, world, 512)
     for depth in (1, 2, 3, 4):

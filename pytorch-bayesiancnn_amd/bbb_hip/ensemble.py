@@ -349,7 +349,8 @@ def _check_precision(precision, net, x, fast_path_allowed):
                                "4-d input with B % 8 == 0, BBB layers + ReLU/Softplus/MaxPool2d/FlattenLayer)")
 
 
-def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precision="fp32", units=None, b_offset=0, groups=1):
+def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precision="fp32", units=None, b_offset=0, groups=1,
+                    share=None):
     """Inference path of mc_logits in the batch-innermost layout ([E, C, H, W, B]): pixel-major GEMMs that
     skip padding taps, activation fused into the GEMM epilogue, pooling on contiguous image vectors.
     units = (S, lo, hi): instead of `draws` whole draws starting at call0, run the work units lo..hi-1 of the draw-major
@@ -357,7 +358,10 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
     b_offset: global index of x's first image (batch-parallel shards): LRT activation noise is keyed by the global image.
     groups = G > 1: x holds G batches back to back ([G * B, C, H, W]) and the launches run G consecutive Monte-Carlo steps of
     `draws` forwards each -- slab g * draws + j = draw j of step g, on batch g, under noise call call0 + g * draws + j, i.e.
-    exactly what G separate steps would compute (GraphedMC steps > 1); returns logits [G * draws, C, B]."""
+    exactly what G separate steps would compute (GraphedMC steps > 1); returns logits [G * draws, C, B].
+    share = (D, off): one rank's part of a group of steps (group_share): `draws` consecutive slabs of the draw-major (step, draw)
+    enumeration with D draws per step, the first being draw `off` of its step; x holds the ceil((draws + off) / D) batches they
+    touch, call0 = the call index of the first local slab; returns logits [draws, C, B]."""
     layers = bayesian_layers(net)
     bbb = [l for l in layers if isinstance(l, _BBBLayer)]
     lrt = [l for l in layers if isinstance(l, _LRTLayer)]
@@ -373,6 +377,17 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
             raise _lib.BBBHipError("several steps per launch: every batch must hold a multiple of 4 (bf16: 8) images")
         B = B // G
         E = G * draws
+        streams = 1
+    x_div0, x_off0, nb = (draws if (G > 1 and draws > 1) else 1), 0, G
+    if share is not None:
+        if G > 1 or (units is not None and units[0] > 1):
+            raise _lib.BBBHipError("a share of a group of steps combines with neither work units nor whole groups")
+        D, off = int(share[0]), int(share[1])
+        nb = -(-(draws + off) // D)
+        if not 0 <= off < D or B % nb or (B // nb) % (8 if bf16 else 4):
+            raise _lib.BBBHipError("share of a group of steps: x must hold the batches it touches, multiples of 4 (bf16: 8) images")
+        B = B // nb
+        x_div0, x_off0 = (D, off) if D > 1 else (1, 0)
         streams = 1
     if units is not None and units[0] > 1:
         S, lo, hi = units
@@ -394,8 +409,8 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
         variances, k2 = _variances_all(lrt, timers)
         kl = k2 if kl is None else kl + k2
     to_cb = ops.to_batch_innermost_bf16 if bf16 else ops.to_batch_innermost
-    if S > 1 or G > 1:                                          # [S, C, H, W, B/S]: one batch-innermost block per slice / per step
-        nblk = S if S > 1 else G
+    if S > 1 or G > 1 or share is not None:                     # [S, C, H, W, B/S]: one batch-innermost block per slice / per step
+        nblk = S if S > 1 else nb
         xt = ops.to_batch_innermost_bf16_slices(x, nblk) if bf16 else ops.to_batch_innermost_slices(x, nblk)
     else:
         xt = to_cb(x).unsqueeze(0)                              # [1, C, H, W, B], shared by all draws
@@ -421,7 +436,7 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
         s3 = False                     # h is an S3 tensor [E, 3, C, H, W, B] (split-bf16 chain)
         boff = int(b_offset)           # global index of the first local "image" (rows multiply at a flatten that cuts images up)
         per_slice = bool(ukw)          # work units: until the first Bayesian layer, h is one block per batch slice
-        x_div = draws if (G > 1 and draws > 1) else 1   # several steps per launch: the first layer's slab e reads batch e // draws
+        x_div, x_off = x_div0, x_off0  # several steps per launch: the first layer's slab e reads batch (e + x_off) // x_div
         i = 0
         while i < len(children):
             mod = children[i]
@@ -436,7 +451,7 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
                     h5 = h if is_conv else h.reshape(h.shape[0], mod.in_features, 1, 1, -1)
                 if h5.dim() != (6 if s3 else 5) or h5.shape[-1] != B:
                     return None                                  # flatten quirk etc.: caller falls back
-                ukw2 = dict(ukw, x_per_slice=per_slice) if ukw else ({"x_div": x_div} if x_div > 1 else {})
+                ukw2 = dict(ukw, x_per_slice=per_slice) if ukw else ({"x_div": x_div, "x_off": x_off} if x_div > 1 else {})
                 per_slice = False
                 x_div = 1
                 if isinstance(mod, _BBBLayer) and bf16:
@@ -474,7 +489,7 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
                     if not is_conv:
                         shp = (mod.out_features, mod.in_features, 1, 1)
                         w_mu, w_var = w_mu.reshape(shp), w_var.reshape(shp)
-                    shared_in = h5.shape[0] == 1 and Es > 1 and not ukw and G == 1
+                    shared_in = h5.shape[0] == 1 and Es > 1 and not ukw and G == 1 and share is None
                     fl = conv_flops(B, h5.shape[1], h5.shape[2], h5.shape[3], w_mu.shape[0], w_mu.shape[2], w_mu.shape[3],
                                     *geom, 1 if shared_in else Es, 2) if timers is not None else None
                     if shared_in:
@@ -492,7 +507,8 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
                                  lambda h5=h5, w_mu=w_mu, w_var=w_var, b_var=b_var, mod=mod, geom=geom, act=act, ukw2=ukw2, boff=boff:
                                  ops.lrt_conv2d_chwn_forward(h5, w_mu, w_var, mod.bias_mu if mod.use_bias else None, b_var,
                                                              seed, call0 + e0, mod._stream_base + 2, *geom, sample=True,
-                                                             act=act, b_offset=boff, **ukw2)[0])
+                                                             act=act, b_offset=boff, **ukw2,
+                                                             **({"n_slabs": Es} if "x_div" in ukw2 else {}))[0])
                 h = y
                 if act is not None:
                     i += 1
@@ -715,7 +731,7 @@ def mc_logits(net, x, draws, seed, call0, fuse_act=True, timers=None, eps=None, 
 
 
 def _local_lse(net, x, draws, seed, call0, mean_over, fuse_act=True, timers=None, streams=1, precision="fp32", units=None, b_offset=0,
-               step_end=None, groups=1, param_alias=None):
+               step_end=None, groups=1, param_alias=None, share=None):
     """(log-sum-exp over the local draws of the per-draw log_softmax [B, C], kl of one forward), staying in the
     batch-innermost layout end to end when the fast path applies.  units = (S, lo, hi): the local work is the unit range
     lo..hi-1 instead of `draws` whole draws (call0 = call index of draw 0); rows of slices without a local unit are -inf.
@@ -723,8 +739,23 @@ def _local_lse(net, x, draws, seed, call0, mean_over, fuse_act=True, timers=None
     device-side call counter; then the second return value is the SCALED kl, and step_end[3] is set to True -- on the paths without
     the fused tail the caller does both itself.
     groups = G > 1: x holds G batches and the launches run G consecutive steps of `draws` forwards each (_mc_logits_chwn);
-    -> [G * B, C], block g = step g's result."""
+    -> [G * B, C], block g = step g's result.
+    share = (D, off): one rank's part of a group of steps (see _mc_logits_chwn; `draws` = its slabs, call0 = its first call)
+    -> [n * B, C] for the n = ceil((draws + off) / D) steps it touches: block k = log-sum-exp over ITS draws of that step, no
+    mean (group_share / GraphedMC steps > 1 with a process group combine the ranks' blocks)."""
     _check_precision(precision, net, x, fuse_act)
+    if share is not None:
+        D, off = int(share[0]), int(share[1])
+        n_steps = -(-(draws + off) // D)
+        out = _mc_logits_chwn(net, x, draws, seed, call0, timers, 1, precision, share=(D, off))
+        if out is None:
+            raise _lib.BBBHipError("a share of a group of steps needs the batch-innermost path")
+        if step_end is not None and timers is None:
+            lse, klf = ops.mc_tail_share(out[0], n_steps, D, off, step_end=(out[1], step_end[0], step_end[1], step_end[2]))
+            step_end[3] = True
+            return lse, klf
+        lse = _run(timers, "mc_tail", 0, lambda: ops.mc_tail_share(out[0], n_steps, D, off))
+        return lse, out[1]
     if int(groups) > 1:
         out = _mc_logits_chwn(net, x, draws, seed, call0, timers, 1, precision, groups=groups)
         if out is None:
@@ -775,6 +806,19 @@ def _local_lse(net, x, draws, seed, call0, mean_over, fuse_act=True, timers=None
     else:
         lse = _run(timers, "mc_tail", 0, lambda: ops.mc_tail(logits, mean_over=mean_over))
     return lse, kl1
+
+
+def group_share(num_ens, steps, rank, world):
+    """A GROUP of `steps` consecutive Monte-Carlo steps dealt out to `world` ranks: the steps * num_ens draws of the group, in
+    draw-major (step, draw) order, are cut into `world` contiguous ranges (draw_range) -- whole draws on whole batches, so every
+    rank's launches are as large as a single device's would be for that many draws; a step whose draws straddle a boundary is
+    combined by the group's one all_gather.  -> (lo, hi, first local step, number of local steps, draws of the first local step
+    that belong to earlier ranks); hi == lo: more ranks than draws."""
+    lo, hi = draw_range(int(steps) * int(num_ens), rank, world)
+    if hi <= lo:
+        return lo, hi, 0, 0, 0
+    g_lo, g_hi = lo // num_ens, (hi - 1) // num_ens
+    return lo, hi, g_lo, g_hi - g_lo + 1, lo % num_ens
 
 
 def units_ok(net, x, fuse_act=True):
@@ -993,8 +1037,6 @@ class GraphedMC:
         _lib.require_device(x)
         self.steps, self.slot = int(steps), 0
         if self.steps > 1:
-            if group is not None:
-                raise _lib.BBBHipError("steps > 1 batches the steps of a single process (no group)")
             with torch.no_grad():
                 if not units_ok(net, x):
                     raise _lib.BBBHipError("steps > 1 needs the batch-innermost path (model / input shape not covered)")
@@ -1007,10 +1049,16 @@ class GraphedMC:
         self.world = 1 if group is None else torch.distributed.get_world_size(group)
         rank = 0 if group is None else torch.distributed.get_rank(group)
         rng.assign_stream_ids(net)
-        with torch.no_grad():                        # the captured step is inference: plan for the inference path
-            self.S, self.lo, self.hi = shard_plan(net, self.x, self.num_ens, rank, self.world, True, precision)
         import os as _os
         self._force_combine = group is not None and _os.environ.get("BBB_FORCE_COMBINE") == "1"   # test hook: N > 1 code path at world 1
+        self.multi = self.world > 1 or self._force_combine
+        if self.steps > 1 and self.multi:
+            # a group of steps over several ranks: contiguous ranges of the group's steps * num_ens draws (group_share)
+            self.S = 1
+            self.lo, self.hi, self.g_lo, self.n_gl, self.g_off = group_share(self.num_ens, self.steps, rank, self.world)
+        else:
+            with torch.no_grad():                    # the captured step is inference: plan for the inference path
+                self.S, self.lo, self.hi = shard_plan(net, self.x, self.num_ens, rank, self.world, True, precision)
         dev = x.device
         self.stride = int(lanes) * self.num_ens * self.steps
         self.start = int(lane) * self.num_ens * self.steps
@@ -1020,7 +1068,8 @@ class GraphedMC:
         self.stream = stream if stream is not None else torch.cuda.Stream(device=dev)
         self.lse = self.kl_local = None
         self.shape = (output_rows(net, tuple(x.shape)) // self.steps, getattr(net, "num_classes", None))
-        self.multi = self.world > 1 or self._force_combine
+        if self.steps > 1 and self.multi:
+            self.shape = (self.shape[0] * self.steps, self.shape[1])       # the collective carries the whole group's rows
         self.fused = False                           # the collective and the reduction over ranks live inside the step's graph
         if self.multi:
             if self.shape[1] is None:
@@ -1078,6 +1127,8 @@ class GraphedMC:
         blocks = g[:, :-1].reshape(self.world_size_for_buffers, *self.shape)
         self.out_lo.copy_(torch.logsumexp(blocks, dim=0) - math.log(self.num_ens))
         kl = g[:, -1].sum()
+        if self.steps > 1:
+            kl = kl / self.steps                     # the ranks' shares add up to the KL of steps * num_ens forwards
         self.out_kl.copy_(kl if self.kl_mode == "sum" else kl / self.num_ens)
 
     def _step_body(self, streams):
@@ -1089,7 +1140,11 @@ class GraphedMC:
             scale = float(n_loc) / self.S
         # the tail launch of the fast path also scales the KL and advances the noise counter (two element-wise launches less)
         end = [scale, self.counter, self.stride, False]
-        if self.steps > 1:
+        if self.steps > 1 and self.multi:
+            B = self.B
+            lse, kl = _local_lse(self.net, self.x[self.g_lo * B:(self.g_lo + self.n_gl) * B], n_loc, self.seed, self.call0 + self.lo, 0,
+                                 precision=self.precision, step_end=end, share=(self.num_ens, self.g_off))
+        elif self.steps > 1:
             lse, kl = _local_lse(self.net, self.x, self.num_ens, self.seed, self.call0, self.num_ens, precision=self.precision,
                                  step_end=end, groups=self.steps)
         elif self.S > 1:
@@ -1102,17 +1157,30 @@ class GraphedMC:
             kl = kl * scale
             self.counter.add_(self.stride)           # part of the graph: next replay of this lane
         if self.multi:                               # pack what this rank contributes to the step's one collective
-            self.send[:-1].copy_(lse.reshape(-1))
+            if self.steps > 1:
+                n = lse.shape[0] // self.n_gl * lse.shape[1]         # floats per step; steps without a local draw stay -inf
+                self.send[self.g_lo * n:(self.g_lo + self.n_gl) * n].copy_(lse.reshape(-1))
+            else:
+                self.send[:-1].copy_(lse.reshape(-1))
             self.send[-1:].copy_(kl.reshape(1))
         return lse, kl
+
+    def _launch(self):
+        """One replay of the lane's graph (+ the eager collective protocol when the collective is not part of it)."""
+        if self.graph is not None:
+            self.graph.replay()
+        self.replays += 1
+        if self.multi and not self.fused:
+            # ONE collective per launch (RCCL on GPUs), eager, on the lane's communication stream
+            _eager_gather(self.recv, self.send, self.group, torch.cuda.current_stream(self.x.device), self.comm_stream)
+            self.post.replay()
 
     def flush(self):
         """steps > 1: replay a partly filled group now (its empty slots recompute the batches they still hold)."""
         if self.steps > 1 and self.slot > 0:
             ctx = torch.cuda.stream(self.stream) if self.own_stream else _null_ctx()
             with ctx:
-                self.graph.replay()
-            self.replays += 1
+                self._launch()
             rng.next_calls((self.steps - self.slot) * self.num_ens)   # the graph consumed the calls of the empty slots too
             self.slot = 0
 
@@ -1130,24 +1198,19 @@ class GraphedMC:
                 self.slot += 1
                 rng.next_calls(self.num_ens)
                 if self.slot == self.steps:
-                    self.graph.replay()
-                    self.replays += 1
+                    self._launch()
                     self.slot = 0
+                if self.multi:
+                    return self.out_lo[g * B:(g + 1) * B], self.out_kl
                 return self.lse[g * B:(g + 1) * B], self.kl_local
             if x is not None:
                 if producer is not None:
                     self.stream.wait_stream(producer)              # whoever produced x on the caller's stream
                 self.x.copy_(x, non_blocking=True)
-            if self.graph is not None:
-                self.graph.replay()
-            self.replays += 1
+            self._launch()
             rng.next_calls(self.num_ens)             # keep the host-side counter in step with the device's
             if not self.multi:
                 return self.lse, self.kl_local
-            if not self.fused:
-                # ONE collective per MC step (RCCL on GPUs), eager, on the lane's communication stream
-                _eager_gather(self.recv, self.send, self.group, torch.cuda.current_stream(self.x.device), self.comm_stream)
-                self.post.replay()
             return self.out_lo, self.out_kl
 
 

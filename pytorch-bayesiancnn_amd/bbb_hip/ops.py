@@ -276,13 +276,14 @@ def _desc_chwn(x, w, stride, padding, dilation, draws, x_shared, w_shared, act):
 
 
 def conv2d_chwn_forward(x, w, bias, stride=1, padding=0, dilation=1, act=None, out=None, units=None, n_units=None,
-                        x_per_slice=False, x_div=1, bf16x3=None, x_s3=False, out_s3=False):
+                        x_per_slice=False, x_div=1, bf16x3=None, x_s3=False, out_s3=False, x_off=0):
     """Batch-innermost conv for the ensemble path.  x: [E|1, Cin, H, W, B] (B % 4 == 0); w: [E|1, Cout, Cin, kh, kw];
     bias [E|1, Cout] or None -> y [E, Cout, Ho, Wo, B].  Padding taps are skipped, not multiplied.
     Work units (ensemble sharding): units = (S, off), n_units = U output slabs; w / bias hold the weight sets of the draws
     the units touch, x is [U, ...] or, for a layer whose input is the same for every draw, the per-slice [S, Cin, H, W, Bs].
     x_div = D > 1 (several Monte-Carlo steps per launch): x holds E / D input slabs and output slab e reads slab e // D
-    (bbb_conv_desc_t::x_unit_div) -- the first layer of G steps x D draws, each step on its own batch.
+    (bbb_conv_desc_t::x_unit_div) -- the first layer of G steps x D draws, each step on its own batch.  x_off (< D): output slab
+    e reads slab (e + x_off) // D -- a rank's share of a group of steps that starts in the middle of a step.
     bf16x3: True / False = run this launch on the split-bf16 kernel or not; None (default) = ops.gemm_mode decides.
     x_s3 / out_s3 (split-bf16 kernel only, B % 8 == 0): the input / output travels in the split activation format S3 -- a bf16
     tensor [E|1, 3, C, H, W, B] holding the hi / mid / lo pieces of the same fp32 values (s3_from_f32 / s3_to_f32)."""
@@ -304,10 +305,10 @@ def conv2d_chwn_forward(x, w, bias, stride=1, padding=0, dilation=1, act=None, o
         _apply_units(d, units, x_per_slice)
     elif int(x_div) > 1:
         E = w.shape[0]
-        if E % int(x_div) or x5.shape[0] * int(x_div) != E:
-            raise _lib.BBBHipError("x_div: x must hold E / x_div input slabs for the E weight sets")
+        if not 0 <= int(x_off) < int(x_div) or x5.shape[0] != -(-(E + int(x_off)) // int(x_div)):
+            raise _lib.BBBHipError("x_div: x must hold ceil((E + x_off) / x_div) input slabs for the E weight sets")
         d, ho, wo = _desc_chwn(x5, w, stride, padding, dilation, E, False, False, act)
-        d.x_unit_div = int(x_div)
+        d.x_unit_div, d.x_unit_off = int(x_div), int(x_off)
     else:
         E = max(x5.shape[0], w.shape[0])
         if x5.shape[0] not in (1, E) or w.shape[0] not in (1, E):
@@ -382,7 +383,7 @@ def maxpool_chwn_s3(x, k, s):
 
 def lrt_conv2d_chwn_forward(x, w_mu, w_var, b_mu, b_var, seed, call0, stream_id, stride=1, padding=0, dilation=1,
                             sample=True, eps=None, want_moments=False, act=None, units=None, n_units=None, b_offset=0,
-                            x_per_slice=False, x_div=1):
+                            x_per_slice=False, x_div=1, x_off=0, n_slabs=None):
     """LRT layer, batch-innermost.  x: [E, Cin, H, W, B] -> (y, act_mu|None, act_var|None) [E, Cout, Ho, Wo, B].
     Work units as in conv2d_chwn_forward (call0 = the call index of the first unit's draw; the noise of unit u is keyed by
     its draw and by the GLOBAL image index slice*B + b).  b_offset: global index of local image 0 (batch-parallel shards)."""
@@ -391,12 +392,14 @@ def lrt_conv2d_chwn_forward(x, w_mu, w_var, b_mu, b_var, seed, call0, stream_id,
     w_mu, w_var = w_mu.contiguous(), w_var.contiguous()
     b_mu = None if b_mu is None else b_mu.contiguous()
     b_var = None if b_var is None else b_var.contiguous()
-    E = x.shape[0] * int(x_div) if (units is None or units[0] <= 1) else int(n_units)
+    E = (int(n_slabs) if n_slabs is not None else x.shape[0] * int(x_div)) if (units is None or units[0] <= 1) else int(n_units)
     d, ho, wo = _desc_chwn(x, w_mu.unsqueeze(0), stride, padding, dilation, E, False, True, act)
     if units is not None and units[0] > 1:
         _apply_units(d, units, x_per_slice)
     elif int(x_div) > 1:
-        d.x_unit_div = int(x_div)                 # several steps per launch: slab e = step e // x_div on that step's batch
+        if not 0 <= int(x_off) < int(x_div) or x.shape[0] != -(-(E + int(x_off)) // int(x_div)):
+            raise _lib.BBBHipError("x_div: x must hold ceil((E + x_off) / x_div) input slabs for the E output slabs")
+        d.x_unit_div, d.x_unit_off = int(x_div), int(x_off)   # several steps per launch: slab e = step (e + x_off) // x_div on that step's batch
     d.b_offset = int(b_offset)
     d.w_draw_stride = 0
     d.b_draw_stride = 0
@@ -525,7 +528,7 @@ def to_batch_innermost_bf16_slices(x, slices):
 
 
 def conv2d_chwn_bf16_forward(x, w, bias, cin_khkw, stride=1, padding=0, dilation=1, act=None, out_f32=False, out=None,
-                             tap_major=False, units=None, n_units=None, x_per_slice=False, x_div=1):
+                             tap_major=False, units=None, n_units=None, x_per_slice=False, x_div=1, x_off=0):
     """bf16 batch-innermost conv.  x: [E|1, Cin, H, W, B] bf16 (B % 8 == 0); w: [E|1, Cout, Kp] bf16 as written by
     sample_weights_bf16 (tap_major = its column order, see bf16_tap_major); cin_khkw = (Cin, kh, kw); bias [E|1, Cout]
     fp32 or None -> y [E, Cout, Ho, Wo, B] bf16 (fp32 when out_f32)."""
@@ -536,9 +539,9 @@ def conv2d_chwn_bf16_forward(x, w, bias, cin_khkw, stride=1, padding=0, dilation
     cin, kh, kw = cin_khkw
     sharded = units is not None and units[0] > 1
     grouped = not sharded and int(x_div) > 1
-    E = int(n_units) if sharded else max(x.shape[0], w.shape[0])
-    if grouped and (E % int(x_div) or x.shape[0] * int(x_div) != E):
-        raise _lib.BBBHipError("x_div: x must hold E / x_div input slabs for the E weight sets")
+    E = int(n_units) if sharded else (w.shape[0] if grouped else max(x.shape[0], w.shape[0]))
+    if grouped and (not 0 <= int(x_off) < int(x_div) or x.shape[0] != -(-(E + int(x_off)) // int(x_div))):
+        raise _lib.BBBHipError("x_div: x must hold ceil((E + x_off) / x_div) input slabs for the E weight sets")
     if not sharded and not grouped and (x.shape[0] not in (1, E) or w.shape[0] not in (1, E)):
         raise _lib.BBBHipError("leading (draw) dims of x and w must be 1 or equal")
     Ex, Cin, H, W, B = x.shape
@@ -551,7 +554,7 @@ def conv2d_chwn_bf16_forward(x, w, bias, cin_khkw, stride=1, padding=0, dilation
     d.draws = E
     d.x_draw_stride = 0 if (Ex == 1 and E > 1 and not sharded and not grouped) else Cin * H * W * B
     if grouped:
-        d.x_unit_div = int(x_div)
+        d.x_unit_div, d.x_unit_off = int(x_div), int(x_off)
     d.w_draw_stride = 0 if (w.shape[0] == 1 and E > 1 and not sharded) else w.shape[1] * w.shape[2]
     d.b_draw_stride = 0 if (bias is None or (bias.shape[0] == 1 and E > 1 and not sharded)) else w.shape[1]
     d.act = {None: 0, "relu": 1, "softplus": 2}[act]
@@ -642,6 +645,29 @@ def mc_tail_groups(logits, groups, draws, mean_over=0, step_end=None):
         check(_lib.lib().bbb_mc_tail_groups_step(logits.data_ptr(), int(groups), int(draws), B, C, int(mean_over), out.data_ptr(),
                                                  ptr(kl_in), float(scale), ptr(kl_out), ptr(counter), int(add) & 0xFFFFFFFF,
                                                  cur_stream(logits.device)), "bbb_mc_tail_groups_step")
+    return out if step_end is None else (out, kl_out)
+
+
+def mc_tail_share(logits, steps, draws, first_off, step_end=None):
+    """Tail of one rank's share of a GROUP of steps: logits [slabs, C, B], slab e = draw (first_off + e) of the draw-major (step,
+    draw) enumeration of `steps` local steps with `draws` draws each -> [steps * B, C], block k = log-sum-exp over the LOCAL draws
+    of local step k of the per-draw log_softmax (no mean: the ranks' blocks are combined by one more log-sum-exp; -inf where the
+    share holds no draw of the step).  step_end as in mc_tail_units."""
+    require_device(logits)
+    logits = logits.contiguous()
+    U, C, B = logits.shape
+    if U > 4096 or not 0 <= int(first_off) < int(draws) or int(steps) * int(draws) < U + int(first_off):
+        raise _lib.BBBHipError("mc_tail_share: the slabs must fit the steps * draws grid, <= 4096 slabs")
+    out = torch.empty((int(steps) * B, C), dtype=torch.float32, device=logits.device)
+    kl_in, scale, counter, add = step_end if step_end is not None else (None, 0.0, None, 0)
+    require_device(kl_in)
+    kl_out = torch.empty((), dtype=torch.float32, device=logits.device) if step_end is not None else None
+    if counter is not None and (counter.dtype != torch.int32 or not counter.is_cuda):
+        raise _lib.BBBHipError("the call counter must be an int32 device tensor")
+    with on_device(logits.device):
+        check(_lib.lib().bbb_mc_tail_share_step(logits.data_ptr(), U, int(steps), int(draws), int(first_off), B, C, out.data_ptr(),
+                                                ptr(kl_in), float(scale), ptr(kl_out), ptr(counter), int(add) & 0xFFFFFFFF,
+                                                cur_stream(logits.device)), "bbb_mc_tail_share_step")
     return out if step_end is None else (out, kl_out)
 
 

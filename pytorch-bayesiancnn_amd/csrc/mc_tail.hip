@@ -77,7 +77,7 @@ __global__ __launch_bounds__(kCbThreads * kCbRows) void mc_tail_cb_kernel(const 
                                                                           int off, int C, float sub, float* __restrict__ out,
                                                                           const float* __restrict__ kl_in, float kl_scale,
                                                                           float* __restrict__ kl_out, uint32_t* counter,
-                                                                          uint32_t counter_add, int grp) {
+                                                                          uint32_t counter_add, int grp, int goff) {
     extern __shared__ float lz[];                       // [ceil(E/S)][64]
     const int tx = threadIdx.x, ty = threadIdx.y, ny = blockDim.y;
     if (blockIdx.x == 0 && tx == 0 && ty == 0) {
@@ -90,8 +90,12 @@ __global__ __launch_bounds__(kCbThreads * kCbRows) void mc_tail_cb_kernel(const 
     const int bb = ok ? b : B - 1;
     const int sl = bb / Bs, bl = bb - sl * Bs;
     const int es = grp > 0 ? 1 : S;                     // slab stride between the draws an image reduces over
-    const int e0 = grp > 0 ? sl * grp : (sl - off % S + S) % S;
-    const int ne = grp > 0 ? grp : (e0 < E ? (E - e0 + S - 1) / S : 0);
+    // groups: step sl owns slabs [sl*grp - goff, (sl+1)*grp - goff), clipped to the launch (a rank's share of a group of steps may
+    // start and end in the middle of a step; goff = draws of the first step that belong to an earlier rank)
+    const int g_lo = sl * grp - goff > 0 ? sl * grp - goff : 0;
+    const int g_hi = (sl + 1) * grp - goff < E ? (sl + 1) * grp - goff : E;
+    const int e0 = grp > 0 ? g_lo : (sl - off % S + S) % S;
+    const int ne = grp > 0 ? (g_hi > g_lo ? g_hi - g_lo : 0) : (e0 < E ? (E - e0 + S - 1) / S : 0);
     for (int k = ty; k < ne; k += ny) {
         const float* p = logits + (int64_t)(e0 + k * es) * C * Bs + bl;
         float mx = -INFINITY;
@@ -309,22 +313,22 @@ __global__ __launch_bounds__(256) void lrt_sample_nchw_kernel(const float* __res
 
 namespace {
 int mc_tail_launch(const float* logits, int units, int slices, int unit_off, int batch_slice, int classes, int mean_over, float* lse_out,
-                   const float* kl_in, float kl_scale, float* kl_out, uint32_t* counter, uint32_t counter_add, int grp, void* stream) {
+                   const float* kl_in, float kl_scale, float* kl_out, uint32_t* counter, uint32_t counter_add, int grp, int goff, void* stream) {
     if ((kl_out != nullptr && kl_in == nullptr) || (((uintptr_t)kl_in | (uintptr_t)kl_out | (uintptr_t)counter) & 3u) != 0) return BBB_EINVAL;
     if (logits == nullptr || lse_out == nullptr || units <= 0 || slices <= 0 || unit_off < 0 || batch_slice <= 0 || classes <= 0 ||
-        mean_over < 0 || units > 4096 || grp < 0 || (grp > 0 && (int64_t)grp * slices != units))
+        mean_over < 0 || units > 4096 || grp < 0 || goff < 0 || (grp > 0 && (goff >= grp || (int64_t)grp * slices < (int64_t)units + goff)))
         return BBB_EINVAL;
     if ((((uintptr_t)logits | (uintptr_t)lse_out) & 3u) != 0) return BBB_EALIGN;
     const float sub = mean_over > 0 ? logf((float)mean_over) : 0.0f;
     const int64_t batch = (int64_t)batch_slice * slices;
     if (batch > 0x7fffffffLL) return BBB_ESHAPE;
     const int blocks = (int)((batch + kCbThreads - 1) / kCbThreads);
-    const int per_slice = (units + slices - 1) / slices;            // local units an image reduces over, at most
+    const int per_slice = grp > 0 ? grp : (units + slices - 1) / slices;   // local units an image reduces over, at most
     const int mx = per_slice > classes ? per_slice : classes;
     const int ny = mx < kCbRows ? mx : kCbRows;
     hipLaunchKernelGGL(mc_tail_cb_kernel, dim3(blocks), dim3(kCbThreads, ny), (size_t)per_slice * kCbThreads * sizeof(float),
                        (hipStream_t)stream, logits, units, batch_slice, slices, unit_off, classes, sub, lse_out, kl_in, kl_scale, kl_out,
-                       counter, counter_add, grp);
+                       counter, counter_add, grp, goff);
     return (int)hipGetLastError();
 }
 }  // namespace
@@ -333,7 +337,7 @@ extern "C" int bbb_mc_tail_units_step(const float* logits, int units, int slices
                                       int mean_over, float* lse_out, const float* kl_in, float kl_scale, float* kl_out,
                                       uint32_t* counter, uint32_t counter_add, void* stream) {
     return mc_tail_launch(logits, units, slices, unit_off, batch_slice, classes, mean_over, lse_out, kl_in, kl_scale, kl_out, counter,
-                          counter_add, 0, stream);
+                          counter_add, 0, 0, stream);
 }
 
 extern "C" int bbb_mc_tail_groups_step(const float* logits, int groups, int draws, int batch, int classes, int mean_over,
@@ -341,7 +345,15 @@ extern "C" int bbb_mc_tail_groups_step(const float* logits, int groups, int draw
                                        uint32_t counter_add, void* stream) {
     if (groups <= 0 || draws <= 0 || (int64_t)groups * draws > 4096) return BBB_EINVAL;
     return mc_tail_launch(logits, groups * draws, groups, 0, batch, classes, mean_over, lse_out, kl_in, kl_scale, kl_out, counter,
-                          counter_add, draws, stream);
+                          counter_add, draws, 0, stream);
+}
+
+extern "C" int bbb_mc_tail_share_step(const float* logits, int slabs, int steps, int draws, int first_off, int batch, int classes,
+                                      float* lse_out, const float* kl_in, float kl_scale, float* kl_out, uint32_t* counter,
+                                      uint32_t counter_add, void* stream) {
+    if (slabs <= 0 || steps <= 0 || draws <= 0 || first_off < 0 || slabs > 4096) return BBB_EINVAL;
+    return mc_tail_launch(logits, slabs, steps, 0, batch, classes, 0, lse_out, kl_in, kl_scale, kl_out, counter, counter_add, draws,
+                          first_off, stream);
 }
 
 extern "C" int bbb_mc_tail_units(const float* logits, int units, int slices, int unit_off, int batch_slice, int classes, int mean_over,

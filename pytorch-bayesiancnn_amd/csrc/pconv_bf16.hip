@@ -85,7 +85,7 @@ __global__ __launch_bounds__(64 * WN * WM * KG + (WS ? 256 : 0)) void pconv_bf16
     const int e = g / p.Ntiles;
     const int ue = p.unit_off + e;                                   // work units, as in pconv_gemm.hip
     const int ew = p.unit_div > 1 ? ue / p.unit_div : e;
-    const int ex = p.x_div > 1 ? e / p.x_div : (p.x_mod > 0 ? ue % p.x_mod : e);
+    const int ex = p.x_div > 1 ? (e + p.x_off) / p.x_div : (p.x_mod > 0 ? ue % p.x_mod : e);
     const int n0 = (g - e * p.Ntiles) * BN;
     const int pix = j / p.nbt;
     const int b0 = (j - pix * p.nbt) * BM;
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void pconv_bf16_smallk_kernel(const PConvArgs 
     const int e = g / p.Ntiles;
     const int ue = p.unit_off + e;
     const int ew = p.unit_div > 1 ? ue / p.unit_div : e;
-    const int ex = p.x_div > 1 ? e / p.x_div : (p.x_mod > 0 ? ue % p.x_mod : e);
+    const int ex = p.x_div > 1 ? (e + p.x_off) / p.x_div : (p.x_mod > 0 ? ue % p.x_mod : e);
     const int n0 = (g - e * p.Ntiles) * BN;
     const int Kp = p.Kp;
 
@@ -687,8 +687,10 @@ extern "C" int bbb_conv2d_chwn_bf16_fwd(const bbb_conv_desc_t* d, const void* x,
     if (d->unit_div < 0 || d->unit_off < 0 || d->x_unit_mod < 0 || (d->unit_div > 1 && d->unit_off >= d->unit_div) ||
         (d->x_unit_mod > 0 && d->x_unit_mod != d->unit_div) || d->w_row_pitch != 0)
         return BBB_EINVAL;
-    if (d->x_unit_div < 0 || (d->x_unit_div > 1 && (d->unit_div > 1 || d->draws % d->x_unit_div != 0))) return BBB_EINVAL;
-    a.x_div = d->x_unit_div;
+    if (d->x_unit_div < 0 || d->x_unit_off < 0 || (d->x_unit_div > 1 && (d->unit_div > 1 || d->x_unit_off >= d->x_unit_div)) ||
+        (d->x_unit_div <= 1 && d->x_unit_off != 0))
+        return BBB_EINVAL;
+    a.x_div = d->x_unit_div; a.x_off = d->x_unit_off;
     a.unit_div = d->unit_div; a.unit_off = d->unit_div > 1 ? d->unit_off : 0; a.x_mod = d->x_unit_mod;
     if (!tap_major && !out_f32 && Kp <= 128 && (int64_t)ho * wo >= 16) {
         // a first layer with a short contraction: weights in registers, a run of pixels per workgroup (pconv_bf16_smallk_kernel)

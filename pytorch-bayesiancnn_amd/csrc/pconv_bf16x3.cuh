@@ -73,7 +73,7 @@ __global__ __launch_bounds__(kThreads) void pconv_bf16x3_kernel(const PConvArgs 
     const int e = g / p.Ntiles;
     const int ue = p.unit_off + e;
     const int ew = p.unit_div > 1 ? ue / p.unit_div : e;
-    const int ex = p.x_div > 1 ? e / p.x_div : (p.x_mod > 0 ? ue % p.x_mod : e);
+    const int ex = p.x_div > 1 ? (e + p.x_off) / p.x_div : (p.x_mod > 0 ? ue % p.x_mod : e);
     const int n0 = (g - e * p.Ntiles) * BN;
     const int pix = j / p.nbt;
     const int b0 = (j - pix * p.nbt) * BM;

@@ -74,7 +74,7 @@ __device__ __forceinline__ void pconv_item(const PConvArgs& p, const int64_t ite
     // -- AlexNet's 6.3 MB input does not fit a 4 MB XCD L2, so in draw-major order every draw re-fetched it from the fabric (78 MB
     // per step for 7 MB of operands, profiles/r03_pmc_FETCH_SIZE.txt), while all draws' weights of such a layer (0.9 MB) do fit.
     int g, j;
-    if (p.x_ds == 0 || p.x_div > 1) {
+    if (p.x_ds == 0 || (p.x_div > 1 && p.x_off == 0 && p.G % (p.x_div * p.Ntiles) == 0)) {
         const int gs = p.x_div > 1 ? p.x_div * p.Ntiles : p.G;       // (draw, channel tile) groups per step
         const int64_t per_step = (int64_t)p.Mtiles * gs;
         const int step = (int)(item / per_step);
@@ -89,7 +89,7 @@ __device__ __forceinline__ void pconv_item(const PConvArgs& p, const int64_t ite
     // work units (ensemble sharding): slab e is unit u = unit_off + e -> weight set u / S, input slab e (or u % S)
     const int ue = p.unit_off + e;
     const int ew = p.unit_div > 1 ? ue / p.unit_div : e;
-    const int ex = p.x_div > 1 ? e / p.x_div : (p.x_mod > 0 ? ue % p.x_mod : e);
+    const int ex = p.x_div > 1 ? (e + p.x_off) / p.x_div : (p.x_mod > 0 ? ue % p.x_mod : e);
     const int n0 = (g - e * p.Ntiles) * BN;
     const int pix = j / p.nbt;
     const int b0 = (j - pix * p.nbt) * BM;

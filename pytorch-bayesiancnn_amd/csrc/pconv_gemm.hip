@@ -191,9 +191,11 @@ int fill(const bbb_conv_desc_t* d, PConvArgs& a) {
     if (d->unit_div < 0 || d->unit_off < 0 || d->x_unit_mod < 0 || d->b_offset < 0) return BBB_EINVAL;
     if (d->unit_div > 1 && d->unit_off >= d->unit_div) return BBB_EINVAL;          // passed reduced modulo S
     if (d->x_unit_mod > 0 && d->x_unit_mod != d->unit_div) return BBB_EINVAL;
-    if (d->x_unit_div < 0 || (d->x_unit_div > 1 && (d->unit_div > 1 || d->draws % d->x_unit_div != 0))) return BBB_EINVAL;
+    if (d->x_unit_div < 0 || d->x_unit_off < 0 || (d->x_unit_div > 1 && (d->unit_div > 1 || d->x_unit_off >= d->x_unit_div)) ||
+        (d->x_unit_div <= 1 && d->x_unit_off != 0))
+        return BBB_EINVAL;
     a.unit_div = d->unit_div; a.unit_off = d->unit_div > 1 ? d->unit_off : 0; a.x_mod = d->x_unit_mod; a.b_off = d->b_offset;
-    a.x_div = d->x_unit_div;
+    a.x_div = d->x_unit_div; a.x_off = d->x_unit_off;
     return 0;
 }
 

@@ -108,9 +108,10 @@ def test_bench_n_gt_1_flow_rehearsed_on_one_device():
     assert j["n_gpus"] == 2 and j["steps"] == 6 and j["scaling"] == "strong" and j["value"] > 0
     # the N > 1 line carries rank 0's roofline for ITS share and the CPU baseline of a rank-0 pre-pass
     _check_roofline(j["roofline"], 157.3)
-    assert j["roofline"]["slabs_per_launch"] == 5 and j["cpu_baseline"]["value"] > 0
+    assert j["roofline"]["slabs_per_launch"] == 20 and j["cpu_baseline"]["value"] > 0          # rank 0: 20 of a group's 40 draws
     assert j["config"]["global_batch"] == 512 and j["config"]["num_ens_total"] == 10          # the metric's workload, not 2x of it
-    assert "work units" in j["config"]["parallelism"] and j["weak_scaling"]["num_ens_total"] == 20
+    assert "groups of 4 steps" in j["config"]["parallelism"] and j["config"]["draws_per_rank"] == [20, 20]
+    assert j["weak_scaling"]["num_ens_total"] == 20
     assert abs(j["value"] - 512 * 10 / (j["ms_per_step"] * 1e-3)) <= 1e-3 * j["value"]
 
 
@@ -120,7 +121,8 @@ def test_bench_gpus_2_as_typed_launches_its_own_ranks():
     env = dict(os.environ, BBB_BENCH_DEVICE="0", BBB_BENCH_BACKEND="gloo")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--no-extras"],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--no-extras",
+                        "--steps-per-launch", "1"],
                        capture_output=True, text=True, timeout=900, env=env)
     assert p.returncode == 0, p.stderr[-3000:]
     j, _ = _split(p.stdout)
@@ -141,7 +143,7 @@ def test_bench_multi_rank_flow_over_rccl_with_one_rank():
     assert p.returncode == 0, p.stderr[-3000:]
     j, _ = _split(p.stdout)
     assert j["n_gpus"] == 1 and j["config"]["ranks_seen"] == 1 and j["config"]["backend"] == "nccl"
-    assert j["config"]["units_per_rank"] == [10] and "4 lane" in j["config"]["launch"]
+    assert j["config"]["draws_per_rank"] == [40] and "2 lane" in j["config"]["launch"] and "4 steps per launch" in j["config"]["launch"]
     assert j["value"] > 0 and j["weak_scaling"]["value"] > 0
     _check_roofline(j["roofline"], 157.3)
-    assert j["roofline"]["slabs_per_launch"] == 10
+    assert j["roofline"]["slabs_per_launch"] == 40

@@ -59,8 +59,23 @@ for lt, ncls in (("bbb", 10), ("lrt", 100)):
             steps.append((lo.clone(), kl.clone()))
         res[tag] = steps
         del pipe
+    # a GROUP of 2 steps per launch dealt to the ranks (group_share), recorded and eager: same steps, same noise calls
+    grp_res = {}
+    for tag, cap in (("fused", True), ("eager", False)):
+        os.environ["BBB_FORCE_COMBINE"] = "1"
+        ensemble.capture_collectives = cap
+        ensemble._capture_probe.clear()
+        rng.manual_seed(7, 200)
+        pipe = ensemble.GraphedPipeline(net, x, E, depth=2, group=group, steps_per_launch=2)
+        views = [pipe.step() for _ in range(4)]
+        pipe.sync()
+        grp_res[tag] = [(a.clone(), b.clone()) for a, b in views]
+        del pipe
     os.environ["BBB_FORCE_COMBINE"] = "0"
     ensemble.capture_collectives = True
+    d_group = max((a[0] - b[0]).abs().max().item() for a, b in zip(res["plain"][:4], grp_res["fused"]))
+    d_group_kl = max(abs(a[1].item() - b[1].item()) / abs(a[1].item()) for a, b in zip(res["plain"][:4], grp_res["fused"]))
+    group_same = all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(grp_res["fused"], grp_res["eager"]))
     same_protocols = all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(res["rccl"], res["rccl_eager"]))
     d_eager = (lo1 - lo0).abs().max().item()
     d_graph = max((a[0] - b[0]).abs().max().item() for a, b in zip(res["plain"], res["rccl"]))
@@ -68,7 +83,7 @@ for lt, ncls in (("bbb", 10), ("lrt", 100)):
     fresh = not torch.equal(res["rccl"][0][0], res["rccl"][1][0])
     out[lt] = dict(d_eager=d_eager, kl_eager=abs(kl1.item() - kl0.item()) / abs(kl0.item()), d_graph=d_graph, d_kl=d_kl, fresh=fresh,
                    scale=lo0.abs().max().item(), finite=bool(torch.isfinite(res["rccl"][-1][0]).all()),
-                   fused=fused, same_protocols=same_protocols)
+                   fused=fused, same_protocols=same_protocols, d_group=d_group, d_group_kl=d_group_kl, group_same=group_same)
 dist.destroy_process_group()
 print("RESULT " + json.dumps(out))
 '''
@@ -87,6 +102,7 @@ def test_step_protocol_through_rccl_world_size_one():
         assert r["finite"] and r["fresh"], (lt, r)
         assert r["d_eager"] <= 3e-6 * max(r["scale"], 1.0) and r["kl_eager"] <= 1e-6, (lt, r)
         assert r["d_graph"] <= 3e-6 * max(r["scale"], 1.0) and r["d_kl"] <= 1e-6, (lt, r)
+        assert r["d_group"] <= 3e-6 * max(r["scale"], 1.0) and r["d_group_kl"] <= 1e-6 and r["group_same"], (lt, r)
         # the recorded collective (one host call per step) and the eager one are the same arithmetic
         assert r["same_protocols"] and r["fused"]["plain"] == [False, False] and r["fused"]["rccl_eager"] == [False, False], (lt, r)
         assert r["fused"]["rccl"] == [True, True], "RCCL refused to record all_gather_into_tensor into a hipGraph: %r" % (r["fused"],)
@@ -122,6 +138,16 @@ with torch.no_grad():
         g_steps.append((lo.clone(), kl.clone()))
     rng.manual_seed(7, 100)
     e_steps = [ensemble.mc_forward(net, x, E) for _ in range(4)]
+    # groups of 4 steps per launch dealt to the ranks as contiguous draw ranges (what bench.py runs at N > 1)
+    del pipe
+    xs = [torch.rand(512, 3, 32, 32, device=dev, generator=torch.Generator(device=dev).manual_seed(11 + i)) for i in range(4)]
+    rng.manual_seed(7, 100)
+    pipe = ensemble.GraphedPipeline(net, x, E, depth=2, group=group, steps_per_launch=4)
+    views = [pipe.step(xs[i]) for i in range(4)]
+    pipe.sync()
+    grp_steps = [(a.clone(), b.clone()) for a, b in views]
+    rng.manual_seed(7, 100)
+    grp_ref = [ensemble.mc_forward(net, xs[i], E) for i in range(4)]
 S, lo_u, hi_u = ensemble.shard_plan(net, x, E, rank, world)
 # every rank must hold the same bits: gather rank 0's result and compare
 ref = loN.clone(); dist.broadcast(ref, 0, group=group)
@@ -129,7 +155,10 @@ out.update(units=hi_u - lo_u, S=S, fused=[bool(l.fused) for l in pipe.lanes], sa
            d_eager=(loN - lo1).abs().max().item(), kl_rel=abs(klN.item() - kl1.item()) / abs(kl1.item()),
            d_graph=max((a[0] - b[0]).abs().max().item() for a, b in zip(g_steps, e_steps)),
            kl_graph=max(abs(a[1].item() - b[1].item()) / abs(b[1].item()) for a, b in zip(g_steps, e_steps)),
+           d_group=max((a[0] - b[0]).abs().max().item() for a, b in zip(grp_steps, grp_ref)),
+           kl_group=max(abs(a[1].item() - b[1].item()) / abs(b[1].item()) for a, b in zip(grp_steps, grp_ref)),
            scale=lo1.abs().max().item())
+out["d_graph"] = max(out["d_graph"], out["d_group"]); out["kl_graph"] = max(out["kl_graph"], out["kl_group"])
 flags = torch.tensor([float(out["same_on_all_ranks"]), out["d_eager"], out["d_graph"]], device=dev)
 dist.all_reduce(flags[:1], op=dist.ReduceOp.MIN, group=group); dist.all_reduce(flags[1:], op=dist.ReduceOp.MAX, group=group)
 dist.barrier(group=group)

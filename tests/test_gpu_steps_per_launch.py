@@ -131,3 +131,45 @@ def test_grouped_steps_refuse_what_they_do_not_cover(env):
     x = torch.rand(64, 3, 32, 32, device="cuda")
     with torch.no_grad(), pytest.raises(BBBHipError):
         env["ens"].GraphedPipeline(net, x[:6], 2, depth=2, steps_per_launch=4)      # B % 4 != 0: no batch-innermost path
+
+
+@pytest.mark.parametrize("lt,E,G,world", [("bbb", 10, 4, 8), ("bbb", 10, 4, 3), ("lrt", 4, 3, 2), ("bbb", 1, 4, 2), ("bbb", 3, 2, 8),
+                                          ("lrt", 5, 2, 4)])
+def test_group_of_steps_dealt_to_ranks_is_the_steps(lt, E, G, world):
+    """N > 1 with several steps per launch (ensemble.group_share): the G * E draws of a group, draw-major, in `world` contiguous
+    ranges -- whole draws on whole batches; a rank's range may start and end in the middle of a step.  Every rank's logits are
+    bitwise the slabs the single steps compute; the ranks' blocks combined by one log-sum-exp are the steps' results; the KL
+    shares add up.  (All ranks simulated on this device; the collective itself: test_gpu_rccl.py.)"""
+    import math
+    from bbb_hip import ensemble, rng, zoo
+    torch.manual_seed(0)
+    net = zoo.getModel("alexnet", 3, 10, P.CONFIG_PRIORS, lt, "softplus").cuda()
+    rng.assign_stream_ids(net)
+    B = 64
+    xs = [torch.rand(B, 3, 32, 32, device="cuda") for _ in range(G)]
+    seed, call0 = 21, 300
+    with torch.no_grad():
+        ref_logits = [ensemble._mc_logits_chwn(net, xs[g], E, seed, call0 + g * E)[0] for g in range(G)]
+        ref = [ensemble._local_lse(net, xs[g], E, seed, call0 + g * E, E) for g in range(G)]
+        blocks = torch.full((world, G * B, 10), -float("inf"), device="cuda")
+        kl_sum = 0.0
+        covered = 0
+        for rank in range(world):
+            lo, hi, g_lo, n_gl, off = ensemble.group_share(E, G, rank, world)
+            if hi <= lo:
+                continue
+            covered += hi - lo
+            xl = torch.cat(xs[g_lo:g_lo + n_gl])
+            lg = ensemble._mc_logits_chwn(net, xl, hi - lo, seed, call0 + lo, share=(E, off))[0]
+            for e in range(hi - lo):
+                d = lo + e
+                assert torch.equal(lg[e], ref_logits[d // E][d % E]), (rank, e)
+            lse, kl1 = ensemble._local_lse(net, xl, hi - lo, seed, call0 + lo, 0, share=(E, off))
+            assert lse.shape == (n_gl * B, 10)
+            blocks[rank, g_lo * B:(g_lo + n_gl) * B] = lse
+            kl_sum = kl_sum + kl1 * float(hi - lo)
+    assert covered == G * E
+    got = torch.logsumexp(blocks, dim=0) - math.log(E)
+    want = torch.cat([r[0] for r in ref])
+    assert torch.allclose(got, want, rtol=0, atol=3e-6 * max(1.0, float(want.abs().max())))
+    assert abs(float(kl_sum) / G - E * float(ref[0][1])) <= 1e-6 * abs(E * float(ref[0][1]))
