@@ -238,6 +238,27 @@ def test_draw_ranges_partition_the_ensemble():
             assert max(sizes) - min(sizes) <= 1
 
 
+def test_group_shares_partition_the_group_of_steps():
+    """ensemble.group_share: the steps * num_ens draws of a group, draw-major, in `world` contiguous ranges; what a rank is told
+    about its range (first local step, local steps, offset into the first one) is consistent with the range, and the per-step
+    KL shares add up to steps * num_ens forwards."""
+    from bbb_hip.ensemble import group_share
+    for E in (1, 3, 10):
+        for G in (1, 2, 4, 5):
+            for world in (1, 2, 3, 8, 64):
+                seen = []
+                for r in range(world):
+                    lo, hi, g_lo, n_gl, off = group_share(E, G, r, world)
+                    if hi <= lo:
+                        assert n_gl == 0
+                        continue
+                    assert g_lo == lo // E and off == lo % E and 0 <= off < E
+                    assert n_gl == -(-(hi - lo + off) // E) and g_lo + n_gl <= G
+                    assert (hi - 1) // E == g_lo + n_gl - 1
+                    seen += list(range(lo, hi))
+                assert seen == list(range(G * E))
+
+
 def test_conv_flops_accounting():
     from bbb_hip.ensemble import conv_flops
     # AlexNet/CIFAR bs=512 per draw (SURVEY.md section 8a): im2col 1.52 / 5.03 / 2.72 / 3.62 / 1.21 GFLOP
