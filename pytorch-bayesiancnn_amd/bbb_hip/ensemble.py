@@ -1024,13 +1024,17 @@ class GraphedMC:
     lane's stream and replays a second small graph for the reduction -- three host calls per step, which matters when 8 ranks
     leave each GPU only ~0.1 ms of work per step.
     step() returns (log_outputs [B, C], kl): buffers overwritten by the lane's next replay.
-    steps > 1 (single process, batch-innermost path): the graph holds `steps` consecutive steps -- `steps` batches, each with
+    steps > 1 (batch-innermost path): the graph holds `steps` consecutive steps -- `steps` batches, each with
     its own num_ens weight draws and its own noise calls (step g, draw j = call g * num_ens + j), exactly what `steps` separate
     replays would compute -- as ONE set of launches of steps * num_ens slabs (a one-draw step of a small model is a chain of ~10
     launch-latency-bound kernels; and the 10-draw launches of the metric step are one or two rounds of workgroups whose ramp and
     tail cost ~13 % of the GEMM and ~10 us of fixed cost in the parameter pass: `steps` of them per launch amortise both).  step(x) then only stores the batch in the next slot and replays when the
     last slot is filled (flush() replays a partly filled group); the (log_outputs, kl) it returns are that slot's views of the
-    graph's output, valid once the group has been replayed and the lane's stream synchronised."""
+    graph's output, valid once the group has been replayed and the lane's stream synchronised.
+    steps > 1 WITH a process group: the steps * num_ens draws of the group are dealt to the ranks as contiguous ranges of whole
+    draws on whole batches (group_share) -- single-device-sized launches on every rank instead of batch slices -- and ONE
+    all_gather of [steps * B * C + 1] floats per group combines them; every rank gets every step's result; all ranks must call
+    step() / flush() in the same sequence."""
 
     def __init__(self, net, x, num_ens, streams=1, kl_mode="sum", lane=0, lanes=1, stream=None, seed_call=None, group=None,
                  precision="fp32", steps=1):
@@ -1191,6 +1195,8 @@ class GraphedMC:
         with ctx:
             if self.steps > 1:
                 g, B = self.slot, self.B
+                if x is not None and self.multi and not (self.hi > self.lo and self.g_lo <= g < self.g_lo + self.n_gl):
+                    x = None                                       # a batch none of this rank's draws reads
                 if x is not None:
                     if producer is not None:
                         self.stream.wait_stream(producer)
