@@ -506,7 +506,7 @@ def run_config(cfg, steps, warmup, pipeline, dev, group=None, world=1, want_roof
                 xg = x.repeat(n_gl, 1, 1, 1)
 
                 def one_pass(t):
-                    seed, call0 = rng.next_calls(G * E)
+                    seed, call0 = rng.next_calls(0)      # (not advanced: only rank 0 runs this, and the ranks' counters must stay equal)
                     ensemble._local_lse(net, xg, hi_u - lo_u, seed, call0 + lo_u, 0, timers=t, precision=prec, share=(E, g_off))
             elif G > 1:                                  # the launches of the timed region: G batches x E draws per launch
                 xg = x.repeat(G, 1, 1, 1)
@@ -516,7 +516,7 @@ def run_config(cfg, steps, warmup, pipeline, dev, group=None, world=1, want_roof
                     ensemble._local_lse(net, xg, E, seed, call0, E, timers=t, precision=prec, groups=G)
             elif multi:                                  # rank 0's share of the sharded step
                 def one_pass(t):
-                    seed, call0 = rng.next_calls(E)
+                    seed, call0 = rng.next_calls(0)      # (not advanced: see above)
                     if S > 1:
                         ensemble._local_lse(net, x, E, seed, call0, 0, timers=t, precision=prec, units=(S, lo_u, hi_u))
                     else:
