@@ -133,9 +133,10 @@ def test_grouped_steps_refuse_what_they_do_not_cover(env):
         env["ens"].GraphedPipeline(net, x[:6], 2, depth=2, steps_per_launch=4)      # B % 4 != 0: no batch-innermost path
 
 
-@pytest.mark.parametrize("lt,E,G,world", [("bbb", 10, 4, 8), ("bbb", 10, 4, 3), ("lrt", 4, 3, 2), ("bbb", 1, 4, 2), ("bbb", 3, 2, 8),
-                                          ("lrt", 5, 2, 4)])
-def test_group_of_steps_dealt_to_ranks_is_the_steps(lt, E, G, world):
+@pytest.mark.parametrize("lt,E,G,world,precision", [("bbb", 10, 4, 8, "fp32"), ("bbb", 10, 4, 3, "fp32"), ("lrt", 4, 3, 2, "fp32"),
+                                                    ("bbb", 1, 4, 2, "fp32"), ("bbb", 3, 2, 8, "fp32"), ("lrt", 5, 2, 4, "fp32"),
+                                                    ("bbb", 10, 4, 8, "bf16"), ("bbb", 5, 3, 4, "bf16x3")])
+def test_group_of_steps_dealt_to_ranks_is_the_steps(lt, E, G, world, precision):
     """N > 1 with several steps per launch (ensemble.group_share): the G * E draws of a group, draw-major, in `world` contiguous
     ranges -- whole draws on whole batches; a rank's range may start and end in the middle of a step.  Every rank's logits are
     bitwise the slabs the single steps compute; the ranks' blocks combined by one log-sum-exp are the steps' results; the KL
@@ -149,8 +150,8 @@ def test_group_of_steps_dealt_to_ranks_is_the_steps(lt, E, G, world):
     xs = [torch.rand(B, 3, 32, 32, device="cuda") for _ in range(G)]
     seed, call0 = 21, 300
     with torch.no_grad():
-        ref_logits = [ensemble._mc_logits_chwn(net, xs[g], E, seed, call0 + g * E)[0] for g in range(G)]
-        ref = [ensemble._local_lse(net, xs[g], E, seed, call0 + g * E, E) for g in range(G)]
+        ref_logits = [ensemble._mc_logits_chwn(net, xs[g], E, seed, call0 + g * E, precision=precision)[0] for g in range(G)]
+        ref = [ensemble._local_lse(net, xs[g], E, seed, call0 + g * E, E, precision=precision) for g in range(G)]
         blocks = torch.full((world, G * B, 10), -float("inf"), device="cuda")
         kl_sum = 0.0
         covered = 0
@@ -160,11 +161,11 @@ def test_group_of_steps_dealt_to_ranks_is_the_steps(lt, E, G, world):
                 continue
             covered += hi - lo
             xl = torch.cat(xs[g_lo:g_lo + n_gl])
-            lg = ensemble._mc_logits_chwn(net, xl, hi - lo, seed, call0 + lo, share=(E, off))[0]
+            lg = ensemble._mc_logits_chwn(net, xl, hi - lo, seed, call0 + lo, share=(E, off), precision=precision)[0]
             for e in range(hi - lo):
                 d = lo + e
                 assert torch.equal(lg[e], ref_logits[d // E][d % E]), (rank, e)
-            lse, kl1 = ensemble._local_lse(net, xl, hi - lo, seed, call0 + lo, 0, share=(E, off))
+            lse, kl1 = ensemble._local_lse(net, xl, hi - lo, seed, call0 + lo, 0, share=(E, off), precision=precision)
             assert lse.shape == (n_gl * B, 10)
             blocks[rank, g_lo * B:(g_lo + n_gl) * B] = lse
             kl_sum = kl_sum + kl1 * float(hi - lo)
