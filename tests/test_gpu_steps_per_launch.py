@@ -139,7 +139,7 @@ def test_grouped_steps_refuse_what_they_do_not_cover(env):
 def test_group_of_steps_dealt_to_ranks_is_the_steps(lt, E, G, world, precision):
     """N > 1 with several steps per launch (ensemble.group_share): the G * E draws of a group, draw-major, in `world` contiguous
     ranges -- whole draws on whole batches; a rank's range may start and end in the middle of a step.  Every rank's logits are
-    bitwise the slabs the single steps compute; the ranks' blocks combined by one log-sum-exp are the steps' results; the KL
+    the slabs the single steps compute (fp32 kernels: bitwise); the ranks' blocks combined by one log-sum-exp are the steps' results; the KL
     shares add up.  (All ranks simulated on this device; the collective itself: test_gpu_rccl.py.)"""
     import math
     from bbb_hip import ensemble, rng, zoo
@@ -164,7 +164,12 @@ def test_group_of_steps_dealt_to_ranks_is_the_steps(lt, E, G, world, precision):
             lg = ensemble._mc_logits_chwn(net, xl, hi - lo, seed, call0 + lo, share=(E, off), precision=precision)[0]
             for e in range(hi - lo):
                 d = lo + e
-                assert torch.equal(lg[e], ref_logits[d // E][d % E]), (rank, e)
+                want_e = ref_logits[d // E][d % E]
+                if precision == "fp32":                      # the fp32 kernels: same bits at every launch size
+                    assert torch.equal(lg[e], want_e), (rank, e)
+                else:                                        # bf16 / split-bf16 pick their kernel form by launch size: same values
+                    tol = (2e-2 if precision == "bf16" else 2e-6) * float(want_e.abs().max())
+                    assert torch.allclose(lg[e], want_e, rtol=0, atol=tol), (rank, e)
             lse, kl1 = ensemble._local_lse(net, xl, hi - lo, seed, call0 + lo, 0, share=(E, off), precision=precision)
             assert lse.shape == (n_gl * B, 10)
             blocks[rank, g_lo * B:(g_lo + n_gl) * B] = lse
@@ -172,5 +177,5 @@ def test_group_of_steps_dealt_to_ranks_is_the_steps(lt, E, G, world, precision):
     assert covered == G * E
     got = torch.logsumexp(blocks, dim=0) - math.log(E)
     want = torch.cat([r[0] for r in ref])
-    assert torch.allclose(got, want, rtol=0, atol=3e-6 * max(1.0, float(want.abs().max())))
+    assert torch.allclose(got, want, rtol=0, atol=(3e-2 if precision == "bf16" else 3e-6) * max(1.0, float(want.abs().max())))
     assert abs(float(kl_sum) / G - E * float(ref[0][1])) <= 1e-6 * abs(E * float(ref[0][1]))
