@@ -202,6 +202,9 @@ int fill(const bbb_conv_desc_t* d, PConvArgs& a) {
 // launches of more 64-image items than this run the in-workgroup form of a layer's split (measured, profiles/r03_notes.md
 // section 2 and r04_notes.md: above ~400 items the cross-workgroup form only adds partial-tile traffic; LRT items carry two
 // accumulator sets and their in-workgroup form runs at 3 waves per SIMD, so the crossover sits higher)
+#ifndef PCONV_ILV_MAX
+#define PCONV_ILV_MAX 12000          // launches of at most this many items interleave their staging loads with the MFMAs (see launch())
+#endif
 #ifndef PCONV_SPLIT_MAX
 #define PCONV_SPLIT_MAX 384
 #endif
@@ -240,7 +243,7 @@ int launch(PConvArgs& a, int draws, hipStream_t st) {
     a.per_xcd = (int32_t)per;
     // staging loads interleaved with the MFMAs (ILV): round 1 measured it a loss beyond ~1.5 rounds of workgroups; re-measured in
     // round 3 on the current kernel (profiles/r03_notes.md section 3) it is a 1-2 % gain up to ~12k items, one or three steps in flight
-    const bool ilv = items <= 12000;
+    const bool ilv = items <= PCONV_ILV_MAX;
     const dim3 grid((unsigned)blocks), block(kThreads);
     if (a.ksplit > 1) {
         // the same summation order inside ONE workgroup per item (pconv_body.cuh, SEQ): no scratch, no extra traffic
