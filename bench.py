@@ -18,10 +18,12 @@ Order of a run: CPU baseline (GPU idle, ~20 s) -> graphs built -> K steps timed 
 `value`) -> `preheat_ms` of the same replays, untimed (the part clocks up under load; a 20-step region is 13 ms) -> W warm-up
 steps -> barrier + sync -> EXACTLY K timed steps -> sync + barrier.
 
-N > 1 is STRONG scaling of the metric's workload: the same 512 images x 10 draws, cut into (draw x batch-slice) work
-units dealt evenly over the ranks (ensemble.shard_plan; 8 ranks: 40 quarter-batch units, 5 each), every rank sampling
-only the weight sets its units touch, ONE all_gather of [B*C + 1] floats per step over RCCL.  value = 512 * 10 / step
-time.  (`weak_scaling`: a short secondary run with 10 draws PER rank, reported next to it.)
+N > 1 is STRONG scaling of the metric's workload, with the same launch structure: the 4 x 10 draws of a group of four steps (each
+step the same 512 images x 10 draws) are dealt to the ranks as contiguous ranges of WHOLE draws on whole batches
+(ensemble.group_share; 8 ranks: 5 draws each, a step's draws on two ranks), every rank sampling only the weight sets its draws
+use, ONE all_gather of [4 * B*C + 1] floats per group over RCCL, recorded into the lane's hipGraph.  value = 512 * 10 / time per
+step.  `--steps-per-launch 1` shards ONE step as (draw x batch-slice) work units instead (ensemble.shard_plan; 8 ranks: 40
+quarter-batch units, 5 each).  (`weak_scaling`: a short secondary run with 10 draws PER rank, reported next to it.)
 
 Output: the LAST line is the contract's JSON object, kept under 2000 characters, with every judged number as a scalar inside
 `roofline` / `cpu_baseline` (the driver's record keeps those two objects' scalars):
@@ -743,10 +745,10 @@ def main():
     ap.add_argument("--no-roofline", action="store_true",
                     help="skip the per-launch roofline passes (profiling runs: the trace then ends with the timed region's graph replays)")
     ap.add_argument("--pipeline", type=int, default=None,
-                    help="independent graphs in flight (hipGraph lanes on separate streams); default 2 (with 4 steps per launch), "
-                         "3 with --steps-per-launch 1, 4 when N > 1 (a rank's share of a step is a few small launches)")
+                    help="independent graphs in flight (hipGraph lanes on separate streams); default by the draws one rank's launch "
+                         "holds: 2 from 30 draws (N = 1, 4 steps per launch), 3 from 10, else 4 (8 ranks: 5 draws per launch)")
     ap.add_argument("--steps-per-launch", type=int, default=None,
-                    help="consecutive Monte-Carlo steps per graph launch (N = 1 only); default 4: measured 0.635 ms per step with 2 lanes "
+                    help="consecutive Monte-Carlo steps per graph launch; default 4: N = 1 measured 0.635 ms per step with 2 lanes "
                          "against 0.650 for one step per launch x 3 lanes (profiles/r04_steps_per_launch_sweep.txt)")
     ap.add_argument("--preheat-ms", type=float, default=400.0, help="untimed replays of the timed graphs before the warm-up steps")
     ap.add_argument("--config", default="metric", choices=list(CONFIGS), help="which BASELINE configuration is the reported value")
