@@ -1040,8 +1040,10 @@ def main():
             print(ln, flush=True)
 
 
-# algorithmic operand + output bytes of the six GEMM launches of one metric step: 185.0 MB read + 209.9 MB written
-ALGORITHMIC_GEMM_BYTES = 394.9e6
+# algorithmic operand + output bytes of the six GEMM launches of one metric step: 185.0 MB read + 147.0 MB
+# written -- conv1 writes its POOLED map (pooling in the launch: 21.0 MB instead of 83.9; 394.9 MB in total with a separate pool1
+# launch, which then reads 83.9 MB and writes 21.0 MB more)
+ALGORITHMIC_GEMM_BYTES = 332.0e6
 
 
 if __name__ == "__main__":

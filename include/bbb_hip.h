@@ -165,6 +165,13 @@ typedef struct bbb_conv_desc {
     int32_t x_unit_off;   /* with x_unit_div = D > 1: output slab e reads input slab (e + x_unit_off) / D, 0 <= x_unit_off < D -- a
                              rank's share of a GROUP of steps starts in the middle of a step (draws x_unit_off .. D-1 of its first
                              step); x then holds ceil((draws + x_unit_off) / D) slabs and draws need not be a multiple of D. */
+    int32_t pool;         /* 1 (bbb_conv2d_chwn_fwd only): the layer is followed by [activation ->] MaxPool2d(kernel 2, stride 2)
+                             and the launch writes the POOLED map y[draws][cout][ho/2][wo/2][batch] -- one workgroup walks the four
+                             conv pixels of a pooling window and keeps the running maximum of act(conv + bias) in registers; bit
+                             for bit bbb_maxpool_chwn(bbb_conv2d_chwn_fwd(...), 2, 2).  Needs even ho and wo and a layer without a
+                             split contraction (bbb_conv2d_chwn_splitk_scratch reports k_split 1), else BBB_EINVAL; items are four
+                             times fewer and four times longer, so it pays for launches that still spread evenly over the chip
+                             (the callers decide: bbb_hip/ops.py pool_fusion_ok).  0: none. */
 } bbb_conv_desc_t;
 
 /*

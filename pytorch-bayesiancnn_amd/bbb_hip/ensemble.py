@@ -480,9 +480,18 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
                     fl = conv_flops(B, *h5.shape[-4:-1], w.shape[1], w.shape[3], w.shape[4], *geom, Es) if timers is not None else None
                     dst = logits_buf[e0:e1] if (logits_buf is not None and i == last_bayes and not is_conv) else None
                     o_s3 = s3_chain and i != last_bayes          # intermediate layers hand their output on already split
-                    y = _run(timers, "conv_gemm", fl, lambda h5=h5, w=w, b=b, geom=geom, act=act, dst=dst, ukw2=ukw2, s3=s3, o_s3=o_s3:
-                             ops.conv2d_chwn_forward(h5, w, b, *geom, act=act, out=dst, bf16x3=bf16x3, x_s3=s3, out_s3=o_s3, **ukw2))
+                    # [activation ->] MaxPool2d(2, 2) after a conv layer: one launch with it when the launch is large enough
+                    # (ops.pool_fusion_ok; same bits as the separate pooling launch)
+                    pool_at = i + (2 if act is not None else 1)
+                    pool_mod = children[pool_at] if pool_at < len(children) and isinstance(children[pool_at], nn.MaxPool2d) else None
+                    fuse_pool = (pool_mod is not None and is_conv and not s3 and not o_s3 and bf16x3 is None and
+                                 ops.pool_fusion_ok(tuple(h5.shape), tuple(w.shape), *geom, Es, pool_mod))
+                    y = _run(timers, "conv_gemm", fl, lambda h5=h5, w=w, b=b, geom=geom, act=act, dst=dst, ukw2=ukw2, s3=s3, o_s3=o_s3, fuse_pool=fuse_pool:
+                             ops.conv2d_chwn_forward(h5, w, b, *geom, act=act, out=dst, bf16x3=bf16x3, x_s3=s3, out_s3=o_s3,
+                                                     pool=fuse_pool, **ukw2))
                     s3 = o_s3
+                    if fuse_pool:
+                        i += 1                                   # the pooling module is done too
                 else:
                     w_var, b_var = variances[mod]
                     w_mu = mod.W_mu
@@ -1039,7 +1048,7 @@ class GraphedMC:
     def __init__(self, net, x, num_ens, streams=1, kl_mode="sum", lane=0, lanes=1, stream=None, seed_call=None, group=None,
                  precision="fp32", steps=1):
         _lib.require_device(x)
-        self.steps, self.slot = int(steps), 0
+        self.steps, self.slot, self.lanes = int(steps), 0, int(lanes)
         if self.steps > 1:
             with torch.no_grad():
                 if not units_ok(net, x):
@@ -1136,6 +1145,10 @@ class GraphedMC:
         self.out_kl.copy_(kl if self.kl_mode == "sum" else kl / self.num_ens)
 
     def _step_body(self, streams):
+        with ops.overlapped_launches(self.lanes > 1):        # (launch-shape choices that depend on what runs beside the launch)
+            return self._step_body_inner(streams)
+
+    def _step_body_inner(self, streams):
         n_loc = self.hi - self.lo
         single = self.world == 1 and not self._force_combine
         if single:

@@ -275,8 +275,73 @@ def _desc_chwn(x, w, stride, padding, dilation, draws, x_shared, w_shared, act):
     return d, ho, wo
 
 
+pool_fusion = True          # a conv layer followed by [activation ->] MaxPool2d(2, 2) may run as ONE launch (bbb_conv_desc_t::pool)
+pool_fuse_min_items = 1536  # a launch with nothing else in flight: only when it still has this many (pooled pixel, 64-channel tile,
+pool_fuse_imbalance = 1.07  # 128-image tile, draw) items and they spread over the 256 CUs to within this factor (4x longer items)
+launches_overlap = False    # set (overlapped_launches) while a caller enqueues work that runs beside other lanes' kernels: the
+                            # under-filled tail of a fused launch is then filled by them, and fusing pays from ~2 items per CU on
+                            # (measured, profiles/r04_notes.md section 7: -2 to -3 % per step at 10 draws x 3 lanes, +4.5 % with one
+                            # lane; at 5 draws per launch it no longer does)
+pool_fuse_min_items_overlapped = 400
+pool_fuse_weight_budget = 1 << 20   # bytes of weight tiles concurrently live per XCD that a fused launch may have (see pool_fusion_ok)
+
+
+class overlapped_launches:
+    """Context: the launches enqueued inside run concurrently with other streams' kernels (a lane of a GraphedPipeline)."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global launches_overlap
+        self.prev, launches_overlap = launches_overlap, self.on
+        return self
+
+    def __exit__(self, *a):
+        global launches_overlap
+        launches_overlap = self.prev
+        return False
+
+
+def pool_fusion_ok(x_shape, w_shape, stride, padding, dilation, draws, pool_module=None):
+    """Should conv2d_chwn_forward(..., pool=True) replace conv + maxpool_chwn(2, 2) for this launch?  Same bits either way; the
+    fused launch saves the pooling launch and 3/4 of the layer's output traffic, but its items are four times fewer and four
+    times longer: chosen when other lanes' kernels run beside it (launches_overlap), else only when its items still fill the chip
+    evenly (measured: profiles/r04_notes.md section 7).
+    x_shape [*, Cin, H, W, B], w_shape [*, Cout, Cin, kh, kw]; pool_module: the nn.MaxPool2d that follows (checked for 2 / 2)."""
+    if not pool_fusion or gemm_mode != "fp32":
+        return False
+    if pool_module is not None:
+        pr = lambda v: (v, v) if isinstance(v, int) else tuple(v)
+        if pr(pool_module.kernel_size) != (2, 2) or pr(pool_module.stride if pool_module.stride is not None else 2) != (2, 2) or \
+                pr(pool_module.padding) != (0, 0) or pr(pool_module.dilation) != (1, 1) or pool_module.ceil_mode or \
+                getattr(pool_module, "return_indices", False):
+            return False
+    B = x_shape[-1]
+    xm = torch.empty((1,) + tuple(x_shape[-4:]), device="meta")
+    wm = torch.empty((1,) + tuple(w_shape[-4:]), device="meta")
+    d, ho, wo = _desc_chwn(xm, wm, stride, padding, dilation, int(draws), False, False, None)
+    if ho % 2 or wo % 2 or B % 4:
+        return False
+    ks = ctypes.c_int32(1)
+    _lib.lib().bbb_conv2d_chwn_splitk_scratch(ctypes.byref(d), 0, ctypes.byref(ks))
+    if ks.value > 1:
+        return False
+    # the weight tiles live in one XCD's L2 at a time: an XCD runs 128 workgroups = 128 / (pooled pixels x image tiles) groups of
+    # items that share a (draw, 64-channel) weight tile -- four times the unfused launch's, whose groups hold four times the items.
+    # AlexNet conv2 on CIFAR maps (4 pooled pixels x 4 tiles: 8 tiles of 410 KB) overflowed the 4 MB L2: 404 MB fetched per step for
+    # 25 MB of operands, and no time gained (profiles/r04_notes.md section 7)
+    per_group = (ho // 2) * (wo // 2) * -(-B // 128)
+    if max(1, 128 // per_group) * 64 * w_shape[-3] * w_shape[-2] * w_shape[-1] * 4 > pool_fuse_weight_budget:
+        return False
+    items = int(draws) * per_group * -(-w_shape[-4] // 64)
+    if launches_overlap:
+        return items >= pool_fuse_min_items_overlapped
+    return items >= pool_fuse_min_items and -(-items // 256) * 256 <= pool_fuse_imbalance * items
+
+
 def conv2d_chwn_forward(x, w, bias, stride=1, padding=0, dilation=1, act=None, out=None, units=None, n_units=None,
-                        x_per_slice=False, x_div=1, bf16x3=None, x_s3=False, out_s3=False, x_off=0):
+                        x_per_slice=False, x_div=1, bf16x3=None, x_s3=False, out_s3=False, x_off=0, pool=False):
     """Batch-innermost conv for the ensemble path.  x: [E|1, Cin, H, W, B] (B % 4 == 0); w: [E|1, Cout, Cin, kh, kw];
     bias [E|1, Cout] or None -> y [E, Cout, Ho, Wo, B].  Padding taps are skipped, not multiplied.
     Work units (ensemble sharding): units = (S, off), n_units = U output slabs; w / bias hold the weight sets of the draws
@@ -286,7 +351,10 @@ def conv2d_chwn_forward(x, w, bias, stride=1, padding=0, dilation=1, act=None, o
     e reads slab (e + x_off) // D -- a rank's share of a group of steps that starts in the middle of a step.
     bf16x3: True / False = run this launch on the split-bf16 kernel or not; None (default) = ops.gemm_mode decides.
     x_s3 / out_s3 (split-bf16 kernel only, B % 8 == 0): the input / output travels in the split activation format S3 -- a bf16
-    tensor [E|1, 3, C, H, W, B] holding the hi / mid / lo pieces of the same fp32 values (s3_from_f32 / s3_to_f32)."""
+    tensor [E|1, 3, C, H, W, B] holding the hi / mid / lo pieces of the same fp32 values (s3_from_f32 / s3_to_f32).
+    pool = True (fp32 kernel, layers without a split contraction, even Ho and Wo): the launch also applies MaxPool2d(2, 2) to the
+    activated output -> y [E, Cout, Ho/2, Wo/2, B], bit for bit maxpool_chwn(conv2d_chwn_forward(...), 2, 2) (pool_fusion_ok says
+    when that pays)."""
     require_device(w, bias)
     require_device(x, dtype=torch.bfloat16 if x_s3 else torch.float32)
     x, w = x.contiguous(), w.contiguous()
@@ -317,6 +385,11 @@ def conv2d_chwn_forward(x, w, bias, stride=1, padding=0, dilation=1, act=None, o
     if x_s3:
         d.x_draw_stride *= 3                                   # bf16 elements per S3 slab
     B = x5.shape[4]
+    if pool:
+        if x_s3 or out_s3 or bf16x3 or ho % 2 or wo % 2:
+            raise _lib.BBBHipError("pool=True: fp32 kernel only, even output height and width")
+        d.pool = 1
+        ho, wo = ho // 2, wo // 2
     shape = (E, 3, w.shape[1], ho, wo, B) if out_s3 else (E, w.shape[1], ho, wo, B)
     odt = torch.bfloat16 if out_s3 else torch.float32
     if out_s3 and B % 8:
@@ -328,13 +401,15 @@ def conv2d_chwn_forward(x, w, bias, stride=1, padding=0, dilation=1, act=None, o
             raise _lib.BBBHipError("out= must be a contiguous tensor of the output's size and dtype")
         y = out.view(shape)
     with on_device(x.device):
-        if x_s3 or out_s3 or ((bf16x3 if bf16x3 is not None else gemm_mode == "bf16x3")
+        if x_s3 or out_s3 or (not pool and (bf16x3 if bf16x3 is not None else gemm_mode == "bf16x3")
                               and E * ho * wo * -(-w.shape[1] // 64) * -(-B // 128) >= bf16x3_min_workgroups):
             check(_lib.lib().bbb_conv2d_chwn_bf16x3_fwd(ctypes.byref(d), x.data_ptr(), w.data_ptr(), ptr(bias), y.data_ptr(),
                                                         (1 if x_s3 else 0) | (2 if out_s3 else 0), cur_stream(x.device)),
                   "bbb_conv2d_chwn_bf16x3_fwd")
             return y
         ks, scr = _split_scratch(d, False, x.device)
+        if ks > 1 and pool:
+            raise _lib.BBBHipError("pool=True: this layer's contraction is split (conv + maxpool_chwn instead)")
         if ks > 1:
             check(_lib.lib().bbb_conv2d_chwn_splitk_fwd(ctypes.byref(d), x.data_ptr(), w.data_ptr(), ptr(bias), y.data_ptr(), ks,
                                                         ptr(scr), 0 if scr is None else scr.numel(), cur_stream(x.device)),

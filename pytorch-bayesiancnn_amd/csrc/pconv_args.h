@@ -26,5 +26,6 @@ struct PConvArgs {
     float* part;         // [items][ksplit][sets][64][BM] partial accumulator tiles
     int32_t px_run;      // pconv_bf16_smallk_kernel: consecutive output pixels per workgroup
     int64_t x_ps, y_ps;  // pconv_bf16x3 S3 operands: elements between the hi / mid / lo planes of an activation slab
+    int32_t pool;        // bbb_conv_desc_t::pool: the launch also applies MaxPool2d(2, 2) to the activated output (pconv_body.cuh, POOL)
     int32_t x_div, x_off; // bbb_conv_desc_t::x_unit_div / x_unit_off: output slab e reads input slab (e + x_off) / x_div (x_div <= 1: slab e)
 };

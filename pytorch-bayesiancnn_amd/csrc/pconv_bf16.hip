@@ -687,6 +687,7 @@ extern "C" int bbb_conv2d_chwn_bf16_fwd(const bbb_conv_desc_t* d, const void* x,
     if (d->unit_div < 0 || d->unit_off < 0 || d->x_unit_mod < 0 || (d->unit_div > 1 && d->unit_off >= d->unit_div) ||
         (d->x_unit_mod > 0 && d->x_unit_mod != d->unit_div) || d->w_row_pitch != 0)
         return BBB_EINVAL;
+    if (d->pool != 0) return BBB_EINVAL;                  // pooling in the launch: the fp32 BBB kernel only
     if (d->x_unit_div < 0 || d->x_unit_off < 0 || (d->x_unit_div > 1 && (d->unit_div > 1 || d->x_unit_off >= d->x_unit_div)) ||
         (d->x_unit_div <= 1 && d->x_unit_off != 0))
         return BBB_EINVAL;

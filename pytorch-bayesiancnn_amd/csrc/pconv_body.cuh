@@ -34,7 +34,13 @@ constexpr int TPC = KCH / BK;            // tiles per chunk
 // without scratch, tickets or partial-tile traffic.  This is what makes the split a property of the LAYER (the plan depends on
 // its geometry only): launches too large to profit from a cross-workgroup split run SEQ, small ones SPLIT, same bits -- a draw
 // computed alone, inside a 10-draw launch, as a work unit of a sharded step or as one of G steps per launch is the same number.
-constexpr int kPlain = 0, kSplit = 1, kSeq = 2;
+// POOL (MODE 3): the layer is followed by [activation ->] MaxPool2d(2, 2): the item is a POOLED pixel and walks the four
+// conv pixels of its window one after the other -- per pixel the unchanged k loop from a zeroed accumulator, then
+// running_max = max(running_max, act(acc + bias)) in accumulation registers -- and stores one pooled row instead of four: the
+// pooling launch and three quarters of the output traffic disappear, the matrix work is exactly the unfused launch's (no tap is
+// multiplied that the unfused launch does not multiply), and the result is bit for bit pool(act(conv + bias)) of the separate
+// launches (max is exact).  Items are four times fewer and four times longer: for launches that still fill the chip evenly.
+constexpr int kPlain = 0, kSplit = 1, kSeq = 2, kPool = 3;
 
 // SEQ keeps its running totals in ACCUMULATION registers through inline asm: they are touched three times per item, and left to
 // the register allocator they became 28-55 extra VGPRs (one resident workgroup less per CU: +5-8 % per launch, measured);
@@ -49,6 +55,8 @@ template <int BM, bool LRT, bool ILV, int MODE = kPlain>
 __device__ __forceinline__ void pconv_item(const PConvArgs& p, const int64_t item, const int ks = 0) {
     constexpr bool SPLIT = MODE == kSplit;
     constexpr bool SEQ = MODE == kSeq;
+    constexpr bool POOL = MODE == kPool;
+    static_assert(!POOL || !LRT, "the pooled form exists for the BBB kernel only");
     constexpr int LDX = BM + 4;
     constexpr int NT = (BM >= 128) ? 2 : 1;              // 32-channel MFMA tiles per wave
     constexpr int MT = (BM == 256) ? 2 : 1;              // 32-image MFMA tiles per wave
@@ -65,6 +73,7 @@ __device__ __forceinline__ void pconv_item(const PConvArgs& p, const int64_t ite
     __shared__ float Ws[1][WSETS][BK * LDW];
     __shared__ int32_t kt_w[2][KCH];   // (k_eff -> weight offset, x row) for a chunk of 256 k_eff = 8 tiles,
     __shared__ int32_t kt_x[2][KCH];   // filled by all 256 threads at once, double buffered
+    __shared__ float sbias[POOL ? BN : 1];   // POOL: the item's 64 bias values (read once per window pixel, in the MFMA layout)
     // (static LDS arrays, one set per instantiation: a kernel should call ONE instantiation of this function)
 
     // ---- item -> (draw, channel tile, pixel, batch tile) ----
@@ -93,20 +102,35 @@ __device__ __forceinline__ void pconv_item(const PConvArgs& p, const int64_t ite
     const int n0 = (g - e * p.Ntiles) * BN;
     const int pix = j / p.nbt;
     const int b0 = (j - pix * p.nbt) * BM;
-    const int oh = pix / p.Wo, ow = pix - oh * p.Wo;
-    // in-bounds tap ranges for this pixel
-    const int ihb = oh * p.sh - p.ph, iwb = ow * p.sw - p.pw;
-    int r_lo = ihb < 0 ? (-ihb + p.dh - 1) / p.dh : 0;
-    int q_lo = iwb < 0 ? (-iwb + p.dw - 1) / p.dw : 0;
-    int r_hi = (p.H - 1 - ihb) >= 0 ? (p.H - 1 - ihb) / p.dh + 1 : 0;
-    int q_hi = (p.W - 1 - iwb) >= 0 ? (p.W - 1 - iwb) / p.dw + 1 : 0;
-    r_hi = r_hi < p.kh ? r_hi : p.kh;
-    q_hi = q_hi < p.kw ? q_hi : p.kw;
-    const int nr = r_hi > r_lo ? r_hi - r_lo : 0;
-    const int nq = q_hi > q_lo ? q_hi - q_lo : 0;
-    const int nrq = nr * nq;
-    const int Keff = p.Cin * nrq;
-    const int ntiles = (Keff + BK - 1) / BK;
+    // POOL: pix is the POOLED pixel; its window's conv pixels are (2 poh + wy, 2 pow + wx)
+    const int Wq = POOL ? p.Wo / 2 : p.Wo;
+    const int oh0 = pix / Wq, ow0 = pix - oh0 * Wq;
+    // in-bounds tap ranges of the current conv pixel (POOL: re-set per window pixel; all wave-uniform)
+    int ihb, iwb, r_lo, q_lo, nq, nrq, Keff, ntiles;
+    float inv_nrq, inv_nq;
+    auto set_pixel = [&](int oh, int ow) {
+        if constexpr (POOL) {            // re-set inside a loop: keep the pixel's state in scalar registers
+            oh = __builtin_amdgcn_readfirstlane(oh);
+            ow = __builtin_amdgcn_readfirstlane(ow);
+        }
+        ihb = oh * p.sh - p.ph;
+        iwb = ow * p.sw - p.pw;
+        r_lo = ihb < 0 ? (-ihb + p.dh - 1) / p.dh : 0;
+        q_lo = iwb < 0 ? (-iwb + p.dw - 1) / p.dw : 0;
+        int r_hi = (p.H - 1 - ihb) >= 0 ? (p.H - 1 - ihb) / p.dh + 1 : 0;
+        int q_hi = (p.W - 1 - iwb) >= 0 ? (p.W - 1 - iwb) / p.dw + 1 : 0;
+        r_hi = r_hi < p.kh ? r_hi : p.kh;
+        q_hi = q_hi < p.kw ? q_hi : p.kw;
+        const int nr = r_hi > r_lo ? r_hi - r_lo : 0;
+        nq = q_hi > q_lo ? q_hi - q_lo : 0;
+        nrq = nr * nq;
+        Keff = p.Cin * nrq;
+        ntiles = (Keff + BK - 1) / BK;
+        // k_eff -> (ci, r, q) with float-reciprocal division + fix-up (exact for k_eff < 2^24)
+        inv_nrq = nrq > 0 ? 1.0f / (float)nrq : 0.0f;
+        inv_nq = nq > 0 ? 1.0f / (float)nq : 0.0f;
+    };
+    set_pixel(POOL ? 2 * oh0 : oh0, POOL ? 2 * ow0 : ow0);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -142,9 +166,6 @@ __device__ __forceinline__ void pconv_item(const PConvArgs& p, const int64_t ite
     float wregA[WSETS][8];
     f32x4 xregA[XPASS];
 
-    // k_eff -> (ci, r, q) with float-reciprocal division + fix-up (exact for k_eff < 2^24)
-    const float inv_nrq = nrq > 0 ? 1.0f / (float)nrq : 0.0f;
-    const float inv_nq = nq > 0 ? 1.0f / (float)nq : 0.0f;
     auto fill_chunk = [&](int chunk) {
         const int k = chunk * KCH + tid;
         uint32_t wo = kWInv, xo = kXInv;
@@ -208,7 +229,7 @@ __device__ __forceinline__ void pconv_item(const PConvArgs& p, const int64_t ite
 
     f32x16 acc[NT][MT];
     f32x16 accv[NT][MT];
-    float tot[SEQ ? NT : 1][SEQ ? MT : 1][16];           // SEQ: running total of the finished ranges' partial sums (AGPRs)
+    float tot[(SEQ || POOL) ? NT : 1][(SEQ || POOL) ? MT : 1][16];   // SEQ: running total of the finished ranges' partial sums; POOL: running maximum (AGPRs)
     float totv[(SEQ && LRT) ? NT : 1][(SEQ && LRT) ? MT : 1][16];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -218,6 +239,7 @@ __device__ __forceinline__ void pconv_item(const PConvArgs& p, const int64_t ite
             for (int r = 0; r < 16; ++r) {
                 acc[t][u][r] = 0.0f; accv[t][u][r] = 0.0f;
                 if constexpr (SEQ) { agpr_write(tot[t][u][r], 0.0f); if constexpr (LRT) agpr_write(totv[t][u][r], 0.0f); }
+                if constexpr (POOL) agpr_write(tot[t][u][r], -__builtin_inff());
             }
 
     const int lrow = lane & 31, lk = lane >> 5;
@@ -263,6 +285,16 @@ __device__ __forceinline__ void pconv_item(const PConvArgs& p, const int64_t ite
         }
     };
 
+    if constexpr (POOL) {
+        // the item's bias values, once (channels >= Cout and a launch without bias read as 0 from the buffer unit)
+        const __amdgpu_buffer_rsrc_t brs0 = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.bias ? p.bias + (int64_t)ew * p.b_ds : p.w), 0, p.bias ? p.Cout * 4 : 0, 0x00020000);
+        if (tid < BN) sbias[tid] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brs0, (uint32_t)(n0 + tid) * 4u, 0, 0));
+        __syncthreads();
+    }
+#pragma clang loop unroll(disable)
+    for (int wp = 0; wp < (POOL ? 4 : 1); ++wp) {
+    if (POOL && wp > 0) set_pixel(2 * oh0 + (wp >> 1), 2 * ow0 + (wp & 1));
     int t0 = 0, t1 = ntiles;
     if constexpr (SPLIT) {
         t0 = (int)((int64_t)ks * ntiles / p.ksplit);
@@ -325,6 +357,30 @@ __device__ __forceinline__ void pconv_item(const PConvArgs& p, const int64_t ite
                         if constexpr (LRT) accv[nt][mt][r] = agpr_read(totv[nt][mt][r]) + accv[nt][mt][r];
                     }
         }
+    }
+    if constexpr (POOL) {
+        // this window pixel is done: running maximum of act(conv + bias), accumulator back to zero for the next pixel
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float bn = sbias[wn + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const float v = bbb::apply_act(acc[nt][mt][r] + bn, p.act);
+                    agpr_write(tot[nt][mt][r], fmaxf(agpr_read(tot[nt][mt][r]), v));
+                    acc[nt][mt][r] = 0.0f;
+                }
+            }
+    }
+    }   // window pixels
+    if constexpr (POOL) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[nt][mt][r] = agpr_read(tot[nt][mt][r]);
     }
 
     if constexpr (SPLIT) {
@@ -431,9 +487,9 @@ __device__ __forceinline__ void pconv_item(const PConvArgs& p, const int64_t ite
 
     // ---- epilogue: rows = channels, lanes = images; bias via buffer loads, stores via buffer stores
     //      (out-of-range channel / image lanes get an out-of-range offset: no branches, no per-element waits) ----
-    const int HoWo = p.Ho * p.Wo;
+    const int HoWo = POOL ? (p.Ho / 2) * (p.Wo / 2) : p.Ho * p.Wo;    // POOL: rows of the pooled map; pix is the pooled pixel
     const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.bias ? p.bias + (int64_t)ew * p.b_ds : p.w), 0, p.bias ? p.Cout * 4 : 0, 0x00020000);
+        const_cast<float*>(p.bias ? p.bias + (int64_t)ew * p.b_ds : p.w), 0, (p.bias && !POOL) ? p.Cout * 4 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
         p.y + (int64_t)e * p.y_ds, 0, (int)((int64_t)p.Cout * HoWo * p.B * 4), 0x00020000);
     if constexpr (!LRT) {
@@ -460,7 +516,7 @@ __device__ __forceinline__ void pconv_item(const PConvArgs& p, const int64_t ite
                             const float bn = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brs, (uint32_t)n * 4u, 0, 0));
                             f32x4 v4 = *reinterpret_cast<const f32x4*>(&T[nl * 32 + b4]);
 #pragma unroll
-                            for (int c = 0; c < 4; ++c) v4[c] = bbb::apply_act(v4[c] + bn, p.act);
+                            for (int c = 0; c < 4; ++c) v4[c] = POOL ? v4[c] : bbb::apply_act(v4[c] + bn, p.act);   // (POOL: applied per window pixel)
                             const uint32_t off = ((bb < p.B) & (n < p.Cout)) ? (uint32_t)(((int64_t)n * HoWo + pix) * p.B + bb) * 4u : kOOB;
                             __builtin_amdgcn_raw_buffer_store_b128(
                                 __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(uint32_t)))) uint32_t, v4), yrs, off, 0, 0);

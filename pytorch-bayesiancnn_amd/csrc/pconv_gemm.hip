@@ -48,6 +48,17 @@ __global__ __launch_bounds__(kThreads) void pconv_gemm_kernel(const PConvArgs p)
     pconv_item<BM, LRT, ILV, SEQ ? kSeq : kPlain>(p, item);
 }
 
+// The layer with its MaxPool2d(2, 2) (pconv_body.cuh, POOL): items are pooled pixels.
+template <bool ILV>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void pconv_gemm_pool_kernel(const PConvArgs p) {
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7;
+    const int64_t item = (int64_t)xcd * p.per_xcd + (bid >> 3);
+    const int64_t item_end = (int64_t)(xcd + 1) * p.per_xcd;
+    if (item >= item_end || item >= (int64_t)p.G * p.Mtiles) return;
+    pconv_item<128, false, ILV, kPool>(p, item);
+}
+
 // Split contraction (pconv_body.cuh, SPLIT): block -> (item, k range).  The ksplit blocks of an item are consecutive, so they
 // land on the same XCD chunk as their item's weight-tile sharers.
 template <int BM, bool LRT, bool ILV>
@@ -196,6 +207,12 @@ int fill(const bbb_conv_desc_t* d, PConvArgs& a) {
         return BBB_EINVAL;
     a.unit_div = d->unit_div; a.unit_off = d->unit_div > 1 ? d->unit_off : 0; a.x_mod = d->x_unit_mod; a.b_off = d->b_offset;
     a.x_div = d->x_unit_div; a.x_off = d->x_unit_off;
+    if (d->pool != 0 && d->pool != 1) return BBB_EINVAL;
+    a.pool = d->pool;
+    if (a.pool) {
+        if ((ho & 1) || (wo & 1)) return BBB_EINVAL;
+        a.y_ds = (int64_t)d->cout * (ho / 2) * (wo / 2) * d->batch;
+    }
     return 0;
 }
 
@@ -219,6 +236,22 @@ int launch(PConvArgs& a, int draws, hipStream_t st) {
     // workgroups per CU, then 64.  A 256-image tile (64x64 per wave) exists but measured 5-10 % slower on every
     // AlexNet layer (3 instead of 4 workgroups per CU); the launcher never selects it.
     // LRT stages two weight tiles and keeps two accumulator sets: 64-wide only.
+    if (a.pool) {
+        // one item per POOLED pixel, 128-image tiles (the callers fuse large launches only)
+        if (LRT || a.ksplit > 1 || a.part != nullptr) return BBB_EINVAL;
+        a.nbt = (a.B + 127) / 128;
+        const int64_t mtp = (pixels / 4) * a.nbt;
+        const int64_t itp = (int64_t)a.G * mtp;
+        if (mtp > 0x7fffffffLL || itp > 0x7fffffffLL - 8) return BBB_ESHAPE;
+        a.Mtiles = (int)mtp;
+        const int64_t perp = (itp + 7) / 8;
+        a.per_xcd = (int32_t)perp;
+        // staging loads up front (ILV = false): with the running maximum in 32 more accumulation registers this form fits four
+        // workgroups per CU (60 + 64 registers) and the interleaved one does not; on launches this large the two forms of the plain
+        // kernel measure the same (profiles/r04_notes.md section 5)
+        hipLaunchKernelGGL((pconv_gemm_pool_kernel<false>), dim3((unsigned)(8 * perp)), dim3(kThreads), 0, st, a);
+        return (int)hipGetLastError();
+    }
     const int64_t nb128 = pixels * ((a.B + 127) / 128) * a.G;
     int bm = (LRT || nb128 < 768) ? 64 : 128;        // (round 3 re-measured 600 / 300: conv4 +10 %, conv5 +25 % slower with 128)
     const int64_t items64 = pixels * ((a.B + 63) / 64) * a.G;
@@ -360,7 +393,7 @@ extern "C" int bbb_conv2d_chwn_bf16x3_fwd(const bbb_conv_desc_t* d, const void* 
     PConvArgs a = {};
     const int rc = fill(d, a);
     if (rc != 0) return rc;
-    if (x == nullptr || w == nullptr || y == nullptr || (flags & ~3u) != 0) return BBB_EINVAL;
+    if (x == nullptr || w == nullptr || y == nullptr || (flags & ~3u) != 0 || a.pool) return BBB_EINVAL;
     if ((((uintptr_t)x | (uintptr_t)y) & 15u) != 0 || (((uintptr_t)w | (uintptr_t)bias) & 3u) != 0) return BBB_EALIGN;
     const bool xs3 = (flags & BBB_S3_IN) != 0, ys3 = (flags & BBB_S3_OUT) != 0;
     if ((xs3 || ys3) && d->batch % 8 != 0) return BBB_ESHAPE;           // S3 rows move as 16-byte vectors of 8 bf16
