@@ -308,13 +308,31 @@ __device__ __forceinline__ void pconv_item(const PConvArgs& p, const int64_t ite
         if ((c0 + 1) * KCH < Keff) fill_chunk(c0 + 1);
         store_tile(0, wregA, xregA);
         __syncthreads();
-        int seq_r = 1;                                                // SEQ: next range boundary = tile index seq_r * ntiles / ksplit
-        int seq_next = SEQ ? (int)((int64_t)seq_r * ntiles / p.ksplit) : 0;
-        for (int t = t0; t < t1; ++t) {
+        // SEQ: the ranges [r * ntiles / S, (r + 1) * ntiles / S) one after the other -- the tile loop (and its software pipeline:
+        // tile t + 1 is prefetched across a range boundary) is the plain one; BETWEEN two ranges the accumulator is added to the
+        // running total and zeroed (an empty range adds a zero partial, exactly as its SPLIT workgroup would)
+        const int nranges = SEQ ? p.ksplit : 1;
+        int t = t0;
+#pragma clang loop unroll(disable)
+        for (int sr = 0; sr < nranges; ++sr) {
+            const int tr1 = SEQ ? (int)((int64_t)(sr + 1) * ntiles / p.ksplit) : t1;
+#pragma clang loop unroll(disable)
+            for (; t < tr1; ++t) {
+                const bool more = (t + 1) < t1;
+                if (more) {
+                    if (ILV) load_addr(t + 1);                        // loads themselves are issued inside mma_tile()
+                    else     load_tile(t + 1, wregA, xregA);          // all loads up front (large launches)
+                }
+                // decode chunk c+1 early in chunk c (c >= c0 + 1; chunk c0 + 1 is decoded in the prologue): its buffer was last
+                // read by load_tile(TPC*c - 1), several barriers ago
+                if ((t % TPC) == 1 && t / TPC >= c0 + 1 && (t / TPC + 1) * KCH < Keff) fill_chunk(t / TPC + 1);
+                mma_tile(more);
+                __syncthreads();                                      // every wave is done reading the LDS stage
+                if (more) store_tile(0, wregA, xregA);
+                __syncthreads();
+            }
             if constexpr (SEQ) {
-                // ranges [r * ntiles / S, (r + 1) * ntiles / S): tile t opens range(s) seq_r.. when it reaches their first tile
-                // (an empty range contributes a zero partial, exactly as its SPLIT workgroup would)
-                while (seq_r < p.ksplit && t == seq_next) {
+                if (sr + 1 < nranges) {
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -328,25 +346,11 @@ __device__ __forceinline__ void pconv_item(const PConvArgs& p, const int64_t ite
                                     accv[nt][mt][r] = 0.0f;
                                 }
                             }
-                    ++seq_r;
-                    seq_next = (int)((int64_t)seq_r * ntiles / p.ksplit);
                 }
             }
-            const bool more = (t + 1) < t1;
-            if (more) {
-                if (ILV) load_addr(t + 1);                            // loads themselves are issued inside mma_tile()
-                else     load_tile(t + 1, wregA, xregA);              // all loads up front (large launches)
-            }
-            // decode chunk c+1 early in chunk c (c >= c0 + 1; chunk c0 + 1 is decoded in the prologue): its buffer was last
-            // read by load_tile(TPC*c - 1), several barriers ago
-            if ((t % TPC) == 1 && t / TPC >= c0 + 1 && (t / TPC + 1) * KCH < Keff) fill_chunk(t / TPC + 1);
-            mma_tile(more);
-            __syncthreads();                                          // every wave is done reading the LDS stage
-            if (more) store_tile(0, wregA, xregA);
-            __syncthreads();
         }
         if constexpr (SEQ) {
-            // the last range's partial sum is added last (ntiles > 0 here, so every boundary 1 .. ksplit-1 was passed above)
+            // the last range's partial sum is added last
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll

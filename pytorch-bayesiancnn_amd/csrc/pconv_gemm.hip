@@ -282,6 +282,8 @@ int launch(PConvArgs& a, int draws, hipStream_t st) {
         // the same summation order inside ONE workgroup per item (pconv_body.cuh, SEQ): no scratch, no extra traffic
         if constexpr (!LRT) {
             if (bm == 128) {
+                // (88-100 VGPRs + 64 accumulation registers = three workgroups per CU; held to four by amdgpu_waves_per_eu the
+                // prefetched tile spills around the range folds and the launch is 4-9 % slower: profiles/r04_notes.md section 4)
                 if (ilv) hipLaunchKernelGGL((pconv_gemm_kernel<128, false, true, true>), grid, block, 0, st, a);
                 else     hipLaunchKernelGGL((pconv_gemm_kernel<128, false, false, true>), grid, block, 0, st, a);
                 return (int)hipGetLastError();
