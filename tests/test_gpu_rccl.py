@@ -7,6 +7,8 @@ sharded into work units over RCCL: every rank's log_outputs / kl equal the singl
 log-sum-exp is the same arithmetic on every rank; vs the one-GPU tail to 3e-6).  This is the test that runs RCCL with N > 1 the
 day a multi-GPU box runs the suite.  (More than one rank per device is not something RCCL allows; world sizes 2-8 are also
 covered with gloo in test_host_cpu.py and with simulated ranks in test_gpu_sharding.py.)
+(3) The same worker with 2 and 3 real ranks on ONE device over gloo: both shardings (work units of one step; groups of four steps
+dealt out as whole draws) against the single-device step, through the eager collective protocol.
 Workers run in subprocesses: a process group is process-global state.  Run with -m gpu."""
 import json
 import os
@@ -115,8 +117,12 @@ import torch, torch.distributed as dist
 import ref_port_torch as P
 from bbb_hip import ensemble, zoo, rng
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-dev = torch.device("cuda", int(os.environ["LOCAL_RANK"])); torch.cuda.set_device(dev)
-dist.init_process_group("nccl", device_id=dev)
+backend = os.environ.get("BBB_TEST_BACKEND", "nccl")                 # "gloo" + BBB_TEST_DEVICE=0: several ranks on ONE device (rehearsal)
+dev = torch.device("cuda", int(os.environ.get("BBB_TEST_DEVICE", os.environ["LOCAL_RANK"]))); torch.cuda.set_device(dev)
+if backend == "nccl":
+    dist.init_process_group("nccl", device_id=dev)
+else:
+    dist.init_process_group(backend)
 group = dist.group.WORLD
 torch.manual_seed(0)
 net = zoo.getModel("alexnet", 3, 10, P.CONFIG_PRIORS, "bbb", "softplus").to(dev)
@@ -169,9 +175,9 @@ if rank == 0:
 '''
 
 
-def _run_ranks(n, port):
+def _run_ranks(n, port, **extra_env):
     import tempfile
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
     for k in ("BBB_FORCE_COMBINE", "WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     with tempfile.TemporaryDirectory() as d:
@@ -195,6 +201,16 @@ def test_rank_worker_under_the_launcher_at_world_size_one():
     the one-GPU boxes the suite usually runs on."""
     r = _run_ranks(1, 29559)
     assert r["units"] == 10 and r["S"] == 1
+
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_rank_worker_with_several_ranks_on_one_device_over_gloo(n):
+    """The multi-GPU worker with 2 and 3 REAL ranks (processes), all on device 0, gloo instead of RCCL (which does not allow two
+    ranks per device): the (draw x batch-slice) work units of one step AND the groups of four steps dealt out as whole draws
+    (3 ranks: 40 draws as 14 + 13 + 13, shares that start and end in the middle of a step) give every rank the single-device
+    results -- eager collective protocol (gloo cannot be recorded into a hipGraph)."""
+    r = _run_ranks(n, 29563 + n, BBB_TEST_BACKEND="gloo", BBB_TEST_DEVICE="0")
+    assert not any(r["fused"]), r
 
 
 def test_sharded_step_over_rccl_on_every_gpu_of_the_box():
