@@ -311,6 +311,23 @@ def pool_fusion_ok(x_shape, w_shape, stride, padding, dilation, draws, pool_modu
     x_shape [*, Cin, H, W, B], w_shape [*, Cout, Cin, kh, kw]; pool_module: the nn.MaxPool2d that follows (checked for 2 / 2)."""
     if not pool_fusion or gemm_mode != "fp32":
         return False
+    key = (tuple(x_shape[-4:]), tuple(w_shape[-4:]), _pair(stride), _pair(padding), _pair(dilation), int(draws), launches_overlap,
+           pool_fuse_min_items, pool_fuse_imbalance, pool_fuse_min_items_overlapped, pool_fuse_weight_budget,
+           None if pool_module is None else (str(pool_module.kernel_size), str(pool_module.stride), str(pool_module.padding),
+                                             str(pool_module.dilation), pool_module.ceil_mode,
+                                             getattr(pool_module, "return_indices", False)))
+    hit = _pool_rule_cache.get(key)
+    if hit is None:
+        if len(_pool_rule_cache) > 512:
+            _pool_rule_cache.clear()
+        hit = _pool_rule_cache[key] = _pool_fusion_rule(x_shape, w_shape, stride, padding, dilation, draws, pool_module)
+    return hit
+
+
+_pool_rule_cache = {}
+
+
+def _pool_fusion_rule(x_shape, w_shape, stride, padding, dilation, draws, pool_module):
     if pool_module is not None:
         pr = lambda v: (v, v) if isinstance(v, int) else tuple(v)
         if pr(pool_module.kernel_size) != (2, 2) or pr(pool_module.stride if pool_module.stride is not None else 2) != (2, 2) or \

@@ -259,6 +259,30 @@ def test_group_shares_partition_the_group_of_steps():
                 assert seen == list(range(G * E))
 
 
+def test_pool_fusion_rule():
+    """ops.pool_fusion_ok (host logic; the kernel: tests/test_gpu_pool_fusion.py): AlexNet conv1 at 40 draws fuses its MaxPool2d(2, 2),
+    conv2 does not (eight 410 KB weight tiles per XCD), a lone 10-draw launch does not, a 10-draw launch beside other lanes does, a
+    5-draw one does not; other pooling windows never."""
+    import torch.nn as nn
+    from bbb_hip import ops
+    p22 = nn.MaxPool2d(2, 2)
+    c1 = lambda E: ((E, 3, 32, 32, 512), (E, 64, 3, 11, 11), 4, 5, 1, E)
+    assert ops.pool_fusion_ok(*c1(40), p22)
+    assert not ops.pool_fusion_ok((40, 64, 4, 4, 512), (40, 192, 64, 5, 5), 1, 2, 1, 40, p22)
+    assert not ops.pool_fusion_ok(*c1(10), p22)
+    with ops.overlapped_launches():
+        assert ops.pool_fusion_ok(*c1(10), p22) and not ops.pool_fusion_ok(*c1(5), p22)
+    assert not ops.launches_overlap
+    assert not ops.pool_fusion_ok(*c1(40), nn.MaxPool2d(3, 2)) and not ops.pool_fusion_ok(*c1(40), nn.MaxPool2d(2, 2, ceil_mode=True))
+    assert not ops.pool_fusion_ok((40, 384, 2, 2, 512), (40, 256, 384, 3, 3), 1, 1, 1, 40, p22)      # the layer's contraction is split
+    saved = ops.pool_fusion
+    try:
+        ops.pool_fusion = False
+        assert not ops.pool_fusion_ok(*c1(40), p22)
+    finally:
+        ops.pool_fusion = saved
+
+
 def test_conv_flops_accounting():
     from bbb_hip.ensemble import conv_flops
     # AlexNet/CIFAR bs=512 per draw (SURVEY.md section 8a): im2col 1.52 / 5.03 / 2.72 / 3.62 / 1.21 GFLOP
