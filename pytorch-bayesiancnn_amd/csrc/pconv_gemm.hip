@@ -247,8 +247,8 @@ int launch(PConvArgs& a, int draws, hipStream_t st) {
         const int64_t perp = (itp + 7) / 8;
         a.per_xcd = (int32_t)perp;
         // staging loads up front (ILV = false): with the running maximum in 32 more accumulation registers this form fits four
-        // workgroups per CU (60 + 64 registers) and the interleaved one does not; on launches this large the two forms of the plain
-        // kernel measure the same (profiles/r04_notes.md section 5)
+        // workgroups per CU (60 + 64 registers) and the interleaved one does not (82 + 64: three; measured 492-494 us against 480-482
+        // for conv1 of the metric step, profiles/r04_notes.md section 7)
         hipLaunchKernelGGL((pconv_gemm_pool_kernel<false>), dim3((unsigned)(8 * perp)), dim3(kThreads), 0, st, a);
         return (int)hipGetLastError();
     }
