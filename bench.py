@@ -32,8 +32,9 @@ Output: the LAST line is the contract's JSON object, kept under 2000 characters,
                  sustained_frac (same FLOPs / ms_per_step), stats_* (5 blocks of K steps), one_step_in_flight_ms (one lane, one step
                  per launch), and the fused reparam+KL pass vs HBM 8 TB/s as reparam_frac / reparam_avg_us / reparam_bytes (also
                  nested: `reparam`).
-  cpu_baseline   the reference's CPU nn.Module path timed on this host's cores (rank 0): the unmodified upstream modules when
-                 /root/reference exists (kind "reference"), else the oracle's bit-identical torch-CPU port (kind "port").
+  cpu_baseline   the reference's CPU nn.Module path timed on this host's cores (rank 0): the unmodified upstream modules (kind
+                 "reference": the checkout, or on the GPU box the archive __graft_entry__.build() packed into oracle/_ref/);
+                 only when neither exists the oracle's bit-identical torch-CPU port (kind "port").
 A line starting with `SECONDARY ` is printed BEFORE it and carries the bulky objects: every other BASELINE configuration with its
 own roofline, the drop-in loop, the split-16-bit mode, the training step, per-launch detail and notes.
 """
@@ -115,11 +116,14 @@ def cpu_baseline(budget_s=20.0):
     cfg = CONFIGS["metric"]
     B, E, C = cfg["B"], cfg["E"], cfg["classes"]
     avail = usable_cpus()
-    ref_dir = "/root/reference"
+    # the UNMODIFIED upstream modules: the checkout in the build container, on the GPU box the byte-for-byte archive that
+    # __graft_entry__.build() packed into oracle/_ref/ (oracle/ref_snapshot.py; test infrastructure, never the product path)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ref_snapshot
+    ref_kind, ref_dir = ref_snapshot.checkout()
     torch.manual_seed(0)
     x = torch.rand(B, 3, 32, 32)
-    if os.path.isdir(os.path.join(ref_dir, "layers")):
-        # the UNMODIFIED upstream modules (build container only: the GPU box has no checkout)
+    if ref_dir is not None:
         kind = "reference"
         saved_path, saved_mods = list(sys.path), {k: v for k, v in sys.modules.items() if k == "layers" or k.startswith("layers.")}
         for k in list(saved_mods):
@@ -129,7 +133,12 @@ def cpu_baseline(budget_s=20.0):
             from models.BayesianModels.BayesianAlexNet import BBBAlexNet as RefAlexNet
             import utils as ref_utils
             import torch.nn.functional as F
-            net = RefAlexNet(C, 3, PRIORS, "bbb", "softplus")
+            # the upstream layers pin themselves to cuda:0 whenever a GPU is visible (layers/BBB/BBBConv.py:27); this leg is the
+            # reference's CPU path, so the modules are CONSTRUCTED seeing what a GPU-less host shows them (nothing upstream is edited)
+            from unittest import mock
+            with mock.patch("torch.cuda.is_available", return_value=False):
+                net = RefAlexNet(C, 3, PRIORS, "bbb", "softplus")
+            assert all(p.device.type == "cpu" for p in net.parameters()) and net.conv1.device.type == "cpu"
 
             def step():                                   # main_bayesian.py:73-80
                 outputs = torch.zeros(B, C, E)
@@ -139,7 +148,9 @@ def cpu_baseline(budget_s=20.0):
                     kl += _kl
                     outputs[:, :, j] = F.log_softmax(net_out, dim=1).data
                 return ref_utils.logmeanexp(outputs, dim=2), kl
-            src = "unmodified upstream modules imported from /root/reference (models.BayesianModels.BayesianAlexNet, utils.logmeanexp)"
+            src = ("unmodified upstream modules (models.BayesianModels.BayesianAlexNet on the upstream layers/, utils.logmeanexp) imported from "
+                   + ("the read-only checkout" if ref_kind == "checkout" else "oracle/_ref/upstream_snapshot.zip (sha256-verified, tree %s)"
+                      % ref_snapshot.manifest()["tree_sha256"][:12]))
         finally:
             sys.path[:] = saved_path
             for k in [k for k in sys.modules if k == "layers" or k.startswith("layers.")]:
@@ -147,7 +158,6 @@ def cpu_baseline(budget_s=20.0):
             sys.modules.update(saved_mods)
     else:
         kind = "port"
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import ref_port_torch as P
         params = P.init_params("alexnet", 3, C, P.CONFIG_PRIORS)
 

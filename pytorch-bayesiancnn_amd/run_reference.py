@@ -3,7 +3,11 @@
 MI355X-native layers.
 
     python run_reference.py --reference /path/to/PyTorch-BayesianCNN --net_type alexnet --dataset CIFAR10 \
-        [--epochs 2] [--synthetic 2048]
+        [--epochs 2] [--synthetic 2048] [--set layer_type=bbb --set batch_size=128] [--literal]
+
+--literal executes main_bayesian.py ITSELF as `__main__` (runpy: its own argparse block, main_bayesian.py:137-142, parses
+--net_type / --dataset); without it the module is imported and `run(dataset, net_type)` called -- the same code either way.
+--set NAME=VALUE assigns attributes of the upstream `config_bayesian` module (the user's configuration file) before the run.
 
 Nothing upstream is edited.  This launcher only prepares the interpreter before `main_bayesian` is imported:
   * sys.path: this package first, so `from layers import ...` in models/BayesianModels/*.py resolves to ours;
@@ -80,8 +84,9 @@ def make_synthetic_data_module(n_train):
     return mod
 
 
-def prepare(reference, synthetic=0):
-    """Everything that has to happen before `import main_bayesian`.  Returns the imported module."""
+def prepare(reference, synthetic=0, import_driver=True):
+    """Everything that has to happen before `import main_bayesian`.  Returns the imported module (None with
+    import_driver=False: the caller executes the file itself)."""
     reference = os.path.abspath(reference)
     if not os.path.isfile(os.path.join(reference, "main_bayesian.py")):
         raise SystemExit(f"{reference} does not look like a PyTorch-BayesianCNN checkout")
@@ -97,7 +102,32 @@ def prepare(reference, synthetic=0):
     stubbed = install_torchvision_stub()
     if synthetic or stubbed:
         sys.modules["data"] = make_synthetic_data_module(synthetic or 2048)
-    return importlib.import_module("main_bayesian")
+    return importlib.import_module("main_bayesian") if import_driver else None
+
+
+def _parse_value(text):
+    import ast
+    try:
+        return ast.literal_eval(text)
+    except (ValueError, SyntaxError):
+        return text
+
+
+def run_literal(reference, net_type, dataset, synthetic=0, overrides=None):
+    """main_bayesian.py executed as a script, unmodified, in this interpreter: `python main_bayesian.py --net_type N --dataset D`."""
+    import runpy
+    prepare(reference, synthetic, import_driver=False)
+    cfg = importlib.import_module("config_bayesian")
+    for k, v in (overrides or {}).items():
+        if not hasattr(cfg, k):
+            raise SystemExit(f"config_bayesian has no attribute {k!r}")
+        setattr(cfg, k, v)
+    saved = sys.argv
+    sys.argv = ["main_bayesian.py", "--net_type", net_type, "--dataset", dataset]
+    try:
+        return runpy.run_path(os.path.join(os.path.abspath(reference), "main_bayesian.py"), run_name="__main__")
+    finally:
+        sys.argv = saved
 
 
 def main():
@@ -107,10 +137,25 @@ def main():
     ap.add_argument("--dataset", default="MNIST")
     ap.add_argument("--epochs", type=int, default=None, help="override config_bayesian.n_epochs")
     ap.add_argument("--synthetic", type=int, default=0, help="serve N random training images instead of torchvision data")
+    ap.add_argument("--set", action="append", default=[], metavar="NAME=VALUE", help="assign config_bayesian.NAME (repeatable)")
+    ap.add_argument("--literal", action="store_true", help="execute main_bayesian.py itself as __main__ instead of importing it")
     args = ap.parse_args()
-    mb = prepare(args.reference, args.synthetic)
+    overrides = {}
+    for item in args.set:
+        k, sep, v = item.partition("=")
+        if not sep:
+            raise SystemExit("--set expects NAME=VALUE")
+        overrides[k] = _parse_value(v)
     if args.epochs is not None:
-        mb.cfg.n_epochs = args.epochs
+        overrides["n_epochs"] = args.epochs
+    if args.literal:
+        run_literal(args.reference, args.net_type, args.dataset, args.synthetic, overrides)
+        return
+    mb = prepare(args.reference, args.synthetic)
+    for k, v in overrides.items():
+        if not hasattr(mb.cfg, k):
+            raise SystemExit(f"config_bayesian has no attribute {k!r}")
+        setattr(mb.cfg, k, v)
     mb.run(args.dataset, args.net_type)
 
 

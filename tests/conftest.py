@@ -10,19 +10,33 @@ for p in (PKG, os.path.join(ROOT, "oracle"), ROOT):
         sys.path.insert(0, p)
 sys.dont_write_bytecode = True
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-REFERENCE = "/root/reference"
+
+
+def _reference_dir():
+    """The unmodified upstream files: /root/reference in the build container, oracle/_ref/upstream_snapshot.zip (packed by
+    __graft_entry__.build(), oracle/ref_snapshot.py) unpacked to a temporary directory on the GPU box; None if neither."""
+    import ref_snapshot
+    return ref_snapshot.checkout()[1]
+
+
+REFERENCE = _reference_dir()
 
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    config.addinivalue_line("markers", "reference: needs the read-only upstream checkout at /root/reference")
+    config.addinivalue_line("markers", "reference: needs the unmodified upstream files (checkout or oracle/_ref snapshot)")
 
 
 def pytest_collection_modifyitems(config, items):
-    have_ref = os.path.isdir(REFERENCE)
+    have_ref = REFERENCE is not None
     for item in items:
         if "reference" in item.keywords and not have_ref:
-            item.add_marker(pytest.mark.skip(reason="/root/reference not present (GPU box)"))
+            item.add_marker(pytest.mark.skip(reason="neither /root/reference nor oracle/_ref/upstream_snapshot.zip present"))
+
+
+@pytest.fixture(scope="session")
+def reference_dir():
+    return REFERENCE
 
 
 @pytest.fixture(scope="session")

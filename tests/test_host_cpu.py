@@ -104,7 +104,7 @@ def test_product_path_refuses_cpu_tensors(built):
 
 def test_no_oracle_import_in_product():
     """The shipped package must never import / call the oracle (or the reference)."""
-    bad = re.compile(r"bbb_numpy|ref_port_torch|/root/reference|import\s+oracle|from\s+oracle")
+    bad = re.compile(r"bbb_numpy|ref_port_torch|ref_snapshot|upstream_snapshot|_ref/|/root/reference|import\s+oracle|from\s+oracle")
     for base, _, files in os.walk(PKG):
         for f in files:
             if f.endswith((".py", ".hip", ".cuh", ".h")):
@@ -173,12 +173,11 @@ def test_zoo_models_have_reference_state_dict(golden, name, cls_name, n_classes,
 
 
 @pytest.mark.reference
-def test_reference_models_build_unchanged_on_our_layers():
-    """Build-container only: the UNMODIFIED upstream model files import `layers` and get ours; structure and
-    state_dict equal the zoo's."""
+def test_reference_models_build_unchanged_on_our_layers(reference_dir):
+    """The UNMODIFIED upstream model files import `layers` and get ours; structure and state_dict equal the zoo's."""
     code = r'''
 import sys; sys.dont_write_bytecode = True
-sys.path.insert(0, "/root/reference"); sys.path.insert(0, "%s")
+sys.path.insert(0, "%s"); sys.path.insert(0, "%s")
 import layers, torch
 assert layers.__file__.startswith("%s"), layers.__file__
 from models.BayesianModels.BayesianAlexNet import BBBAlexNet
@@ -194,7 +193,7 @@ for ref, ours, cin in ((BBBAlexNet, zoo.BBBAlexNet, 3), (BBBLeNet, zoo.BBBLeNet,
         assert {k: tuple(v.shape) for k, v in a.state_dict().items()} == {k: tuple(v.shape) for k, v in b.state_dict().items()}
         assert type(a.conv1).__module__.startswith("layers.")
 print("OK")
-''' % (PKG, PKG)
+''' % (reference_dir, PKG, PKG)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-3000:]
 
@@ -527,7 +526,7 @@ def test_data_parallel_gradient_allreduce_over_gloo(tmp_path, world):
 
 
 @pytest.mark.reference
-def test_reference_driver_imports_unchanged_through_the_launcher():
+def test_reference_driver_imports_unchanged_through_the_launcher(reference_dir):
     """N4: run_reference.prepare() makes the UNMODIFIED main_bayesian importable on today's torch / numpy without
     torchvision, with `layers` resolving to this package; getModel builds our layers; the synthetic `data` module has the
     reference's interface.  (run() itself needs an MI355X and the checkout on the same host.)"""
@@ -535,7 +534,7 @@ def test_reference_driver_imports_unchanged_through_the_launcher():
 import sys
 sys.path.insert(0, "%s")
 import run_reference as rr
-mb = rr.prepare("/root/reference", synthetic=64)
+mb = rr.prepare("%s", synthetic=64)
 import numpy as np, torch, layers
 assert layers.__file__.startswith("%s")
 assert np.Inf == np.inf
@@ -552,7 +551,7 @@ assert callable(mb.train_model) and callable(mb.validate_model) and callable(mb.
 ck = {k: tuple(v.shape) for k, v in net.state_dict().items()}
 assert list(ck)[:4] == ["conv1.W_mu", "conv1.W_rho", "conv1.bias_mu", "conv1.bias_rho"]
 print("OK")
-''' % (PKG, PKG)
+''' % (PKG, reference_dir, PKG)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-3000:]
 

@@ -180,12 +180,12 @@ def test_eps_stream_moments_and_windows():
 
 
 @pytest.mark.reference
-def test_port_matches_live_reference():
-    """Build-container only: the port against the live, unmodified upstream modules."""
+def test_port_matches_live_reference(reference_dir):
+    """The port against the live, unmodified upstream modules."""
     import subprocess
     code = r'''
 import sys; sys.dont_write_bytecode=True
-sys.path.insert(0, "/root/reference"); sys.path.insert(0, "%s")
+sys.path.insert(0, "%s"); sys.path.insert(0, "%s")
 import torch, numpy as np
 import ref_port_torch as P
 from models.BayesianModels.BayesianAlexNet import BBBAlexNet
@@ -196,7 +196,7 @@ torch.manual_seed(5); params = P.init_params("alexnet", 3, 10, P.CONFIG_PRIORS);
 torch.manual_seed(6); b, kb = P.forward("alexnet", params, x2, "bbb", "softplus")
 assert torch.equal(a, b) and torch.equal(ka, kb), (float((a-b).abs().max()), float(ka), float(kb))
 print("OK")
-''' % os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+''' % (reference_dir, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:]
 
@@ -242,7 +242,7 @@ def test_bf16_storage_model_is_a_small_perturbation_of_the_fp32_oracle():
 
 
 @pytest.mark.reference
-def test_port_times_like_the_live_reference():
+def test_port_times_like_the_live_reference(reference_dir):
     """bench.py's cpu_baseline uses the port where /root/reference does not exist (the GPU box): besides producing the same
     bits, the port must COST the same as the unmodified modules on the same cores.  One AlexNet draw at bs=256, interleaved
     runs, minimum of 9 each, within 5 % in at least one of up to eight attempts (shared build hosts are noisy: a neighbour's
@@ -250,7 +250,7 @@ def test_port_times_like_the_live_reference():
     import subprocess
     code = r"""
 import sys, time; sys.dont_write_bytecode = True
-sys.path.insert(0, %r); sys.path.insert(0, "/root/reference")
+sys.path.insert(0, %r); sys.path.insert(0, %r)
 import torch
 import ref_port_torch as P
 from models.BayesianModels.BayesianAlexNet import BBBAlexNet
@@ -274,7 +274,7 @@ with torch.no_grad():
         best = r if best is None or abs(r - 1) < abs(best - 1) else best
         if abs(r - 1) <= 0.05: break
 print("RATIO %%.4f" %% best)
-""" % os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+""" % (os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"), reference_dir)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     ratio = float(r.stdout.split("RATIO")[1])
