@@ -23,7 +23,30 @@ _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 # makes that unsafe: the watchdog thread may query an event it still holds for a finished eager collective after the cache gave
 # the same event to a collective under capture -> hipErrorCapturedEvent -> terminate().  Read when a process group is created, so
 # it must be set before that; if it was not "0" then, ensemble keeps collectives outside its graphs.  A value the user exported wins.
+# What was true BEFORE this import decides (ensemble.collective_capture_ok): torch reads the variable when a ProcessGroupNCCL is
+# constructed, so a group that already existed while the variable was not "0" still runs with the cache on, whatever we set now.
+_event_cache_off_before_import = _os.environ.get("TORCH_NCCL_CUDA_EVENT_CACHE") == "0"
 _os.environ.setdefault("TORCH_NCCL_CUDA_EVENT_CACHE", "0")
+
+
+def _dist_initialized_now():
+    try:
+        import torch.distributed as _dist
+        return bool(_dist.is_available() and _dist.is_initialized())
+    except Exception:
+        return False
+
+
+_dist_initialized_before_import = _dist_initialized_now()
+
+
+def nccl_event_cache_known_off():
+    """True when every NCCL process group of this process was (or will be) constructed with TORCH_NCCL_CUDA_EVENT_CACHE=0: the
+    variable was already "0" when this package was imported, or no process group existed yet at that point (the import set it) and
+    nobody changed it since.  False = unknown -> collectives stay outside hipGraphs (the eager protocol)."""
+    if _os.environ.get("TORCH_NCCL_CUDA_EVENT_CACHE") != "0":
+        return False
+    return _event_cache_off_before_import or not _dist_initialized_before_import
 
 from . import _lib, rng, ops  # noqa: E402,F401
 from ._lib import BBBHipError, LIB_PATH  # noqa: E402,F401

@@ -14,6 +14,7 @@ all_gather of [B*C + 1] floats (the block + its share of the KL sum) over RCCL i
 in rank order -- every rank ends with the same bits.
 """
 import math
+import weakref
 
 import torch
 import torch.nn as nn
@@ -420,12 +421,12 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
     n_out = getattr(children[last_bayes], "out_features", None) if tail_is_last else None
     logits_buf = torch.empty((E, n_out, B), dtype=torch.float32, device=x.device) if n_out is not None else None
 
-    bf16x3 = True if precision == "bf16x3" else None        # None: ops.gemm_mode decides
+    bf16x3 = True if precision == "bf16x3" else None        # None: the current LaunchConfig's gemm_mode decides
     # split-bf16 mode, steps large enough that every conv launch takes that kernel: the activations between the layers travel in
     # the split format S3 (three bf16 planes holding the exact fp32 values; ops.conv2d_chwn_forward x_s3 / out_s3) -- each
     # element is cut into its pieces ONCE, by the launch that produces it, instead of by every workgroup that stages it
-    s3_chain = ((precision == "bf16x3" or ops.gemm_mode == "bf16x3") and not bf16 and not lrt and bool(bbb) and B % 8 == 0
-                and E * B >= ops.s3_min_images and tail_is_last)
+    s3_chain = ((precision == "bf16x3" or ops.current_config().gemm_mode == "bf16x3") and not bf16 and not lrt and bool(bbb) and B % 8 == 0
+                and E * B >= ops.current_config().s3_min_images and tail_is_last)
 
     def run(e0, e1):
         """Layers for draws [e0, e1) on the current stream -> logits [e1-e0, C, B] (or None: fall back)."""
@@ -943,61 +944,154 @@ def _eager_gather(recv, send, group, lane_stream, comm_stream):
 
 capture_collectives = True     # a sharded GraphedMC step records its ONE all_gather inside the step's hipGraph when the backend allows
                                # it (RCCL does; probed once per process group): one host call per step instead of three
-_capture_probe = {}
-_lane_groups = {}
+capture_probe_timeout_s = 60.0 # the probe's collectives run under this wall-clock watchdog (a rank that never arrives must not
+                               # hang the job: the others fall back to the eager protocol and say so)
+_capture_probe = weakref.WeakKeyDictionary()     # process group object -> bool (NOT id(group): ids are reused after destruction)
+_lane_groups = weakref.WeakKeyDictionary()       # process group object -> {lane: private communicator}
+last_protocol = {"collective": None, "reason": None}   # what the last collective_capture_ok decided and why (bench.py prints it)
+
+
+def _spans_world(group):
+    import torch.distributed as dist
+    return group is None or dist.get_world_size(group) == dist.get_world_size()
 
 
 def lane_group(group, lane):
-    """The communicator lane `lane` of a pipeline records into its graphs.  Lane 0 uses `group` itself; every further lane gets
-    its OWN communicator over the same ranks (created collectively, once, cached): graphs of different lanes replay on different
-    streams, and two collectives of ONE communicator must never run concurrently or in different orders on different ranks --
-    eager process-group calls are serialised by torch, recorded ones are not."""
+    """The communicator lane `lane` of a pipeline RECORDS into its graphs: always a PRIVATE one over the same ranks (created
+    collectively, once per (group, lane), cached on the group object) -- never the caller's `group` itself, whose eager collectives
+    (the caller's own, torch's barrier) are serialised by torch but would be unordered with a recorded one: two collectives of ONE
+    communicator must never run concurrently or in different orders on different ranks.  dist.new_group has to be entered by every
+    rank of the default group, so recording is only offered for groups that span WORLD (collective_capture_ok checks)."""
     import torch.distributed as dist
-    if lane == 0 or group is None:
+    if group is None:
         return group
-    key = (id(group), int(lane))
-    if key not in _lane_groups:
-        g = _lane_groups[key] = dist.new_group(ranks=dist.get_process_group_ranks(group), backend="nccl")
-        # the communicator must exist before a collective of it is recorded: one eager call, on the CURRENT stream -- never on a
-        # stream that will be captured (see _eager_gather)
-        dev = torch.device("cuda", torch.cuda.current_device())
-        t = torch.zeros((4,), device=dev)
-        dist.all_gather_into_tensor(torch.empty((4 * dist.get_world_size(g),), device=dev), t, group=g)
-        torch.cuda.synchronize(dev)
-    return _lane_groups[key]
+    lanes = _lane_groups.get(group)
+    if lanes is None:
+        lanes = _lane_groups[group] = {}
+    if lane not in lanes:
+        backend = dist.get_backend(group)
+        g = lanes[lane] = dist.new_group(ranks=dist.get_process_group_ranks(group), backend=backend)
+        if backend == "nccl":
+            # the communicator must exist before a collective of it is recorded: one eager call, on the CURRENT stream -- never on
+            # a stream that will be captured (see _eager_gather)
+            dev = torch.device("cuda", torch.cuda.current_device())
+            t = torch.zeros((4,), device=dev)
+            dist.all_gather_into_tensor(torch.empty((4 * dist.get_world_size(g),), device=dev), t, group=g)
+            torch.cuda.synchronize(dev)
+    return lanes[lane]
 
 
-def collective_capture_ok(group, device):
-    """Can this process group's all_gather_into_tensor be recorded into a hipGraph?  Probed ONCE per group with a 4-float
-    gather on a side stream (capture, two replays, result checked), and agreed on by all ranks (all_reduce MIN) so that every
-    rank takes the same protocol.  Only the "nccl" (= RCCL) backend is tried: gloo collectives run on the host."""
+def _with_watchdog(fn, timeout_s):
+    """Run fn() on a helper thread; (True, result) or (False, exception | None when it did not return within timeout_s).  A
+    collective that never completes cannot be cancelled -- the helper thread is left behind (daemon) and the caller moves on to the
+    eager protocol / reports the stall instead of sitting in the driver's lease forever."""
+    import threading
+    box = {}
+
+    def run():
+        try:
+            box["value"] = fn()
+        except BaseException as exc:                 # noqa: BLE001 (reported to the caller)
+            box["error"] = exc
+
+    dev = torch.cuda.current_device() if torch.cuda.is_available() else None
+
+    def entry():
+        if dev is not None:
+            torch.cuda.set_device(dev)
+        run()
+
+    t = threading.Thread(target=entry, daemon=True, name="bbb-collective-probe")
+    t.start()
+    t.join(timeout_s)
+    if t.is_alive():
+        return False, None
+    if "error" in box:
+        return False, box["error"]
+    return True, box.get("value")
+
+
+def _local_capture_preconditions(group, device):
+    """This rank's own view: may its all_gather be recorded?  (reason string when not.)  No collective is entered here."""
     import torch.distributed as dist
-    key = id(group)
-    if key in _capture_probe:
-        return _capture_probe[key]
-    ok = False
-    try:
-        # torch's NCCL event cache hands an event that a finished eager collective's Work still references to the next collective;
-        # when that one is being CAPTURED the watchdog's query of the old Work throws hipErrorCapturedEvent and terminates the
-        # process (reproduced: profiles/r04_notes.md).  bbb_hip/__init__.py and bench.py switch the cache off before a process
-        # group exists; without that (a group created before this package was imported) collectives stay outside the graphs.
-        import os as _os
-        if capture_collectives and _os.environ.get("TORCH_NCCL_CUDA_EVENT_CACHE") == "0" and dist.get_backend(group) == "nccl" \
-                and torch.device(device).type == "cuda":
-            world, rank = dist.get_world_size(group), dist.get_rank(group)
+    from . import nccl_event_cache_known_off
+    if not capture_collectives:
+        return "capture_collectives is off"
+    if dist.get_backend(group) != "nccl":
+        return "backend %s runs its collectives on the host" % dist.get_backend(group)
+    if torch.device(device).type != "cuda":
+        return "not a GPU device"
+    # torch's NCCL event cache hands an event that a finished eager collective's Work still references to the next collective;
+    # when that one is being CAPTURED the watchdog's query of the old Work throws hipErrorCapturedEvent and terminates the
+    # process (reproduced: profiles/r04_notes.md).  The cache is read when a ProcessGroupNCCL is CONSTRUCTED: only a process whose
+    # groups were all built with TORCH_NCCL_CUDA_EVENT_CACHE=0 may record (bbb_hip/__init__.py keeps the evidence).
+    if not nccl_event_cache_known_off():
+        return "a process group may predate TORCH_NCCL_CUDA_EVENT_CACHE=0 (import bbb_hip, or export it, before init_process_group)"
+    if not _spans_world(group):
+        return "the group is a strict sub-group of WORLD (private lane communicators need every rank in new_group)"
+    return None
+
+
+def collective_capture_ok(group, device, _force_probe=False, _stall_s=0.0):
+    """Can this process group's all_gather_into_tensor be recorded into a hipGraph?  Decided ONCE per group and AGREED by all
+    ranks: every rank -- whatever its own preconditions or its own probe said -- enters the same agreement all_reduce (MIN of
+    "I can"), so no rank is left in a collective the others never enter.  Only "nccl" (= RCCL) is probed: a 4-float gather on a
+    PRIVATE communicator (lane_group), captured on a side stream, replayed twice, result checked.  The probe's collectives run
+    under a wall-clock watchdog (capture_probe_timeout_s): a stall yields the eager protocol, not a hang.
+    (_force_probe / _stall_s: test hooks -- run the agreement protocol on a host backend too / sleep before entering it.)"""
+    import torch.distributed as dist
+    if group in _capture_probe:
+        return _capture_probe[group]
+    reason = _local_capture_preconditions(group, device)
+    gloo_like = dist.get_backend(group) != "nccl" and not _force_probe
+    if gloo_like:
+        # host-side backends never record; every rank knows that without talking (the backend is a property of the group)
+        _capture_probe[group] = False
+        last_protocol.update(collective="eager", reason=reason)
+        return False
+    if not _spans_world(group):
+        # (sub-groups: lane_group cannot be entered -- every rank of the sub-group knows it: no probe, no agreement needed)
+        _capture_probe[group] = False
+        last_protocol.update(collective="eager", reason=reason)
+        return False
+
+    cancelled = []                                   # set when the watchdog gave up: a late helper thread must not start talking
+
+    def agree(mine, pg):
+        # ALWAYS entered by every rank, outside every try/except that swallows errors -- on a PRIVATE agreement communicator, so
+        # that a rank that stalls here (the watchdog then abandons this thread inside the collective) leaves the caller's own
+        # group untouched for the eager protocol
+        if cancelled:
+            raise RuntimeError("probe abandoned")
+        flag = torch.tensor([1.0 if mine else 0.0], device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=pg)
+        return bool(flag.item() > 0.5)
+
+    def probe():
+        if _stall_s:
+            import time
+            time.sleep(_stall_s)
+        if cancelled:
+            raise RuntimeError("probe abandoned")
+        apg = lane_group(group, "agree")
+        # phase 1: do ALL ranks meet their local preconditions?  (a rank that does not must not leave the others alone in new_group)
+        if not agree(reason is None, apg):
+            return False, reason or "another rank's preconditions do not allow recording"
+        # phase 2: every rank records + replays a 4-float gather on a private communicator, then the ranks agree on the outcome
+        ok, why = True, None
+        try:
+            pg = lane_group(group, "probe")                                   # created collectively by all ranks
+            world, rank = dist.get_world_size(pg), dist.get_rank(pg)
             send = torch.full((4,), float(rank + 1), device=device)
             recv = torch.zeros((4 * world,), device=device)
-            dist.all_gather_into_tensor(recv, send, group=group)          # the communicator exists before anything is captured
-            torch.cuda.synchronize(device)                                # (eager, on the current stream; the capture uses a fresh one)
             side = torch.cuda.Stream(device=device)
             g = torch.cuda.CUDAGraph()
             try:
                 with ops.graph_capture(g, side):
-                    dist.all_gather_into_tensor(recv, send, group=group)
-                local = True
-            except Exception:                                             # a backend that refuses capture: fall back, do not fail
-                local = False
-            if local:
+                    dist.all_gather_into_tensor(recv, send, group=pg)
+            except Exception as exc:                                          # a backend that refuses capture: fall back, do not fail
+                ok, why = False, "capture refused: %s" % type(exc).__name__
+            if ok:
                 for v in (5.0, 9.0):
                     send.fill_(v + rank)
                     recv.zero_()
@@ -1006,13 +1100,25 @@ def collective_capture_ok(group, device):
                         g.replay()
                     side.synchronize()
                     want = torch.arange(world, device=device, dtype=torch.float32).repeat_interleave(4) + v
-                    local = local and bool(torch.equal(recv, want))
-            flag = torch.tensor([1.0 if local else 0.0], device=device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-            ok = bool(flag.item() > 0.5)
-    except Exception:
+                    if not bool(torch.equal(recv, want)):
+                        ok, why = False, "a replayed all_gather returned wrong data"
+        except Exception as exc:                                              # noqa: BLE001
+            ok, why = False, "probe failed: %s: %s" % (type(exc).__name__, str(exc)[:120])
+        agreed = agree(ok, apg)
+        if ok and not agreed:
+            why = "another rank cannot record its collectives"
+        return agreed, why
+
+    done, res = _with_watchdog(probe, capture_probe_timeout_s)
+    if done:
+        ok, why = res
+    else:
+        cancelled.append(True)
         ok = False
-    _capture_probe[key] = ok
+        why = ("the capture probe did not finish within %.0f s (a rank is missing or stalled)" % capture_probe_timeout_s) if res is None \
+            else "probe raised %s: %s" % (type(res).__name__, str(res)[:120])
+    _capture_probe[group] = ok
+    last_protocol.update(collective="recorded" if ok else "eager", reason=None if ok else why)
     return ok
 
 
@@ -1046,9 +1152,12 @@ class GraphedMC:
     step() / flush() in the same sequence."""
 
     def __init__(self, net, x, num_ens, streams=1, kl_mode="sum", lane=0, lanes=1, stream=None, seed_call=None, group=None,
-                 precision="fp32", steps=1):
+                 precision="fp32", steps=1, launch_config=None):
         _lib.require_device(x)
         self.steps, self.slot, self.lanes = int(steps), 0, int(lanes)
+        # the launch-shape / arithmetic-mode choices this graph is planned and captured under: a snapshot, so that later changes of
+        # the process defaults (or another pipeline built with other modes) never reach into this one
+        self.launch_config = (launch_config if launch_config is not None else ops.current_config()).copy(launches_overlap=int(lanes) > 1)
         if self.steps > 1:
             with torch.no_grad():
                 if not units_ok(net, x):
@@ -1070,7 +1179,7 @@ class GraphedMC:
             self.S = 1
             self.lo, self.hi, self.g_lo, self.n_gl, self.g_off = group_share(self.num_ens, self.steps, rank, self.world)
         else:
-            with torch.no_grad():                    # the captured step is inference: plan for the inference path
+            with torch.no_grad(), ops.use_config(self.launch_config):   # the captured step is inference: plan for the inference path
                 self.S, self.lo, self.hi = shard_plan(net, self.x, self.num_ens, rank, self.world, True, precision)
         dev = x.device
         self.stride = int(lanes) * self.num_ens * self.steps
@@ -1097,8 +1206,11 @@ class GraphedMC:
             self.out_kl = torch.empty((), dtype=torch.float32, device=dev)
             self.recv.zero_()
         can_fuse = self.multi and collective_capture_ok(group, dev)
-        if can_fuse and int(lanes) > 1:
-            self.group = lane_group(group, int(lane))            # (every rank builds the same lanes in the same order)
+        if can_fuse:
+            self.group = lane_group(group, int(lane))            # a PRIVATE communicator per lane, lane 0 included: a recorded collective
+                                                                 # never shares one with the caller's eager ones (every rank builds the
+                                                                 # same lanes in the same order)
+        self.protocol = "recorded" if can_fuse else ("eager" if self.multi else "none")
         if self.hi > self.lo or can_fuse:
             self.stream.wait_stream(torch.cuda.current_stream(dev))
             with torch.no_grad(), torch.cuda.stream(self.stream), rng.device_call_offset(self.counter):
@@ -1145,7 +1257,7 @@ class GraphedMC:
         self.out_kl.copy_(kl if self.kl_mode == "sum" else kl / self.num_ens)
 
     def _step_body(self, streams):
-        with ops.overlapped_launches(self.lanes > 1):        # (launch-shape choices that depend on what runs beside the launch)
+        with ops.use_config(self.launch_config):             # (incl. launches_overlap: choices that depend on what runs beside the launch)
             return self._step_body_inner(streams)
 
     def _step_body_inner(self, streams):
@@ -1240,15 +1352,20 @@ class GraphedLogits:
     noise stream (seed fixed at capture), bit for bit what _mc_logits_chwn(net, x, K, seed, call) launches eagerly.  The output
     buffer belongs to the graph and is overwritten by the next run(): callers clone what they keep."""
 
-    def __init__(self, net, x, K, precision="fp32"):
+    def __init__(self, net, x, K, precision="fp32", launch_config=None):
         _lib.require_device(x)
         self.K, self.precision = int(K), precision
+        self.launch_config = (launch_config if launch_config is not None else ops.current_config()).copy()
         self.x = x.detach().clone()
         self.seed, self.call0 = rng.next_calls(0)
         dev = x.device
         self.counter = torch.zeros((1,), dtype=torch.int32, device=dev)
         self.graph = None
-        side = torch.cuda.Stream(device=dev)
+        # the capture stream stays alive as long as the graph does: ops' per-stream scratch (KL partials, split-contraction
+        # tickets) is keyed by the raw stream handle and its address is baked into the captured launches; a handle returned to
+        # torch's stream pool could be handed to a LATER graph, which would then share that scratch with this one while both
+        # replay on different streams
+        side = self._capture_stream = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.no_grad(), torch.cuda.stream(side), rng.device_call_offset(self.counter):
             for _ in range(2):                       # warm-up on a side stream (allocator, lazy module state, scratch growth)
@@ -1262,7 +1379,8 @@ class GraphedLogits:
         self.graph = g
 
     def _body(self, net):
-        out = _mc_logits_chwn(net, self.x, self.K, self.seed, self.call0, precision=self.precision)
+        with ops.use_config(self.launch_config):
+            out = _mc_logits_chwn(net, self.x, self.K, self.seed, self.call0, precision=self.precision)
         if out is None:
             return None
         return out[0].permute(0, 2, 1).contiguous(), out[1]
@@ -1297,15 +1415,18 @@ class GraphedPipeline:
     slot i % G of lane (i // G) % depth and the lane replays when its G slots are filled -- same noise calls per step as G = 1;
     sync() replays partly filled groups first."""
 
-    def __init__(self, net, x, num_ens, depth=2, streams=1, kl_mode="sum", group=None, precision="fp32", steps_per_launch=1):
+    def __init__(self, net, x, num_ens, depth=2, streams=1, kl_mode="sum", group=None, precision="fp32", steps_per_launch=1,
+                 launch_config=None):
         seed_call = rng.next_calls(0)
+        self.launch_config = (launch_config if launch_config is not None else ops.current_config()).copy()
         # lane streams come from a per-device pool and are REUSED by later pipelines: HIP maps streams onto a handful of hardware
         # queues round-robin, and a process that keeps creating streams (one pipeline per configuration, as bench.py does) ends up
         # with lanes that share a queue and stop overlapping (measured: the same 3-lane pipeline 15-18 % slower when built late)
         pool = _lane_streams(x.device, depth)
         self.G = int(steps_per_launch)
         self.lanes = [GraphedMC(net, x, num_ens, streams=streams, kl_mode=kl_mode, lane=l, lanes=depth,
-                                stream=pool[l], seed_call=seed_call, group=group, precision=precision, steps=self.G)
+                                stream=pool[l], seed_call=seed_call, group=group, precision=precision, steps=self.G,
+                                launch_config=self.launch_config)
                       for l in range(depth)]
         self.i = 0
         self.dev = x.device

@@ -158,12 +158,18 @@ class _MCForward(torch.autograd.Function):
             i += 1
         logits = h.reshape(E, -1, B)
         ctx.cfg, ctx.tape, ctx.meta = cfg, tape, (mus, rhos, ids, pm, ps, tuple(x.shape))
+        ctx.launch_config = ops.current_config()              # backward runs on autograd's device thread: carry the modes along
         ctx.x_nchw = x.detach()
         ctx.versions = [(p, p._version) for p in params]      # backward re-reads the live (mu, rho): they must not have moved
         return logits, kl
 
     @staticmethod
     def backward(ctx, g_logits, g_kl):
+        with ops.use_config(ctx.launch_config):
+            return _MCForward._backward(ctx, g_logits, g_kl)
+
+    @staticmethod
+    def _backward(ctx, g_logits, g_kl):
         cfg, tape = ctx.cfg, ctx.tape
         _check_versions(ctx.versions)
         cfg["spent"] = True                                    # layers/_fused.py: no further draws are served from this graph
@@ -279,12 +285,18 @@ class _MCForwardLRT(torch.autograd.Function):
                 h = h.reshape(h.shape[0], m.num_features, 1, 1, B)
             i += 1
         ctx.cfg, ctx.tape = cfg, tape
+        ctx.launch_config = ops.current_config()
         ctx.x_nchw = x.detach()
         ctx.versions = [(p, p._version) for p in params]
         return h.reshape(h.shape[0], -1, B)
 
     @staticmethod
     def backward(ctx, g_logits):
+        with ops.use_config(ctx.launch_config):
+            return _MCForwardLRT._backward(ctx, g_logits)
+
+    @staticmethod
+    def _backward(ctx, g_logits):
         tape = ctx.tape
         _check_versions(ctx.versions)
         ctx.cfg["spent"] = True

@@ -8,6 +8,9 @@ anywhere.  Activations, pooling and the loss tail use torch autograd (element-wi
 """
 import contextlib
 import ctypes
+import sys
+import threading
+import types
 
 import torch
 
@@ -216,19 +219,97 @@ def graph_capture(graph, stream=None):
             gc.enable()
 
 
-gemm_mode = "fp32"  # "bf16x3": the batch-innermost BBB GEMM launches (inference AND the role-swapped gradient launches of the
-                    # training path) run their contraction on the 16-bit matrix pipe at fp32 accuracy (bbb_conv2d_chwn_bf16x3_fwd:
-                    # every operand element split into three bf16 pieces while staged, six products, fp32 accumulation).  Range-free
-                    # (bf16 has fp32's exponent range: no operand windows or scales).  Opt-in: results agree with the fp32 kernel
-                    # to rounding, not bit for bit.  LRT layers keep the fused fp32 kernel (one staged x tile feeds both of its
-                    # contractions; a split form would need twelve operand planes in LDS).
-bf16x3_min_workgroups = 256  # smaller launches stay on the fp32 kernel (and the layer's split contraction): measured faster there
-s3_min_images = 2048         # split-bf16 mode: steps of at least this many (draw x image) rows keep their activations in the split
-                             # format S3 between layers (ensemble._mc_logits_chwn); smaller steps split while staging, per launch
+class LaunchConfig:
+    """The launch-shape / arithmetic-mode choices of the batch-innermost path, as ONE object instead of process-wide switches.
+
+    A `GraphedMC` / `GraphedPipeline` / `GraphedLogits` / `GraphedTrainStep` snapshots the configuration that is current when it
+    is built (or takes `launch_config=`) and enqueues every launch under it, so two models -- or two pipelines of one model --
+    with different modes coexist in one process and on several threads.  `ops.gemm_mode = ...` and friends still exist: they
+    read / write the fields of the process DEFAULT configuration (what applies when nobody asked for anything else).
+
+    gemm_mode   "fp32" | "bf16x3": the batch-innermost BBB GEMM launches (inference AND the role-swapped gradient launches of the
+                training path) run their contraction on the 16-bit matrix pipe at fp32 accuracy (bbb_conv2d_chwn_bf16x3_fwd:
+                every operand element split into three bf16 pieces while staged, six products, fp32 accumulation).  Range-free
+                (bf16 has fp32's exponent range: no operand windows or scales).  Opt-in: results agree with the fp32 kernel
+                to rounding, not bit for bit.  LRT layers keep the fused fp32 kernel (one staged x tile feeds both of its
+                contractions; a split form would need twelve operand planes in LDS).
+    bf16x3_min_workgroups   smaller launches stay on the fp32 kernel (and the layer's split contraction): measured faster there
+    s3_min_images   split-bf16 mode: steps of at least this many (draw x image) rows keep their activations in the split format S3
+                between layers (ensemble._mc_logits_chwn); smaller steps split while staging, per launch
+    split_k     layers with few (pixel, channel-tile) groups and a long contraction (AlexNet conv4 / conv5) add their k ranges'
+                partial sums in range order (bbb_conv2d_chwn_splitk_fwd): a property of the LAYER, identical for every launch
+                size and partition.  False: the plain fmaf chain everywhere (bit-identical to the reference-layout kernel).
+    pool_fusion a conv layer followed by [activation ->] MaxPool2d(2, 2) may run as ONE launch (bbb_conv_desc_t::pool)
+    pool_fuse_min_items / pool_fuse_imbalance   a launch with nothing else in flight: only when it still has this many (pooled pixel,
+                64-channel tile, 128-image tile, draw) items and they spread over the 256 CUs to within this factor (4x longer items)
+    launches_overlap   the caller enqueues work that runs beside other lanes' kernels: the under-filled tail of a fused launch is
+                then filled by them, and fusing pays from ~2 items per CU on (measured, profiles/r04_notes.md section 7: -2 to
+                -3 % per step at 10 draws x 3 lanes, +4.5 % with one lane; at 5 draws per launch it no longer does)
+    pool_fuse_weight_budget   bytes of weight tiles concurrently live per XCD that a fused launch may have (see pool_fusion_ok)"""
+    FIELDS = ("gemm_mode", "bf16x3_min_workgroups", "s3_min_images", "split_k", "pool_fusion", "pool_fuse_min_items",
+              "pool_fuse_imbalance", "launches_overlap", "pool_fuse_min_items_overlapped", "pool_fuse_weight_budget")
+    __slots__ = FIELDS
+
+    def __init__(self, **kw):
+        self.gemm_mode = "fp32"
+        self.bf16x3_min_workgroups = 256
+        self.s3_min_images = 2048
+        self.split_k = True
+        self.pool_fusion = True
+        self.pool_fuse_min_items = 1536
+        self.pool_fuse_imbalance = 1.07
+        self.launches_overlap = False
+        self.pool_fuse_min_items_overlapped = 400
+        self.pool_fuse_weight_budget = 1 << 20
+        for k, v in kw.items():
+            setattr(self, k, v)              # (unknown names raise: __slots__)
+
+    def copy(self, **kw):
+        c = LaunchConfig(**{k: getattr(self, k) for k in self.FIELDS})
+        for k, v in kw.items():
+            setattr(c, k, v)
+        return c
+
+    def key(self):
+        """Hashable value of every field (cache keys: a result / a captured graph depends on all of them)."""
+        return tuple(getattr(self, k) for k in self.FIELDS)
+
+    def __repr__(self):
+        return "LaunchConfig(%s)" % ", ".join("%s=%r" % (k, getattr(self, k)) for k in self.FIELDS)
+
+
+_default_config = LaunchConfig()
+_tls = threading.local()
+
+
+def current_config():
+    """The configuration launches are enqueued under right now: the innermost `use_config` of THIS thread, else the process default."""
+    st = getattr(_tls, "stack", None)
+    return st[-1] if st else _default_config
+
+
+class use_config:
+    """Context: enqueue under `cfg` (a LaunchConfig), or under the current configuration with some fields replaced
+    (`use_config(gemm_mode="bf16x3")`).  Thread-local, re-entrant."""
+
+    def __init__(self, cfg=None, **fields):
+        self.cfg, self.fields = cfg, fields
+
+    def __enter__(self):
+        base = self.cfg if self.cfg is not None else current_config()
+        cfg = base.copy(**self.fields) if self.fields else base
+        st = getattr(_tls, "stack", None)
+        if st is None:
+            st = _tls.stack = []
+        st.append(cfg)
+        return cfg
+
+    def __exit__(self, *a):
+        _tls.stack.pop()
+        return False
+
+
 _split_plans = {}
-split_k = True     # layers with few (pixel, channel-tile) groups and a long contraction (AlexNet conv4 / conv5) add their k ranges'
-                   # partial sums in range order (bbb_conv2d_chwn_splitk_fwd): a property of the LAYER, identical for every launch
-                   # size and partition.  False: the plain fmaf chain everywhere (bit-identical to the reference-layout kernel).
 
 
 def _split_scratch(d, lrt, device):
@@ -238,7 +319,7 @@ def _split_scratch(d, lrt, device):
     zero-initialised per-(device, stream) buffer whose arrival tickets stay zero from launch to launch) is only there when
     this launch is small enough for the cross-workgroup form -- larger launches run the same summation order inside one
     workgroup per tile."""
-    if not split_k:
+    if not current_config().split_k:
         return 1, None
     pkey = (bytes(d), bool(lrt))
     plan = _split_plans.get(pkey)
@@ -275,32 +356,11 @@ def _desc_chwn(x, w, stride, padding, dilation, draws, x_shared, w_shared, act):
     return d, ho, wo
 
 
-pool_fusion = True          # a conv layer followed by [activation ->] MaxPool2d(2, 2) may run as ONE launch (bbb_conv_desc_t::pool)
-pool_fuse_min_items = 1536  # a launch with nothing else in flight: only when it still has this many (pooled pixel, 64-channel tile,
-pool_fuse_imbalance = 1.07  # 128-image tile, draw) items and they spread over the 256 CUs to within this factor (4x longer items)
-launches_overlap = False    # set (overlapped_launches) while a caller enqueues work that runs beside other lanes' kernels: the
-                            # under-filled tail of a fused launch is then filled by them, and fusing pays from ~2 items per CU on
-                            # (measured, profiles/r04_notes.md section 7: -2 to -3 % per step at 10 draws x 3 lanes, +4.5 % with one
-                            # lane; at 5 draws per launch it no longer does)
-pool_fuse_min_items_overlapped = 400
-pool_fuse_weight_budget = 1 << 20   # bytes of weight tiles concurrently live per XCD that a fused launch may have (see pool_fusion_ok)
-
-
-class overlapped_launches:
+class overlapped_launches(use_config):
     """Context: the launches enqueued inside run concurrently with other streams' kernels (a lane of a GraphedPipeline)."""
 
     def __init__(self, on=True):
-        self.on = bool(on)
-
-    def __enter__(self):
-        global launches_overlap
-        self.prev, launches_overlap = launches_overlap, self.on
-        return self
-
-    def __exit__(self, *a):
-        global launches_overlap
-        launches_overlap = self.prev
-        return False
+        super().__init__(launches_overlap=bool(on))
 
 
 def pool_fusion_ok(x_shape, w_shape, stride, padding, dilation, draws, pool_module=None):
@@ -309,10 +369,11 @@ def pool_fusion_ok(x_shape, w_shape, stride, padding, dilation, draws, pool_modu
     times longer: chosen when other lanes' kernels run beside it (launches_overlap), else only when its items still fill the chip
     evenly (measured: profiles/r04_notes.md section 7).
     x_shape [*, Cin, H, W, B], w_shape [*, Cout, Cin, kh, kw]; pool_module: the nn.MaxPool2d that follows (checked for 2 / 2)."""
-    if not pool_fusion or gemm_mode != "fp32":
+    cfg = current_config()
+    if not cfg.pool_fusion or cfg.gemm_mode != "fp32":
         return False
-    key = (tuple(x_shape[-4:]), tuple(w_shape[-4:]), _pair(stride), _pair(padding), _pair(dilation), int(draws), launches_overlap,
-           pool_fuse_min_items, pool_fuse_imbalance, pool_fuse_min_items_overlapped, pool_fuse_weight_budget,
+    key = (tuple(x_shape[-4:]), tuple(w_shape[-4:]), _pair(stride), _pair(padding), _pair(dilation), int(draws), cfg.launches_overlap,
+           cfg.pool_fuse_min_items, cfg.pool_fuse_imbalance, cfg.pool_fuse_min_items_overlapped, cfg.pool_fuse_weight_budget,
            None if pool_module is None else (str(pool_module.kernel_size), str(pool_module.stride), str(pool_module.padding),
                                              str(pool_module.dilation), pool_module.ceil_mode,
                                              getattr(pool_module, "return_indices", False)))
@@ -328,6 +389,7 @@ _pool_rule_cache = {}
 
 
 def _pool_fusion_rule(x_shape, w_shape, stride, padding, dilation, draws, pool_module):
+    cfg = current_config()
     if pool_module is not None:
         pr = lambda v: (v, v) if isinstance(v, int) else tuple(v)
         if pr(pool_module.kernel_size) != (2, 2) or pr(pool_module.stride if pool_module.stride is not None else 2) != (2, 2) or \
@@ -349,12 +411,12 @@ def _pool_fusion_rule(x_shape, w_shape, stride, padding, dilation, draws, pool_m
     # AlexNet conv2 on CIFAR maps (4 pooled pixels x 4 tiles: 8 tiles of 410 KB) overflowed the 4 MB L2: 404 MB fetched per step for
     # 25 MB of operands, and no time gained (profiles/r04_notes.md section 7)
     per_group = (ho // 2) * (wo // 2) * -(-B // 128)
-    if max(1, 128 // per_group) * 64 * w_shape[-3] * w_shape[-2] * w_shape[-1] * 4 > pool_fuse_weight_budget:
+    if max(1, 128 // per_group) * 64 * w_shape[-3] * w_shape[-2] * w_shape[-1] * 4 > cfg.pool_fuse_weight_budget:
         return False
     items = int(draws) * per_group * -(-w_shape[-4] // 64)
-    if launches_overlap:
-        return items >= pool_fuse_min_items_overlapped
-    return items >= pool_fuse_min_items and -(-items // 256) * 256 <= pool_fuse_imbalance * items
+    if cfg.launches_overlap:
+        return items >= cfg.pool_fuse_min_items_overlapped
+    return items >= cfg.pool_fuse_min_items and -(-items // 256) * 256 <= cfg.pool_fuse_imbalance * items
 
 
 def conv2d_chwn_forward(x, w, bias, stride=1, padding=0, dilation=1, act=None, out=None, units=None, n_units=None,
@@ -418,8 +480,8 @@ def conv2d_chwn_forward(x, w, bias, stride=1, padding=0, dilation=1, act=None, o
             raise _lib.BBBHipError("out= must be a contiguous tensor of the output's size and dtype")
         y = out.view(shape)
     with on_device(x.device):
-        if x_s3 or out_s3 or (not pool and (bf16x3 if bf16x3 is not None else gemm_mode == "bf16x3")
-                              and E * ho * wo * -(-w.shape[1] // 64) * -(-B // 128) >= bf16x3_min_workgroups):
+        if x_s3 or out_s3 or (not pool and (bf16x3 if bf16x3 is not None else current_config().gemm_mode == "bf16x3")
+                              and E * ho * wo * -(-w.shape[1] // 64) * -(-B // 128) >= current_config().bf16x3_min_workgroups):
             check(_lib.lib().bbb_conv2d_chwn_bf16x3_fwd(ctypes.byref(d), x.data_ptr(), w.data_ptr(), ptr(bias), y.data_ptr(),
                                                         (1 if x_s3 else 0) | (2 if out_s3 else 0), cur_stream(x.device)),
                   "bbb_conv2d_chwn_bf16x3_fwd")
@@ -1368,3 +1430,22 @@ def conv2d_chwn_weight_grad_shared_input(g_pre, x_nchw, w_shape, stride, padding
                                              cur_stream(g_pre.device)), "bbb_conv2d_chwn_fwd")
     gw = y.sum(0) if S > 1 else y[0]
     return gw[:, :J].reshape(E, Cout, Cin, kh, kw)
+
+
+class _OpsModule(types.ModuleType):
+    """`ops.gemm_mode`, `ops.split_k`, ... read and write the fields of the process-default LaunchConfig (compatibility with the
+    round-1..4 switches; prefer `use_config` / `launch_config=`)."""
+
+    def __getattr__(self, name):                     # only reached when the module dict has no such name
+        if name in LaunchConfig.FIELDS:
+            return getattr(_default_config, name)
+        raise AttributeError(f"module {self.__name__!r} has no attribute {name!r}")
+
+    def __setattr__(self, name, value):
+        if name in LaunchConfig.FIELDS:
+            setattr(_default_config, name, value)
+        else:
+            super().__setattr__(name, value)
+
+
+sys.modules[__name__].__class__ = _OpsModule

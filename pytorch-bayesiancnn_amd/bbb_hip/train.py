@@ -279,9 +279,10 @@ class GraphedTrainStep:
     `warmup` real training iterations run eagerly on the capture stream first.
     The optimizer must be FusedAdam(capturable=True) (or another capturable optimizer that keeps lr on the device)."""
 
-    def __init__(self, net, optimizer, x, target, num_ens, beta, train_size, warmup=3, weak_net=False):
+    def __init__(self, net, optimizer, x, target, num_ens, beta, train_size, warmup=3, weak_net=False, launch_config=None):
         from . import rng
         _lib.require_device(x)
+        self.launch_config = (launch_config if launch_config is not None else ops.current_config()).copy()
         # weak_net (train_step's self-capture keeps this object ON the net): no net -> state -> step -> net cycle, so dropping the
         # net frees the graph then and there instead of whenever the cyclic collector runs (possibly inside another capture)
         self._net = weakref.ref(net) if weak_net else (lambda n=net: n)
@@ -326,6 +327,10 @@ class GraphedTrainStep:
         return self._net()
 
     def _body(self):
+        with ops.use_config(self.launch_config):
+            return self._body_inner()
+
+    def _body_inner(self):
         from . import fast_train
         params = [p for g in self.opt.param_groups for p in g["params"] if p.requires_grad]
         # The autograd graph of a captured step is rooted at FRESH leaves that share the parameters' storage, and differentiated

@@ -82,6 +82,16 @@ __global__ __launch_bounds__(256) void lrt_glue_kernel(const float* __restrict__
     reinterpret_cast<f32x4*>(out)[i] = o;
 }
 
+// the same arithmetic one element per thread: any element count, 4-byte alignment (views with a storage offset, 3-channel inputs)
+__global__ __launch_bounds__(256) void lrt_glue_scalar_kernel(const float* __restrict__ a, const float* __restrict__ x,
+                                                              const float* __restrict__ b, float* __restrict__ out, int64_t n,
+                                                              int64_t xn, int mode) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float xv = x[mode == 0 ? i : i % xn];
+    out[i] = mode == 0 ? xv * xv : fmaf(2.0f * xv, b[i], a[i]);
+}
+
 }  // namespace
 
 extern "C" int bbb_plane_sum(const float* x, float* out, int64_t outer, int64_t rows, int64_t cols, int64_t row_pitch, int64_t outer_stride,
@@ -107,10 +117,13 @@ extern "C" int bbb_sum_leading(const float* x, float* out, int64_t outer, int64_
 extern "C" int bbb_lrt_glue(const float* a, const float* x, const float* b, float* out, int64_t n, int64_t x_n, int mode, void* stream) {
     if (x == nullptr || out == nullptr || n <= 0 || (mode != 0 && mode != 1)) return BBB_EINVAL;
     if (mode == 1 && (a == nullptr || b == nullptr || x_n <= 0 || n % x_n != 0)) return BBB_EINVAL;
-    if (n % 4 != 0 || (mode == 1 && x_n % 4 != 0)) return BBB_ESHAPE;
-    if ((((uintptr_t)a | (uintptr_t)x | (uintptr_t)b | (uintptr_t)out) & 15u) != 0) return BBB_EALIGN;
-    const int64_t blocks = (n / 4 + 255) / 256;
+    if ((((uintptr_t)a | (uintptr_t)x | (uintptr_t)b | (uintptr_t)out) & 3u) != 0) return BBB_EALIGN;
+    // 16-byte vectors when every operand allows it; otherwise (ragged element counts, views with a storage offset) the scalar
+    // kernel: the same products and the same fmaf per element, so the result does not depend on which one ran
+    const bool vec = n % 4 == 0 && (mode == 0 || x_n % 4 == 0) && (((uintptr_t)a | (uintptr_t)x | (uintptr_t)b | (uintptr_t)out) & 15u) == 0;
+    const int64_t blocks = ((vec ? n / 4 : n) + 255) / 256;
     if (blocks > 0x7fffffffLL) return BBB_ESHAPE;
-    hipLaunchKernelGGL(lrt_glue_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, x, b, out, n / 4, mode == 1 ? x_n / 4 : 1, mode);
+    if (vec) hipLaunchKernelGGL(lrt_glue_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, x, b, out, n / 4, mode == 1 ? x_n / 4 : 1, mode);
+    else     hipLaunchKernelGGL(lrt_glue_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, x, b, out, n, mode == 1 ? x_n : 1, mode);
     return (int)hipGetLastError();
 }

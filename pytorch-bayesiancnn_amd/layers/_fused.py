@@ -85,7 +85,7 @@ def _logit_graph(wrapper, st, x, K, seed, pver):
     if not speculation.get("graph_after"):
         return None
     cache = st.setdefault("logit_graphs", {})
-    key = (tuple(x.shape), x.dtype, x.device.index, int(K), int(seed), tuple(p[1] for p in pver[1:]), ops.split_k, ops.gemm_mode)
+    key = (tuple(x.shape), x.dtype, x.device.index, int(K), int(seed), tuple(p[1] for p in pver[1:]), ops.current_config().key())
     ent = cache.get(key)
     if ent is None:
         ent = cache[key] = [0, None]
@@ -95,8 +95,14 @@ def _logit_graph(wrapper, st, x, K, seed, pver):
         cache[key] = cache.pop(key)                            # most recently used last
     ent[0] += 1
     if ent[1] is None and ent[0] >= int(speculation["graph_after"]):
-        g = ensemble.GraphedLogits(wrapper, x, K)
-        ent[1] = g if g.graph is not None else False
+        # an optimisation of a forward the eager path serves anyway: whatever goes wrong while warming up / capturing (allocator,
+        # a capture the runtime refuses) must not surface from the user's net(x) -- this key simply stays eager
+        try:
+            g = ensemble.GraphedLogits(wrapper, x, K)
+            ent[1] = g if g.graph is not None else False
+        except Exception as exc:                       # noqa: BLE001
+            ent[1] = False
+            st["logit_graph_error"] = "%s: %s" % (type(exc).__name__, str(exc)[:200])
     return ent[1] or None
 
 

@@ -260,3 +260,14 @@ def test_training_glue_kernels_vs_torch():
     want = a.double() + 2.0 * x.double() * b.double()
     assert float((got.double() - want).abs().max()) <= 1e-6 * float(want.abs().max())
     assert float((ops.lrt_input_grad_combine(a, a, b) - torch.addcmul(a, a, b, value=2.0)).abs().max()) <= 1e-5
+    # ragged element counts and views with a storage offset (these used to raise BBB_ESHAPE / BBB_EALIGN in backward):
+    # the scalar variant runs, same products, same fmaf
+    x3 = torch.randn(512, 3, 5, 5, device="cuda")[1:]                        # 511 * 75 elements, data_ptr 300 bytes past an allocation
+    assert x3.contiguous().data_ptr() % 16 != 0 or x3.numel() % 4 != 0
+    assert torch.equal(ops.square(x3), x3 * x3)
+    a7, b7, x7 = torch.randn(3, 7, 9, device="cuda"), torch.randn(3, 7, 9, device="cuda"), torch.randn(1, 7, 9, device="cuda")
+    got = ops.lrt_input_grad_combine(a7, x7, b7)
+    assert torch.equal(got, torch.addcmul(a7, (2.0 * x7).expand_as(b7), b7)) or \
+        float((got.double() - (a7.double() + 2.0 * x7.double() * b7.double())).abs().max()) <= 1e-6 * 10
+    off = torch.randn(4 * 64 + 1, device="cuda")[1:].view(4, 64)             # 4-byte aligned only
+    assert torch.equal(ops.square(off), off * off)

@@ -112,6 +112,35 @@ def test_no_oracle_import_in_product():
                 assert not bad.search(txt), f"{f} references the oracle"
 
 
+def test_launch_config_object_replaces_the_process_wide_switches():
+    """ops.LaunchConfig: module attributes are views of the DEFAULT configuration; use_config is thread-local and nests."""
+    import threading
+    from bbb_hip import ops
+    d = ops.current_config()
+    assert d is ops._default_config and ops.gemm_mode == "fp32" and ops.split_k is True and ops.pool_fusion is True
+    ops.gemm_mode = "bf16x3"
+    try:
+        assert d.gemm_mode == "bf16x3" and "gemm_mode" not in vars(ops)      # stored in the object, not as a module global
+    finally:
+        ops.gemm_mode = "fp32"
+    with ops.use_config(gemm_mode="bf16x3", split_k=False) as c:
+        assert ops.current_config() is c and c.gemm_mode == "bf16x3" and not c.split_k and d.gemm_mode == "fp32"
+        assert ops.gemm_mode == "fp32"                                       # the attribute still names the default
+        with ops.overlapped_launches(True) as c2:
+            assert c2.launches_overlap and c2.gemm_mode == "bf16x3" and not c.launches_overlap
+        seen = []
+        t = threading.Thread(target=lambda: seen.append(ops.current_config()))
+        t.start(); t.join()
+        assert seen[0] is d                                                  # another thread: untouched
+        assert ops.current_config() is c
+    assert ops.current_config() is d
+    assert c.key() != d.key() and d.copy().key() == d.key() and len(d.key()) == len(ops.LaunchConfig.FIELDS)
+    with pytest.raises(AttributeError):
+        ops.LaunchConfig(no_such_knob=1)
+    with pytest.raises(AttributeError):
+        ops.no_such_attribute
+
+
 # ---------------------------------------------------------------- drop-in surface
 def test_layers_surface_matches_reference_contract():
     import inspect
@@ -413,6 +442,93 @@ def test_unit_sharded_ensemble_over_gloo(tmp_path, world, E, B, S_expected):
     for r, p in enumerate(procs):
         out, err = p.communicate(timeout=240)
         assert p.returncode == 0 and f"RANK_OK {r}" in out, err[-3000:]
+
+
+_PROBE_WORKER = r'''
+import os, sys, time
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from bbb_hip import ensemble
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % os.environ["MASTER_PORT"], rank=rank, world_size=world)
+g = dist.group.WORLD
+stalled_run = float(sys.argv[2]) > 0
+stall = float(sys.argv[2]) if rank == 1 else 0.0
+ensemble.capture_probe_timeout_s = 3.0
+t0 = time.time()
+ok = ensemble.collective_capture_ok(g, torch.device("cpu"), _force_probe=True, _stall_s=stall)
+dt = time.time() - t0
+assert ok is False and ensemble.last_protocol["collective"] == "eager"
+assert ensemble.collective_capture_ok(g, torch.device("cpu")) is False           # cached per group OBJECT
+if stalled_run:
+    assert 2.5 < dt < 8.0, dt                                   # the watchdog, not the stalled rank, ended the wait
+    assert "did not finish" in ensemble.last_protocol["reason"], ensemble.last_protocol
+else:
+    assert dt < 3.0 and "gloo" in ensemble.last_protocol["reason"], ensemble.last_protocol     # phase 1: every rank said "cannot", agreed
+# the caller's own group is untouched by an abandoned probe: the eager protocol works on it
+recv = torch.zeros(2 * world); send = torch.full((2,), float(rank + 1))
+dist.all_gather_into_tensor(recv, send, group=g)
+assert recv.tolist() == [float(r + 1) for r in range(world) for _ in range(2)]
+print("RANK_OK", rank, "FALLBACK", ensemble.last_protocol["reason"], flush=True)
+os._exit(0)                                                     # (an abandoned helper thread may still sit in its rendezvous)
+'''
+
+
+@pytest.mark.parametrize("stall", [0.0, 6.0])
+def test_capture_probe_agrees_and_survives_a_stalled_rank_over_gloo(tmp_path, stall):
+    """ADVICE r04 / review item 7: every rank enters the same agreement collectives whatever its local preconditions say (here:
+    a host backend -> all say "cannot" and agree), and a rank that never arrives costs the others the watchdog's 3 s, after which
+    they run the eager protocol on their untouched group instead of hanging."""
+    script = tmp_path / "probe_worker.py"
+    script.write_text(_PROBE_WORKER)
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), PKG, str(stall)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    for r, p in enumerate(procs):
+        out, err = p.communicate(timeout=120)
+        assert p.returncode == 0 and f"RANK_OK {r}" in out, err[-3000:]
+        if stall:
+            assert "FALLBACK the capture probe did not finish" in out
+
+
+def test_recording_needs_evidence_that_the_nccl_event_cache_is_off():
+    """ADVICE r04 (medium): the variable is read when a ProcessGroupNCCL is CONSTRUCTED; a group that predates the import (when
+    the variable was not "0") still has the cache on, and re-reading the environment after our own setdefault proves nothing."""
+    code = r'''
+import os, sys
+sys.path.insert(0, %r)
+os.environ.pop("TORCH_NCCL_CUDA_EVENT_CACHE", None)
+import torch, torch.distributed as dist
+mode = sys.argv[1]
+if mode == "group_first":
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%%s" %% sys.argv[2], rank=0, world_size=1)
+elif mode == "exported":
+    os.environ["TORCH_NCCL_CUDA_EVENT_CACHE"] = "0"
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%%s" %% sys.argv[2], rank=0, world_size=1)
+import bbb_hip
+assert os.environ["TORCH_NCCL_CUDA_EVENT_CACHE"] == "0"
+print("KNOWN_OFF", bbb_hip.nccl_event_cache_known_off())
+if mode == "import_first":
+    os.environ["TORCH_NCCL_CUDA_EVENT_CACHE"] = "1"
+    print("AFTER_CHANGE", bbb_hip.nccl_event_cache_known_off())
+''' % PKG
+    import socket
+    for mode, want in (("import_first", "KNOWN_OFF True"), ("group_first", "KNOWN_OFF False"), ("exported", "KNOWN_OFF True")):
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        r = subprocess.run([sys.executable, "-c", code, mode, str(port)], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0 and want in r.stdout, (mode, r.stdout, r.stderr[-2000:])
+        if mode == "import_first":
+            assert "AFTER_CHANGE False" in r.stdout
 
 
 def test_plan_slices_and_output_rows():
