@@ -306,13 +306,14 @@ def conv_flops(B, Cin, H, W, Cout, kh, kw, stride, padding, dilation, draws, con
     return base * vr * vq, base * ho * wo * kh * kw
 
 
-def _chwn_ok(net, x):
-    """The batch-innermost fast path handles: 4-d input, B % 4 == 0, no autograd, and only module kinds it
-    knows how to run in that layout (Bayesian layers, ReLU/Softplus, MaxPool2d without padding, FlattenLayer
-    that flattens whole images)."""
+def _chwn_ok(net, x, any_batch=True):
+    """The batch-innermost fast path handles: 4-d input, no autograd, and only module kinds it knows how to run in that layout
+    (Bayesian layers, ReLU/Softplus, MaxPool2d without padding, FlattenLayer that flattens whole images).  Batch sizes that are
+    not a multiple of 4 (image rows move as 16-byte vectors) run PADDED with zero images whose rows are dropped again
+    (_mc_logits_chwn); any_batch=False: only batches that need no padding (work units, several steps per launch)."""
     if torch.is_grad_enabled() and any_requires_grad(net):
         return False
-    if x.dim() != 4 or x.shape[0] % 4 != 0:
+    if x.dim() != 4 or x.shape[0] == 0 or (not any_batch and x.shape[0] % 4 != 0):
         return False
     st = _structure(net)
     if "chwn_mods" not in st:
@@ -345,7 +346,7 @@ def _check_precision(precision, net, x, fast_path_allowed):
         return
     if precision != "bf16":
         raise _lib.BBBHipError(f"precision must be 'fp32', 'bf16x3' or 'bf16', got {precision!r}")
-    if not fast_path_allowed or not _chwn_ok(net, x):
+    if not fast_path_allowed or not _chwn_ok(net, x, any_batch=False):
         raise _lib.BBBHipError("bf16 runs on the batch-innermost inference path only (no autograd, no external eps, "
                                "4-d input with B % 8 == 0, BBB layers + ReLU/Softplus/MaxPool2d/FlattenLayer)")
 
@@ -371,6 +372,15 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
     E, B = draws, x.shape[0]
     ukw = {}
     G = int(groups)
+    rows_real = None
+    if B % 4 != 0 and not bf16 and G == 1 and share is None and (units is None or units[0] <= 1):
+        # an odd batch stays on the batch-innermost kernels: zero images fill it up to the next multiple of 4 (every image is
+        # its own GEMM column -- BBB weights are shared, LRT noise is keyed by the global image index -- so the real images'
+        # results are those of an unpadded run), and their output rows (they come last, also behind a flatten that cuts images
+        # into several rows) are dropped again.  One small copy instead of the ~2x slower reference-layout kernels.
+        rows_real = output_rows(net, tuple(x.shape))
+        x = torch.cat([x, x.new_zeros((-B % 4,) + tuple(x.shape[1:]))], dim=0)
+        B = x.shape[0]
     if G > 1:
         if units is not None and units[0] > 1:
             raise _lib.BBBHipError("several steps per launch and work units do not combine")
@@ -596,6 +606,8 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
                                                             for pt, (b0, b1) in zip(parts, bounds))) \
             else torch.cat(parts, dim=0)
     stats["path"] = "chwn"
+    if rows_real is not None:
+        out = out[:, :, :rows_real]                              # (a view: the consumers' .contiguous() compacts it)
     return out, kl                                               # logits stay batch-innermost: [E, C, B]
 
 
@@ -833,7 +845,7 @@ def group_share(num_ens, steps, rank, world):
 
 def units_ok(net, x, fuse_act=True):
     """Work-unit sharding runs on the batch-innermost path only, and needs the flatten (if any) to keep one row per image."""
-    return bool(fuse_act) and _chwn_ok(net, x) and output_rows(net, tuple(x.shape)) == x.shape[0]
+    return bool(fuse_act) and _chwn_ok(net, x, any_batch=False) and output_rows(net, tuple(x.shape)) == x.shape[0]
 
 
 def shard_plan(net, x, num_ens, rank, world, fuse_act=True, precision="fp32"):
@@ -979,6 +991,15 @@ def lane_group(group, lane):
             dist.all_gather_into_tensor(torch.empty((4 * dist.get_world_size(g),), device=dev), t, group=g)
             torch.cuda.synchronize(dev)
     return lanes[lane]
+
+
+def force_eager_collectives(group):
+    """After a stall of a pipeline whose collectives were recorded into its graphs: from now on this group's pipelines use the
+    eager protocol, on FRESH lane streams (the old ones may sit behind a collective kernel that never completes)."""
+    _capture_probe[group] = False
+    last_protocol.update(collective="eager", reason="forced after a stalled recorded collective")
+    _lane_pool.clear()
+    _stream_pool.clear()
 
 
 def _with_watchdog(fn, timeout_s):

@@ -51,16 +51,24 @@ def test_bench_json_contract_default():
     _check_roofline(r, 157.3)
     # every judged number is a first-level scalar of `roofline` (what the driver's record keeps), the reparam pass also nested
     for k in ("per_launch_us", "slabs_per_launch", "sustained_frac", "stats_median", "stats_p10", "stats_p90", "one_step_in_flight_ms",
-              "one_step_per_launch_ms", "reparam_frac", "reparam_avg_us", "reparam_bytes", "reparam_group_frac", "dropin_loop_value"):
+              "one_step_per_launch_ms", "reparam_frac", "reparam_avg_us", "reparam_bytes", "reparam_draws", "reparam_10draw_frac",
+              "reparam_hbm_resident_frac", "dropin_loop_value", "timed_by", "value_above_p90", "odd_batch_510_value", "hooked_loop_value"):
         assert k in r and not isinstance(r[k], (dict, list)), k
     assert r["slabs_per_launch"] == 40 and len(r["per_launch_us"].split("/")) == 6
     assert r["stats_p10"] <= r["stats_median"] <= r["stats_p90"]
-    assert set(r["reparam"]) == {"frac", "avg_us", "bytes"} and r["reparam"]["bytes"] == (8 + 4 * 10) * 2175946
+    # reparam_frac is the launch shape the timed region runs: 4 steps x 10 draws per launch (review r04: "make the judged line say
+    # what the timed region does"); the 10-draw launch and the HBM-resident probe are named scalars beside it
+    assert r["reparam_draws"] == 40 and r["reparam_bytes"] == (8 + 4 * 40) * 2175946
     assert abs(r["reparam_frac"] - r["reparam_bytes"] / (r["reparam_avg_us"] * 1e-6) / 8e12) < 2e-3
+    assert 0 < r["reparam_hbm_resident_frac"] < 1 and 0 < r["reparam_10draw_frac"] < 1.2
+    assert r["value_above_p90"] == (j["value"] > r["stats_p90"]) and "hipGraph" in r["timed_by"]
     # the secondary line: the objects of rounds 1-3, unabridged
     for k in ("roofline_detail", "roofline_reparam", "stats", "one_step_in_flight", "one_step_per_launch", "dropin_loop", "configs",
-              "training_step", "split_bf16"):
+              "training_step", "split_bf16", "slow_paths"):
         assert k in sec, k
+    sp = sec["slow_paths"]
+    assert "error" not in sp and sp["odd_batch_510"]["value"] > sp["odd_batch_510_reference_layout"]["value"] > 0
+    assert sp["forward_hook_dropin_loop"]["value"] > 0
     rr = sec["roofline_reparam"]
     assert rr["bound"] == "hbm" and rr["peak"] == 8000.0 and abs(rr["frac"] - rr["achieved"] / rr["peak"]) < 1e-3
     assert "error" not in sec["dropin_loop"] and sec["dropin_loop"]["value"] > 0
@@ -110,6 +118,7 @@ def test_bench_n_gt_1_flow_rehearsed_on_one_device():
     _check_roofline(j["roofline"], 157.3)
     assert j["roofline"]["slabs_per_launch"] == 20 and j["cpu_baseline"]["value"] > 0          # rank 0: 20 of a group's 40 draws
     assert j["config"]["global_batch"] == 512 and j["config"]["num_ens_total"] == 10          # the metric's workload, not 2x of it
+    assert j["config"]["backend_mode"].startswith("eager all_gather") and "gloo" in j["config"]["backend_mode"]
     assert "groups of 4 steps" in j["config"]["parallelism"] and j["config"]["draws_per_rank"] == [20, 20]
     assert j["weak_scaling"]["num_ens_total"] == 20
     assert abs(j["value"] - 512 * 10 / (j["ms_per_step"] * 1e-3)) <= 1e-3 * j["value"]
@@ -143,7 +152,28 @@ def test_bench_multi_rank_flow_over_rccl_with_one_rank():
     assert p.returncode == 0, p.stderr[-3000:]
     j, _ = _split(p.stdout)
     assert j["n_gpus"] == 1 and j["config"]["ranks_seen"] == 1 and j["config"]["backend"] == "nccl"
+    assert j["config"]["backend_mode"].startswith("all_gather recorded"), j["config"]["backend_mode"]
     assert j["config"]["draws_per_rank"] == [40] and "2 lane" in j["config"]["launch"] and "4 steps per launch" in j["config"]["launch"]
     assert j["value"] > 0 and j["weak_scaling"]["value"] > 0
     _check_roofline(j["roofline"], 157.3)
     assert j["roofline"]["slabs_per_launch"] == 40
+
+
+def test_bench_first_contact_watchdog_ends_a_stalled_sharded_run():
+    """Review r04 item 8: a rank that never finishes its first sharded replays must not cost the driver its lease.  Two ranks on one
+    device over gloo; rank 1 sleeps inside the first-contact section (test hook); both ranks' watchdogs (8 s here) fire, rank 0
+    prints a line in the judged format with "error" and the processes exit with code 3 -- within seconds, not at the launcher's
+    timeout."""
+    import time
+    env = dict(os.environ, BBB_BENCH_DEVICE="0", BBB_BENCH_BACKEND="gloo", BBB_BENCH_FIRST_CONTACT_TIMEOUT_S="8",
+               BBB_BENCH_TEST_STALL_S="600", BBB_BENCH_TEST_STALL_RANK="1")
+    t0 = time.time()
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                        "--no-extras", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+    assert time.time() - t0 < 240
+    assert p.returncode != 0
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{") and '"error"' in ln]
+    assert lines, p.stdout[-2000:] + p.stderr[-2000:]
+    j = json.loads(lines[-1])
+    assert j["value"] is None and "first sharded replays did not complete" in j["error"] and j["n_gpus"] == 2
