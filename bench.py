@@ -1101,11 +1101,11 @@ def main():
                 if name == args.config:
                     continue
                 try:
-                    # single-draw configurations are a dozen 10-20 us launches per step: four lanes AND four consecutive steps per
+                    # single-draw configurations are a dozen 10-20 us launches per step: four lanes AND sixteen consecutive steps per
                     # launch (profiles/r03_notes.md sections 4, 9); the 25-draw and 224x224 steps fill the chip: three lanes
                     small = c["E"] == 1 and c["hw"] == 32
                     depth = 4 if small else 3
-                    spl = 4 if small else 1
+                    spl = 16 if small else 1                  # (round 5 sweep, profiles/r05_notes.md section 3: 4 -> 16 steps per launch)
                     nst = max(10, args.steps // 2)
                     nst = -(-nst // (spl * depth)) * spl * depth
                     r, n2, x2 = run_config(c, nst, 5, depth, dev, want_roofline=True, timer_steps=3, steps_per_launch=spl, preheat_s=0.15)

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define BBB_ABI_VERSION 8
+#define BBB_ABI_VERSION 9
 #define BBB_MAX_SEGMENTS 16
 
 #define BBB_EINVAL (-1)   /* bad argument (null pointer, non-positive size, too many segments) */
@@ -171,7 +171,12 @@ typedef struct bbb_conv_desc {
                              for bit bbb_maxpool_chwn(bbb_conv2d_chwn_fwd(...), 2, 2).  Needs even ho and wo and a layer without a
                              split contraction (bbb_conv2d_chwn_splitk_scratch reports k_split 1), else BBB_EINVAL; items are four
                              times fewer and four times longer, so it pays for launches that still spread evenly over the chip
-                             (the callers decide: bbb_hip/ops.py pool_fusion_ok).  0: none. */
+                             (the callers decide: bbb_hip/ops.py pool_fusion_ok).  0: none.
+                             bbb_conv2d_chwn_bf16_fwd (ABI 9): 1 = MaxPool2d(2, 2), (k << 8) | s = MaxPool2d(k, s); admitted: 2 / 2
+                             and 3 / 2, for first layers with a row pitch <= 128 (weights in registers: 3Conv3FC conv1, LeNet
+                             conv1) -> y [draws][cout][hp][wp][B]; the maximum is taken over the fp32 contraction results, then
+                             bias, activation and the bf16 rounding once per pooled pixel (non-decreasing: the same values as
+                             bbb_maxpool_chwn_bf16 of the unfused launch). */
 } bbb_conv_desc_t;
 
 /*

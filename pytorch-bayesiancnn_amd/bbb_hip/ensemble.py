@@ -475,12 +475,20 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
                         if timers is not None else None
                     is_logits = logits_buf is not None and i == last_bayes and not is_conv
                     dst = logits_buf[e0:e1] if is_logits else None
+                    tapm = is_conv and ops.bf16_tap_major(tuple(mod.W_mu.shape))
+                    of32 = i == last_bayes and tail_is_last
+                    # [activation ->] MaxPool2d after a first layer with a short contraction: one launch (ops.bf16_pool_fusion_ok)
+                    pool_at = i + (2 if act is not None else 1)
+                    pool_mod = children[pool_at] if pool_at < len(children) and isinstance(children[pool_at], nn.MaxPool2d) else None
+                    fuse_pool = is_conv and ops.bf16_pool_fusion_ok(ckk, tapm, of32, pool_mod)
+                    pool_ks = (pool_mod.kernel_size, pool_mod.stride if pool_mod.stride is not None else pool_mod.kernel_size) if fuse_pool else None
                     # (operands bound as defaults: bench.py's LaunchRecorder replays these closures after the loop has moved on)
                     y = _run(timers, "conv_gemm", fl,
-                             lambda h5=h5, w=w, b=b, ckk=ckk, geom=geom, act=act, dst=dst, ukw2=ukw2, mod=mod, is_conv=is_conv, i=i:
-                             ops.conv2d_chwn_bf16_forward(h5, w, b, ckk, *geom, act=act, out_f32=(i == last_bayes and tail_is_last),
-                                                          out=dst, tap_major=is_conv and ops.bf16_tap_major(tuple(mod.W_mu.shape)),
-                                                          **ukw2))
+                             lambda h5=h5, w=w, b=b, ckk=ckk, geom=geom, act=act, dst=dst, ukw2=ukw2, tapm=tapm, of32=of32, pool_ks=pool_ks:
+                             ops.conv2d_chwn_bf16_forward(h5, w, b, ckk, *geom, act=act, out_f32=of32, out=dst, tap_major=tapm,
+                                                          pool=pool_ks, **ukw2))
+                    if fuse_pool:
+                        i += 1                                   # the pooling module is done too
                 elif isinstance(mod, _BBBLayer):
                     w, b = sampled[mod]
                     if not ukw:

@@ -681,11 +681,31 @@ def to_batch_innermost_bf16_slices(x, slices):
     return y
 
 
+def bf16_pool_fusion_ok(cin_khkw, tap_major, out_f32, pool_module):
+    """May conv2d_chwn_bf16_forward(..., pool=(k, s)) replace conv + maxpool_chwn_bf16(k, s)?  First layers with a short
+    contraction (row pitch <= 128: 3Conv3FC conv1, LeNet conv1 -- pconv_bf16_smallk_pool_kernel) followed by [activation ->]
+    MaxPool2d(2, 2) or MaxPool2d(3, 2) without padding / dilation / ceil_mode.  Same values as the two launches (the maximum is
+    taken before bias, activation and rounding, which are non-decreasing)."""
+    if not current_config().pool_fusion or pool_module is None or tap_major or out_f32:
+        return False
+    cin, kh, kw = cin_khkw
+    if bf16_row_pitch(cin * kh * kw) > 128:
+        return False
+    pr = lambda v: (v, v) if isinstance(v, int) else tuple(v)
+    ks = (pr(pool_module.kernel_size), pr(pool_module.stride if pool_module.stride is not None else pool_module.kernel_size))
+    if ks not in (((2, 2), (2, 2)), ((3, 3), (2, 2))):
+        return False
+    return pr(pool_module.padding) == (0, 0) and pr(pool_module.dilation) == (1, 1) and not pool_module.ceil_mode and \
+        not getattr(pool_module, "return_indices", False)
+
+
 def conv2d_chwn_bf16_forward(x, w, bias, cin_khkw, stride=1, padding=0, dilation=1, act=None, out_f32=False, out=None,
-                             tap_major=False, units=None, n_units=None, x_per_slice=False, x_div=1, x_off=0):
+                             tap_major=False, units=None, n_units=None, x_per_slice=False, x_div=1, x_off=0, pool=None):
     """bf16 batch-innermost conv.  x: [E|1, Cin, H, W, B] bf16 (B % 8 == 0); w: [E|1, Cout, Kp] bf16 as written by
     sample_weights_bf16 (tap_major = its column order, see bf16_tap_major); cin_khkw = (Cin, kh, kw); bias [E|1, Cout]
-    fp32 or None -> y [E, Cout, Ho, Wo, B] bf16 (fp32 when out_f32)."""
+    fp32 or None -> y [E, Cout, Ho, Wo, B] bf16 (fp32 when out_f32).
+    pool = (k, s): the launch also applies MaxPool2d(k, s) to the activated output -> [E, Cout, Hp, Wp, B] (bf16_pool_fusion_ok
+    says when the library has that form)."""
     require_device(x, w, dtype=torch.bfloat16)
     require_device(bias)
     x, w = x.contiguous(), w.contiguous()
@@ -716,6 +736,10 @@ def conv2d_chwn_bf16_forward(x, w, bias, cin_khkw, stride=1, padding=0, dilation
         _apply_units(d, units, x_per_slice)
     ho = (H + 2 * ph - dh * (kh - 1) - 1) // sh + 1
     wo = (W + 2 * pw - dw * (kw - 1) - 1) // sw + 1
+    if pool is not None:
+        pk, pst = int(pool[0]), int(pool[1])
+        d.pool = 1 if (pk, pst) == (2, 2) else ((pk << 8) | pst)
+        ho, wo = (ho - pk) // pst + 1, (wo - pk) // pst + 1
     shape = (E, w.shape[1], ho, wo, B)
     dt = torch.float32 if out_f32 else torch.bfloat16
     if out is None:

@@ -541,6 +541,249 @@ __global__ __launch_bounds__(256) void pconv_bf16_smallk_kernel(const PConvArgs 
     }
 }
 
+// ---- first layers followed by [activation ->] MaxPool2d(pk, ps): the pooling inside the launch ----
+// 3Conv3FC conv1 (bf16, bs 256, 16 steps per launch) is 104 us of which most is the per-pixel epilogue and the 268 MB it stores;
+// the 3 x 3 / 2 pooling launch behind it reads those 268 MB again (63 us at the HBM rate).  Here a workgroup owns `csplit`-th of
+// a POOLED row for its 256 images and 32 / 64 channels: it walks the conv pixels of that strip column by column (pk rows each),
+// per pixel the unchanged contraction of pconv_bf16_smallk_kernel, then max into the (at most two, pk <= 2 ps) pooling windows
+// that contain the column -- in fp32, BEFORE bias, activation and rounding: x -> round_bf16(act(x + bias)) is non-decreasing, so
+// max-then-epilogue equals epilogue-then-max element for element -- and runs the epilogue ONCE per pooled pixel: 4.5x fewer
+// epilogues and stored bytes for 3 x 3 / 2 windows, against pk / ps (1.5x) the contraction work for the rows two pooled rows
+// share.  Image-row offsets are decoded per column (pk x KR entries, one per thread) into a two-deep table.
+template <int NT, int KS>
+__global__ __launch_bounds__(256) void pconv_bf16_smallk_pool_kernel(const PConvArgs p) {
+    constexpr int BM = 256, BN = 32 * NT, KR = KS * 16, LDXB = BM + 32, TP = 64 + 8, PKMAX = 3;
+    constexpr int XPASS = KR / 8;
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+    uint16_t* Xs = smem;                                          // [KR][LDXB]
+    uint16_t* Tall = Xs + KR * LDXB;                              // [4 waves][BN][TP] epilogue staging
+    int32_t* kt = reinterpret_cast<int32_t*>(Tall + 4 * BN * TP); // [2][PKMAX][KR] image-row offsets of the current / next column
+
+    const int pk = p.pool >> 8, ps = p.pool & 255;
+    const int Hp = (p.Ho - pk) / ps + 1, Wp = (p.Wo - pk) / ps + 1;
+    const int csplit = p.px_run;                                  // workgroups per pooled row
+    const int wpc = (Wp + csplit - 1) / csplit;                   // pooled pixels per workgroup
+    const int bid = blockIdx.x, xcd = bid & 7;
+    const int64_t item = (int64_t)xcd * p.per_xcd + (bid >> 3);
+    const int64_t item_end = (int64_t)(xcd + 1) * p.per_xcd;
+    const int64_t per_g = (int64_t)Hp * csplit * p.nbt;
+    if (item >= item_end || item >= (int64_t)p.G * per_g) return;
+    const int g = (int)(item / per_g);
+    int rem = (int)(item - (int64_t)g * per_g);
+    const int ph = rem / (csplit * p.nbt);
+    rem -= ph * csplit * p.nbt;
+    const int cs = rem / p.nbt;
+    const int b0 = (rem - cs * p.nbt) * BM;
+    const int pw0 = cs * wpc;
+    const int pw1 = (pw0 + wpc) < Wp ? (pw0 + wpc) : Wp;
+    if (pw0 >= pw1) return;
+    const int c0 = pw0 * ps, c1 = (pw1 - 1) * ps + pk - 1;        // conv columns of the strip (inclusive)
+    const int r0 = ph * ps;                                       // first conv row
+    const int e = g / p.Ntiles;
+    const int ue = p.unit_off + e;
+    const int ew = p.unit_div > 1 ? ue / p.unit_div : e;
+    const int ex = p.x_div > 1 ? (e + p.x_off) / p.x_div : (p.x_mod > 0 ? ue % p.x_mod : e);
+    const int n0 = (g - e * p.Ntiles) * BN;
+    const int Kp = p.Kp;
+    const int HpWp = Hp * Wp;
+
+    const int tid = (int)threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave * 64;
+    const int lrow = lane & 31, lk = lane >> 5;
+
+    constexpr uint32_t kOOB = 0xFFFFFFF0u;
+    const uint32_t kXInv = p.x_inv;
+    const uint16_t* xb = reinterpret_cast<const uint16_t*>(p.x) + (int64_t)ex * p.x_ds;
+    const uint16_t* wb = reinterpret_cast<const uint16_t*>(p.w) + (int64_t)ew * p.w_ds;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(xb), 0, (int)((int64_t)p.Cin * p.H * p.W * p.B * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(wb), 0, (int)((int64_t)p.Cout * Kp * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.bias ? p.bias + (int64_t)ew * p.b_ds : reinterpret_cast<const float*>(p.w)), 0, p.bias ? p.Cout * 4 : 0, 0x00020000);
+    char* yb = reinterpret_cast<char*>(p.y) + (int64_t)e * p.y_ds * 2;
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(yb, 0, (int)((int64_t)p.Cout * HpWp * p.B * 2), 0x00020000);
+
+    // image-row offsets of column c's pk pixels: reference (ci, r, q) order, padding taps and k >= K invalid; one entry per thread
+    const float inv_khkw = 1.0f / (float)p.khkw, inv_kw = 1.0f / (float)p.kw, inv_kr = 1.0f / (float)KR;
+    auto fill_col = [&](int c) {
+        int32_t* dst = kt + (c & 1) * (PKMAX * KR);
+        for (int i = tid; i < pk * KR; i += 256) {
+            int rr = (int)((float)i * inv_kr);
+            int k = i - rr * KR;
+            if (k < 0) { --rr; k += KR; } else if (k >= KR) { ++rr; k -= KR; }
+            uint32_t xo = kXInv;
+            if (k < p.K) {
+                int ci = (int)((float)k * inv_khkw);
+                int rq = k - ci * p.khkw;
+                if (rq < 0) { --ci; rq += p.khkw; } else if (rq >= p.khkw) { ++ci; rq -= p.khkw; }
+                int r = (int)((float)rq * inv_kw);
+                int q = rq - r * p.kw;
+                if (q < 0) { --r; q += p.kw; } else if (q >= p.kw) { ++r; q -= p.kw; }
+                const int ih = (r0 + rr) * p.sh - p.ph + r * p.dh, iw = c * p.sw - p.pw + q * p.dw;
+                if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) xo = (uint32_t)((ci * p.H + ih) * p.W + iw) * (uint32_t)p.B * 2u;
+            }
+            dst[rr * KR + k] = (int32_t)xo;
+        }
+    };
+    fill_col(c0);
+    // weights: MFMA A operands straight from global memory, kept for the whole strip
+    bf16x8 a[NT][KS];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            const int n = n0 + nt * 32 + lrow, k = kk * 16 + lk * 8;
+            const uint32_t off = (n < p.Cout && k < Kp) ? (uint32_t)(n * Kp + k) * 2u : kOOB;
+            a[nt][kk] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, off, 0, 0));
+        }
+    f32x4 bq[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4)
+            bq[nt][r4] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, (uint32_t)(n0 + nt * 32 + 8 * r4 + 4 * lk) * 4u, 0, 0));
+
+    const int xkr = tid >> 5, xb8 = (tid & 31) * 8;
+    const uint32_t xcol = (uint32_t)(b0 + xb8) * 2u;
+    u32x4 xreg[XPASS];
+    auto load_x = [&](int c, int rr) {
+        const int32_t* src = kt + (c & 1) * (PKMAX * KR) + rr * KR;
+#pragma unroll
+        for (int ps2 = 0; ps2 < XPASS; ++ps2)
+            xreg[ps2] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (uint32_t)src[xkr + ps2 * 8] + xcol, 0, 0));
+    };
+    auto store_x = [&]() {
+#pragma unroll
+        for (int ps2 = 0; ps2 < XPASS; ++ps2) *reinterpret_cast<u32x4*>(&Xs[(xkr + ps2 * 8) * LDXB + xb8]) = xreg[ps2];
+    };
+    const int tg = lane >> 4, tt = lane & 15;
+    const int tr_off = ((8 * (tg >> 1) + (tt >> 2)) * LDXB + wm + 16 * (tg & 1) + 4 * (tt & 3));
+    typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+    uint16_t* T = Tall + wave * (BN * TP);
+
+    f32x16 pnew[NT][2], pold[NT][2];          // running maxima of the window that starts latest / of the one before it
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { pnew[nt][mt][r] = -__builtin_inff(); pold[nt][mt][r] = -__builtin_inff(); }
+
+    __syncthreads();                                               // column c0's offsets visible
+    load_x(c0, 0);
+    store_x();
+    __syncthreads();
+#pragma clang loop unroll(disable)
+    for (int c = c0; c <= c1; ++c) {
+        // the windows this column belongs to (wave-uniform): w_hi starts latest (c / ps), w_hi - 1 may still be open
+        const int w_hi = c / ps;
+        const bool hi_ok = w_hi < pw1;                             // (>= pw0 by construction; the strip's last columns lie past its last window's start)
+        const bool starts = c == w_hi * ps;                        // a window position starts at this column (inside the strip or not)
+        const bool hi_first = hi_ok && starts;
+        const bool lo_ok = (w_hi - 1) >= pw0 && c <= (w_hi - 1) * ps + pk - 1;
+        if (starts) {
+            // the window that was the newest becomes the older one (still open only where windows overlap, pk > ps)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) pold[nt][mt] = pnew[nt][mt];
+        }
+#pragma clang loop unroll(disable)
+        for (int rr = 0; rr < pk; ++rr) {
+            const bool last_row = rr + 1 == pk;
+            const bool more = !(last_row && c == c1);
+            if (rr == 0 && c < c1) fill_col(c + 1);                // (its buffer was last read a column ago: barriers in between)
+            if (more) { if (!last_row) load_x(c, rr + 1); else load_x(c + 1, 0); }
+            f32x16 acc[NT][2];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[nt][mt][r] = 0.0f;
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                bf16x8 b[2];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const s16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(&Xs[tr_off + mt * 32 + kk * 16 * LDXB]));
+                    const s16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(&Xs[tr_off + mt * 32 + (kk * 16 + 4) * LDXB]));
+                    b[mt] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[nt][kk], b[mt], acc[nt][mt], 0, 0, 0);
+            }
+            // this conv pixel into its windows (fp32 contraction results: the epilogue comes after the maximum)
+            const bool hi_reset = hi_first && rr == 0;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = acc[nt][mt][r];
+                        if (hi_ok) pnew[nt][mt][r] = hi_reset ? v : fmaxf(pnew[nt][mt][r], v);
+                        if (lo_ok) pold[nt][mt][r] = fmaxf(pold[nt][mt][r], v);
+                    }
+            // a window is complete after the last row of its last column: older window first (overlapping windows), else the
+            // newest (pk <= ps); the host admits only geometries where at most one window closes per column
+            const bool emit_lo = last_row && lo_ok && c == (w_hi - 1) * ps + pk - 1;
+            const bool emit_hi = last_row && !emit_lo && hi_ok && c == w_hi * ps + pk - 1;
+            if (emit_lo || emit_hi) {
+                const int ppix = ph * Wp + (emit_lo ? w_hi - 1 : w_hi);
+                auto stage_block = [&](auto act) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int r4 = 0; r4 < 4; ++r4) {
+                            const int nl = nt * 32 + 8 * r4 + 4 * lk;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                                for (int mt = 0; mt < 2; ++mt) {
+                                    const float m = emit_lo ? pold[nt][mt][r4 * 4 + i] : pnew[nt][mt][r4 * 4 + i];
+                                    T[(nl + i) * TP + mt * 32 + lrow] = f2bf(act(m + bq[nt][r4][i]));
+                                }
+                        }
+                };
+                if (p.act == 2)      stage_block([](float v) { return bbb::apply_act(v, 2); });
+                else if (p.act == 1) stage_block([](float v) { return fmaxf(v, 0.0f); });
+                else                 stage_block([](float v) { return v; });
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int ps2 = 0; ps2 < 4 * NT; ++ps2) {
+                    const int v = ps2 * 64 + lane;
+                    const int row = v >> 3, grp = v & 7;
+                    const u32x4 q = *reinterpret_cast<const u32x4*>(&T[row * TP + grp * 8]);
+                    const int n = n0 + row, b = b0 + wm + grp * 8;
+                    const uint32_t off = ((b < p.B) & (n < p.Cout)) ? (uint32_t)(((int64_t)n * HpWp + ppix) * p.B + b) * 2u : kOOB;
+                    __builtin_amdgcn_raw_buffer_store_b128(q, yrs, off, 0, 0);
+                }
+            }
+            __syncthreads();                                       // every wave has read this pixel's rows
+            if (more) store_x();
+            __syncthreads();                                       // the next pixel's rows (and the next column's offsets) are in LDS
+        }
+    }
+}
+
+template <int NT, int KS>
+int launch_smallk_pool(const PConvArgs& a, int64_t blocks, hipStream_t st) {
+    constexpr int kSmem = (KS * 16 * (256 + 32) + 4 * 32 * NT * 72) * 2 + 2 * 3 * KS * 16 * 4;
+    static_assert(kSmem <= 160 * 1024, "LDS");
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(&pconv_bf16_smallk_pool_kernel<NT, KS>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, kSmem);
+        if (er != hipSuccess) return (int)er;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((pconv_bf16_smallk_pool_kernel<NT, KS>), dim3((unsigned)blocks), dim3(256), kSmem, st, a);
+    return (int)hipGetLastError();
+}
+
 template <int NT, int KS>
 int launch_smallk(const PConvArgs& a, int64_t blocks, hipStream_t st) {
     constexpr int kSmem = (KS * 16 * (256 + 32) + 4 * 32 * NT * 72) * 2 + 16 * KS * 16 * 4;      // px_run <= 16
@@ -687,12 +930,44 @@ extern "C" int bbb_conv2d_chwn_bf16_fwd(const bbb_conv_desc_t* d, const void* x,
     if (d->unit_div < 0 || d->unit_off < 0 || d->x_unit_mod < 0 || (d->unit_div > 1 && d->unit_off >= d->unit_div) ||
         (d->x_unit_mod > 0 && d->x_unit_mod != d->unit_div) || d->w_row_pitch != 0)
         return BBB_EINVAL;
-    if (d->pool != 0) return BBB_EINVAL;                  // pooling in the launch: the fp32 BBB kernel only
+    // pooling in the launch (bbb_conv_desc_t::pool): first layers with a short contraction only (pconv_bf16_smallk_pool_kernel);
+    // 1 = MaxPool2d(2, 2), (k << 8) | s otherwise; admitted: 2 / 2 and 3 / 2 (at most one window closes per conv column)
+    int pool_k = 0, pool_s = 0;
+    if (d->pool != 0) {
+        pool_k = d->pool == 1 ? 2 : (d->pool >> 8);
+        pool_s = d->pool == 1 ? 2 : (d->pool & 255);
+        if (!((pool_k == 2 && pool_s == 2) || (pool_k == 3 && pool_s == 2)) || ho < pool_k || wo < pool_k) return BBB_EINVAL;
+        if (tap_major || out_f32 || Kp > 128) return BBB_EINVAL;
+    }
     if (d->x_unit_div < 0 || d->x_unit_off < 0 || (d->x_unit_div > 1 && (d->unit_div > 1 || d->x_unit_off >= d->x_unit_div)) ||
         (d->x_unit_div <= 1 && d->x_unit_off != 0))
         return BBB_EINVAL;
     a.x_div = d->x_unit_div; a.x_off = d->x_unit_off;
     a.unit_div = d->unit_div; a.unit_off = d->unit_div > 1 ? d->unit_off : 0; a.x_mod = d->x_unit_mod;
+    if (pool_k != 0) {
+        const int nt = a.Cout <= 32 ? 1 : 2;
+        const int ks = Kp <= 32 ? 2 : (Kp <= 80 ? 5 : 8);
+        a.Ntiles = (a.Cout + 32 * nt - 1) / (32 * nt);
+        a.G = a.Ntiles * d->draws;
+        a.nbt = (a.B + 255) / 256;
+        a.pool = (pool_k << 8) | pool_s;
+        const int hp = (ho - pool_k) / pool_s + 1, wp = (wo - pool_k) / pool_s + 1;
+        a.y_ds = (int64_t)d->cout * hp * wp * d->batch;
+        // workgroups per pooled row: enough strips for >= 512 workgroups (2 per CU), each at least two pooled pixels wide (a strip
+        // of n pooled pixels computes n * ps + pk - ps conv columns: the narrower, the more columns are computed twice)
+        const int64_t rows = (int64_t)a.G * a.nbt * hp;
+        int csplit = (int)((512 + rows - 1) / rows);
+        const int max_split = wp >= 2 ? wp / 2 : 1;
+        csplit = csplit < 1 ? 1 : (csplit > max_split ? max_split : csplit);
+        a.px_run = csplit;
+        const int64_t items = rows * csplit;
+        const int64_t per = (items + 7) / 8;
+        if (8 * per > 0x7fffffffLL) return BBB_ESHAPE;
+        a.per_xcd = (int32_t)per;
+        hipStream_t st = (hipStream_t)stream;
+        if (nt == 1) return ks == 2 ? launch_smallk_pool<1, 2>(a, 8 * per, st) : ks == 5 ? launch_smallk_pool<1, 5>(a, 8 * per, st) : launch_smallk_pool<1, 8>(a, 8 * per, st);
+        return ks == 2 ? launch_smallk_pool<2, 2>(a, 8 * per, st) : ks == 5 ? launch_smallk_pool<2, 5>(a, 8 * per, st) : launch_smallk_pool<2, 8>(a, 8 * per, st);
+    }
     if (!tap_major && !out_f32 && Kp <= 128 && (int64_t)ho * wo >= 16) {
         // a first layer with a short contraction: weights in registers, a run of pixels per workgroup (pconv_bf16_smallk_kernel)
         const int nt = a.Cout <= 32 ? 1 : 2;

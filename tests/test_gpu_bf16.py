@@ -106,6 +106,56 @@ def test_short_row_first_layer_kernel_equals_the_general_kernel(env, B, Cin, H, 
         assert torch.equal(y32.to(torch.bfloat16), y16), float((y32 - y16.float()).abs().max())
 
 
+@pytest.mark.parametrize("B,Cin,H,W,Cout,k,s,p,E,xs,pk", [
+    (256, 3, 32, 32, 32, 5, 1, 2, 16, False, 3),  # 3Conv3FC conv1 + MaxPool2d(3, 2), 16 one-draw steps per launch: strips of 5 pooled pixels
+    (256, 3, 32, 32, 32, 5, 1, 2, 1, True, 3),    # one step: strips of 2 pooled pixels (the narrowest)
+    (264, 3, 32, 32, 32, 5, 1, 2, 2, True, 3),    # ragged second image tile
+    (64, 1, 32, 32, 6, 5, 1, 0, 3, True, 2),      # LeNet conv1 + MaxPool2d(2, 2): K = 25, 6 channels, 28 x 28 -> 14 x 14
+    (40, 6, 9, 7, 70, 3, 1, 1, 2, False, 3),      # K = 54, three channel tiles, 9 x 7 -> 4 x 3 (odd widths: a conv column unused)
+    (16, 8, 11, 10, 40, 4, 1, 1, 2, False, 2),    # K = 128: eight steps; 10 x 9 -> 5 x 4 (last conv row / column unused by 2 / 2)
+    (8, 3, 8, 8, 32, 5, 1, 2, 1, True, 3),        # tiny map: 8 x 8 -> 3 x 3, one strip per row
+])
+def test_pooled_first_layer_equals_conv_then_pool(env, B, Cin, H, W, Cout, k, s, p, E, xs, pk):
+    """bbb_conv_desc_t::pool on the bf16 path (pconv_bf16_smallk_pool_kernel): the maximum over the window's fp32 contraction
+    results, then bias + activation + rounding once -- element for element what maxpool_chwn_bf16 makes of the unfused launch
+    (x -> round(act(x + bias)) is non-decreasing)."""
+    ops = env["ops"]
+    torch.manual_seed(B + Cout + pk)
+    x = _bf(torch.randn(1 if xs else E, Cin, H, W, B, device="cuda"))
+    w = torch.randn(E, Cout, Cin, k, k, device="cuda") * 0.2
+    bias = torch.randn(E, Cout, device="cuda")
+    for act in ("softplus", "relu", None):
+        y = ops.conv2d_chwn_bf16_forward(x, _pack_w(w), bias, (Cin, k, k), s, p, 1, act=act)
+        want = ops.maxpool_chwn_bf16(y, pk, 2)
+        got = ops.conv2d_chwn_bf16_forward(x, _pack_w(w), bias, (Cin, k, k), s, p, 1, act=act, pool=(pk, 2))
+        assert got.dtype == torch.bfloat16 and got.shape == want.shape, (got.shape, want.shape)
+        assert torch.equal(got, want), (act, float((got.float() - want.float()).abs().max()))
+    # no bias
+    y = ops.conv2d_chwn_bf16_forward(x, _pack_w(w), None, (Cin, k, k), s, p, 1, act="softplus")
+    got = ops.conv2d_chwn_bf16_forward(x, _pack_w(w), None, (Cin, k, k), s, p, 1, act="softplus", pool=(pk, 2))
+    assert torch.equal(got, ops.maxpool_chwn_bf16(y, pk, 2))
+
+
+def test_pooled_first_layer_rejects_what_it_does_not_cover(env):
+    ops = env["ops"]
+    from bbb_hip import BBBHipError
+    x = _bf(torch.randn(1, 64, 8, 8, 16, device="cuda"))
+    w = torch.randn(1, 32, 64, 3, 3, device="cuda")
+    with pytest.raises(BBBHipError):                                         # K = 576: not a short-row first layer
+        ops.conv2d_chwn_bf16_forward(x, _pack_w(w), None, (64, 3, 3), 1, 1, 1, pool=(2, 2))
+    x1 = _bf(torch.randn(1, 3, 16, 16, 16, device="cuda"))
+    w1 = torch.randn(1, 8, 3, 3, 3, device="cuda")
+    with pytest.raises(BBBHipError):                                         # 3 / 3 windows: not admitted
+        ops.conv2d_chwn_bf16_forward(x1, _pack_w(w1), None, (3, 3, 3), 1, 1, 1, pool=(3, 3))
+    import torch.nn as nn
+    assert ops.bf16_pool_fusion_ok((3, 5, 5), False, False, nn.MaxPool2d(3, 2)) and ops.bf16_pool_fusion_ok((1, 5, 5), False, False, nn.MaxPool2d(2))
+    assert not ops.bf16_pool_fusion_ok((32, 5, 5), True, False, nn.MaxPool2d(3, 2))
+    assert not ops.bf16_pool_fusion_ok((3, 5, 5), False, False, nn.MaxPool2d(3, 2, padding=1))
+    assert not ops.bf16_pool_fusion_ok((3, 5, 5), False, False, nn.MaxPool2d(3, 2, ceil_mode=True))
+    with ops.use_config(pool_fusion=False):
+        assert not ops.bf16_pool_fusion_ok((3, 5, 5), False, False, nn.MaxPool2d(3, 2))
+
+
 def test_sampled_weights_bf16_are_the_rounded_fp32_samples(env):
     """Same Philox stream, same fp32 arithmetic, one nearest-even rounding; pad columns untouched (zero); biases fp32."""
     torch.manual_seed(0)
