@@ -537,7 +537,7 @@ def maxpool_chwn_s3(x, k, s):
 
 def lrt_conv2d_chwn_forward(x, w_mu, w_var, b_mu, b_var, seed, call0, stream_id, stride=1, padding=0, dilation=1,
                             sample=True, eps=None, want_moments=False, act=None, units=None, n_units=None, b_offset=0,
-                            x_per_slice=False, x_div=1, x_off=0, n_slabs=None):
+                            x_per_slice=False, x_div=1, x_off=0, n_slabs=None, pool=False):
     """LRT layer, batch-innermost.  x: [E, Cin, H, W, B] -> (y, act_mu|None, act_var|None) [E, Cout, Ho, Wo, B].
     Work units as in conv2d_chwn_forward (call0 = the call index of the first unit's draw; the noise of unit u is keyed by
     its draw and by the GLOBAL image index slice*B + b).  b_offset: global index of local image 0 (batch-parallel shards)."""
@@ -557,7 +557,13 @@ def lrt_conv2d_chwn_forward(x, w_mu, w_var, b_mu, b_var, seed, call0, stream_id,
     d.b_offset = int(b_offset)
     d.w_draw_stride = 0
     d.b_draw_stride = 0
-    shape = (E, w_mu.shape[0], ho, wo, x.shape[4])
+    if pool:
+        # [activation ->] MaxPool2d(2, 2) inside the launch (pconv_body.cuh, POOL + LRT): the sampling epilogue per window pixel with
+        # the CONV output's noise elements, running maximum in registers -- bit for bit maxpool_chwn of the unpooled launch
+        if want_moments or ho % 2 or wo % 2:
+            raise _lib.BBBHipError("pool=True: even output height / width, and no moment outputs (the unpooled pixels are not kept)")
+        d.pool = 1
+    shape = (E, w_mu.shape[0], ho // 2, wo // 2, x.shape[4]) if pool else (E, w_mu.shape[0], ho, wo, x.shape[4])
     y = torch.empty(shape, dtype=torch.float32, device=x.device)
     am = torch.empty(shape, dtype=torch.float32, device=x.device) if want_moments else None
     av = torch.empty(shape, dtype=torch.float32, device=x.device) if want_moments else None
@@ -565,6 +571,8 @@ def lrt_conv2d_chwn_forward(x, w_mu, w_var, b_mu, b_var, seed, call0, stream_id,
         eps = eps.contiguous()
     with on_device(x.device):
         ks, scr = _split_scratch(d, True, x.device)
+        if pool and ks > 1:
+            raise _lib.BBBHipError("pool=True: this layer's contraction is split (conv + maxpool_chwn instead)")
         check(_lib.lib().bbb_lrt_conv2d_chwn_splitk_fwd(ctypes.byref(d), x.data_ptr(), w_mu.data_ptr(), w_var.data_ptr(), ptr(b_mu),
                                                         ptr(b_var), y.data_ptr(), ptr(am), ptr(av), ptr(eps), seed,
                                                         call0 & 0xFFFFFFFF, stream_id, 1 if sample else 0,

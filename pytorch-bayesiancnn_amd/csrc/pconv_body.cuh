@@ -56,7 +56,7 @@ __device__ __forceinline__ void pconv_item(const PConvArgs& p, const int64_t ite
     constexpr bool SPLIT = MODE == kSplit;
     constexpr bool SEQ = MODE == kSeq;
     constexpr bool POOL = MODE == kPool;
-    static_assert(!POOL || !LRT, "the pooled form exists for the BBB kernel only");
+    static_assert(!POOL || !LRT || BM == 64, "the pooled LRT form: 64-image tiles (one accumulator pair per wave)");
     constexpr int LDX = BM + 4;
     constexpr int NT = (BM >= 128) ? 2 : 1;              // 32-channel MFMA tiles per wave
     constexpr int MT = (BM == 256) ? 2 : 1;              // 32-image MFMA tiles per wave
@@ -74,6 +74,7 @@ __device__ __forceinline__ void pconv_item(const PConvArgs& p, const int64_t ite
     __shared__ int32_t kt_w[2][KCH];   // (k_eff -> weight offset, x row) for a chunk of 256 k_eff = 8 tiles,
     __shared__ int32_t kt_x[2][KCH];   // filled by all 256 threads at once, double buffered
     __shared__ float sbias[POOL ? BN : 1];   // POOL: the item's 64 bias values (read once per window pixel, in the MFMA layout)
+    __shared__ float sbias2[(POOL && LRT) ? BN : 1];   // ... and the 64 bias variances of an LRT layer
     // (static LDS arrays, one set per instantiation: a kernel should call ONE instantiation of this function)
 
     // ---- item -> (draw, channel tile, pixel, batch tile) ----
@@ -290,6 +291,11 @@ __device__ __forceinline__ void pconv_item(const PConvArgs& p, const int64_t ite
         const __amdgpu_buffer_rsrc_t brs0 = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(p.bias ? p.bias + (int64_t)ew * p.b_ds : p.w), 0, p.bias ? p.Cout * 4 : 0, 0x00020000);
         if (tid < BN) sbias[tid] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brs0, (uint32_t)(n0 + tid) * 4u, 0, 0));
+        if constexpr (LRT) {
+            const __amdgpu_buffer_rsrc_t brs2 = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(p.bias2 ? p.bias2 + (int64_t)ew * p.b_ds : p.w), 0, p.bias2 ? p.Cout * 4 : 0, 0x00020000);
+            if (tid < BN) sbias2[tid] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brs2, (uint32_t)(n0 + tid) * 4u, 0, 0));
+        }
         __syncthreads();
     }
 #pragma clang loop unroll(disable)
@@ -362,7 +368,7 @@ __device__ __forceinline__ void pconv_item(const PConvArgs& p, const int64_t ite
                     }
         }
     }
-    if constexpr (POOL) {
+    if constexpr (POOL && !LRT) {
         // this window pixel is done: running maximum of act(conv + bias), accumulator back to zero for the next pixel
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -376,6 +382,46 @@ __device__ __forceinline__ void pconv_item(const PConvArgs& p, const int64_t ite
                     acc[nt][mt][r] = 0.0f;
                 }
             }
+    }
+    if constexpr (POOL && LRT) {
+        // the LRT layer's window pixel: out = act(act_mu + sqrt(act_var) * eps) exactly as the unpooled epilogue computes it (same
+        // noise element: the canonical NCHW index of the CONV output), then the running maximum
+        const int pixc = (2 * oh0 + (wp >> 1)) * p.Wo + 2 * ow0 + (wp & 1);
+        const int HoWoC = p.Ho * p.Wo;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int b = b0 + wm + mt * 32 + lrow;
+            const int bglob = b + p.b_off + (p.unit_div > 1 ? (ue % p.unit_div) * p.B : 0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int nl = wn + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                    const int n = n0 + nl;
+                    float v = acc[nt][mt][r] + sbias[nl];
+                    const float var = 1e-16f + (accv[nt][mt][r] + sbias2[nl]);
+                    if (p.sample) {
+                        float z;
+                        if (p.eps_ext) {
+                            // (lanes past the batch / channel edge: their rows are never stored; keep the read in bounds)
+                            const bool in = (b < p.B) & (n < p.Cout);
+                            z = in ? p.eps_ext[(int64_t)e * ((int64_t)p.Cout * HoWoC * p.B) + ((int64_t)n * HoWoC + pixc) * p.B + b] : 0.0f;
+                        } else {
+                            const uint64_t idx = (uint64_t)(((int64_t)bglob * p.Cout + n) * HoWoC + pixc);
+                            float z4[4];
+                            bbb::normal4(idx >> 2, p.stream_id, p.call0 + (p.call_dev ? *p.call_dev : 0u) + (uint32_t)ew, p.k0, p.k1, z4);
+                            const int c = (int)(idx & 3);
+                            z = c == 0 ? z4[0] : c == 1 ? z4[1] : c == 2 ? z4[2] : z4[3];
+                        }
+                        v = v + __builtin_amdgcn_sqrtf(var) * z;
+                    }
+                    v = bbb::apply_act(v, p.act);
+                    agpr_write(tot[nt][mt][r], fmaxf(agpr_read(tot[nt][mt][r]), v));
+                    acc[nt][mt][r] = 0.0f;
+                    accv[nt][mt][r] = 0.0f;
+                    __builtin_amdgcn_sched_barrier(0);     // one element's Philox at a time: interleaved, sixteen of them hold ~90 VGPRs
+                }
+        }
     }
     }   // window pixels
     if constexpr (POOL) {
@@ -496,7 +542,8 @@ __device__ __forceinline__ void pconv_item(const PConvArgs& p, const int64_t ite
         const_cast<float*>(p.bias ? p.bias + (int64_t)ew * p.b_ds : p.w), 0, (p.bias && !POOL) ? p.Cout * 4 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
         p.y + (int64_t)e * p.y_ds, 0, (int)((int64_t)p.Cout * HoWo * p.B * 4), 0x00020000);
-    if constexpr (!LRT) {
+    if constexpr (!LRT || POOL) {
+        // (pooled LRT items end like pooled BBB items: `acc` holds finished output values)
         // Every wave transposes its 32 x 32 accumulator tile(s) through LDS (the X stage is free after the k loop) so that a
         // lane ends up with FOUR consecutive images of one channel: 8 16-byte stores and 8 bias loads per lane instead of 32 +
         // 32 four-byte ones (measured neutral at 4 workgroups per CU -- profiles/r03_notes.md section 3; the split form's

@@ -59,6 +59,16 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4, 4))
     pconv_item<128, false, ILV, kPool>(p, item);
 }
 
+// The pooled LRT layer: 64-image tiles, dual accumulators, the sampling epilogue per window pixel.
+__global__ __launch_bounds__(kThreads) void pconv_gemm_pool_lrt_kernel(const PConvArgs p) {
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7;
+    const int64_t item = (int64_t)xcd * p.per_xcd + (bid >> 3);
+    const int64_t item_end = (int64_t)(xcd + 1) * p.per_xcd;
+    if (item >= item_end || item >= (int64_t)p.G * p.Mtiles) return;
+    pconv_item<64, true, false, kPool>(p, item);
+}
+
 // Split contraction (pconv_body.cuh, SPLIT): block -> (item, k range).  The ksplit blocks of an item are consecutive, so they
 // land on the same XCD chunk as their item's weight-tile sharers.
 template <int BM, bool LRT, bool ILV>
@@ -237,9 +247,10 @@ int launch(PConvArgs& a, int draws, hipStream_t st) {
     // AlexNet layer (3 instead of 4 workgroups per CU); the launcher never selects it.
     // LRT stages two weight tiles and keeps two accumulator sets: 64-wide only.
     if (a.pool) {
-        // one item per POOLED pixel, 128-image tiles (the callers fuse large launches only)
-        if (LRT || a.ksplit > 1 || a.part != nullptr) return BBB_EINVAL;
-        a.nbt = (a.B + 127) / 128;
+        // one item per POOLED pixel, 128-image tiles (LRT: 64) (the callers fuse large launches only)
+        if (a.ksplit > 1 || a.part != nullptr) return BBB_EINVAL;
+        if (LRT && (a.y_mu != nullptr || a.y_var != nullptr)) return BBB_EINVAL;    // the moments of unpooled pixels are not kept
+        a.nbt = (a.B + (LRT ? 63 : 127)) / (LRT ? 64 : 128);
         const int64_t mtp = (pixels / 4) * a.nbt;
         const int64_t itp = (int64_t)a.G * mtp;
         if (mtp > 0x7fffffffLL || itp > 0x7fffffffLL - 8) return BBB_ESHAPE;
@@ -249,7 +260,8 @@ int launch(PConvArgs& a, int draws, hipStream_t st) {
         // staging loads up front (ILV = false): with the running maximum in 32 more accumulation registers this form fits four
         // workgroups per CU (60 + 64 registers) and the interleaved one does not (82 + 64: three; measured 492-494 us against 480-482
         // for conv1 of the metric step, profiles/r04_notes.md section 7)
-        hipLaunchKernelGGL((pconv_gemm_pool_kernel<false>), dim3((unsigned)(8 * perp)), dim3(kThreads), 0, st, a);
+        if constexpr (LRT) hipLaunchKernelGGL(pconv_gemm_pool_lrt_kernel, dim3((unsigned)(8 * perp)), dim3(kThreads), 0, st, a);
+        else               hipLaunchKernelGGL((pconv_gemm_pool_kernel<false>), dim3((unsigned)(8 * perp)), dim3(kThreads), 0, st, a);
         return (int)hipGetLastError();
     }
     const int64_t nb128 = pixels * ((a.B + 127) / 128) * a.G;

@@ -110,3 +110,35 @@ def test_ensemble_takes_the_fused_launch_for_large_launches_and_keeps_its_bits()
     assert res[True][3] == 3 and res[True][5] == 2                    # a lone 10-draw step keeps it; a lane of a pipeline does not
     assert torch.equal(res[True][0], res[False][0])
     assert torch.equal(res[True][0][:10], res[True][2]) and torch.equal(res[True][2], res[True][4])   # ... all the same bits
+
+
+@pytest.mark.parametrize("geom", [
+    dict(E=3, Cin=3, H=32, Cout=64, k=11, s=4, p=5, B=128),      # AlexNet conv1 (LRT): 8x8 -> 4x4
+    dict(E=2, Cin=64, H=4, Cout=192, k=5, s=1, p=2, B=256),      # AlexNet conv2 (LRT): 4x4 -> 2x2
+    dict(E=2, Cin=16, H=6, Cout=100, k=3, s=1, p=1, B=96),       # ragged channel tile and ragged 64-image tile
+])
+@pytest.mark.parametrize("act", [None, "relu", "softplus"])
+def test_fused_pool_lrt_is_lrt_conv_then_pool_bit_for_bit(geom, act):
+    """pool = 1 on the LRT launch (round 5): per window pixel the sampling epilogue act(act_mu + sqrt(act_var) * eps) with the
+    noise element of the CONV output's canonical NCHW index -- the Philox stream of the unpooled launch -- then the running maximum."""
+    from bbb_hip import ops, _lib
+    g = torch.Generator(device="cuda").manual_seed(7)
+    E, Cin, H, Cout, k, B = geom["E"], geom["Cin"], geom["H"], geom["Cout"], geom["k"], geom["B"]
+    x = torch.randn(E, Cin, H, H, B, device="cuda", generator=g)
+    w_mu = torch.randn(Cout, Cin, k, k, device="cuda", generator=g) * 0.1
+    w_var = torch.rand(Cout, Cin, k, k, device="cuda", generator=g) * 1e-2
+    b_mu = torch.randn(Cout, device="cuda", generator=g)
+    b_var = torch.rand(Cout, device="cuda", generator=g) * 1e-2
+    g3 = (geom["s"], geom["p"], 1)
+    for sample in (True, False):
+        y, _, _ = ops.lrt_conv2d_chwn_forward(x, w_mu, w_var, b_mu, b_var, 99, 5, 17, *g3, sample=sample, act=act, b_offset=3)
+        want = ops.maxpool_chwn(y, 2, 2)
+        got, _, _ = ops.lrt_conv2d_chwn_forward(x, w_mu, w_var, b_mu, b_var, 99, 5, 17, *g3, sample=sample, act=act, b_offset=3, pool=True)
+        assert got.shape == want.shape and torch.equal(got, want), (sample, float((got - want).abs().max()))
+    # external noise (the replay entry), no bias
+    eps = torch.randn(E, Cout, y.shape[2], y.shape[3], B, device="cuda", generator=g)
+    y, _, _ = ops.lrt_conv2d_chwn_forward(x, w_mu, w_var, None, None, 99, 5, 17, *g3, eps=eps, act=act)
+    got, _, _ = ops.lrt_conv2d_chwn_forward(x, w_mu, w_var, None, None, 99, 5, 17, *g3, eps=eps, act=act, pool=True)
+    assert torch.equal(got, ops.maxpool_chwn(y, 2, 2))
+    with pytest.raises(_lib.BBBHipError):
+        ops.lrt_conv2d_chwn_forward(x, w_mu, w_var, b_mu, b_var, 99, 5, 17, *g3, act=act, pool=True, want_moments=True)
