@@ -1069,10 +1069,16 @@ def collective_capture_ok(group, device, _force_probe=False, _stall_s=0.0):
     under a wall-clock watchdog (capture_probe_timeout_s): a stall yields the eager protocol, not a hang.
     (_force_probe / _stall_s: test hooks -- run the agreement protocol on a host backend too / sleep before entering it.)"""
     import torch.distributed as dist
-    if group in _capture_probe:
-        return _capture_probe[group]
+    try:
+        if group in _capture_probe:
+            return _capture_probe[group]
+        backend = dist.get_backend(group)
+    except (TypeError, ValueError, RuntimeError) as exc:
+        # not a process group torch knows (a stand-in object in a simulation, a destroyed group): nothing to record into
+        last_protocol.update(collective="eager", reason="no usable process group: %s" % type(exc).__name__)
+        return False
     reason = _local_capture_preconditions(group, device)
-    gloo_like = dist.get_backend(group) != "nccl" and not _force_probe
+    gloo_like = backend != "nccl" and not _force_probe
     if gloo_like:
         # host-side backends never record; every rank knows that without talking (the backend is a property of the group)
         _capture_probe[group] = False
