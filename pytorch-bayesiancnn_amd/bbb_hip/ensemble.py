@@ -480,7 +480,7 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
                     # [activation ->] MaxPool2d after a first layer with a short contraction: one launch (ops.bf16_pool_fusion_ok)
                     pool_at = i + (2 if act is not None else 1)
                     pool_mod = children[pool_at] if pool_at < len(children) and isinstance(children[pool_at], nn.MaxPool2d) else None
-                    fuse_pool = is_conv and ops.bf16_pool_fusion_ok(ckk, tapm, of32, pool_mod)
+                    fuse_pool = is_conv and ops.bf16_pool_fusion_ok(ckk, tapm, of32, pool_mod, tuple(h5.shape), geom, Es)
                     pool_ks = (pool_mod.kernel_size, pool_mod.stride if pool_mod.stride is not None else pool_mod.kernel_size) if fuse_pool else None
                     # (operands bound as defaults: bench.py's LaunchRecorder replays these closures after the loop has moved on)
                     y = _run(timers, "conv_gemm", fl,

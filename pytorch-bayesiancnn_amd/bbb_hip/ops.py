@@ -247,7 +247,8 @@ class LaunchConfig:
                 -3 % per step at 10 draws x 3 lanes, +4.5 % with one lane; at 5 draws per launch it no longer does)
     pool_fuse_weight_budget   bytes of weight tiles concurrently live per XCD that a fused launch may have (see pool_fusion_ok)"""
     FIELDS = ("gemm_mode", "bf16x3_min_workgroups", "s3_min_images", "split_k", "pool_fusion", "pool_fuse_min_items",
-              "pool_fuse_imbalance", "launches_overlap", "pool_fuse_min_items_overlapped", "pool_fuse_weight_budget")
+              "pool_fuse_imbalance", "launches_overlap", "pool_fuse_min_items_overlapped", "pool_fuse_weight_budget",
+              "bf16_pool_fuse_min_rows", "bf16_pool_fuse_min_rows_overlapped")
     __slots__ = FIELDS
 
     def __init__(self, **kw):
@@ -261,6 +262,8 @@ class LaunchConfig:
         self.launches_overlap = False
         self.pool_fuse_min_items_overlapped = 400
         self.pool_fuse_weight_budget = 1 << 20
+        self.bf16_pool_fuse_min_rows = 96              # (bf16_pool_fusion_ok) pooled rows x image tiles x slabs for the pooled
+        self.bf16_pool_fuse_min_rows_overlapped = 60   # first-layer form of the bf16 path to pay; ... beside other lanes' kernels
         for k, v in kw.items():
             setattr(self, k, v)              # (unknown names raise: __slots__)
 
@@ -689,11 +692,15 @@ def to_batch_innermost_bf16_slices(x, slices):
     return y
 
 
-def bf16_pool_fusion_ok(cin_khkw, tap_major, out_f32, pool_module):
-    """May conv2d_chwn_bf16_forward(..., pool=(k, s)) replace conv + maxpool_chwn_bf16(k, s)?  First layers with a short
+def bf16_pool_fusion_ok(cin_khkw, tap_major, out_f32, pool_module, x_shape=None, geom=None, draws=1):
+    """Should conv2d_chwn_bf16_forward(..., pool=(k, s)) replace conv + maxpool_chwn_bf16(k, s)?  First layers with a short
     contraction (row pitch <= 128: 3Conv3FC conv1, LeNet conv1 -- pconv_bf16_smallk_pool_kernel) followed by [activation ->]
     MaxPool2d(2, 2) or MaxPool2d(3, 2) without padding / dilation / ceil_mode.  Same values as the two launches (the maximum is
-    taken before bias, activation and rounding, which are non-decreasing)."""
+    taken before bias, activation and rounding, which are non-decreasing), so the choice never changes a result.
+    x_shape [*, Cin, H, W, B] + geom (stride, padding, dilation) + draws: the launch -- its workgroups walk a strip of a pooled row
+    pixel by pixel (a serial chain of load -> LDS -> MFMA steps), which only pays once the launch holds enough strips to fill the
+    chip: 3Conv3FC conv1 + pool1 at bs 256: 16 steps per launch 167 -> 125 us, 4 steps 46.5 -> 52.8, 1 step 18.4 -> 38.8
+    (profiles/r05_notes.md section 3).  Without x_shape: only whether the library HAS the form."""
     if not current_config().pool_fusion or pool_module is None or tap_major or out_f32:
         return False
     cin, kh, kw = cin_khkw
@@ -703,8 +710,21 @@ def bf16_pool_fusion_ok(cin_khkw, tap_major, out_f32, pool_module):
     ks = (pr(pool_module.kernel_size), pr(pool_module.stride if pool_module.stride is not None else pool_module.kernel_size))
     if ks not in (((2, 2), (2, 2)), ((3, 3), (2, 2))):
         return False
-    return pr(pool_module.padding) == (0, 0) and pr(pool_module.dilation) == (1, 1) and not pool_module.ceil_mode and \
-        not getattr(pool_module, "return_indices", False)
+    if not (pr(pool_module.padding) == (0, 0) and pr(pool_module.dilation) == (1, 1) and not pool_module.ceil_mode and
+            not getattr(pool_module, "return_indices", False)):
+        return False
+    if x_shape is None:
+        return True
+    (sh, sw), (ph, pw), (dh, dw) = _pair(geom[0]), _pair(geom[1]), _pair(geom[2])
+    H, W, B = x_shape[-3], x_shape[-2], x_shape[-1]
+    ho = (H + 2 * ph - dh * (kh - 1) - 1) // sh + 1
+    wo = (W + 2 * pw - dw * (kw - 1) - 1) // sw + 1
+    pk, pst = ks[0][0], ks[1][0]
+    if ho < pk or wo < pk:
+        return False
+    rows = int(draws) * -(-B // 256) * ((ho - pk) // pst + 1)
+    cfg = current_config()
+    return rows >= (cfg.bf16_pool_fuse_min_rows_overlapped if cfg.launches_overlap else cfg.bf16_pool_fuse_min_rows)
 
 
 def conv2d_chwn_bf16_forward(x, w, bias, cin_khkw, stride=1, padding=0, dilation=1, act=None, out_f32=False, out=None,

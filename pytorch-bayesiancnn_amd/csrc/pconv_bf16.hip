@@ -953,12 +953,23 @@ extern "C" int bbb_conv2d_chwn_bf16_fwd(const bbb_conv_desc_t* d, const void* x,
         a.pool = (pool_k << 8) | pool_s;
         const int hp = (ho - pool_k) / pool_s + 1, wp = (wo - pool_k) / pool_s + 1;
         a.y_ds = (int64_t)d->cout * hp * wp * d->batch;
-        // workgroups per pooled row: enough strips for >= 512 workgroups (2 per CU), each at least two pooled pixels wide (a strip
-        // of n pooled pixels computes n * ps + pk - ps conv columns: the narrower, the more columns are computed twice)
+        // workgroups per pooled row.  A strip of n pooled pixels walks n * ps + pk - ps conv columns, so narrow strips compute
+        // shared columns twice, wide strips leave the chip short of workgroups: take the split whose launch costs least in
+        // (rounds of resident workgroups: 2 per CU at this kernel's register footprint) x (columns of its widest strip).
+        // 3Conv3FC conv1, 16 steps per launch (240 pooled rows): 2 strips of 8 / 7 pooled pixels = 480 workgroups, one round, 17
+        // columns (3 strips = 720 workgroups = two rounds of 11: measured 128 us against 1xx, profiles/r05_notes.md section 3)
         const int64_t rows = (int64_t)a.G * a.nbt * hp;
-        int csplit = (int)((512 + rows - 1) / rows);
+        const int64_t slots = 512;
+        int csplit = 1;
+        int64_t best = -1;
         const int max_split = wp >= 2 ? wp / 2 : 1;
-        csplit = csplit < 1 ? 1 : (csplit > max_split ? max_split : csplit);
+        for (int c = 1; c <= max_split; ++c) {
+            const int wpc = (wp + c - 1) / c;
+            const int used = (wp + wpc - 1) / wpc;                // strips that actually hold pixels
+            const int64_t rounds = (rows * used + slots - 1) / slots;
+            const int64_t cost = rounds * (wpc * pool_s + pool_k - pool_s);
+            if (best < 0 || cost < best) { best = cost; csplit = c; }
+        }
         a.px_run = csplit;
         const int64_t items = rows * csplit;
         const int64_t per = (items + 7) / 8;
