@@ -572,6 +572,11 @@ def run_config(cfg, steps, warmup, pipeline, dev, group=None, world=1, want_roof
             torch.cuda.synchronize(dev)
             per = G                                      # the recorded launches cover (this rank's share of) G steps
             eager = gemm_roofline(timers.summary(), timer_steps * per, prec, cfg is CONFIGS["metric"] and not multi)
+            rpk = timers.summary().get("reparam_kl")
+            if rpk and rpk["n"]:
+                # the parameter pass where the step runs it: first launch of a pass, the GEMMs behind it (HIP events, eager single stream)
+                out["reparam_in_step"] = {"avg_us": round(1e3 * rpk["ms"] / rpk["n"], 2), "launches": rpk["n"],
+                                          "draws": (G * E) if not multi else (hi_u - lo_u)}
             # the same launches in the timed region's launch mode: every GEMM launch of the step replayed 20x back to back
             # inside its own hipGraph (no host, no event packets between kernels), pre-heated, HIP events around 3 replays
             rec = LaunchRecorder()
@@ -1062,9 +1067,13 @@ def main():
                 if G > 1:
                     second["roofline_reparam_steps_per_launch"] = rpg
                 if out["roofline"] is not None:
+                    ris = head.get("reparam_in_step")
+                    if ris and ris["draws"] == cfg["E"] * G:
+                        out["roofline"]["reparam_in_step_frac"] = round((8 + 4 * ris["draws"]) * n_params / (ris["avg_us"] * 1e-6) / (PEAK_HBM_GBS * 1e9), 4)
+                        second["reparam_in_step"] = ris
                     hb = rp.get("hbm_resident_probe", {})
                     out["roofline"].update(reparam_frac=rpg["frac"], reparam_avg_us=rpg["avg_us"], reparam_draws=cfg["E"] * G,
-                                           reparam_bytes=rpg["bytes_per_launch"], reparam_traffic=rp.get("traffic"),
+                                           reparam_traffic=rp.get("traffic"),
                                            reparam_10draw_frac=rp["frac"],
                                            reparam_hbm_resident_frac=(round(hb["E10_GBps"] / PEAK_HBM_GBS, 4) if "E10_GBps" in hb else None),
                                            device_copy_GBps=hb.get("device_copy_GBps"))
