@@ -58,7 +58,7 @@ import torch  # noqa: E402
 PRIORS = {"prior_mu": 0, "prior_sigma": 0.1, "posterior_mu_initial": (0, 0.1), "posterior_rho_initial": (-5, 0.1)}
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense v_mfma_f32_32x32x16_bf16 peak (same guide)
-FIRST_CONTACT_TIMEOUT_S = float(os.environ.get("BBB_BENCH_FIRST_CONTACT_TIMEOUT_S", "120"))   # watchdog around a sharded run's first replays
+FIRST_CONTACT_TIMEOUT_S = float(os.environ.get("BBB_BENCH_FIRST_CONTACT_TIMEOUT_S", "300"))   # watchdog around a sharded run's first replays
 PEAK_HBM_GBS = 8000.0             # HBM3E spec (6.3 TB/s achievable)
 
 # BASELINE.json: metric config + configs[1..4] (configs[0] is the reference's CPU-only plumbing case)
@@ -207,7 +207,7 @@ def profile_traffic(kind):
     by profiles/collect.sh): (read_bytes, written_bytes, source) or None.  FETCH_SIZE x2 = the gfx950 wide-load correction."""
     out = {}
     tag = None
-    for t in ("r04", "r03", "r02"):                # the newest committed PMC passes
+    for t in ("r05", "r04", "r03", "r02"):         # the newest committed PMC passes
         if all(os.path.exists(os.path.join(ROOT, "profiles", f"{t}_pmc_{c}.txt")) for c in ("FETCH_SIZE", "WRITE_SIZE")):
             tag = t
             break

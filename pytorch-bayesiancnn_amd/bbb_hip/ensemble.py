@@ -964,8 +964,9 @@ def _eager_gather(recv, send, group, lane_stream, comm_stream):
 
 capture_collectives = True     # a sharded GraphedMC step records its ONE all_gather inside the step's hipGraph when the backend allows
                                # it (RCCL does; probed once per process group): one host call per step instead of three
-capture_probe_timeout_s = 60.0 # the probe's collectives run under this wall-clock watchdog (a rank that never arrives must not
-                               # hang the job: the others fall back to the eager protocol and say so)
+capture_probe_timeout_s = 120.0  # the probe's collectives run under this wall-clock watchdog (a rank that never arrives must not
+                                 # hang the job: the others fall back to the eager protocol and say so); generous: it covers the
+                                 # creation of two communicators (seconds each on an 8-GPU node)
 _capture_probe = weakref.WeakKeyDictionary()     # process group object -> bool (NOT id(group): ids are reused after destruction)
 _lane_groups = weakref.WeakKeyDictionary()       # process group object -> {lane: private communicator}
 last_protocol = {"collective": None, "reason": None}   # what the last collective_capture_ok decided and why (bench.py prints it)
