@@ -56,3 +56,24 @@ print("OK")
 ''' % os.path.join(ROOT, "oracle")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-3000:]
+
+
+@pytest.mark.reference
+def test_bench_cpu_baseline_times_the_upstream_modules_from_the_archive():
+    """bench.py's CPU leg as the GPU box runs it: no checkout, the archive unpacked, the upstream BBBAlexNet on the upstream
+    layers (constructed seeing no GPU), kind "reference"."""
+    if R.manifest() is None:
+        pytest.skip("no oracle/_ref/upstream_snapshot.zip")
+    code = r'''
+import sys, json; sys.dont_write_bytecode = True
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import ref_snapshot as R
+R.UPSTREAM = "/nonexistent"
+import bench
+r = bench.cpu_baseline(0.5)
+assert r["kind"] == "reference" and r["value"] > 0 and r["steps_timed"] >= 2, r
+assert "upstream_snapshot.zip" in r["sample"] and "sha256" in r["sample"], r["sample"]
+print("OK", r["value"], r["cores"])
+''' % (os.path.join(ROOT, "oracle"), ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-3000:]
