@@ -1293,7 +1293,8 @@ class GraphedMC:
         self.out_kl.copy_(kl if self.kl_mode == "sum" else kl / self.num_ens)
 
     def _step_body(self, streams):
-        with ops.use_config(self.launch_config):             # (incl. launches_overlap: choices that depend on what runs beside the launch)
+        # (launch_config incl. launches_overlap: choices that depend on what runs beside the launch; scratch owned by this graph)
+        with ops.use_config(self.launch_config), ops.scratch_scope(self):
             return self._step_body_inner(streams)
 
     def _step_body_inner(self, streams):
@@ -1397,20 +1398,19 @@ class GraphedLogits:
         dev = x.device
         self.counter = torch.zeros((1,), dtype=torch.int32, device=dev)
         self.graph = None
-        # the capture stream stays alive as long as the graph does: ops' per-stream scratch (KL partials, split-contraction
-        # tickets) is keyed by the raw stream handle and its address is baked into the captured launches; a handle returned to
-        # torch's stream pool could be handed to a LATER graph, which would then share that scratch with this one while both
-        # replay on different streams
-        side = self._capture_stream = torch.cuda.Stream(device=dev)
+        # captured on a throw-away stream, replayed on the caller's current stream: the scratch its launches record (KL partial
+        # slots, split-contraction tickets) therefore belongs to THIS graph (ops.scratch_scope), not to the capture stream -- whose
+        # handle torch's stream pool may hand to a later capture while this graph is still replayed elsewhere
+        side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.no_grad(), torch.cuda.stream(side), rng.device_call_offset(self.counter):
+        with torch.no_grad(), torch.cuda.stream(side), rng.device_call_offset(self.counter), ops.scratch_scope(self):
             for _ in range(2):                       # warm-up on a side stream (allocator, lazy module state, scratch growth)
                 if self._body(net) is None:
                     return                           # this model / input does not fit the batch-innermost path
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         g = torch.cuda.CUDAGraph()
-        with torch.no_grad(), rng.device_call_offset(self.counter), ops.graph_capture(g, side):
+        with torch.no_grad(), rng.device_call_offset(self.counter), ops.graph_capture(g, side), ops.scratch_scope(self):
             self.logits, self.kl = self._body(net)
         self.graph = g
 

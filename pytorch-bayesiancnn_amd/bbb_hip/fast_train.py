@@ -159,13 +159,14 @@ class _MCForward(torch.autograd.Function):
         logits = h.reshape(E, -1, B)
         ctx.cfg, ctx.tape, ctx.meta = cfg, tape, (mus, rhos, ids, pm, ps, tuple(x.shape))
         ctx.launch_config = ops.current_config()              # backward runs on autograd's device thread: carry the modes along
+        ctx.scratch_token = ops.current_scratch_token()
         ctx.x_nchw = x.detach()
         ctx.versions = [(p, p._version) for p in params]      # backward re-reads the live (mu, rho): they must not have moved
         return logits, kl
 
     @staticmethod
     def backward(ctx, g_logits, g_kl):
-        with ops.use_config(ctx.launch_config):
+        with ops.use_config(ctx.launch_config), ops.scratch_scope(token=ctx.scratch_token):
             return _MCForward._backward(ctx, g_logits, g_kl)
 
     @staticmethod
@@ -286,13 +287,14 @@ class _MCForwardLRT(torch.autograd.Function):
             i += 1
         ctx.cfg, ctx.tape = cfg, tape
         ctx.launch_config = ops.current_config()
+        ctx.scratch_token = ops.current_scratch_token()
         ctx.x_nchw = x.detach()
         ctx.versions = [(p, p._version) for p in params]
         return h.reshape(h.shape[0], -1, B)
 
     @staticmethod
     def backward(ctx, g_logits):
-        with ops.use_config(ctx.launch_config):
+        with ops.use_config(ctx.launch_config), ops.scratch_scope(token=ctx.scratch_token):
             return _MCForwardLRT._backward(ctx, g_logits)
 
     @staticmethod

@@ -8,9 +8,11 @@ anywhere.  Activations, pooling and the loss tail use torch autograd (element-wi
 """
 import contextlib
 import ctypes
+import itertools
 import sys
 import threading
 import types
+import weakref
 
 import torch
 
@@ -21,6 +23,57 @@ _scratch = {}
 _retired = []     # outgrown scratch buffers: a captured hipGraph may have their address baked in, so they are NEVER freed (a
                   # second pipeline / a larger model captured on the same stream must not pull the first graph's tickets or KL
                   # slots out from under it).  Sizes at least double, so a stream retires < its final size in total.
+
+
+_scope_tls = threading.local()
+_scope_ids = itertools.count(1)
+
+
+class scratch_scope:
+    """Context: launches enqueued inside take their scratch buffers (KL partial slots, split-contraction tickets / partial tiles)
+    from a set that belongs to `owner` instead of the per-(device, stream) set.  For captured graphs: the buffers' addresses are
+    baked into the recorded launches, and a graph may be replayed on another stream than it was captured on (GraphedLogits) while
+    torch's stream pool hands the capture stream's HANDLE to a later capture -- keyed by stream, the two graphs would then share
+    tickets while replaying concurrently.  Keyed by owner, every graph has its own; the set is dropped when the owner dies."""
+
+    def __init__(self, owner=None, token=None):
+        if owner is None:                            # re-enter a scope by its token (autograd's device thread: fast_train backward)
+            self.tok = token
+            return
+        tok = getattr(owner, "_bbb_scratch_token", None)
+        if tok is None:
+            tok = next(_scope_ids)
+            try:
+                owner._bbb_scratch_token = tok
+                weakref.finalize(owner, _release_scope, tok)
+            except (AttributeError, TypeError):
+                pass
+        self.tok = tok
+
+    def __enter__(self):
+        self.prev = getattr(_scope_tls, "tok", None)
+        _scope_tls.tok = self.tok
+        return self
+
+    def __exit__(self, *a):
+        _scope_tls.tok = self.prev
+        return False
+
+
+def current_scratch_token():
+    return getattr(_scope_tls, "tok", None)
+
+
+def _release_scope(tok):
+    for k in [k for k in _scratch if isinstance(k[2], tuple) and k[2][:2] == ("scope", tok)]:
+        del _scratch[k]
+
+
+def _scratch_key(device, kind):
+    # (inside a scope still one set per stream: a captured step may fan its draws out over side streams that run concurrently)
+    tok = getattr(_scope_tls, "tok", None)
+    st = cur_stream(device)
+    return (device.index, kind, ("scope", tok, st) if tok is not None else st)
 
 
 def _grow(key, need, make):
@@ -36,7 +89,7 @@ def _grow(key, need, make):
 def _partials(device, n):
     # one scratch buffer per (device, stream): launches on different streams (graph lanes, a second model) may overlap.
     # every slot starts as "not published yet" (0xFF bytes); each launch re-arms the slots it consumed
-    return _grow((device.index, "kl", cur_stream(device)), max(int(n), 4096),
+    return _grow(_scratch_key(device, "kl"), max(int(n), 4096),
                  lambda m: torch.full((m,), -1, dtype=torch.int64, device=device).view(torch.float64))
 
 
@@ -335,7 +388,7 @@ def _split_scratch(d, lrt, device):
         return 1, None
     if need <= 0:
         return ks_v, None
-    buf = _grow((device.index, "splitk", cur_stream(device)), max(int(need), 1 << 22),
+    buf = _grow(_scratch_key(device, "splitk"), max(int(need), 1 << 22),
                 lambda m: torch.zeros(m, dtype=torch.uint8, device=device))
     return ks_v, buf
 

@@ -327,7 +327,7 @@ class GraphedTrainStep:
         return self._net()
 
     def _body(self):
-        with ops.use_config(self.launch_config):
+        with ops.use_config(self.launch_config), ops.scratch_scope(self):
             return self._body_inner()
 
     def _body_inner(self):

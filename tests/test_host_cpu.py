@@ -790,6 +790,35 @@ def test_speculation_cache_does_not_travel_with_copies_of_the_net():
     assert sp.streak == 5
 
 
+def test_scratch_scope_gives_every_graph_its_own_buffers(monkeypatch):
+    """ops.scratch_scope: scratch keyed by the owning graph object instead of the stream (torch's stream pool reuses
+    handles; a graph replayed on another stream than it was captured on must not share tickets with a later capture)."""
+    import gc
+    from bbb_hip import ops
+    monkeypatch.setattr(ops, "cur_stream", lambda device: 7)       # (no GPU here: one stream handle)
+
+    class Owner:
+        pass
+
+    a, b = Owner(), Owner()
+    dev = torch.device("cpu")
+    with ops.scratch_scope(a):
+        ka = ops._scratch_key(dev, "kl")
+        with ops.scratch_scope(b):
+            kb = ops._scratch_key(dev, "kl")
+            tok_b = ops.current_scratch_token()
+        assert ops._scratch_key(dev, "kl") == ka
+    assert ka != kb and ka[2][0] == "scope" and ka[2][2] == kb[2][2] and ops.current_scratch_token() is None   # (same stream, two owners)
+    with ops.scratch_scope(a):
+        assert ops._scratch_key(dev, "kl") == ka               # the same owner, the same set
+    with ops.scratch_scope(token=tok_b):
+        assert ops._scratch_key(dev, "kl") == kb               # re-entered by token (autograd's device thread)
+    ops._scratch[kb] = torch.zeros(4)
+    del b
+    gc.collect()
+    assert kb not in ops._scratch                              # dropped with its owner
+
+
 def test_outgrown_scratch_buffers_are_retired_not_freed():
     """ops._grow: a scratch buffer (split-contraction tickets / partial tiles, KL partial slots) that a later, larger launch
     outgrows stays alive -- a hipGraph captured earlier on the same stream has its address baked in."""
