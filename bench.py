@@ -193,7 +193,20 @@ def cpu_baseline(budget_s=20.0):
     tg = run(nt, budget_s * 0.25, True)                   # validate_model does not disable autograd (main_bayesian.py:65-86)
     torch.set_num_threads(avail)
     n = B * E
-    return {"value": round(n / med, 1), "unit": "samples/s", "cores": nt, "kind": kind,
+    # beside the CPU path: the SAME unmodified modules on this box's GPU through PyTorch-ROCm's own kernels (ATen / MIOpen / rocBLAS; eps
+    # from the CPU generator, copied over: layers/BBB/BBBConv.py:63) -- what a user of the reference gets on an MI355X today.  A
+    # subprocess (oracle/ref_gpu_path.py; MIOpen picks its kernels in the first step) with a hard time limit; a reported baseline.
+    ref_gpu = None
+    if kind == "reference" and torch.cuda.is_available():
+        import subprocess
+        try:
+            pr = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "ref_gpu_path.py"), "2.5"], capture_output=True, text=True,
+                                timeout=120)
+            line = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
+            ref_gpu = json.loads(line[-1]) if (pr.returncode == 0 and line) else {"error": (pr.stderr or "no output")[-200:]}
+        except Exception as exc:                         # noqa: BLE001 (a baseline must never take the bench down)
+            ref_gpu = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:160])}
+    return {"value": round(n / med, 1), "unit": "samples/s", "cores": nt, "kind": kind, "reference_gpu_path": ref_gpu,
             "p10": round(n / pctl(ts, 0.9), 1), "p90": round(n / pctl(ts, 0.1), 1), "steps_timed": len(ts),
             "autograd_enabled": {"value": round(n / statistics.median(tg), 1), "p10": round(n / pctl(tg, 0.9), 1),
                                  "p90": round(n / pctl(tg, 0.1), 1), "steps_timed": len(tg)},
@@ -1137,8 +1150,13 @@ def main():
             out["cpu_baseline"] = {"value": cpu["value"], "unit": cpu["unit"], "cores": cpu["cores"], "kind": cpu["kind"],
                                    "sample": "%d MC steps 512x10 fp32 no_grad, median; %s" % (
                                        cpu["steps_timed"], "upstream modules" if cpu["kind"] == "reference" else "bit-identical port"),
-                                   "p10": cpu["p10"], "p90": cpu["p90"], "cpu_model": cpu["cpu_model"],
+                                   "p10": cpu["p10"], "p90": cpu["p90"],           # (cpu_model, thread counts: SECONDARY cpu_baseline_detail)
                                    "autograd_value": cpu["autograd_enabled"]["value"]}
+            rg = cpu.get("reference_gpu_path") or {}
+            if "no_grad" in rg:
+                # the upstream modules on THIS GPU (ATen / MIOpen / rocBLAS + CPU-side eps): the reference's own GPU path, same step
+                out["cpu_baseline"]["reference_gpu_value"] = rg["no_grad"]["samples_per_s"]
+                out["speedup_vs_reference_gpu"] = round(out["value"] / rg["no_grad"]["samples_per_s"], 1)
             out["speedup_vs_cpu"] = round(out["value"] / cpu["value"], 1)
         final_lines = (["SECONDARY " + json.dumps(second)] if second else []) + [json.dumps(compact(out))]
     def flush_c_stdio():

@@ -94,6 +94,11 @@ def test_bench_driver_invocation_line_is_short_and_complete():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
     assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0
+    if cb["kind"] == "reference":
+        # the same upstream modules on this box's GPU (PyTorch-ROCm's own kernels): a second reported baseline
+        assert cb["reference_gpu_value"] > cb["value"] and j["speedup_vs_reference_gpu"] > 10
+        assert sec["cpu_baseline_detail"]["reference_gpu_path"]["no_grad"]["ms_per_step"] > 1.0
+        assert "cpu_model" in sec["cpu_baseline_detail"]
     assert abs(j["value"] - j["roofline"]["stats_median"]) <= 0.08 * j["roofline"]["stats_median"]
     assert j["speedup_vs_cpu"] > 10
 

@@ -104,7 +104,7 @@ def test_product_path_refuses_cpu_tensors(built):
 
 def test_no_oracle_import_in_product():
     """The shipped package must never import / call the oracle (or the reference)."""
-    bad = re.compile(r"bbb_numpy|ref_port_torch|ref_snapshot|upstream_snapshot|_ref/|/root/reference|import\s+oracle|from\s+oracle")
+    bad = re.compile(r"bbb_numpy|ref_port_torch|ref_snapshot|ref_gpu_path|upstream_snapshot|_ref/|/root/reference|import\s+oracle|from\s+oracle")
     for base, _, files in os.walk(PKG):
         for f in files:
             if f.endswith((".py", ".hip", ".cuh", ".h")):
