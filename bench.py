@@ -1129,6 +1129,8 @@ def main():
                     depth = 4 if small else 3
                     spl = 16 if small else 1                  # (round 5 sweep, profiles/r05_notes.md section 3: 4 -> 16 steps per launch)
                     nst = max(10, args.steps // 2)
+                    if spl > 1:
+                        nst = max(nst, 4 * spl * depth)       # at least four groups per lane: one replay per lane is all ramp
                     nst = -(-nst // (spl * depth)) * spl * depth
                     r, n2, x2 = run_config(c, nst, 5, depth, dev, want_roofline=True, timer_steps=3, steps_per_launch=spl, preheat_s=0.15)
                     r["steps_in_flight"] = depth
