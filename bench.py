@@ -649,7 +649,7 @@ def dropin_loop(dev, steps):
 def slow_paths(dev, steps):
     """The corners of the Python layer on the scoreboard (review r04 items 6 / 9): an odd batch (B = 510: padded onto the
     batch-innermost kernels since round 5; `layout="nchw"` = the reference-layout kernels it used to drop to), and a model with a
-    forward hook (the fused path does not call the children, so the drop-in loop takes the per-layer reference-layout path)."""
+    forward hook (the fused path does not call the children, so the drop-in loop takes the per-layer path: one launch per module)."""
     from bbb_hip import ensemble, rng
     cfg = dict(CONFIGS["metric"], B=510)
     net, x = build_net(cfg, dev)
@@ -696,7 +696,8 @@ def slow_paths(dev, steps):
         return outputs
 
     out["forward_hook_dropin_loop"] = dict(rate(loop, max(5, steps // 4), cfgm["B"]),
-                                           launch="for j in range(10): net(x), a forward hook on conv3 -> per-layer reference-layout path, eager")
+                                           launch="for j in range(10): net(x), a forward hook on conv3 -> per-layer path (each conv on the batch-innermost kernel "
+                                                  "between layout transposes since round 5, torch activations / pooling), eager")
     h.remove()
     assert seen
     return out

@@ -953,6 +953,53 @@ def to_batch_innermost(x):
     return out
 
 
+def from_batch_innermost(y):
+    """[C, H, W, B] -> [B, C, H, W] (the same LDS-tiled transpose, the other way round)."""
+    require_device(y)
+    y = y.contiguous()
+    B = y.shape[-1]
+    out = torch.empty((B,) + tuple(y.shape[:-1]), dtype=torch.float32, device=y.device)
+    with on_device(y.device):
+        check(_lib.lib().bbb_transpose2d(y.data_ptr(), out.data_ptr(), y.numel() // B, B, cur_stream(y.device)), "bbb_transpose2d")
+    return out
+
+
+def _layer_on_fast_kernels(x4, *operands):
+    """The per-layer path of the drop-in layers (a model with forward hooks, modules the whole-model path does not know, ...):
+    may THIS layer's convolution run on the batch-innermost kernel between two layout transposes?  Inference only (the
+    reference-layout kernels carry the autograd wiring), a 4-d fp32 GPU batch with B % 4 == 0."""
+    if not (torch.is_tensor(x4) and x4.is_cuda and x4.dim() == 4 and x4.dtype == torch.float32 and x4.shape[0] % 4 == 0 and x4.shape[0] > 0):
+        return False
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x4,) + operands):
+        return False
+    return True
+
+
+def conv2d_layer(x4, w, b, stride, padding, dilation):
+    """BBB conv layer of the per-layer path: x4 [B, Cin, H, W], w [1, Cout, Cin, kh, kw], b [1, Cout] | None -> [B, Cout, Ho, Wo].
+    Inference takes the pixel-major batch-innermost kernel (padding taps skipped, the layer's split contraction: the kernel of
+    the whole-model path) between two transposes -- 3-5x faster than the reference-layout kernel at bs 512; everything else the
+    reference-layout autograd function."""
+    if _layer_on_fast_kernels(x4, w, b):
+        # (the plain fmaf chain, not the layer's split contraction: bit for bit the reference-layout kernel's result, which is what
+        # this path promises -- tests/test_gpu_models.py::test_batched_ensemble_equals_loop)
+        with use_config(split_k=False):
+            y = conv2d_chwn_forward(to_batch_innermost(x4).unsqueeze(0), w, b, stride, padding, dilation, bf16x3=False)
+        return from_batch_innermost(y[0])
+    return conv2d(x4.unsqueeze(0), w, b, stride, padding, dilation).squeeze(0)
+
+
+def lrt_conv2d_layer(x4, w_mu, w_var, b_mu, b_var, seed, call, stream_id, stride, padding, dilation, sample, eps):
+    """LRT conv layer of the per-layer path (same noise elements on either kernel: the canonical NCHW index keys them)."""
+    if eps is None and _layer_on_fast_kernels(x4, w_mu, w_var, b_mu, b_var):
+        with use_config(split_k=False):
+            y = lrt_conv2d_chwn_forward(to_batch_innermost(x4).unsqueeze(0), w_mu, w_var, b_mu, b_var, seed, call, stream_id, stride,
+                                        padding, dilation, sample=sample)[0]
+        return from_batch_innermost(y[0])
+    return lrt_conv2d(x4.unsqueeze(0), w_mu, w_var, b_mu, b_var, seed, call, stream_id, stride, padding, dilation, sample=sample,
+                      eps=eps).squeeze(0)
+
+
 def to_batch_innermost_slices(x, slices):
     """[S*Bs, C, H, W] -> [S, C, H, W, Bs]: one batch-innermost block per batch slice (the input of a rank's work units), as ONE
     batched transpose launch."""

@@ -43,8 +43,7 @@ class BBBConv2d(_BBBLayer):
 
     def forward(self, input, sample=True):
         w, b = self._weights(sample)
-        y = ops.conv2d(input.unsqueeze(0), w, b, self.stride, self.padding, self.dilation)
-        return y.squeeze(0)
+        return ops.conv2d_layer(input, w, b, self.stride, self.padding, self.dilation)
 
 
 class BBBLinear(_BBBLayer):

@@ -52,6 +52,11 @@ class BBBConv2d(_LRTLayer):
 
     def forward(self, x, sample=True):
         w_var, b_var = self._variances()
+        if self.eps_source is None and x.dim() == 4:
+            seed, call = rng.layer_call()
+            return ops.lrt_conv2d_layer(x, self.W_mu, w_var, self.bias_mu if self.use_bias else None, b_var, seed, call,
+                                        self._stream_base + 2, self.stride, self.padding, self.dilation,
+                                        bool(self.training or sample), None)
         y = self._lrt(x.unsqueeze(0), self.W_mu, (w_var, b_var), sample, self.stride, self.padding, self.dilation)
         return y.squeeze(0)
 
