@@ -51,7 +51,7 @@ def test_bench_json_contract_default():
     _check_roofline(r, 157.3)
     # every judged number is a first-level scalar of `roofline` (what the driver's record keeps), the reparam pass also nested
     for k in ("per_launch_us", "slabs_per_launch", "sustained_frac", "stats_median", "stats_p10", "stats_p90", "one_step_in_flight_ms",
-              "one_step_per_launch_ms", "reparam_frac", "reparam_avg_us", "reparam_draws", "reparam_10draw_frac", "reparam_in_step_frac",
+              "one_step_per_launch_ms", "reparam_frac", "reparam_avg_us", "reparam_draws", "reparam_10draw_frac", "reparam_back_to_back_frac",
               "reparam_hbm_resident_frac", "dropin_loop_value", "timed_by", "value_above_p90", "odd_batch_510_value", "hooked_loop_value"):
         assert k in r and not isinstance(r[k], (dict, list)), k
     assert r["slabs_per_launch"] == 40 and len(r["per_launch_us"].split("/")) == 6
@@ -61,7 +61,10 @@ def test_bench_json_contract_default():
     nbytes = (8 + 4 * 40) * 2175946                     # (8 + 4 E) bytes per parameter element, E = 40 draws per launch
     assert r["reparam_draws"] == 40 and sec["roofline_reparam_steps_per_launch"]["bytes_per_launch"] == nbytes
     assert abs(r["reparam_frac"] - nbytes / (r["reparam_avg_us"] * 1e-6) / 8e12) < 2e-3
-    assert 0.3 < r["reparam_in_step_frac"] < 1.0
+    reg = sec["roofline_reparam_in_region"]             # the launch in the region's context: [reparam, conv1] pairs minus conv1 alone
+    assert "error" not in reg and reg["draws_per_launch"] == 40 and reg["frac"] == r["reparam_frac"]
+    assert abs(reg["avg_us"] - (reg["pair_us"] - reg["gemm_alone_us"])) < 0.02
+    assert 0.3 < r["reparam_back_to_back_frac"] < 1.0 and r["reparam_back_to_back_frac"] == sec["roofline_reparam_steps_per_launch"]["frac"]
     assert 0 < r["reparam_hbm_resident_frac"] < 1 and 0 < r["reparam_10draw_frac"] < 1.2
     assert r["value_above_p90"] == (j["value"] > r["stats_p90"]) and "hipGraph" in r["timed_by"]
     # the secondary line: the objects of rounds 1-3, unabridged
