@@ -315,8 +315,9 @@ class LaunchConfig:
         self.launches_overlap = False
         self.pool_fuse_min_items_overlapped = 400
         self.pool_fuse_weight_budget = 1 << 20
-        self.bf16_pool_fuse_min_rows = 96              # (bf16_pool_fusion_ok) pooled rows x image tiles x slabs for the pooled
-        self.bf16_pool_fuse_min_rows_overlapped = 60   # first-layer form of the bf16 path to pay; ... beside other lanes' kernels
+        self.bf16_pool_fuse_min_rows = 0               # (bf16_pool_fusion_ok) pooled rows x image tiles x slabs from which the pooled
+        self.bf16_pool_fuse_min_rows_overlapped = 0    # first-layer form of the bf16 path is taken (0: always -- the library's
+                                                       # window-resident form wins from one step per launch on); ... beside other lanes
         for k, v in kw.items():
             setattr(self, k, v)              # (unknown names raise: __slots__)
 
@@ -750,10 +751,10 @@ def bf16_pool_fusion_ok(cin_khkw, tap_major, out_f32, pool_module, x_shape=None,
     contraction (row pitch <= 128: 3Conv3FC conv1, LeNet conv1 -- pconv_bf16_smallk_pool_kernel) followed by [activation ->]
     MaxPool2d(2, 2) or MaxPool2d(3, 2) without padding / dilation / ceil_mode.  Same values as the two launches (the maximum is
     taken before bias, activation and rounding, which are non-decreasing), so the choice never changes a result.
-    x_shape [*, Cin, H, W, B] + geom (stride, padding, dilation) + draws: the launch -- its workgroups walk a strip of a pooled row
-    pixel by pixel (a serial chain of load -> LDS -> MFMA steps), which only pays once the launch holds enough strips to fill the
-    chip: 3Conv3FC conv1 + pool1 at bs 256: 16 steps per launch 167 -> 125 us, 4 steps 46.5 -> 52.8, 1 step 18.4 -> 38.8
-    (profiles/r05_notes.md section 3).  Without x_shape: only whether the library HAS the form."""
+    x_shape [*, Cin, H, W, B] + geom (stride, padding, dilation) + draws: the launch (the thresholds of the current LaunchConfig;
+    0 = always: the library picks the window-resident form for small launches and the strip form for large ones, and one of them
+    beats the two launches at every size measured -- 3Conv3FC conv1 + pool1 at bs 256, us per launch: 1 step 18.4 -> 16.8, 4 steps
+    46.5 -> 37.4, 16 steps 167 -> 125; profiles/r05_notes.md section 3).  Without x_shape: only whether the library HAS the form."""
     if not current_config().pool_fusion or pool_module is None or tap_major or out_f32:
         return False
     cin, kh, kw = cin_khkw

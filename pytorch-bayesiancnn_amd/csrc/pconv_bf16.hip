@@ -769,6 +769,253 @@ __global__ __launch_bounds__(256) void pconv_bf16_smallk_pool_kernel(const PConv
     }
 }
 
+// ---- the pooled first layer with its input WINDOW resident in LDS (round 5, second form) ----
+// pconv_bf16_smallk_pool_kernel fetches a [K][256-image] tile of image rows per conv pixel (40 KB for 3Conv3FC conv1) although
+// neighbouring pixels share 4/5 of their taps: measured, half of its time is that traffic (the kernel without its loads: 58 of
+// 104 us, profiles/r05_notes.md).  Here a workgroup (128 images, <= 32 channels) loads the input window of its strip ONCE --
+// Cin x WR x WC image rows: 189 rows of 256 B for a strip of two 3 x 3 / 2 pooled pixels of a 5 x 5 stride-1 layer -- and every conv
+// pixel reads its B operands straight out of it: ds_read_tr16_b64 takes a per-lane row address, so the k -> (ci, r, q) -> window-row
+// map is ten per-lane offsets plus one per-pixel offset, no staging, no barrier inside the pixel loop (the waves run free), operand
+// reads of the next pixel in flight under the current pixel's MFMAs.  Out-of-image taps are rows the loader filled with zeros (the
+// buffer unit returns 0 for their out-of-range offsets); k >= K reads a zero row.  Same MFMA sequence per output element as the
+// other forms: bit-identical.
+constexpr int kWinPasses = 13;             // 16-row passes of the window loader: windows of up to 13 * 16 - 1 = 207 image rows (+ the zero row)
+
+template <int KS>
+__global__ __launch_bounds__(256) void pconv_bf16_smallk_poolwin_kernel(const PConvArgs p) {
+    constexpr int BM = 128, LDXB = BM + 32, TP = 32 + 8;
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+
+    const int pk = p.pool >> 8, ps = p.pool & 255;
+    const int Hp = (p.Ho - pk) / ps + 1, Wp = (p.Wo - pk) / ps + 1;
+    const int nstr = p.px_run;                                    // strips per pooled row
+    const int wpc = (Wp + nstr - 1) / nstr;                       // pooled pixels per strip
+    const int bid = blockIdx.x, xcd = bid & 7;
+    const int64_t item = (int64_t)xcd * p.per_xcd + (bid >> 3);
+    const int64_t item_end = (int64_t)(xcd + 1) * p.per_xcd;
+    const int64_t per_g = (int64_t)Hp * nstr * p.nbt;
+    if (item >= item_end || item >= (int64_t)p.G * per_g) return;
+    const int g = (int)(item / per_g);
+    int rem = (int)(item - (int64_t)g * per_g);
+    const int ph = rem / (nstr * p.nbt);
+    rem -= ph * nstr * p.nbt;
+    const int cs = rem / p.nbt;
+    const int b0 = (rem - cs * p.nbt) * BM;
+    const int pw0 = cs * wpc;
+    const int pw1 = (pw0 + wpc) < Wp ? (pw0 + wpc) : Wp;
+    if (pw0 >= pw1) return;
+    const int c0 = pw0 * ps, c1 = (pw1 - 1) * ps + pk - 1;        // conv columns of the strip (inclusive)
+    const int ncols = c1 - c0 + 1;
+    const int r0 = ph * ps;
+    const int e = g / p.Ntiles;
+    const int ue = p.unit_off + e;
+    const int ew = p.unit_div > 1 ? ue / p.unit_div : e;
+    const int ex = p.x_div > 1 ? (e + p.x_off) / p.x_div : (p.x_mod > 0 ? ue % p.x_mod : e);
+    const int n0 = (g - e * p.Ntiles) * 32;
+    const int Kp = p.Kp;
+    const int HpWp = Hp * Wp;
+    // the window: input rows / columns the strip's conv pixels touch
+    const int WR = (pk - 1) * p.sh + (p.kh - 1) * p.dh + 1;
+    const int WC = (ncols - 1) * p.sw + (p.kw - 1) * p.dw + 1;
+    const int NR = p.Cin * WR * WC;                               // + one all-zero row at index NR
+    uint16_t* Xw = smem;                                          // [NR + 1][LDXB]
+    uint16_t* Tall = smem + (size_t)p.Mtiles * LDXB;              // p.Mtiles = rows the host sized the window for (widest strip + 1)
+
+    const int tid = (int)threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave * 32;
+    const int lrow = lane & 31, lk = lane >> 5;
+
+    constexpr uint32_t kOOB = 0xFFFFFFF0u;
+    const uint32_t kXInv = p.x_inv;
+    const uint16_t* xb = reinterpret_cast<const uint16_t*>(p.x) + (int64_t)ex * p.x_ds;
+    const uint16_t* wb = reinterpret_cast<const uint16_t*>(p.w) + (int64_t)ew * p.w_ds;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(xb), 0, (int)((int64_t)p.Cin * p.H * p.W * p.B * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(wb), 0, (int)((int64_t)p.Cout * Kp * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.bias ? p.bias + (int64_t)ew * p.b_ds : reinterpret_cast<const float*>(p.w)), 0, p.bias ? p.Cout * 4 : 0, 0x00020000);
+    char* yb = reinterpret_cast<char*>(p.y) + (int64_t)e * p.y_ds * 2;
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(yb, 0, (int)((int64_t)p.Cout * HpWp * p.B * 2), 0x00020000);
+
+    // weights: MFMA A operands straight from global memory, kept for the whole strip (issued first: in flight under the window load)
+    bf16x8 a[KS];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+        const int n = n0 + lrow, k = kk * 16 + lk * 8;
+        const uint32_t off = (n < p.Cout && k < Kp) ? (uint32_t)(n * Kp + k) * 2u : kOOB;
+        a[kk] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, off, 0, 0));
+    }
+    f32x4 bq[4];
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4)
+        bq[r4] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, (uint32_t)(n0 + 8 * r4 + 4 * lk) * 4u, 0, 0));
+
+    // ---- the window, once: 16 lanes x 16 bytes per image row, 16 rows per pass; EVERY pass's load is issued before the first
+    //      store (one memory round trip for the whole window: the host keeps it <= kWinPasses * 16 rows) ----
+    {
+        const int l16 = tid & 15, rsub = tid >> 4;
+        const uint32_t xcol = (uint32_t)(b0 + l16 * 8) * 2u;
+        const int ih0 = r0 * p.sh - p.ph, iw0 = c0 * p.sw - p.pw;
+        const int wrc = WR * WC;
+        const float inv_wrc = 1.0f / (float)wrc, inv_wc = 1.0f / (float)WC;
+        u32x4 v[kWinPasses];
+#pragma unroll
+        for (int u = 0; u < kWinPasses; ++u) {
+            const int row = u * 16 + rsub;
+            uint32_t xo = kXInv;
+            if (row < NR) {
+                int ci = (int)((float)row * inv_wrc);
+                int r2 = row - ci * wrc;
+                if (r2 < 0) { --ci; r2 += wrc; } else if (r2 >= wrc) { ++ci; r2 -= wrc; }
+                int wr = (int)((float)r2 * inv_wc);
+                int wc = r2 - wr * WC;
+                if (wc < 0) { --wr; wc += WC; } else if (wc >= WC) { ++wr; wc -= WC; }
+                const int ih = ih0 + wr, iw = iw0 + wc;
+                if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) xo = (uint32_t)((ci * p.H + ih) * p.W + iw) * (uint32_t)p.B * 2u;
+            }
+            v[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xo + xcol, 0, 0));
+        }
+#pragma unroll
+        for (int u = 0; u < kWinPasses; ++u) {
+            const int row = u * 16 + rsub;
+            if (row <= NR) *reinterpret_cast<u32x4*>(&Xw[row * LDXB + l16 * 8]) = v[u];         // (row NR: its offset is invalid -> zeros)
+        }
+    }
+    // per-lane window offsets (BYTES) of the k rows this lane SUPPLIES to a transpose read (row t >> 2 of its 16-lane group's four,
+    // k half by the group): k -> (ci, r, q) -> ((ci * WR + r * dh) * WC + q * dw) * LDXB; k >= K: the zero row, pixel offset masked out
+    const int tg = lane >> 4, tt = lane & 15;
+    const int colo = wm + 16 * (tg & 1) + 4 * (tt & 3);
+    uint32_t kbase[KS][2], kmask[KS][2];
+    const float inv_khkw = 1.0f / (float)p.khkw, inv_kw = 1.0f / (float)p.kw;
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = kk * 16 + 8 * (tg >> 1) + (tt >> 2) + 4 * h;
+            uint32_t v = (uint32_t)(NR * LDXB + colo) * 2u, m = 0u;
+            if (k < p.K) {
+                int ci = (int)((float)k * inv_khkw);             // float-reciprocal division + fix-up (exact for these sizes)
+                int rq = k - ci * p.khkw;
+                if (rq < 0) { --ci; rq += p.khkw; } else if (rq >= p.khkw) { ++ci; rq -= p.khkw; }
+                int r = (int)((float)rq * inv_kw);
+                int q = rq - r * p.kw;
+                if (q < 0) { --r; q += p.kw; } else if (q >= p.kw) { ++r; q -= p.kw; }
+                v = (uint32_t)(((ci * WR + r * p.dh) * WC + q * p.dw) * LDXB + colo) * 2u;
+                m = 0xFFFFFFFFu;
+            }
+            kbase[kk][h] = v;
+            kmask[kk][h] = m;
+        }
+    typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+    typedef __attribute__((address_space(3))) char* lds_char_ptr;
+    const lds_char_ptr xw_lds = (lds_char_ptr)Xw;
+    auto load_b = [&](uint32_t pixoff, bf16x8 (&b)[KS]) {
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            const s16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(xw_lds + (kbase[kk][0] + (pixoff & kmask[kk][0]))));
+            const s16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(xw_lds + (kbase[kk][1] + (pixoff & kmask[kk][1]))));
+            b[kk] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+    };
+    uint16_t* T = Tall + wave * (32 * TP);
+    // max without the canonicalisation fmaxf asks for (both operands are arithmetic results): ONE instruction per element
+    auto vmax = [](float x, float y) { float d; asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y)); return d; };
+
+    f32x16 pnew, pold;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { pnew[r] = -__builtin_inff(); pold[r] = -__builtin_inff(); }
+
+    __syncthreads();                                               // the window is in LDS; from here on the waves run free
+    const int npx = ncols * pk;
+    const uint32_t rstep = (uint32_t)(p.sh * WC * LDXB) * 2u, cstep = (uint32_t)(p.sw * LDXB) * 2u;
+    int cc = 0, rr = 0;                                            // column / row of the CURRENT pixel inside the strip
+    // one conv pixel: operands `bc` are in registers (or in flight), the next pixel's go into `bn`
+    auto pixel = [&](int t, bf16x8 (&bc)[KS], bf16x8 (&bn)[KS]) {
+        int ncc = cc, nrr = rr + 1;                                // column-major walk: the rows of a column, then the next column
+        if (nrr == pk) { nrr = 0; ++ncc; }
+        if (t + 1 < npx) load_b((uint32_t)nrr * rstep + (uint32_t)ncc * cstep, bn);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk], bc[kk], acc, 0, 0, 0);
+        // windows of this column (see pconv_bf16_smallk_pool_kernel); wave-uniform BRANCHES: as selects the two window updates were
+        // ~140 VALU instructions per pixel against five MFMAs, and the kernel was bound by them
+        const int c = c0 + cc;
+        const int w_hi = c / ps;
+        const bool hi_ok = w_hi < pw1;
+        const bool starts = c == w_hi * ps;
+        const bool lo_ok = (w_hi - 1) >= pw0 && c <= (w_hi - 1) * ps + pk - 1;
+        if (starts && rr == 0) { pold = pnew; asm volatile("" ::: "memory"); }
+        if (hi_ok) {
+            if (starts && rr == 0) {
+                pnew = acc;
+                asm volatile("" ::: "memory");
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pnew[r] = vmax(pnew[r], acc[r]);
+                asm volatile("" ::: "memory");
+            }
+        }
+        if (lo_ok) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pold[r] = vmax(pold[r], acc[r]);
+            asm volatile("" ::: "memory");
+        }
+        const bool last_row = rr + 1 == pk;
+        const bool emit_lo = last_row && lo_ok && c == (w_hi - 1) * ps + pk - 1;
+        const bool emit_hi = last_row && !emit_lo && hi_ok && c == w_hi * ps + pk - 1;
+        if (emit_lo || emit_hi) {
+            const int ppix = ph * Wp + (emit_lo ? w_hi - 1 : w_hi);
+            auto stage_block = [&](auto act) {
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int nl = 8 * r4 + 4 * lk;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float m = emit_lo ? pold[r4 * 4 + i] : pnew[r4 * 4 + i];
+                        T[(nl + i) * TP + lrow] = f2bf(act(m + bq[r4][i]));
+                    }
+                }
+            };
+            if (p.act == 2)      stage_block([](float v) { return bbb::apply_act(v, 2); });
+            else if (p.act == 1) stage_block([](float v) { return fmaxf(v, 0.0f); });
+            else                 stage_block([](float v) { return v; });
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int ps2 = 0; ps2 < 2; ++ps2) {
+                const int v = ps2 * 64 + lane;
+                const int row = v >> 2, grp = v & 3;
+                const u32x4 q = *reinterpret_cast<const u32x4*>(&T[row * TP + grp * 8]);
+                const int n = n0 + row, b = b0 + wm + grp * 8;
+                const uint32_t off = ((b < p.B) & (n < p.Cout)) ? (uint32_t)(((int64_t)n * HpWp + ppix) * p.B + b) * 2u : kOOB;
+                __builtin_amdgcn_raw_buffer_store_b128(q, yrs, off, 0, 0);
+            }
+        }
+        cc = ncc; rr = nrr;
+    };
+    bf16x8 b0r[KS], b1r[KS];                                        // two operand sets, used alternately: no register copies
+    load_b(0u, b0r);
+#pragma clang loop unroll(disable)
+    for (int t = 0; t < npx; t += 2) {
+        pixel(t, b0r, b1r);
+        if (t + 1 < npx) pixel(t + 1, b1r, b0r);
+    }
+}
+
+template <int KS>
+int launch_smallk_poolwin(const PConvArgs& a, int64_t blocks, int smem_bytes, hipStream_t st) {
+    static int attr_bytes = 0;
+    if (smem_bytes > attr_bytes) {
+        hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(&pconv_bf16_smallk_poolwin_kernel<KS>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+        if (er != hipSuccess) return (int)er;
+        attr_bytes = smem_bytes;
+    }
+    hipLaunchKernelGGL((pconv_bf16_smallk_poolwin_kernel<KS>), dim3((unsigned)blocks), dim3(256), smem_bytes, st, a);
+    return (int)hipGetLastError();
+}
+
 template <int NT, int KS>
 int launch_smallk_pool(const PConvArgs& a, int64_t blocks, hipStream_t st) {
     constexpr int kSmem = (KS * 16 * (256 + 32) + 4 * 32 * NT * 72) * 2 + 2 * 3 * KS * 16 * 4;
@@ -953,6 +1200,40 @@ extern "C" int bbb_conv2d_chwn_bf16_fwd(const bbb_conv_desc_t* d, const void* x,
         a.pool = (pool_k << 8) | pool_s;
         const int hp = (ho - pool_k) / pool_s + 1, wp = (wo - pool_k) / pool_s + 1;
         a.y_ds = (int64_t)d->cout * hp * wp * d->batch;
+        // the window-resident form (pconv_bf16_smallk_poolwin_kernel): <= 32 channels, 128-image tiles, the widest strip whose input
+        // window (+ one zero row) and epilogue staging fit 72 KB of LDS (two workgroups per CU).  Its workgroups are short (one
+        // memory round trip for the window, 15 pixels, two pooled outputs: ~8 us each), so it wins where the strip form is a
+        // latency chain -- small launches -- and ties / loses by 2-3 % once the strip form fills the chip (3Conv3FC conv1 + pool1,
+        // bs 256, us per launch, window / strip / conv + pool launches: 2 steps 20 / 39 / 27, 4 steps 37 / 53 / 47, 6 steps 55 / 54 /
+        // 82, 8 steps 71 / 68 / 82, 16 steps 128 / 125 / 167; profiles/r05_notes.md section 3): below 90 pooled rows x image tiles
+        if (nt == 1 && (int64_t)a.G * a.nbt * hp < 90) {
+            const int WRw = (pool_k - 1) * a.sh + (a.kh - 1) * a.dh + 1;
+            int best_n = 0;
+            for (int n = 1; n <= wp; ++n) {
+                const int cols = (n - 1) * pool_s + pool_k;
+                const int WCw = (cols - 1) * a.sw + (a.kw - 1) * a.dw + 1;
+                const int64_t bytes = ((int64_t)a.Cin * WRw * WCw + 1) * (128 + 32) * 2 + 4 * 32 * 40 * 2;
+                if (bytes <= 72 * 1024 && a.Cin * WRw * WCw + 1 <= kWinPasses * 16) best_n = n;
+            }
+            if (best_n >= 1) {
+                const int nstr = (wp + best_n - 1) / best_n;
+                const int wpc = (wp + nstr - 1) / nstr;               // what the kernel derives from nstr
+                const int cols = (wpc - 1) * pool_s + pool_k;
+                const int WCw = (cols - 1) * a.sw + (a.kw - 1) * a.dw + 1;
+                const int rows = a.Cin * WRw * WCw + 1;
+                a.Mtiles = rows;
+                a.px_run = nstr;
+                a.nbt = (a.B + 127) / 128;
+                const int64_t itemsw = (int64_t)a.G * a.nbt * hp * nstr;
+                const int64_t perw = (itemsw + 7) / 8;
+                if (8 * perw > 0x7fffffffLL) return BBB_ESHAPE;
+                a.per_xcd = (int32_t)perw;
+                const int smem_bytes = rows * (128 + 32) * 2 + 4 * 32 * 40 * 2;
+                hipStream_t stw = (hipStream_t)stream;
+                return ks == 2 ? launch_smallk_poolwin<2>(a, 8 * perw, smem_bytes, stw)
+                     : ks == 5 ? launch_smallk_poolwin<5>(a, 8 * perw, smem_bytes, stw) : launch_smallk_poolwin<8>(a, 8 * perw, smem_bytes, stw);
+            }
+        }
         // workgroups per pooled row.  A strip of n pooled pixels walks n * ps + pk - ps conv columns, so narrow strips compute
         // shared columns twice, wide strips leave the chip short of workgroups: take the split whose launch costs least in
         // (rounds of resident workgroups: 2 per CU at this kernel's register footprint) x (columns of its widest strip).

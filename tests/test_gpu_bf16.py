@@ -154,14 +154,15 @@ def test_pooled_first_layer_rejects_what_it_does_not_cover(env):
     assert not ops.bf16_pool_fusion_ok((3, 5, 5), False, False, nn.MaxPool2d(3, 2, ceil_mode=True))
     with ops.use_config(pool_fusion=False):
         assert not ops.bf16_pool_fusion_ok((3, 5, 5), False, False, nn.MaxPool2d(3, 2))
-    # the launch-size rule: 3Conv3FC conv1 at bs 256 pays from ~7 steps per launch alone, from 4 beside other lanes
+    # the launch-size thresholds live in the LaunchConfig (0 = always: one of the library's two forms wins at every size)
     g3 = (1, 2, 1)
-    assert ops.bf16_pool_fusion_ok((3, 5, 5), False, False, nn.MaxPool2d(3, 2), (16, 3, 32, 32, 256), g3, 16)
-    assert not ops.bf16_pool_fusion_ok((3, 5, 5), False, False, nn.MaxPool2d(3, 2), (4, 3, 32, 32, 256), g3, 4)
-    assert not ops.bf16_pool_fusion_ok((3, 5, 5), False, False, nn.MaxPool2d(3, 2), (1, 3, 32, 32, 256), g3, 1)
-    with ops.overlapped_launches():
-        assert ops.bf16_pool_fusion_ok((3, 5, 5), False, False, nn.MaxPool2d(3, 2), (4, 3, 32, 32, 256), g3, 4)
-        assert not ops.bf16_pool_fusion_ok((3, 5, 5), False, False, nn.MaxPool2d(3, 2), (1, 3, 32, 32, 256), g3, 1)
+    assert ops.bf16_pool_fusion_ok((3, 5, 5), False, False, nn.MaxPool2d(3, 2), (1, 3, 32, 32, 256), g3, 1)
+    with ops.use_config(bf16_pool_fuse_min_rows=96, bf16_pool_fuse_min_rows_overlapped=60):
+        assert ops.bf16_pool_fusion_ok((3, 5, 5), False, False, nn.MaxPool2d(3, 2), (16, 3, 32, 32, 256), g3, 16)
+        assert not ops.bf16_pool_fusion_ok((3, 5, 5), False, False, nn.MaxPool2d(3, 2), (4, 3, 32, 32, 256), g3, 4)
+        with ops.overlapped_launches():
+            assert ops.bf16_pool_fusion_ok((3, 5, 5), False, False, nn.MaxPool2d(3, 2), (4, 3, 32, 32, 256), g3, 4)
+            assert not ops.bf16_pool_fusion_ok((3, 5, 5), False, False, nn.MaxPool2d(3, 2), (1, 3, 32, 32, 256), g3, 1)
 
 
 def test_sampled_weights_bf16_are_the_rounded_fp32_samples(env):
