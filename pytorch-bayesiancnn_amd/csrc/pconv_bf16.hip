@@ -782,7 +782,7 @@ __global__ __launch_bounds__(256) void pconv_bf16_smallk_pool_kernel(const PConv
 constexpr int kWinPasses = 13;             // 16-row passes of the window loader: windows of up to 13 * 16 - 1 = 207 image rows (+ the zero row)
 
 template <int KS>
-__global__ __launch_bounds__(256) void pconv_bf16_smallk_poolwin_kernel(const PConvArgs p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void pconv_bf16_smallk_poolwin_kernel(const PConvArgs p) {
     constexpr int BM = 128, LDXB = BM + 32, TP = 32 + 8;
     extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
 
@@ -852,13 +852,13 @@ __global__ __launch_bounds__(256) void pconv_bf16_smallk_poolwin_kernel(const PC
 
     // ---- the window, once: 16 lanes x 16 bytes per image row, 16 rows per pass; EVERY pass's load is issued before the first
     //      store (one memory round trip for the whole window: the host keeps it <= kWinPasses * 16 rows) ----
+    const int l16 = tid & 15, rsub = tid >> 4;
+    u32x4 wv[kWinPasses];
     {
-        const int l16 = tid & 15, rsub = tid >> 4;
         const uint32_t xcol = (uint32_t)(b0 + l16 * 8) * 2u;
         const int ih0 = r0 * p.sh - p.ph, iw0 = c0 * p.sw - p.pw;
         const int wrc = WR * WC;
         const float inv_wrc = 1.0f / (float)wrc, inv_wc = 1.0f / (float)WC;
-        u32x4 v[kWinPasses];
 #pragma unroll
         for (int u = 0; u < kWinPasses; ++u) {
             const int row = u * 16 + rsub;
@@ -873,15 +873,10 @@ __global__ __launch_bounds__(256) void pconv_bf16_smallk_poolwin_kernel(const PC
                 const int ih = ih0 + wr, iw = iw0 + wc;
                 if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) xo = (uint32_t)((ci * p.H + ih) * p.W + iw) * (uint32_t)p.B * 2u;
             }
-            v[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xo + xcol, 0, 0));
-        }
-#pragma unroll
-        for (int u = 0; u < kWinPasses; ++u) {
-            const int row = u * 16 + rsub;
-            if (row <= NR) *reinterpret_cast<u32x4*>(&Xw[row * LDXB + l16 * 8]) = v[u];         // (row NR: its offset is invalid -> zeros)
+            wv[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xo + xcol, 0, 0));
         }
     }
-    // per-lane window offsets (BYTES) of the k rows this lane SUPPLIES to a transpose read (row t >> 2 of its 16-lane group's four,
+    // -- while the window is in flight: per-lane window offsets (BYTES) of the k rows this lane SUPPLIES to a transpose read (row t >> 2 of its 16-lane group's four,
     // k half by the group): k -> (ci, r, q) -> ((ci * WR + r * dh) * WC + q * dw) * LDXB; k >= K: the zero row, pixel offset masked out
     const int tg = lane >> 4, tt = lane & 15;
     const int colo = wm + 16 * (tg & 1) + 4 * (tt & 3);
@@ -906,6 +901,12 @@ __global__ __launch_bounds__(256) void pconv_bf16_smallk_poolwin_kernel(const PC
             kbase[kk][h] = v;
             kmask[kk][h] = m;
         }
+    // (the per-lane offset tables above were computed while the window's loads were in flight)
+#pragma unroll
+    for (int u = 0; u < kWinPasses; ++u) {
+        const int row = u * 16 + rsub;
+        if (row <= NR) *reinterpret_cast<u32x4*>(&Xw[row * LDXB + l16 * 8]) = wv[u];             // (row NR: its offset is invalid -> zeros)
+    }
     typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
     typedef __attribute__((address_space(3))) char* lds_char_ptr;
     const lds_char_ptr xw_lds = (lds_char_ptr)Xw;
@@ -928,27 +929,26 @@ __global__ __launch_bounds__(256) void pconv_bf16_smallk_poolwin_kernel(const PC
     __syncthreads();                                               // the window is in LDS; from here on the waves run free
     const int npx = ncols * pk;
     const uint32_t rstep = (uint32_t)(p.sh * WC * LDXB) * 2u, cstep = (uint32_t)(p.sw * LDXB) * 2u;
-    int cc = 0, rr = 0;                                            // column / row of the CURRENT pixel inside the strip
-    // one conv pixel: operands `bc` are in registers (or in flight), the next pixel's go into `bn`
-    auto pixel = [&](int t, bf16x8 (&bc)[KS], bf16x8 (&bn)[KS]) {
-        int ncc = cc, nrr = rr + 1;                                // column-major walk: the rows of a column, then the next column
-        if (nrr == pk) { nrr = 0; ++ncc; }
-        if (t + 1 < npx) load_b((uint32_t)nrr * rstep + (uint32_t)ncc * cstep, bn);
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk], bc[kk], acc, 0, 0, 0);
+    // Conv pixels are walked column-major (the rows of a column, then the next column) and processed in PAIRS: the two pixels'
+    // MFMA chains (five dependent instructions each) are issued interleaved, so neither waits on its own latency; the window
+    // maxima are then updated in pixel order.  The next pair's operand reads are issued before the current pair's MFMAs.
+    int cc = 0, rr = 0;                                            // position of the next pixel whose operands are to be fetched
+    auto fetch_next = [&](bf16x8 (&b)[KS]) {                       // operand reads of the pixel at (cc, rr); advances the position
+        load_b((uint32_t)rr * rstep + (uint32_t)cc * cstep, b);
+        if (++rr == pk) { rr = 0; ++cc; }
+    };
+    int ucc = 0, urr = 0;                                          // position of the next pixel whose result is to be consumed
+    auto update = [&](const f32x16& acc) {
         // windows of this column (see pconv_bf16_smallk_pool_kernel); wave-uniform BRANCHES: as selects the two window updates were
         // ~140 VALU instructions per pixel against five MFMAs, and the kernel was bound by them
-        const int c = c0 + cc;
+        const int c = c0 + ucc;
         const int w_hi = c / ps;
         const bool hi_ok = w_hi < pw1;
         const bool starts = c == w_hi * ps;
         const bool lo_ok = (w_hi - 1) >= pw0 && c <= (w_hi - 1) * ps + pk - 1;
-        if (starts && rr == 0) { pold = pnew; asm volatile("" ::: "memory"); }
+        if (starts && urr == 0) { pold = pnew; asm volatile("" ::: "memory"); }
         if (hi_ok) {
-            if (starts && rr == 0) {
+            if (starts && urr == 0) {
                 pnew = acc;
                 asm volatile("" ::: "memory");
             } else {
@@ -962,25 +962,20 @@ __global__ __launch_bounds__(256) void pconv_bf16_smallk_poolwin_kernel(const PC
             for (int r = 0; r < 16; ++r) pold[r] = vmax(pold[r], acc[r]);
             asm volatile("" ::: "memory");
         }
-        const bool last_row = rr + 1 == pk;
+        const bool last_row = urr + 1 == pk;
         const bool emit_lo = last_row && lo_ok && c == (w_hi - 1) * ps + pk - 1;
         const bool emit_hi = last_row && !emit_lo && hi_ok && c == w_hi * ps + pk - 1;
         if (emit_lo || emit_hi) {
             const int ppix = ph * Wp + (emit_lo ? w_hi - 1 : w_hi);
-            auto stage_block = [&](auto act) {
 #pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    const int nl = 8 * r4 + 4 * lk;
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int nl = 8 * r4 + 4 * lk;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float m = emit_lo ? pold[r4 * 4 + i] : pnew[r4 * 4 + i];
-                        T[(nl + i) * TP + lrow] = f2bf(act(m + bq[r4][i]));
-                    }
+                for (int i = 0; i < 4; ++i) {
+                    const float m = emit_lo ? pold[r4 * 4 + i] : pnew[r4 * 4 + i];
+                    T[(nl + i) * TP + lrow] = f2bf(bbb::apply_act(m + bq[r4][i], p.act));
                 }
-            };
-            if (p.act == 2)      stage_block([](float v) { return bbb::apply_act(v, 2); });
-            else if (p.act == 1) stage_block([](float v) { return fmaxf(v, 0.0f); });
-            else                 stage_block([](float v) { return v; });
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int ps2 = 0; ps2 < 2; ++ps2) {
@@ -992,14 +987,34 @@ __global__ __launch_bounds__(256) void pconv_bf16_smallk_poolwin_kernel(const PC
                 __builtin_amdgcn_raw_buffer_store_b128(q, yrs, off, 0, 0);
             }
         }
-        cc = ncc; rr = nrr;
+        if (++urr == pk) { urr = 0; ++ucc; }
     };
-    bf16x8 b0r[KS], b1r[KS];                                        // two operand sets, used alternately: no register copies
-    load_b(0u, b0r);
+    // one PAIR of pixels t, t + 1: both MFMA chains interleaved, then -- the matrix instructions have read their operands -- the next
+    // pair's operand reads into the SAME two register sets (in flight under the window updates below), then the updates in pixel order
+    bf16x8 bA[KS], bB[KS];
+    fetch_next(bA);
+    if (npx > 1) fetch_next(bB);
 #pragma clang loop unroll(disable)
     for (int t = 0; t < npx; t += 2) {
-        pixel(t, b0r, b1r);
-        if (t + 1 < npx) pixel(t + 1, b1r, b0r);
+        const bool two = t + 1 < npx;
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+        if (two) {
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk], bA[kk], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk], bB[kk], acc1, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk], bA[kk], acc0, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 2 < npx) fetch_next(bA);
+        if (t + 3 < npx) fetch_next(bB);
+        update(acc0);
+        if (two) update(acc1);
     }
 }
 
