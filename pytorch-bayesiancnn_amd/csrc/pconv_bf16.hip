@@ -682,11 +682,16 @@ __global__ __launch_bounds__(256) void pconv_bf16_smallk_pool_kernel(const PConv
         const bool hi_first = hi_ok && starts;
         const bool lo_ok = (w_hi - 1) >= pw0 && c <= (w_hi - 1) * ps + pk - 1;
         if (starts) {
-            // the window that was the newest becomes the older one (still open only where windows overlap, pk > ps)
+            // the window that was the newest becomes the older one (still open only where windows overlap, pk > ps); the new one
+            // starts from -inf
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) pold[nt][mt] = pnew[nt][mt];
+                for (int mt = 0; mt < 2; ++mt) {
+                    pold[nt][mt] = pnew[nt][mt];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) pnew[nt][mt][r] = -__builtin_inff();
+                }
         }
 #pragma clang loop unroll(disable)
         for (int rr = 0; rr < pk; ++rr) {
@@ -715,8 +720,11 @@ __global__ __launch_bounds__(256) void pconv_bf16_smallk_pool_kernel(const PConv
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[nt][kk], b[mt], acc[nt][mt], 0, 0, 0);
             }
-            // this conv pixel into its windows (fp32 contraction results: the epilogue comes after the maximum)
-            const bool hi_reset = hi_first && rr == 0;
+            // this conv pixel into its windows (fp32 contraction results: the epilogue comes after the maximum).  Both running maxima
+            // are updated UNCONDITIONALLY: `pold` is dead between the column that closes its window and the next window start (where
+            // it is overwritten), `pnew` is dead past the strip's last window start -- so values outside a window only ever land in
+            // a register nobody reads.  One raw v_max_f32 per maximum (fmaxf canonicalises its operands first; both are arithmetic
+            // results): 2 VALU instructions per accumulator element instead of ~8 (strip form 124.6 -> 111 us at 16 steps per launch).
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -724,8 +732,11 @@ __global__ __launch_bounds__(256) void pconv_bf16_smallk_pool_kernel(const PConv
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const float v = acc[nt][mt][r];
-                        if (hi_ok) pnew[nt][mt][r] = hi_reset ? v : fmaxf(pnew[nt][mt][r], v);
-                        if (lo_ok) pold[nt][mt][r] = fmaxf(pold[nt][mt][r], v);
+                        float mh, ml;
+                        asm("v_max_f32 %0, %1, %2" : "=v"(mh) : "v"(pnew[nt][mt][r]), "v"(v));
+                        asm("v_max_f32 %0, %1, %2" : "=v"(ml) : "v"(pold[nt][mt][r]), "v"(v));
+                        pnew[nt][mt][r] = mh;
+                        pold[nt][mt][r] = ml;
                     }
             // a window is complete after the last row of its last column: older window first (overlapping windows), else the
             // newest (pk <= ps); the host admits only geometries where at most one window closes per column
@@ -946,6 +957,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const bool hi_ok = w_hi < pw1;
         const bool starts = c == w_hi * ps;
         const bool lo_ok = (w_hi - 1) >= pw0 && c <= (w_hi - 1) * ps + pk - 1;
+        // (wave-uniform branches here: this form's pixel is ~330 instructions, and skipping the update of a closed window pays --
+        // measured against the unconditional updates of the strip form: 34.8 vs 45.9 us at four steps per launch)
         if (starts && urr == 0) { pold = pnew; asm volatile("" ::: "memory"); }
         if (hi_ok) {
             if (starts && urr == 0) {
@@ -1218,10 +1231,10 @@ extern "C" int bbb_conv2d_chwn_bf16_fwd(const bbb_conv_desc_t* d, const void* x,
         // the window-resident form (pconv_bf16_smallk_poolwin_kernel): <= 32 channels, 128-image tiles, the widest strip whose input
         // window (+ one zero row) and epilogue staging fit 72 KB of LDS (two workgroups per CU).  Its workgroups are short (one
         // memory round trip for the window, 15 pixels, two pooled outputs: ~8 us each), so it wins where the strip form is a
-        // latency chain -- small launches -- and ties / loses by 2-3 % once the strip form fills the chip (3Conv3FC conv1 + pool1,
-        // bs 256, us per launch, window / strip / conv + pool launches: 2 steps 20 / 39 / 27, 4 steps 37 / 53 / 47, 6 steps 55 / 54 /
-        // 82, 8 steps 71 / 68 / 82, 16 steps 128 / 125 / 167; profiles/r05_notes.md section 3): below 90 pooled rows x image tiles
-        if (nt == 1 && (int64_t)a.G * a.nbt * hp < 90) {
+        // latency chain -- small launches -- and loses once the strip form fills the chip (3Conv3FC conv1 + pool1, bs 256, us per
+        // launch, window / strip / conv + pool launches: 1 step 15.8 / 38.8 / 18.4, 4 steps 34.8 / 52.8 / 46.5, 5-6 steps 45.8 / 44.2 /
+        // 82, 16 steps 128 / 101 / 167; profiles/r05_notes.md section 3): below 70 pooled rows x image tiles
+        if (nt == 1 && (int64_t)a.G * a.nbt * hp < 70) {
             const int WRw = (pool_k - 1) * a.sh + (a.kh - 1) * a.dh + 1;
             int best_n = 0;
             for (int n = 1; n <= wp; ++n) {
