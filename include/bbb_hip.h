@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define BBB_ABI_VERSION 9
+#define BBB_ABI_VERSION 10
 #define BBB_MAX_SEGMENTS 16
 
 #define BBB_EINVAL (-1)   /* bad argument (null pointer, non-positive size, too many segments) */
@@ -333,9 +333,20 @@ int bbb_lrt_sample_nchw(const float* act_mu, const float* act_var, float* y, int
  *   y: [draws][cout][ho][wo][B]       bf16, or fp32 with BBB_BF16_OUT_F32 (the logits layer feeding bbb_mc_tail)
  * d->w_draw_stride counts bf16 elements (cout*Kp per draw when dense).  Same contraction as bbb_conv2d_chwn_fwd
  * (layers/BBB/BBBConv.py:77, BBBLinear.py:70) on v_mfma_f32_32x32x16_bf16.  BBB layers only (no LRT variant).
+ * Channel-interleaved activations (ABI 10): [draws][C / 8][h][w][B][8] -- the 8 channels 8g .. 8g + 7 of an image are 16 adjacent
+ * bytes, so a lane's MFMA operand (8 consecutive channels of one image) is ONE 16-byte load and a conv layer needs neither LDS
+ * staging nor transposing reads for its images.  Same element count and draw strides as the batch-innermost tensor; same values.
+ *   BBB_BF16_X_C8    x is in that layout.  Accepted where the library has a kernel that reads it: tap-major rows of 32 input
+ *                    channels, 5 x 5 taps, stride 1, dilation 1, padding < 5, bf16 output (3Conv3FC conv2: a strip of three output
+ *                    pixels per workgroup, every input position fetched once for all the pixels it is a tap of); BBB_EINVAL else.
+ *   BBB_BF16_OUT_C8  y is written in that layout (cout % 8 == 0).  Accepted by the pooled first-layer forms (d->pool != 0) and
+ *                    together with BBB_BF16_X_C8; BBB_EINVAL else.
+ * Bit for bit the results of the batch-innermost forms (the same MFMA sequence per output element).
  */
 #define BBB_BF16_OUT_F32      1u
 #define BBB_BF16_W_TAP_MAJOR  2u
+#define BBB_BF16_X_C8         4u   /* x is channel-interleaved: [draws|1][cin / 8][h][w][B][8] (ABI 10) */
+#define BBB_BF16_OUT_C8       8u   /* y is written channel-interleaved: [draws][cout / 8][ho][wo][B][8] (ABI 10) */
 int bbb_conv2d_chwn_bf16_fwd(const bbb_conv_desc_t* d, const void* x, const void* w, const float* bias, void* y,
                              uint32_t flags, void* stream);
 /* nn.MaxPool2d(k, s) on [planes][h][w][B] bf16 (B % 8 == 0); exact (max commutes with the rounding). */

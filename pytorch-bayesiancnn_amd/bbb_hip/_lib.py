@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede CDLL: shares torch's HIP runtime)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BBB_HIP_LIB") or os.path.join(_HERE, "libbbb_hip.so")   # env override: experiments only
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 MAX_SEGMENTS = 16
 SIGMA_SQUARED = 1
 KL_TEXTBOOK = 2

@@ -460,7 +460,8 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
                     h5 = h if is_conv else h.reshape(h.shape[0], 3, mod.in_features, 1, 1, -1)
                 else:
                     h5 = h if is_conv else h.reshape(h.shape[0], mod.in_features, 1, 1, -1)
-                if h5.dim() != (6 if s3 else 5) or h5.shape[-1] != B:
+                c8 = bf16 and h5.dim() == 6                      # channel-interleaved [E, C / 8, H, W, B, 8] (ops.to_c8), written by the layer before
+                if h5.dim() != (6 if (s3 or c8) else 5) or h5.shape[4 if c8 else -1] != B:
                     return None                                  # flatten quirk etc.: caller falls back
                 ukw2 = dict(ukw, x_per_slice=per_slice) if ukw else ({"x_div": x_div, "x_off": x_off} if x_div > 1 else {})
                 per_slice = False
@@ -471,7 +472,7 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
                         w = w[e0:e1]
                         b = None if b is None else b[e0:e1]
                     ckk = (mod.in_channels, *mod.kernel_size) if is_conv else (mod.in_features, 1, 1)
-                    fl = conv_flops(B, h5.shape[1], h5.shape[2], h5.shape[3], w.shape[1], ckk[1], ckk[2], *geom, Es) \
+                    fl = conv_flops(B, h5.shape[1] * (8 if c8 else 1), h5.shape[2], h5.shape[3], w.shape[1], ckk[1], ckk[2], *geom, Es) \
                         if timers is not None else None
                     is_logits = logits_buf is not None and i == last_bayes and not is_conv
                     dst = logits_buf[e0:e1] if is_logits else None
@@ -482,11 +483,22 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
                     pool_mod = children[pool_at] if pool_at < len(children) and isinstance(children[pool_at], nn.MaxPool2d) else None
                     fuse_pool = is_conv and ops.bf16_pool_fusion_ok(ckk, tapm, of32, pool_mod, tuple(h5.shape), geom, Es)
                     pool_ks = (pool_mod.kernel_size, pool_mod.stride if pool_mod.stride is not None else pool_mod.kernel_size) if fuse_pool else None
+                    # the pooled first layer writes its output channel-interleaved when the layer that reads it has the strip form over
+                    # that layout (3Conv3FC conv1 + pool1 -> conv2; ops.bf16_c8_input_ok): same values, 8 channels of an image adjacent
+                    out_c8 = False
+                    nb = children[pool_at + 1] if (fuse_pool and pool_at + 1 < len(children)) else None
+                    if isinstance(nb, _BBBConv) and w.shape[1] % 8 == 0 and dst is None:
+                        hw = [(h5.shape[2 + a] + 2 * _p2(geom[1])[a] - _p2(geom[2])[a] * (ckk[1 + a] - 1) - 1) // _p2(geom[0])[a] + 1 for a in (0, 1)]
+                        hw = [(v - _p2(pool_ks[0])[a]) // _p2(pool_ks[1])[a] + 1 for a, v in enumerate(hw)]
+                        out_c8 = ops.bf16_c8_input_ok((nb.in_channels, *nb.kernel_size), (nb.stride, nb.padding, nb.dilation),
+                                                      ops.bf16_tap_major(tuple(nb.W_mu.shape)), pool_at + 1 == last_bayes and tail_is_last,
+                                                      (hw[0], hw[1], B), Es)
                     # (operands bound as defaults: bench.py's LaunchRecorder replays these closures after the loop has moved on)
                     y = _run(timers, "conv_gemm", fl,
-                             lambda h5=h5, w=w, b=b, ckk=ckk, geom=geom, act=act, dst=dst, ukw2=ukw2, tapm=tapm, of32=of32, pool_ks=pool_ks:
+                             lambda h5=h5, w=w, b=b, ckk=ckk, geom=geom, act=act, dst=dst, ukw2=ukw2, tapm=tapm, of32=of32, pool_ks=pool_ks,
+                             out_c8=out_c8:
                              ops.conv2d_chwn_bf16_forward(h5, w, b, ckk, *geom, act=act, out_f32=of32, out=dst, tap_major=tapm,
-                                                          pool=pool_ks, **ukw2))
+                                                          pool=pool_ks, out_c8=out_c8, **ukw2))
                     if fuse_pool:
                         i += 1                                   # the pooling module is done too
                 elif isinstance(mod, _BBBLayer):
@@ -1429,6 +1441,10 @@ class GraphedLogits:
         self.counter.fill_(d - (1 << 32) if d >= (1 << 31) else d)     # the kernels add it modulo 2^32
         self.graph.replay()
         return self.logits, self.kl
+
+
+def _p2(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
 
 
 class _null_ctx:

@@ -301,7 +301,7 @@ class LaunchConfig:
     pool_fuse_weight_budget   bytes of weight tiles concurrently live per XCD that a fused launch may have (see pool_fusion_ok)"""
     FIELDS = ("gemm_mode", "bf16x3_min_workgroups", "s3_min_images", "split_k", "pool_fusion", "pool_fuse_min_items",
               "pool_fuse_imbalance", "launches_overlap", "pool_fuse_min_items_overlapped", "pool_fuse_weight_budget",
-              "bf16_pool_fuse_min_rows", "bf16_pool_fuse_min_rows_overlapped")
+              "bf16_pool_fuse_min_rows", "bf16_pool_fuse_min_rows_overlapped", "bf16_c8", "bf16_c8_min_items")
     __slots__ = FIELDS
 
     def __init__(self, **kw):
@@ -318,6 +318,9 @@ class LaunchConfig:
         self.bf16_pool_fuse_min_rows = 0               # (bf16_pool_fusion_ok) pooled rows x image tiles x slabs from which the pooled
         self.bf16_pool_fuse_min_rows_overlapped = 0    # first-layer form of the bf16 path is taken (0: always -- the library's
                                                        # window-resident form wins from one step per launch on); ... beside other lanes
+        self.bf16_c8 = True                            # (bf16_c8_input_ok) channel-interleaved activations between a pooled first layer and a
+        self.bf16_c8_min_items = 0                     # layer that has the strip form over them, for launches of at least this many strip
+                                                       # workgroups (0: always -- measured faster from one step per launch on); False: never
         for k, v in kw.items():
             setattr(self, k, v)              # (unknown names raise: __slots__)
 
@@ -782,15 +785,23 @@ def bf16_pool_fusion_ok(cin_khkw, tap_major, out_f32, pool_module, x_shape=None,
 
 
 def conv2d_chwn_bf16_forward(x, w, bias, cin_khkw, stride=1, padding=0, dilation=1, act=None, out_f32=False, out=None,
-                             tap_major=False, units=None, n_units=None, x_per_slice=False, x_div=1, x_off=0, pool=None):
+                             tap_major=False, units=None, n_units=None, x_per_slice=False, x_div=1, x_off=0, pool=None,
+                             out_c8=False):
     """bf16 batch-innermost conv.  x: [E|1, Cin, H, W, B] bf16 (B % 8 == 0); w: [E|1, Cout, Kp] bf16 as written by
     sample_weights_bf16 (tap_major = its column order, see bf16_tap_major); cin_khkw = (Cin, kh, kw); bias [E|1, Cout]
     fp32 or None -> y [E, Cout, Ho, Wo, B] bf16 (fp32 when out_f32).
     pool = (k, s): the launch also applies MaxPool2d(k, s) to the activated output -> [E, Cout, Hp, Wp, B] (bf16_pool_fusion_ok
-    says when the library has that form)."""
+    says when the library has that form).
+    Channel-interleaved activations ("c8", see to_c8): a 6-d x [E|1, Cin / 8, H, W, B, 8] is read as such (bf16_c8_input_ok says
+    which layers have that form); out_c8=True writes y as [E, Cout / 8, Ho, Wo, B, 8] (bf16_c8_output_ok)."""
     require_device(x, w, dtype=torch.bfloat16)
     require_device(bias)
     x, w = x.contiguous(), w.contiguous()
+    x_c8 = x.dim() == 6
+    if x_c8:
+        if x.shape[5] != 8:
+            raise _lib.BBBHipError("a 6-d input is [E, Cin / 8, H, W, B, 8]")
+        x = x.view(x.shape[0], x.shape[1] * 8, x.shape[2], x.shape[3], x.shape[4])      # same bytes; only the element order differs
     bias = None if bias is None else bias.contiguous()
     cin, kh, kw = cin_khkw
     sharded = units is not None and units[0] > 1
@@ -822,7 +833,9 @@ def conv2d_chwn_bf16_forward(x, w, bias, cin_khkw, stride=1, padding=0, dilation
         pk, pst = int(pool[0]), int(pool[1])
         d.pool = 1 if (pk, pst) == (2, 2) else ((pk << 8) | pst)
         ho, wo = (ho - pk) // pst + 1, (wo - pk) // pst + 1
-    shape = (E, w.shape[1], ho, wo, B)
+    if out_c8 and (out_f32 or w.shape[1] % 8):
+        raise _lib.BBBHipError("out_c8: bf16 output with a multiple of 8 channels")
+    shape = (E, w.shape[1] // 8, ho, wo, B, 8) if out_c8 else (E, w.shape[1], ho, wo, B)
     dt = torch.float32 if out_f32 else torch.bfloat16
     if out is None:
         y = torch.empty(shape, dtype=dt, device=x.device)
@@ -832,9 +845,51 @@ def conv2d_chwn_bf16_forward(x, w, bias, cin_khkw, stride=1, padding=0, dilation
         y = out.view(shape)
     with on_device(x.device):
         check(_lib.lib().bbb_conv2d_chwn_bf16_fwd(ctypes.byref(d), x.data_ptr(), w.data_ptr(), ptr(bias), y.data_ptr(),
-                                                  (1 if out_f32 else 0) | (2 if tap_major else 0), cur_stream(x.device)),
+                                                  (1 if out_f32 else 0) | (2 if tap_major else 0) | (4 if x_c8 else 0) |
+                                                  (8 if out_c8 else 0), cur_stream(x.device)),
               "bbb_conv2d_chwn_bf16_fwd")
     return y
+
+
+def bf16_c8_input_ok(cin_khkw, geom, tap_major, out_f32, x_shape=None, draws=1):
+    """Does conv2d_chwn_bf16_forward have a kernel that reads THIS layer's input channel-interleaved (a 6-d x, see to_c8), and
+    should the launch take it?  pconv_bf16_strip8_kernel: tap-major rows of 32 input channels, 5 x 5 taps, stride 1, no dilation,
+    padding < 5, bf16 output (3Conv3FC conv2: 131-153 us on the general kernel at bs 256 x 16 steps per launch, 88-100 us here).  The
+    producer must then write that layout (out_c8: the pooled first-layer forms and the strip form itself).
+    x_shape (H, W, B) + draws: the launch, for LaunchConfig.bf16_c8_min_items (strip workgroups: a strip of three pixels of an output
+    row x 64 channels x 128 images).  0 = always: 3Conv3FC conv2 at bs 256, us per launch, general kernel / strip form: 1 step 18.1 /
+    15.0, 2 steps 33.7 / 20.8, 4 steps 43.4 / 30.9, 8 steps 71.3 / 47.8, 16 steps 131-153 / 88-100 (profiles/r05_notes.md section 8).
+    Values: the strip form always adds a pixel's taps in one fixed order (the general kernel's order with ONE k-group, which is what
+    that kernel uses for launches of 512 workgroups and more) -- bit-identical there, rounding-level differences against the
+    general kernel's two- / four-group launches."""
+    cfg = current_config()
+    if not cfg.bf16_c8 or not tap_major or out_f32:
+        return False
+    cin, kh, kw = cin_khkw
+    (sh, sw), (ph, pw), (dh, dw) = _pair(geom[0]), _pair(geom[1]), _pair(geom[2])
+    if not (cin == 32 and (kh, kw) == (5, 5) and (sh, sw) == (1, 1) and (dh, dw) == (1, 1) and ph < kh and pw < kw):
+        return False
+    if x_shape is None:
+        return True
+    H, W, B = x_shape
+    ho, wo = H + 2 * ph - kh + 1, W + 2 * pw - kw + 1
+    if ho < 1 or wo < 1:
+        return False
+    return int(draws) * ho * -(-wo // 3) * -(-B // 128) >= cfg.bf16_c8_min_items
+
+
+def to_c8(x):
+    """[E, C, H, W, B] -> the channel-interleaved layout [E, C / 8, H, W, B, 8] (8 consecutive channels of an image adjacent in
+    memory: an MFMA operand of the bf16 kernels is then one 16-byte load).  A torch permute: tests and one-off conversions; inside
+    the batched path the producing kernel writes the layout itself (out_c8)."""
+    E, C, H, W, B = x.shape
+    return x.view(E, C // 8, 8, H, W, B).permute(0, 1, 3, 4, 5, 2).contiguous()
+
+
+def from_c8(x):
+    """The inverse of to_c8: [E, C / 8, H, W, B, 8] -> [E, C, H, W, B]."""
+    E, C8, H, W, B, _ = x.shape
+    return x.permute(0, 1, 5, 2, 3, 4).reshape(E, C8 * 8, H, W, B).contiguous()
 
 
 def maxpool_chwn_bf16(x, k, s):

@@ -33,6 +33,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -759,6 +760,29 @@ __global__ __launch_bounds__(256) void pconv_bf16_smallk_pool_kernel(const PConv
                                 }
                         }
                 };
+                // channel-interleaved output (BBB_BF16_OUT_C8): a lane's four consecutive channels of an image are 8 adjacent bytes of
+                // [cout / 8][hp][wp][B][8] -- straight from the registers, a wave-store covers 32 images x 16 B
+                auto store_c8 = [&](auto act) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int r4 = 0; r4 < 4; ++r4)
+#pragma unroll
+                            for (int mt = 0; mt < 2; ++mt) {
+                                uint32_t h[4];
+#pragma unroll
+                                for (int i = 0; i < 4; ++i)
+                                    h[i] = f2bf(act((emit_lo ? pold[nt][mt][r4 * 4 + i] : pnew[nt][mt][r4 * 4 + i]) + bq[nt][r4][i]));
+                                const int n = n0 + nt * 32 + 8 * r4, b = b0 + wm + mt * 32 + lrow;
+                                const uint32_t off = ((b < p.B) & (n < p.Cout)) ? (uint32_t)((((int64_t)(n >> 3) * HpWp + ppix) * p.B + b) * 16 + lk * 8) : kOOB;
+                                __builtin_amdgcn_raw_buffer_store_b64(u32x2{h[0] | (h[1] << 16), h[2] | (h[3] << 16)}, yrs, off, 0, 0);
+                            }
+                };
+                if (p.y_c8) {
+                    if (p.act == 2)      store_c8([](float v) { return bbb::apply_act(v, 2); });
+                    else if (p.act == 1) store_c8([](float v) { return fmaxf(v, 0.0f); });
+                    else                 store_c8([](float v) { return v; });
+                } else {
                 if (p.act == 2)      stage_block([](float v) { return bbb::apply_act(v, 2); });
                 else if (p.act == 1) stage_block([](float v) { return fmaxf(v, 0.0f); });
                 else                 stage_block([](float v) { return v; });
@@ -771,6 +795,7 @@ __global__ __launch_bounds__(256) void pconv_bf16_smallk_pool_kernel(const PConv
                     const int n = n0 + row, b = b0 + wm + grp * 8;
                     const uint32_t off = ((b < p.B) & (n < p.Cout)) ? (uint32_t)(((int64_t)n * HpWp + ppix) * p.B + b) * 2u : kOOB;
                     __builtin_amdgcn_raw_buffer_store_b128(q, yrs, off, 0, 0);
+                }
                 }
             }
             __syncthreads();                                       // every wave has read this pixel's rows
@@ -980,6 +1005,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const bool emit_hi = last_row && !emit_lo && hi_ok && c == w_hi * ps + pk - 1;
         if (emit_lo || emit_hi) {
             const int ppix = ph * Wp + (emit_lo ? w_hi - 1 : w_hi);
+            if (p.y_c8) {
+                // channel-interleaved output (BBB_BF16_OUT_C8): 8 bytes per lane and channel quad, straight from the registers
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    uint32_t h[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) h[i] = f2bf(bbb::apply_act((emit_lo ? pold[r4 * 4 + i] : pnew[r4 * 4 + i]) + bq[r4][i], p.act));
+                    const int n = n0 + 8 * r4, b = b0 + wm + lrow;
+                    const uint32_t off = ((b < p.B) & (n < p.Cout)) ? (uint32_t)((((int64_t)(n >> 3) * HpWp + ppix) * p.B + b) * 16 + lk * 8) : kOOB;
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{h[0] | (h[1] << 16), h[2] | (h[3] << 16)}, yrs, off, 0, 0);
+                }
+            } else {
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
                 const int nl = 8 * r4 + 4 * lk;
@@ -998,6 +1035,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const int n = n0 + row, b = b0 + wm + grp * 8;
                 const uint32_t off = ((b < p.B) & (n < p.Cout)) ? (uint32_t)(((int64_t)n * HpWp + ppix) * p.B + b) * 2u : kOOB;
                 __builtin_amdgcn_raw_buffer_store_b128(q, yrs, off, 0, 0);
+            }
             }
         }
         if (++urr == pk) { urr = 0; ++ucc; }
@@ -1029,6 +1067,222 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         update(acc0);
         if (two) update(acc1);
     }
+}
+
+// ---- the strip form over CHANNEL-INTERLEAVED activations ("c8": [C / 8][H][W][B][8], BBB_BF16_X_C8) ----
+// In the batch-innermost layout a lane's MFMA B operand -- 8 consecutive channels of one image -- is 8 elements a whole plane apart,
+// which is why every other kernel here stages image rows through LDS and transposes them on the way out (ds_read_tr16_b64): measured
+// on pconv_bf16_strip_kernel, the LDS writes, the transposing reads and the barriers between them are 51 of its 107 us, and they
+// do not overlap with the MFMAs.  With 8 channels of an image adjacent in memory the operand IS a 16-byte load: lane (image, k half)
+// reads channels 16 cib + 8 half .. + 7 of its image at the position, 32 images = 512 contiguous bytes.  No LDS, no transposes and
+// no barriers on the image side at all; the waves of a workgroup (4 x 32 images, all 64 channels each) only share the tap row's
+// weights, staged through LDS once per tap row.  Same MFMA sequence per output element: bit for bit the other forms' result.
+template <int P, int KW, int DB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void pconv_bf16_strip8_kernel(const PConvArgs p) {
+    constexpr int CIN = 32, CIB = CIN / 16, BM = 128, TP = 32 + 8;
+    constexpr int NC = P + KW - 1;                                // window columns of a strip
+    constexpr int NCP = (NC + DB - 1) / DB * DB;                  // padded: the operand set of a position is c' % DB, statically
+    constexpr int LDA = KW * CIN + 8;                             // weight row pitch (elements): conflict-free 16-byte reads
+    constexpr int ASEG = KW * CIN / 8, APASS = (64 * ASEG + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+    uint16_t* As = smem;                                          // [2][64][LDA]; the epilogue staging [4][64][TP] aliases it afterwards
+
+    const int nstr = p.px_run;                                    // strips per output row
+    const int bid = blockIdx.x, xcd = bid & 7;
+    const int64_t item = (int64_t)xcd * p.per_xcd + (bid >> 3);
+    const int64_t item_end = (int64_t)(xcd + 1) * p.per_xcd;
+    const int64_t per_g = (int64_t)p.Ho * nstr * p.nbt;
+    if (item >= item_end || item >= (int64_t)p.G * per_g) return;
+    const int g = (int)(item / per_g);
+    int rem = (int)(item - (int64_t)g * per_g);
+    const int oh = rem / (nstr * p.nbt);
+    rem -= oh * nstr * p.nbt;
+    const int cs = rem / p.nbt;
+    const int b0 = (rem - cs * p.nbt) * BM;
+    const int ow0 = cs * P;
+    const int npix = (p.Wo - ow0) < P ? (p.Wo - ow0) : P;
+    const int e = g / p.Ntiles;
+    const int ue = p.unit_off + e;
+    const int ew = p.unit_div > 1 ? ue / p.unit_div : e;
+    const int ex = p.x_div > 1 ? (e + p.x_off) / p.x_div : (p.x_mod > 0 ? ue % p.x_mod : e);
+    const int n0 = (g - e * p.Ntiles) * 64;
+    const int Kp = p.Kp;
+    const int HoWo = p.Ho * p.Wo;
+    const int ihb = oh - p.ph, c0 = ow0 - p.pw;                   // stride 1, dilation 1
+    const int r_lo = ihb < 0 ? -ihb : 0;
+    const int r_hi = (p.H - ihb) < p.kh ? (p.H - ihb) : p.kh;
+    uint32_t cmask = 0;                                           // window columns inside the image
+#pragma unroll
+    for (int c = 0; c < NC; ++c) cmask |= (c0 + c >= 0 && c0 + c < p.W) ? (1u << c) : 0u;
+    auto colok = [&](int c) { return c < NC && ((cmask >> (c < NC ? c : 0)) & 1u) != 0; };
+
+    const int tid = (int)threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave * 32;
+    const int lrow = lane & 31, lk = lane >> 5;
+
+    constexpr uint32_t kOOB = 0xFFFFFFF0u;
+    const uint16_t* xb = reinterpret_cast<const uint16_t*>(p.x) + (int64_t)ex * p.x_ds;
+    const uint16_t* wb = reinterpret_cast<const uint16_t*>(p.w) + (int64_t)ew * p.w_ds;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(xb), 0, (int)((int64_t)p.Cin * p.H * p.W * p.B * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(wb), 0, (int)((int64_t)p.Cout * Kp * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.bias ? p.bias + (int64_t)ew * p.b_ds : reinterpret_cast<const float*>(p.w)), 0, p.bias ? p.Cout * 4 : 0, 0x00020000);
+    char* yb = reinterpret_cast<char*>(p.y) + (int64_t)e * p.y_ds * 2;
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(yb, 0, (int)((int64_t)p.Cout * HoWo * p.B * 2), 0x00020000);
+
+    // MFMA B operands of a position, straight from memory: lane (image lrow, k half lk), channel block 2 cib + lk
+    const uint32_t col_b = (uint32_t)p.B * 16u, row_b = (uint32_t)p.W * col_b, blk_b = (uint32_t)p.H * row_b;
+    const uint32_t xbase = (uint32_t)lk * blk_b + (uint32_t)(b0 + wm + lrow) * 16u + (uint32_t)ihb * row_b + (uint32_t)c0 * col_b;   // (mod 2^32)
+    bf16x8 bfr[DB][CIB];
+    // (unconditional: a position outside the image or past the last tap row fetches out of range, i.e. zeros nobody multiplies --
+    // with branches around the loads the compiler drains every outstanding load at every position)
+    auto load_pos = [&](int set, int r, int c, bool ok) {
+        const uint32_t o = xbase + (uint32_t)r * row_b + (uint32_t)c * col_b;
+#pragma unroll
+        for (int cib = 0; cib < CIB; ++cib)
+            bfr[set][cib] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xrs, ok ? o + (uint32_t)(2 * cib) * blk_b : kOOB, 0, 0));
+    };
+    // weights of a tap row: 64 rows of KW * CIN consecutive k (tap-major), 16-byte segments dealt out to the 256 threads
+    u32x4 areg[APASS];
+    auto load_aseg = [&](int i, int r, bool ok) {
+        const int idx = tid + 256 * i;
+        const int row = idx / ASEG, seg = idx - row * ASEG;
+        const uint32_t off = (ok && idx < 64 * ASEG && n0 + row < p.Cout) ? (uint32_t)((n0 + row) * Kp + r * (KW * CIN) + seg * 8) * 2u : kOOB;
+        areg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, off, 0, 0));
+    };
+    auto store_aseg = [&](int i, int slot) {
+        const int idx = tid + 256 * i;
+        const int row = idx / ASEG, seg = idx - row * ASEG;
+        if (idx < 64 * ASEG) *reinterpret_cast<u32x4*>(&As[slot * (64 * LDA) + row * LDA + seg * 8]) = areg[i];
+    };
+
+    f32x16 acc[P][2];
+#pragma unroll
+    for (int j = 0; j < P; ++j)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][nt][r] = 0.0f;
+
+    static_assert(NCP >= DB && NCP % DB == 0, "static operand sets per window column");
+    static_assert(NCP >= APASS + 2, "a tap row's segments are requested and stored within one pass over the window");
+#pragma unroll
+    for (int k = 0; k < APASS; ++k) load_aseg(k, r_lo, true);
+#pragma unroll
+    for (int c = 0; c < DB; ++c) load_pos(c, r_lo, c, colok(c));
+#pragma unroll
+    for (int k = 0; k < APASS; ++k) store_aseg(k, 0);
+    for (int r = r_lo; r < r_hi; ++r) {
+        const int aslot = (r - r_lo) & 1;
+        const bool more_r = r + 1 < r_hi;
+        __syncthreads();                                          // this tap row's weights are in LDS (written during the row before)
+        bf16x8 a[KW][CIB][2];
+#pragma unroll
+        for (int q = 0; q < KW; ++q)
+#pragma unroll
+            for (int cib = 0; cib < CIB; ++cib)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    a[q][cib][nt] = *reinterpret_cast<const bf16x8*>(&As[aslot * (64 * LDA) + (nt * 32 + lrow) * LDA + q * CIN + cib * 16 + lk * 8]);
+#pragma unroll
+        for (int c = 0; c < NCP; ++c) {
+            // the next tap row's weights, a 16-byte segment per thread and position: requested at position c, in LDS two positions later
+            if (c < APASS) load_aseg(c, r + 1, more_r);
+            if (c >= 2 && c - 2 < APASS) store_aseg(c - 2, aslot ^ 1);
+            if (colok(c)) {
+#pragma unroll
+                for (int cib = 0; cib < CIB; ++cib)
+#pragma unroll
+                    for (int j = 0; j < P; ++j) {
+                        const int q = c - j;
+                        if (q >= 0 && q < KW) {
+#pragma unroll
+                            for (int nt = 0; nt < 2; ++nt)
+                                acc[j][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[q][cib][nt], bfr[c % DB][cib], acc[j][nt], 0, 0, 0);
+                        }
+                    }
+            }
+            {   // the position DB ahead goes into the operand set just consumed
+                const int cn = (c + DB) % NCP;
+                const bool wrap = (c + DB) >= NCP;
+                load_pos(c % DB, wrap ? r + 1 : r, cn, colok(cn) && (!wrap || more_r));
+            }
+        }
+    }
+
+    // ---- epilogue: per pixel, bias + activation + rounding in registers, wave-private LDS transpose, 16-byte stores ----
+    __syncthreads();                                              // the weight rows are dead: their memory is the staging area now
+    uint16_t* T = As + wave * (64 * TP);
+    f32x4 bq[2][4];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4)
+            bq[nt][r4] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, (uint32_t)(n0 + nt * 32 + 8 * r4 + 4 * lk) * 4u, 0, 0));
+    if (p.y_c8) {
+        // channel-interleaved output: a lane's four consecutive channels of an image are 8 adjacent bytes -- no transpose, and a
+        // wave-store covers 32 images x 16 B = 512 contiguous bytes
+        auto emit = [&](auto act) {
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                if (j < npix) {
+                    const int pix = oh * p.Wo + ow0 + j;
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int r4 = 0; r4 < 4; ++r4) {
+                            uint32_t lo = (uint32_t)f2bf(act(acc[j][nt][r4 * 4 + 0] + bq[nt][r4][0])) | ((uint32_t)f2bf(act(acc[j][nt][r4 * 4 + 1] + bq[nt][r4][1])) << 16);
+                            uint32_t hi = (uint32_t)f2bf(act(acc[j][nt][r4 * 4 + 2] + bq[nt][r4][2])) | ((uint32_t)f2bf(act(acc[j][nt][r4 * 4 + 3] + bq[nt][r4][3])) << 16);
+                            const int n = n0 + nt * 32 + 8 * r4, b = b0 + wm + lrow;
+                            const uint32_t off = ((b < p.B) & (n < p.Cout)) ? (uint32_t)((((int64_t)(n >> 3) * HoWo + pix) * p.B + b) * 16 + lk * 8) : kOOB;
+                            __builtin_amdgcn_raw_buffer_store_b64(u32x2{lo, hi}, yrs, off, 0, 0);
+                        }
+                }
+            }
+        };
+        if (p.act == 2)      emit([](float v) { return bbb::apply_act(v, 2); });
+        else if (p.act == 1) emit([](float v) { return fmaxf(v, 0.0f); });
+        else                 emit([](float v) { return v; });
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+        if (j < npix) {
+            const int pix = oh * p.Wo + ow0 + j;
+            auto stage_block = [&](auto act) {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            T[(nt * 32 + 8 * r4 + 4 * lk + i) * TP + lrow] = f2bf(act(acc[j][nt][r4 * 4 + i] + bq[nt][r4][i]));
+            };
+            if (p.act == 2)      stage_block([](float v) { return bbb::apply_act(v, 2); });
+            else if (p.act == 1) stage_block([](float v) { return fmaxf(v, 0.0f); });
+            else                 stage_block([](float v) { return v; });
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const int v = ps * 64 + lane;
+                const int row = v >> 2, grp = v & 3;
+                const u32x4 q = *reinterpret_cast<const u32x4*>(&T[row * TP + grp * 8]);
+                const int n = n0 + row, b = b0 + wm + grp * 8;
+                const uint32_t off = ((b < p.B) & (n < p.Cout)) ? (uint32_t)(((int64_t)n * HoWo + pix) * p.B + b) * 2u : kOOB;
+                __builtin_amdgcn_raw_buffer_store_b128(q, yrs, off, 0, 0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the staging rows are read before the next pixel overwrites them
+        }
+    }
+}
+
+template <int P, int KW, int DB>
+int launch_strip8(const PConvArgs& a, int64_t blocks, hipStream_t st) {
+    constexpr int kSmem = 2 * 64 * (KW * 32 + 8) * 2;
+    static_assert(4 * 64 * 40 <= 2 * 64 * (KW * 32 + 8), "epilogue staging aliases the weight rows");
+    hipLaunchKernelGGL((pconv_bf16_strip8_kernel<P, KW, DB>), dim3((unsigned)blocks), dim3(256), kSmem, st, a);
+    return (int)hipGetLastError();
 }
 
 template <int KS>
@@ -1177,7 +1431,8 @@ extern "C" int bbb_conv2d_chwn_bf16_fwd(const bbb_conv_desc_t* d, const void* x,
         return BBB_EINVAL;
     if (d->batch % 8 != 0) return BBB_ESHAPE;        // rows of 16-byte vectors of 8 bf16 images
     if (tap_major && d->cin % 8 != 0) return BBB_ESHAPE;   // a 16-byte weight vector must not straddle two taps
-    if ((flags & ~(BBB_BF16_OUT_F32 | BBB_BF16_W_TAP_MAJOR)) != 0) return BBB_EINVAL;
+    if ((flags & ~(BBB_BF16_OUT_F32 | BBB_BF16_W_TAP_MAJOR | BBB_BF16_X_C8 | BBB_BF16_OUT_C8)) != 0) return BBB_EINVAL;
+    const bool x_c8 = (flags & BBB_BF16_X_C8) != 0, out_c8 = (flags & BBB_BF16_OUT_C8) != 0;
     const int ho = (d->h + 2 * d->pad_h - d->dil_h * (d->kh - 1) - 1) / d->stride_h + 1;
     const int wo = (d->w + 2 * d->pad_w - d->dil_w * (d->kw - 1) - 1) / d->stride_w + 1;
     if (ho <= 0 || wo <= 0) return BBB_ESHAPE;
@@ -1213,6 +1468,8 @@ extern "C" int bbb_conv2d_chwn_bf16_fwd(const bbb_conv_desc_t* d, const void* x,
         pool_s = d->pool == 1 ? 2 : (d->pool & 255);
         if (!((pool_k == 2 && pool_s == 2) || (pool_k == 3 && pool_s == 2)) || ho < pool_k || wo < pool_k) return BBB_EINVAL;
         if (tap_major || out_f32 || Kp > 128) return BBB_EINVAL;
+        if (x_c8 || (out_c8 && d->cout % 8 != 0)) return BBB_EINVAL;
+        a.y_c8 = out_c8 ? 1 : 0;
     }
     if (d->x_unit_div < 0 || d->x_unit_off < 0 || (d->x_unit_div > 1 && (d->unit_div > 1 || d->x_unit_off >= d->x_unit_div)) ||
         (d->x_unit_div <= 1 && d->x_unit_off != 0))
@@ -1288,6 +1545,25 @@ extern "C" int bbb_conv2d_chwn_bf16_fwd(const bbb_conv_desc_t* d, const void* x,
         if (nt == 1) return ks == 2 ? launch_smallk_pool<1, 2>(a, 8 * per, st) : ks == 5 ? launch_smallk_pool<1, 5>(a, 8 * per, st) : launch_smallk_pool<1, 8>(a, 8 * per, st);
         return ks == 2 ? launch_smallk_pool<2, 2>(a, 8 * per, st) : ks == 5 ? launch_smallk_pool<2, 5>(a, 8 * per, st) : launch_smallk_pool<2, 8>(a, 8 * per, st);
     }
+    if (x_c8) {
+        // channel-interleaved input: the strip form that reads its MFMA operands straight from memory (pconv_bf16_strip8_kernel).
+        // Tap-major rows of 32 input channels, 5 x 5 taps, stride 1, no dilation (3Conv3FC conv2); bf16 output in either layout.
+        if (!(tap_major && !out_f32 && (!out_c8 || a.Cout % 8 == 0) && a.Cin == 32 && a.kh == 5 && a.kw == 5 && a.sh == 1 && a.sw == 1 &&
+              a.dh == 1 && a.dw == 1 && a.pw < a.kw && a.ph < a.kh))
+            return BBB_EINVAL;
+        constexpr int P8 = 3;
+        a.y_c8 = out_c8 ? 1 : 0;
+        a.Ntiles = (a.Cout + 63) / 64;
+        a.G = a.Ntiles * d->draws;
+        a.nbt = (a.B + 127) / 128;
+        a.px_run = (wo + P8 - 1) / P8;
+        const int64_t sitems = (int64_t)a.G * ho * a.px_run * a.nbt;
+        const int64_t sper = (sitems + 7) / 8;
+        if (8 * sper > 0x7fffffffLL) return BBB_ESHAPE;
+        a.per_xcd = (int32_t)sper;
+        return launch_strip8<P8, 5, 4>(a, 8 * sper, (hipStream_t)stream);
+    }
+    if (out_c8) return BBB_EINVAL;                    // only the pooled first-layer forms and the strip form write that layout
     if (!tap_major && !out_f32 && Kp <= 128 && (int64_t)ho * wo >= 16) {
         // a first layer with a short contraction: weights in registers, a run of pixels per workgroup (pconv_bf16_smallk_kernel)
         const int nt = a.Cout <= 32 ? 1 : 2;

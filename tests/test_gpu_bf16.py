@@ -165,6 +165,130 @@ def test_pooled_first_layer_rejects_what_it_does_not_cover(env):
             assert not ops.bf16_pool_fusion_ok((3, 5, 5), False, False, nn.MaxPool2d(3, 2), (1, 3, 32, 32, 256), g3, 1)
 
 
+@pytest.mark.parametrize("E,H,W,Cout,pad,B,xs", [
+    (16, 15, 15, 64, 2, 256, False),     # 3Conv3FC conv2 at 16 steps per launch
+    (3, 9, 13, 48, 2, 200, False),       # ragged image tile (200 = 128 + 72), a partial channel tile, a width that is no multiple of 3
+    (2, 12, 16, 64, 0, 128, True),       # no padding, one input slab shared by the draws
+    (5, 8, 11, 100, 1, 136, False),      # two channel tiles (the second ragged), padding 1
+    (4, 5, 5, 64, 2, 256, False),        # a 5 x 5 map: every pixel is a border pixel
+    (2, 9, 9, 64, 4, 32, False),         # padding 4: up to four of five taps outside on either side
+    (1, 6, 4, 8, 2, 8, False),           # one strip narrower than its width, 8 images, 8 channels
+])
+def test_strip_form_over_channel_interleaved_input_equals_the_general_kernel(env, E, H, W, Cout, pad, B, xs):
+    """BBB_BF16_X_C8 / pconv_bf16_strip8_kernel (3Conv3FC conv2's shape family: tap-major rows of 32 channels, 5 x 5, stride 1): the
+    strip form reads [C / 8][H][W][B][8] activations straight into its MFMA operands and issues, per output element, the general
+    kernel's one-k-group MFMA sequence -- so its result is that kernel's, bit for bit, in either output layout and WHATEVER the
+    launch size (the general kernel's small launches differ from its large ones by rounding)."""
+    ops = env["ops"]
+    torch.manual_seed(E * 100 + W)
+    x = _bf(torch.rand(1 if xs else E, 32, H, W, B, device="cuda"))
+    w = _pack_w(torch.randn(E, Cout, 32, 5, 5, device="cuda") * 0.05, tap_major=True)
+    bias = torch.randn(E, Cout, device="cuda") * 0.1
+    x8 = ops.to_c8(x)
+    assert x8.shape == (x.shape[0], 4, H, W, B, 8) and torch.equal(ops.from_c8(x8), x)
+    # the reference launch: the general kernel with ONE k-group, i.e. as part of a launch of >= 512 workgroups (smaller launches
+    # split a pixel's contraction over k-groups: another summation order) -- the same operands repeated along the draw dimension
+    R = -(-1100 // (E * x.shape[2] * x.shape[3]))
+    rep = lambda t: None if t is None else t.repeat(R, *([1] * (t.dim() - 1)))
+    for act, b in (("softplus", bias), ("relu", bias), (None, None)):
+        want = ops.conv2d_chwn_bf16_forward(x if xs else rep(x), rep(w), rep(b), (32, 5, 5), 1, pad, 1, act=act, tap_major=True)[:E]
+        small = ops.conv2d_chwn_bf16_forward(x, w, b, (32, 5, 5), 1, pad, 1, act=act, tap_major=True)
+        assert float((small.float() - want.float()).abs().max()) <= 2.0 ** -6 * max(1.0, float(want.float().abs().max()))
+        got = ops.conv2d_chwn_bf16_forward(x8, w, b, (32, 5, 5), 1, pad, 1, act=act, tap_major=True)
+        assert got.shape == want.shape and torch.equal(got, want), (act, float((got.float() - want.float()).abs().max()))
+        if Cout % 8 == 0:
+            got8 = ops.conv2d_chwn_bf16_forward(x8, w, b, (32, 5, 5), 1, pad, 1, act=act, tap_major=True, out_c8=True)
+            assert got8.shape == (E, Cout // 8, want.shape[2], want.shape[3], B, 8)
+            assert torch.equal(ops.from_c8(got8), want), act
+
+
+def test_strip_form_work_units_and_grouped_steps(env):
+    """The strip form under the launch shapes of the batched path: several steps per launch (output slab e reads input slab e) and
+    a rank's work units (unit u = draw u // S with batch slice u % S) -- against the general kernel on the same descriptors."""
+    ops = env["ops"]
+    torch.manual_seed(5)
+    S, E, B = 2, 3, 64                                  # 2 batch slices x 3 draws = 6 units; this rank holds units 1 .. 4
+    xs = _bf(torch.rand(S, 32, 7, 9, B, device="cuda"))
+    w = _pack_w(torch.randn(E, 64, 32, 5, 5, device="cuda") * 0.05, tap_major=True)
+    bias = torch.randn(E, 64, device="cuda") * 0.1
+    kw = dict(units=(S, 1), n_units=4, x_per_slice=True)     # (slices, first unit)
+    got = ops.conv2d_chwn_bf16_forward(ops.to_c8(xs), w, bias, (32, 5, 5), 1, 2, 1, act="softplus", tap_major=True, **kw)
+    # unit u of this rank = global unit 1 + u: draw (1 + u) // S, batch slice (1 + u) % S -- as plain launches of the strip form
+    for u in range(4):
+        e, sl = (1 + u) // S, (1 + u) % S
+        one = ops.conv2d_chwn_bf16_forward(ops.to_c8(xs[sl:sl + 1]), w[e:e + 1], bias[e:e + 1], (32, 5, 5), 1, 2, 1, act="softplus", tap_major=True)
+        assert torch.equal(got[u], one[0]), u
+    want = ops.conv2d_chwn_bf16_forward(xs, w, bias, (32, 5, 5), 1, 2, 1, act="softplus", tap_major=True, **kw)
+    assert float((got.float() - want.float()).abs().max()) <= 2.0 ** -6 * max(1.0, float(want.float().abs().max()))
+
+
+@pytest.mark.parametrize("B,E,pk", [(256, 16, 3), (256, 2, 3), (64, 1, 2), (200, 5, 3)])
+def test_pooled_first_layer_writes_the_channel_interleaved_layout(env, B, E, pk):
+    """BBB_BF16_OUT_C8 on both pooled first-layer forms (the strip form of large launches, the window-resident form of small ones):
+    the same values as the batch-innermost output, 8 channels of an image adjacent."""
+    ops = env["ops"]
+    torch.manual_seed(B + E)
+    x = _bf(torch.rand(E, 3, 32, 32, B, device="cuda"))
+    w = _pack_w(torch.randn(E, 32, 3, 5, 5, device="cuda") * 0.2)
+    bias = torch.randn(E, 32, device="cuda")
+    for act in ("softplus", None):
+        want = ops.conv2d_chwn_bf16_forward(x, w, bias, (3, 5, 5), 1, 2, 1, act=act, pool=(pk, 2))
+        got = ops.conv2d_chwn_bf16_forward(x, w, bias, (3, 5, 5), 1, 2, 1, act=act, pool=(pk, 2), out_c8=True)
+        assert got.shape == (E, 4, want.shape[2], want.shape[3], B, 8)
+        assert torch.equal(ops.from_c8(got), want), act
+
+
+def test_channel_interleaved_forms_reject_what_they_do_not_cover(env):
+    ops = env["ops"]
+    from bbb_hip import BBBHipError
+    x8 = ops.to_c8(_bf(torch.rand(1, 64, 6, 6, 16, device="cuda")))
+    w = _pack_w(torch.randn(1, 64, 64, 5, 5, device="cuda"), tap_major=True)
+    with pytest.raises(BBBHipError):                                         # 64 input channels: no strip form
+        ops.conv2d_chwn_bf16_forward(x8, w, None, (64, 5, 5), 1, 2, 1, tap_major=True)
+    x = _bf(torch.rand(1, 32, 6, 6, 16, device="cuda"))
+    w32 = _pack_w(torch.randn(1, 64, 32, 5, 5, device="cuda"), tap_major=True)
+    with pytest.raises(BBBHipError):                                         # the general kernel writes batch-innermost only
+        ops.conv2d_chwn_bf16_forward(x, w32, None, (32, 5, 5), 1, 2, 1, tap_major=True, out_c8=True)
+    with pytest.raises(BBBHipError):                                         # stride 2
+        ops.conv2d_chwn_bf16_forward(ops.to_c8(x), w32, None, (32, 5, 5), 2, 2, 1, tap_major=True)
+    assert ops.bf16_c8_input_ok((32, 5, 5), (1, 2, 1), True, False)
+    assert not ops.bf16_c8_input_ok((32, 5, 5), (1, 2, 1), False, False)     # reference-order rows
+    assert not ops.bf16_c8_input_ok((32, 5, 5), (1, 2, 1), True, True)       # fp32 logits
+    assert not ops.bf16_c8_input_ok((64, 5, 5), (1, 1, 1), True, False) and not ops.bf16_c8_input_ok((32, 3, 3), (1, 1, 1), True, False)
+    assert not ops.bf16_c8_input_ok((32, 5, 5), (2, 2, 1), True, False) and not ops.bf16_c8_input_ok((32, 5, 5), (1, 5, 1), True, False)
+    with ops.use_config(bf16_c8=False):
+        assert not ops.bf16_c8_input_ok((32, 5, 5), (1, 2, 1), True, False)
+
+
+@pytest.mark.parametrize("B,E,G", [(256, 1, 1), (256, 4, 1), (256, 1, 4), (256, 1, 16)])
+def test_3conv3fc_bf16_with_and_without_the_interleaved_layout(env, B, E, G):
+    """Whole model: conv1 + pool1 hand their output to conv2 channel-interleaved (LaunchConfig.bf16_c8) -- the logits are the same
+    bits as on the batch-innermost layout throughout (where the general kernel runs conv2 with one k-group), eager, captured, and
+    with several steps per launch."""
+    ops, ens = env["ops"], env["ens"]
+    torch.manual_seed(3)
+    net = env["zoo"].BBB3Conv3FC(10, 3, P.CONFIG_PRIORS, "bbb", "softplus").cuda()
+    env["rng"].assign_stream_ids(net)
+    x = torch.rand(B * G, 3, 32, 32, device="cuda")
+    outs = {}
+    for on in (False, True):
+        with torch.no_grad(), ops.use_config(bf16_c8=on):
+            env["rng"].manual_seed(11, call=0)
+            if G == 1:
+                lo, kl = ens.mc_forward(net, x, E, precision="bf16")
+            else:
+                pipe = ens.GraphedPipeline(net, x[:B], E, depth=1, steps_per_launch=G, precision="bf16")
+                bufs = [pipe.step(x[g * B:(g + 1) * B])[0] for g in range(G)]
+                pipe.sync()
+                lo = torch.stack([b.clone() for b in bufs])
+            outs[on] = lo.clone()
+    if E * G >= 4:      # conv2 on the general kernel: >= 512 workgroups, one k-group -- the order the strip form always uses
+        assert torch.equal(outs[True], outs[False])
+    else:               # the general kernel's small launches split a pixel's contraction over k-groups: rounding-level differences
+        scale = max(1.0, float(outs[False].abs().max()))
+        assert float((outs[True] - outs[False]).abs().max()) <= 2e-2 * scale
+
+
 def test_sampled_weights_bf16_are_the_rounded_fp32_samples(env):
     """Same Philox stream, same fp32 arithmetic, one nearest-even rounding; pad columns untouched (zero); biases fp32."""
     torch.manual_seed(0)
