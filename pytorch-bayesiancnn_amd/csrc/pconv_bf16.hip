@@ -551,8 +551,10 @@ __global__ __launch_bounds__(256) void pconv_bf16_smallk_kernel(const PConvArgs 
 // max-then-epilogue equals epilogue-then-max element for element -- and runs the epilogue ONCE per pooled pixel: 4.5x fewer
 // epilogues and stored bytes for 3 x 3 / 2 windows, against pk / ps (1.5x) the contraction work for the rows two pooled rows
 // share.  Image-row offsets are decoded per column (pk x KR entries, one per thread) into a two-deep table.
-template <int NT, int KS>
-__global__ __launch_bounds__(256) void pconv_bf16_smallk_pool_kernel(const PConvArgs p) {
+// (two waves per SIMD for the 32-channel form in either output layout: the channel-interleaved epilogue would otherwise take 231
+// registers and lose the second wave; the 64-channel form needs more than 256 and runs one)
+template <int NT, int KS, bool C8>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT == 1 ? 2 : 1))) void pconv_bf16_smallk_pool_kernel(const PConvArgs p) {
     constexpr int BM = 256, BN = 32 * NT, KR = KS * 16, LDXB = BM + 32, TP = 64 + 8, PKMAX = 3;
     constexpr int XPASS = KR / 8;
     extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
@@ -724,8 +726,10 @@ __global__ __launch_bounds__(256) void pconv_bf16_smallk_pool_kernel(const PConv
             // this conv pixel into its windows (fp32 contraction results: the epilogue comes after the maximum).  Both running maxima
             // are updated UNCONDITIONALLY: `pold` is dead between the column that closes its window and the next window start (where
             // it is overwritten), `pnew` is dead past the strip's last window start -- so values outside a window only ever land in
-            // a register nobody reads.  One raw v_max_f32 per maximum (fmaxf canonicalises its operands first; both are arithmetic
-            // results): 2 VALU instructions per accumulator element instead of ~8 (strip form 124.6 -> 111 us at 16 steps per launch).
+            // a register nobody reads.  One instruction per maximum: med3(a, v, +inf) = max(a, v) (fmaxf canonicalises its operands first;
+            // both are arithmetic results) -- 2 VALU instructions per accumulator element instead of ~8 (strip form 124.6 -> 111 us at 16
+            // steps per launch).  An intrinsic, not inline asm: the compiler must see the read of the MFMA's result registers to
+            // keep the wait states that hazard needs (an asm v_max_f32 here computed wrong maxima once the schedule changed).
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -733,11 +737,8 @@ __global__ __launch_bounds__(256) void pconv_bf16_smallk_pool_kernel(const PConv
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const float v = acc[nt][mt][r];
-                        float mh, ml;
-                        asm("v_max_f32 %0, %1, %2" : "=v"(mh) : "v"(pnew[nt][mt][r]), "v"(v));
-                        asm("v_max_f32 %0, %1, %2" : "=v"(ml) : "v"(pold[nt][mt][r]), "v"(v));
-                        pnew[nt][mt][r] = mh;
-                        pold[nt][mt][r] = ml;
+                        pnew[nt][mt][r] = __builtin_amdgcn_fmed3f(pnew[nt][mt][r], v, __builtin_inff());
+                        pold[nt][mt][r] = __builtin_amdgcn_fmed3f(pold[nt][mt][r], v, __builtin_inff());
                     }
             // a window is complete after the last row of its last column: older window first (overlapping windows), else the
             // newest (pk <= ps); the host admits only geometries where at most one window closes per column
@@ -778,7 +779,7 @@ __global__ __launch_bounds__(256) void pconv_bf16_smallk_pool_kernel(const PConv
                                 __builtin_amdgcn_raw_buffer_store_b64(u32x2{h[0] | (h[1] << 16), h[2] | (h[3] << 16)}, yrs, off, 0, 0);
                             }
                 };
-                if (p.y_c8) {
+                if constexpr (C8) {
                     if (p.act == 2)      store_c8([](float v) { return bbb::apply_act(v, 2); });
                     else if (p.act == 1) store_c8([](float v) { return fmaxf(v, 0.0f); });
                     else                 store_c8([](float v) { return v; });
@@ -817,7 +818,7 @@ __global__ __launch_bounds__(256) void pconv_bf16_smallk_pool_kernel(const PConv
 // other forms: bit-identical.
 constexpr int kWinPasses = 13;             // 16-row passes of the window loader: windows of up to 13 * 16 - 1 = 207 image rows (+ the zero row)
 
-template <int KS>
+template <int KS, bool C8>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void pconv_bf16_smallk_poolwin_kernel(const PConvArgs p) {
     constexpr int BM = 128, LDXB = BM + 32, TP = 32 + 8;
     extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
@@ -956,7 +957,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     };
     uint16_t* T = Tall + wave * (32 * TP);
     // max without the canonicalisation fmaxf asks for (both operands are arithmetic results): ONE instruction per element
-    auto vmax = [](float x, float y) { float d; asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y)); return d; };
+    // (med3(x, y, +inf) = max(x, y); an intrinsic rather than an asm v_max_f32, so that the compiler sees the read of MFMA results)
+    auto vmax = [](float x, float y) { return __builtin_amdgcn_fmed3f(x, y, __builtin_inff()); };
 
     f32x16 pnew, pold;
 #pragma unroll
@@ -1005,7 +1007,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const bool emit_hi = last_row && !emit_lo && hi_ok && c == w_hi * ps + pk - 1;
         if (emit_lo || emit_hi) {
             const int ppix = ph * Wp + (emit_lo ? w_hi - 1 : w_hi);
-            if (p.y_c8) {
+            if constexpr (C8) {
                 // channel-interleaved output (BBB_BF16_OUT_C8): 8 bytes per lane and channel quad, straight from the registers
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) {
@@ -1285,32 +1287,44 @@ int launch_strip8(const PConvArgs& a, int64_t blocks, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
-template <int KS>
-int launch_smallk_poolwin(const PConvArgs& a, int64_t blocks, int smem_bytes, hipStream_t st) {
+template <int KS, bool C8>
+int launch_smallk_poolwin_c(const PConvArgs& a, int64_t blocks, int smem_bytes, hipStream_t st) {
     static int attr_bytes = 0;
     if (smem_bytes > attr_bytes) {
-        hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(&pconv_bf16_smallk_poolwin_kernel<KS>),
+        hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(&pconv_bf16_smallk_poolwin_kernel<KS, C8>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
         if (er != hipSuccess) return (int)er;
         attr_bytes = smem_bytes;
     }
-    hipLaunchKernelGGL((pconv_bf16_smallk_poolwin_kernel<KS>), dim3((unsigned)blocks), dim3(256), smem_bytes, st, a);
+    hipLaunchKernelGGL((pconv_bf16_smallk_poolwin_kernel<KS, C8>), dim3((unsigned)blocks), dim3(256), smem_bytes, st, a);
+    return (int)hipGetLastError();
+}
+
+// (the output layout is a template parameter: with both epilogues in one kernel the strip form needs 241 registers instead of 213 and
+// loses its second wave per SIMD -- 101 -> 153 us on 3Conv3FC conv1 + pool1 at 16 steps per launch)
+template <int KS>
+int launch_smallk_poolwin(const PConvArgs& a, int64_t blocks, int smem_bytes, hipStream_t st) {
+    return a.y_c8 ? launch_smallk_poolwin_c<KS, true>(a, blocks, smem_bytes, st) : launch_smallk_poolwin_c<KS, false>(a, blocks, smem_bytes, st);
+}
+
+template <int NT, int KS, bool C8>
+int launch_smallk_pool_c(const PConvArgs& a, int64_t blocks, hipStream_t st) {
+    constexpr int kSmem = (KS * 16 * (256 + 32) + 4 * 32 * NT * 72) * 2 + 2 * 3 * KS * 16 * 4;
+    static_assert(kSmem <= 160 * 1024, "LDS");
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(&pconv_bf16_smallk_pool_kernel<NT, KS, C8>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, kSmem);
+        if (er != hipSuccess) return (int)er;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((pconv_bf16_smallk_pool_kernel<NT, KS, C8>), dim3((unsigned)blocks), dim3(256), kSmem, st, a);
     return (int)hipGetLastError();
 }
 
 template <int NT, int KS>
 int launch_smallk_pool(const PConvArgs& a, int64_t blocks, hipStream_t st) {
-    constexpr int kSmem = (KS * 16 * (256 + 32) + 4 * 32 * NT * 72) * 2 + 2 * 3 * KS * 16 * 4;
-    static_assert(kSmem <= 160 * 1024, "LDS");
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(&pconv_bf16_smallk_pool_kernel<NT, KS>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, kSmem);
-        if (er != hipSuccess) return (int)er;
-        attr_done = true;
-    }
-    hipLaunchKernelGGL((pconv_bf16_smallk_pool_kernel<NT, KS>), dim3((unsigned)blocks), dim3(256), kSmem, st, a);
-    return (int)hipGetLastError();
+    return a.y_c8 ? launch_smallk_pool_c<NT, KS, true>(a, blocks, st) : launch_smallk_pool_c<NT, KS, false>(a, blocks, st);
 }
 
 template <int NT, int KS>
