@@ -141,6 +141,32 @@ def test_launch_config_object_replaces_the_process_wide_switches():
         ops.no_such_attribute
 
 
+def test_channel_interleaved_layout_helpers_and_rule():
+    """The "c8" activation layout of the bf16 path ([E][C/8][H][W][B][8], include/bbb_hip.h BBB_BF16_X_C8 / _OUT_C8): the torch
+    restatement used by the tests is a permutation and its own inverse, element (e, c, h, w, b) lands at [e, c // 8, h, w, b, c % 8];
+    the host rule admits exactly the layers the library has the strip form for and follows the LaunchConfig."""
+    import torch
+    from bbb_hip import ops
+    x = torch.arange(2 * 16 * 3 * 5 * 8, dtype=torch.float32).reshape(2, 16, 3, 5, 8).to(torch.bfloat16)
+    x8 = ops.to_c8(x)
+    assert x8.shape == (2, 2, 3, 5, 8, 8) and x8.is_contiguous() and torch.equal(ops.from_c8(x8), x)
+    assert x8[1, 1, 2, 4, 7, 5] == x[1, 13, 2, 4, 7]
+    hdr = open(os.path.join(ROOT, "include", "bbb_hip.h")).read()
+    assert "#define BBB_BF16_X_C8         4u" in hdr and "#define BBB_BF16_OUT_C8       8u" in hdr
+    ok = ops.bf16_c8_input_ok
+    assert ok((32, 5, 5), (1, 2, 1), True, False) and ok((32, 5, 5), ((1, 1), (0, 4), (1, 1)), True, False)
+    assert not ok((32, 5, 5), (1, 2, 1), False, False) and not ok((32, 5, 5), (1, 2, 1), True, True)
+    assert not ok((64, 5, 5), (1, 2, 1), True, False) and not ok((32, 3, 3), (1, 1, 1), True, False)
+    assert not ok((32, 5, 5), (2, 2, 1), True, False) and not ok((32, 5, 5), (1, 2, 2), True, False) and not ok((32, 5, 5), (1, 5, 1), True, False)
+    assert ok((32, 5, 5), (1, 2, 1), True, False, (15, 15, 256), 1)                       # default: from one step per launch on
+    with ops.use_config(bf16_c8_min_items=512):
+        assert not ok((32, 5, 5), (1, 2, 1), True, False, (15, 15, 256), 1)             # 15 rows x 5 strips x 2 image tiles = 150
+        assert ok((32, 5, 5), (1, 2, 1), True, False, (15, 15, 256), 4)
+    with ops.use_config(bf16_c8=False):
+        assert not ok((32, 5, 5), (1, 2, 1), True, False)
+    assert not ok((32, 5, 5), (1, 0, 1), True, False, (4, 4, 256), 16)                    # no output pixel at all
+
+
 # ---------------------------------------------------------------- drop-in surface
 def test_layers_surface_matches_reference_contract():
     import inspect
