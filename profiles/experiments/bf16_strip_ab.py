@@ -1,5 +1,5 @@
-"""The strip forms (a strip of output pixels per workgroup; "c8" = pconv_bf16_strip8_kernel over channel-interleaved input, numbers =
-the archived LDS form of profiles/experiments/lds_strip/) against the general bf16 kernel on 3Conv3FC conv2 (bs 256, G steps
+"""The strip form (a strip of output pixels per workgroup; "c8" = pconv_bf16_strip8_kernel over channel-interleaved input) against the
+general bf16 kernel on 3Conv3FC conv2 (bs 256, G steps
 per launch): time per launch and a hash of the output bytes (the strip form promises the general kernel's bits), plus ragged shapes
 (hash only).  Needs build_var/libbbb_force.so (bf16_shape_sweep_build.sh), whose launcher reads BBB_BF16_STRIP = P * 10 + D.
 usage: bf16_strip_ab.py [G]"""
@@ -70,8 +70,6 @@ if __name__ == "__main__":
     G = int(sys.argv[1]) if len(sys.argv) > 1 else 16
     for v in VARIANTS:
         env = dict(os.environ, BF16_STRIP_CHILD="1", BBB_BF16_STRIP="0" if v == "c8" else str(v))
-        if os.path.exists(os.path.join(ROOT, "build_var", "libbbb_force.so")):      # (the archived LDS strip form: variants 32, 34, ...)
-            env["BBB_HIP_LIB"] = os.path.join(ROOT, "build_var", "libbbb_force.so")
         if v == "c8":
             env["BF16_STRIP_C8"] = "1"
         try:
