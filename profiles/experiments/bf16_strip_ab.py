@@ -1,8 +1,7 @@
 """The strip form (a strip of output pixels per workgroup; "c8" = pconv_bf16_strip8_kernel over channel-interleaved input) against the
-general bf16 kernel on 3Conv3FC conv2 (bs 256, G steps
-per launch): time per launch and a hash of the output bytes (the strip form promises the general kernel's bits), plus ragged shapes
-(hash only).  Needs build_var/libbbb_force.so (bf16_shape_sweep_build.sh), whose launcher reads BBB_BF16_STRIP = P * 10 + D.
-usage: bf16_strip_ab.py [G]"""
+general bf16 kernel on 3Conv3FC conv2 (bs 256, G steps per launch): time per launch and a hash of the output bytes (the strip form
+promises the general kernel's one-k-group bits: equal hashes from G = 4 on), plus ragged shapes (hash only; "+" = the
+channel-interleaved OUTPUT holds the same tensor).  Runs on the shipped library.     usage: bf16_strip_ab.py [G]"""
 import hashlib, json, os, statistics, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 VARIANTS = [0, "c8"]
