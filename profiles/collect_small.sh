@@ -9,7 +9,7 @@ OUT=$R/gpurun_out
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 { echo "# rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_WAIT_INST_ANY -- python bench.py --steps 16 --warmup 16 --no-graph --config <c> --steps-per-launch 16   (eager single-stream passes of 16 one-draw steps per launch)"
-  for C in "configs[1]" "configs[2]"; do
+  for C in ${SMALL_CONFIGS:-"configs[1]" "configs[2]"}; do
     rm -rf /tmp/pm && mkdir -p /tmp/pm
     rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_WAIT_INST_ANY -d /tmp/pm -o pm -- python $R/bench.py --steps 16 --warmup 16 --no-graph --config "$C" --steps-per-launch 16 > /tmp/pm_log.txt 2>&1
     echo "## $C"
