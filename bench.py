@@ -278,7 +278,7 @@ def gemm_roofline(agg, timer_steps, precision, metric_cfg):
         g = {k: agg["conv_gemm"][k] + agg["lrt_gemm"][k] for k in ("ms", "n", "work", "work_im2col")}
     tf = g["work"] / (g["ms"] * 1e-3) / 1e12
     peak = PEAK_BF16_MFMA_TFLOPS if precision == "bf16" else PEAK_F32_MFMA_TFLOPS
-    kern = ("pconv_bf16_kernel (v_mfma_f32_32x32x16_bf16, batch-innermost, LDS transpose reads)" if precision == "bf16" else
+    kern = ("pconv_bf16_* (v_mfma_f32_32x32x16_bf16: pooled first layer, strip form over channel-interleaved input, general kernel)" if precision == "bf16" else
             "pconv_gemm_kernel (fp32 v_mfma_f32_32x32x2_f32, batch-innermost, in-bounds taps only)")
     r = {"bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
          "traffic": None, "kernel": kern + ", all conv/linear launches of a step",

@@ -9,10 +9,12 @@ dev = torch.device("cuda:0"); torch.cuda.set_device(0)
 names = sys.argv[1].split(",") if len(sys.argv) > 1 else ["configs[1]", "configs[2]"]
 for name in names:
     c = bench.CONFIGS[name]
-    for G, depth in ((4, 4), (8, 4), (8, 2), (16, 2), (16, 4), (32, 2)):
+    combos = [tuple(int(v) for v in c.split(":")) for c in os.environ["SWEEP"].split(",")] if os.environ.get("SWEEP") else \
+        ((4, 4), (8, 4), (8, 2), (16, 2), (16, 4), (32, 2))
+    for G, depth in combos:
         vals = []
         try:
-            for _ in range(3):
+            for _ in range(int(os.environ.get("SWEEP_REPS", "3"))):
                 nst = G * depth * 6
                 r, n2, x2 = bench.run_config(c, nst, G * depth, depth, dev, want_roofline=False, steps_per_launch=G, preheat_s=0.15, single_lane=False)
                 vals.append(r["ms_per_step"])
