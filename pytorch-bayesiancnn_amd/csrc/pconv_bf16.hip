@@ -1287,6 +1287,94 @@ int launch_strip8(const PConvArgs& a, int64_t blocks, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
+// ---- classifiers with a handful of outputs and a long row (3Conv3FC fc3: 1000 -> 10) ----
+// On the MFMA kernel this layer is ONE 64-channel tile per 128 images with 10 of its 64 rows alive, walked as a serial chain of 64-k
+// tiles by 2 .. 32 workgroups: 16.5 us per launch whatever the launch holds (0.2 % matrix-pipe busy).  It is 80 kflop per image --
+// plain FMAs finish it in the time the chain needs for two of its tiles.  A workgroup takes 32 images of a draw: thread (k slice, 8
+// images) walks its slice of the row -- one 16-byte image vector and NP weight values per k, fp32 fmaf in ascending k -- and the
+// slices' partial sums are added in slice order through LDS: a fixed summation order, independent of the launch.
+template <int NP>
+__global__ __launch_bounds__(256) void pconv_bf16_fewout_kernel(const PConvArgs p) {
+    constexpr int NSL = 64, TI = 32;                              // k slices x 4 groups of 8 images
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+    float* red = reinterpret_cast<float*>(smem);                  // [NSL][NP][TI] partial sums
+    const int nbt = p.nbt;
+    const int64_t item = blockIdx.x;
+    const int e = (int)(item / nbt);
+    const int b0 = (int)(item - (int64_t)e * nbt) * TI;
+    const int ue = p.unit_off + e;
+    const int ew = p.unit_div > 1 ? ue / p.unit_div : e;
+    const int ex = p.x_div > 1 ? (e + p.x_off) / p.x_div : (p.x_mod > 0 ? ue % p.x_mod : e);
+    const int Kp = p.Kp;
+    const int tid = (int)threadIdx.x, grp = tid & 3, sl = tid >> 2;
+    const int kps = p.px_run;                                     // k per slice (a multiple of 8)
+    const int k0 = sl * kps;
+
+    constexpr uint32_t kOOB = 0xFFFFFFF0u;
+    const uint16_t* xb = reinterpret_cast<const uint16_t*>(p.x) + (int64_t)ex * p.x_ds;
+    const uint16_t* wb = reinterpret_cast<const uint16_t*>(p.w) + (int64_t)ew * p.w_ds;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(xb), 0, (int)((int64_t)p.K * p.B * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(wb), 0, (int)((int64_t)p.Cout * Kp * 2), 0x00020000);
+
+    float acc[NP][8];
+#pragma unroll
+    for (int n = 0; n < NP; ++n)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[n][i] = 0.0f;
+    const int b = b0 + grp * 8;
+    auto bf = [](uint32_t v, int hi) { return __builtin_bit_cast(float, hi ? (v & 0xFFFF0000u) : (v << 16)); };
+    for (int kc = 0; kc < kps; kc += 8) {
+        const int k = k0 + kc;                                    // 8 consecutive k: one 16-byte weight vector per output row
+        u32x4 wv[NP], xv[8];
+#pragma unroll
+        for (int n = 0; n < NP; ++n)
+            wv[n] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, (n < p.Cout && k < Kp) ? (uint32_t)(n * Kp + k) * 2u : kOOB, 0, 0));
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            xv[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (k + j < p.K && b < p.B) ? (uint32_t)((k + j) * p.B + b) * 2u : kOOB, 0, 0));
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int n = 0; n < NP; ++n) {
+                const float w = bf(wv[n][j >> 1], j & 1);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[n][i] = __builtin_fmaf(w, bf(xv[j][i >> 1], i & 1), acc[n][i]);
+            }
+    }
+#pragma unroll
+    for (int n = 0; n < NP; ++n)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) red[(sl * NP + n) * TI + grp * 8 + i] = acc[n][i];
+    __syncthreads();
+    const int nsl = p.G;                                          // slices that hold any k
+    const int HoWo = 1;
+    for (int o = tid; o < p.Cout * TI; o += 256) {
+        const int n = o / TI, i = o - n * TI;
+        float s = red[n * TI + i];
+        for (int q = 1; q < nsl; ++q) s += red[(q * NP + n) * TI + i];
+        const float bv = p.bias ? p.bias[(int64_t)ew * p.b_ds + n] : 0.0f;
+        const float v = bbb::apply_act(s + bv, p.act);
+        const int bb = b0 + i;
+        if (bb < p.B) {
+            if (p.sample) reinterpret_cast<float*>(p.y)[(int64_t)e * p.y_ds + (int64_t)n * p.B + bb] = v;                       // fp32 output
+            else reinterpret_cast<uint16_t*>(p.y)[(int64_t)e * p.y_ds + (int64_t)n * p.B + bb] = f2bf(v);
+        }
+    }
+}
+
+template <int NP>
+int launch_fewout(const PConvArgs& a, int64_t blocks, hipStream_t st) {
+    constexpr int kSmem = 64 * NP * 32 * 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(&pconv_bf16_fewout_kernel<NP>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmem);
+        if (er != hipSuccess) return (int)er;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((pconv_bf16_fewout_kernel<NP>), dim3((unsigned)blocks), dim3(256), kSmem, st, a);
+    return (int)hipGetLastError();
+}
+
 template <int KS, bool C8>
 int launch_smallk_poolwin_c(const PConvArgs& a, int64_t blocks, int smem_bytes, hipStream_t st) {
     static int attr_bytes = 0;
@@ -1596,6 +1684,18 @@ extern "C" int bbb_conv2d_chwn_bf16_fwd(const bbb_conv_desc_t* d, const void* x,
         hipStream_t st = (hipStream_t)stream;
         if (nt == 1) return ks == 2 ? launch_smallk<1, 2>(a, 8 * per, st) : ks == 5 ? launch_smallk<1, 5>(a, 8 * per, st) : launch_smallk<1, 8>(a, 8 * per, st);
         return ks == 2 ? launch_smallk<2, 2>(a, 8 * per, st) : ks == 5 ? launch_smallk<2, 5>(a, 8 * per, st) : launch_smallk<2, 8>(a, 8 * per, st);
+    }
+    if (a.Cout <= 16 && K >= 512 && a.kh == 1 && a.kw == 1 && a.H == 1 && a.W == 1 && a.ph == 0 && a.pw == 0) {
+        // a classifier with a handful of outputs and a long row: plain FMAs, k slices summed in a fixed order (pconv_bf16_fewout_kernel)
+        const int kps = (int)(((Kp + 63) / 64 + 7) / 8) * 8;
+        a.px_run = kps;
+        a.G = (int)((Kp + kps - 1) / kps);                // slices that hold any k (<= 64)
+        a.nbt = (a.B + 31) / 32;
+        a.sample = out_f32 ? 1 : 0;
+        const int64_t fitems = (int64_t)d->draws * a.nbt;
+        if (fitems > 0x7fffffffLL) return BBB_ESHAPE;
+        hipStream_t fst = (hipStream_t)stream;
+        return a.Cout <= 10 ? launch_fewout<10>(a, fitems, fst) : launch_fewout<16>(a, fitems, fst);
     }
     // tile shape: LDS-pipe cycles per unit of useful work (see the kernel comment), including the waste of ragged
     // channel / image tiles: 128x128 -> 256, 64x256 -> 288, 64x128 (two waves) -> 320

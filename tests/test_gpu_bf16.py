@@ -289,6 +289,34 @@ def test_3conv3fc_bf16_with_and_without_the_interleaved_layout(env, B, E, G):
         assert float((outs[True] - outs[False]).abs().max()) <= 2e-2 * scale
 
 
+@pytest.mark.parametrize("E,B,K,Cout,out_f32,act", [
+    (16, 256, 1000, 10, True, None),          # 3Conv3FC fc3 at 16 steps per launch
+    (3, 40, 520, 10, True, "softplus"),       # ragged image tile, a row that is no multiple of the slice length
+    (2, 136, 1040, 16, False, "relu"),        # 16 outputs, bf16 output
+    (1, 8, 512, 7, True, None),               # the smallest row that takes this kernel, one image group
+])
+def test_few_output_classifier_kernel(env, E, B, K, Cout, out_f32, act):
+    """pconv_bf16_fewout_kernel (<= 16 outputs, rows of >= 512: 3Conv3FC fc3): fp32 FMAs over k slices added in a fixed order --
+    against the exact contraction of the same bf16 operands, and the same bits whether a draw is launched alone or with others."""
+    ops = env["ops"]
+    torch.manual_seed(K + Cout)
+    x = _bf(torch.randn(E, K, 1, 1, B, device="cuda"))
+    w = torch.randn(E, Cout, K, 1, 1, device="cuda") / K ** 0.5
+    bias = torch.randn(E, Cout, device="cuda")
+    wp = _pack_w(w)
+    got = ops.conv2d_chwn_bf16_forward(x, wp, bias, (K, 1, 1), 1, 0, 1, act=act, out_f32=out_f32)
+    assert got.shape == (E, Cout, 1, 1, B) and got.dtype == (torch.float32 if out_f32 else torch.bfloat16)
+    ref = torch.einsum("enk,ekb->enb", wp[:, :, :K].double(), x[:, :, 0, 0].double()) + bias[:, :, None].double()
+    ref = {None: lambda t: t, "relu": torch.relu, "softplus": torch.nn.functional.softplus}[act](ref)
+    tol = (2e-5 if out_f32 else 2.0 ** -8) * max(1.0, float(ref.abs().max()))
+    assert float((got.double()[:, :, 0, 0] - ref).abs().max()) <= tol
+    one = ops.conv2d_chwn_bf16_forward(x[E - 1:], wp[E - 1:], bias[E - 1:], (K, 1, 1), 1, 0, 1, act=act, out_f32=out_f32)
+    assert torch.equal(one[0], got[E - 1])
+    nob = ops.conv2d_chwn_bf16_forward(x, wp, None, (K, 1, 1), 1, 0, 1, act=None, out_f32=out_f32)
+    ref0 = torch.einsum("enk,ekb->enb", wp[:, :, :K].double(), x[:, :, 0, 0].double())
+    assert float((nob.double()[:, :, 0, 0] - ref0).abs().max()) <= tol
+
+
 def test_sampled_weights_bf16_are_the_rounded_fp32_samples(env):
     """Same Philox stream, same fp32 arithmetic, one nearest-even rounding; pad columns untouched (zero); biases fp32."""
     torch.manual_seed(0)
