@@ -784,19 +784,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT == 1 ? 2
                     else if (p.act == 1) store_c8([](float v) { return fmaxf(v, 0.0f); });
                     else                 store_c8([](float v) { return v; });
                 } else {
-                if (p.act == 2)      stage_block([](float v) { return bbb::apply_act(v, 2); });
-                else if (p.act == 1) stage_block([](float v) { return fmaxf(v, 0.0f); });
-                else                 stage_block([](float v) { return v; });
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (p.act == 2)      stage_block([](float v) { return bbb::apply_act(v, 2); });
+                    else if (p.act == 1) stage_block([](float v) { return fmaxf(v, 0.0f); });
+                    else                 stage_block([](float v) { return v; });
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-                for (int ps2 = 0; ps2 < 4 * NT; ++ps2) {
-                    const int v = ps2 * 64 + lane;
-                    const int row = v >> 3, grp = v & 7;
-                    const u32x4 q = *reinterpret_cast<const u32x4*>(&T[row * TP + grp * 8]);
-                    const int n = n0 + row, b = b0 + wm + grp * 8;
-                    const uint32_t off = ((b < p.B) & (n < p.Cout)) ? (uint32_t)(((int64_t)n * HpWp + ppix) * p.B + b) * 2u : kOOB;
-                    __builtin_amdgcn_raw_buffer_store_b128(q, yrs, off, 0, 0);
-                }
+                    for (int ps2 = 0; ps2 < 4 * NT; ++ps2) {
+                        const int v = ps2 * 64 + lane;
+                        const int row = v >> 3, grp = v & 7;
+                        const u32x4 q = *reinterpret_cast<const u32x4*>(&T[row * TP + grp * 8]);
+                        const int n = n0 + row, b = b0 + wm + grp * 8;
+                        const uint32_t off = ((b < p.B) & (n < p.Cout)) ? (uint32_t)(((int64_t)n * HpWp + ppix) * p.B + b) * 2u : kOOB;
+                        __builtin_amdgcn_raw_buffer_store_b128(q, yrs, off, 0, 0);
+                    }
                 }
             }
             __syncthreads();                                       // every wave has read this pixel's rows
@@ -1020,24 +1020,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
             } else {
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const int nl = 8 * r4 + 4 * lk;
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int nl = 8 * r4 + 4 * lk;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float m = emit_lo ? pold[r4 * 4 + i] : pnew[r4 * 4 + i];
-                    T[(nl + i) * TP + lrow] = f2bf(bbb::apply_act(m + bq[r4][i], p.act));
+                    for (int i = 0; i < 4; ++i) {
+                        const float m = emit_lo ? pold[r4 * 4 + i] : pnew[r4 * 4 + i];
+                        T[(nl + i) * TP + lrow] = f2bf(bbb::apply_act(m + bq[r4][i], p.act));
+                    }
                 }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int ps2 = 0; ps2 < 2; ++ps2) {
-                const int v = ps2 * 64 + lane;
-                const int row = v >> 2, grp = v & 3;
-                const u32x4 q = *reinterpret_cast<const u32x4*>(&T[row * TP + grp * 8]);
-                const int n = n0 + row, b = b0 + wm + grp * 8;
-                const uint32_t off = ((b < p.B) & (n < p.Cout)) ? (uint32_t)(((int64_t)n * HpWp + ppix) * p.B + b) * 2u : kOOB;
-                __builtin_amdgcn_raw_buffer_store_b128(q, yrs, off, 0, 0);
-            }
+                for (int ps2 = 0; ps2 < 2; ++ps2) {
+                    const int v = ps2 * 64 + lane;
+                    const int row = v >> 2, grp = v & 3;
+                    const u32x4 q = *reinterpret_cast<const u32x4*>(&T[row * TP + grp * 8]);
+                    const int n = n0 + row, b = b0 + wm + grp * 8;
+                    const uint32_t off = ((b < p.B) & (n < p.Cout)) ? (uint32_t)(((int64_t)n * HpWp + ppix) * p.B + b) * 2u : kOOB;
+                    __builtin_amdgcn_raw_buffer_store_b128(q, yrs, off, 0, 0);
+                }
             }
         }
         if (++urr == pk) { urr = 0; ++ucc; }
