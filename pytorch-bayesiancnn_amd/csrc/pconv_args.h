@@ -28,5 +28,6 @@ struct PConvArgs {
     int64_t x_ps, y_ps;  // pconv_bf16x3 S3 operands: elements between the hi / mid / lo planes of an activation slab
     int32_t pool;        // bbb_conv_desc_t::pool: the launch also applies MaxPool2d(2, 2) to the activated output (pconv_body.cuh, POOL)
     int32_t x_div, x_off; // bbb_conv_desc_t::x_unit_div / x_unit_off: output slab e reads input slab (e + x_off) / x_div (x_div <= 1: slab e)
+    int32_t y_f32;       // pconv_bf16_fewout_kernel: y is fp32 (the logits layer) instead of bf16
     int32_t y_c8;        // pconv_bf16.hip: y is written channel-interleaved, [cout / 8][ho][wo][B][8] (BBB_BF16_OUT_C8)
 };

@@ -1356,7 +1356,7 @@ __global__ __launch_bounds__(256) void pconv_bf16_fewout_kernel(const PConvArgs 
         const float v = bbb::apply_act(s + bv, p.act);
         const int bb = b0 + i;
         if (bb < p.B) {
-            if (p.sample) reinterpret_cast<float*>(p.y)[(int64_t)e * p.y_ds + (int64_t)n * p.B + bb] = v;                       // fp32 output
+            if (p.y_f32) reinterpret_cast<float*>(p.y)[(int64_t)e * p.y_ds + (int64_t)n * p.B + bb] = v;                       // fp32 output
             else reinterpret_cast<uint16_t*>(p.y)[(int64_t)e * p.y_ds + (int64_t)n * p.B + bb] = f2bf(v);
         }
     }
@@ -1691,7 +1691,7 @@ extern "C" int bbb_conv2d_chwn_bf16_fwd(const bbb_conv_desc_t* d, const void* x,
         a.px_run = kps;
         a.G = (int)((Kp + kps - 1) / kps);                // slices that hold any k (<= 64)
         a.nbt = (a.B + 31) / 32;
-        a.sample = out_f32 ? 1 : 0;
+        a.y_f32 = out_f32 ? 1 : 0;
         const int64_t fitems = (int64_t)d->draws * a.nbt;
         if (fitems > 0x7fffffffLL) return BBB_ESHAPE;
         hipStream_t fst = (hipStream_t)stream;
