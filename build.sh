@@ -7,15 +7,30 @@ mkdir -p build
 FLAGS="${BBB_EXTRA_FLAGS:-} --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wall -Wno-unused-variable"
 objs=()
 pids=()
+# An object is rebuilt when its source or ANY file it included last time is newer (hipcc -MD writes build/<name>.d: the
+# dependency list of the compile that produced the object -- pconv_gemm.o depends on pconv_body.cuh and pconv_bf16x3.cuh, which a
+# fixed list of headers missed), when it has no dependency file yet, or when a listed file has disappeared.
+stale() {  # $1 = object, $2 = source
+  local o=$1 f=$2 d=${1%.o}.d dep
+  [ -f "$o" ] && [ -f "$d" ] || return 0
+  [ "$f" -nt "$o" ] && return 0
+  for dep in $(sed -e 's/^[^:]*://' -e 's/\\$//' "$d"); do
+    [ -e "$dep" ] || return 0
+    [ "$dep" -nt "$o" ] && return 0
+  done
+  return 1
+}
 for f in csrc/*.hip; do
   o=build/$(basename "${f%.hip}").o
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ csrc/bbb_common.cuh -nt "$o" ] || [ ../include/bbb_hip.h -nt "$o" ] || [ csrc/pconv_args.h -nt "$o" ]; then
-    rm -f "$o"                       # a failed compile must not leave a stale object for the link step
-    "$HIPCC" $FLAGS -c "$f" -o "$o" &
+  if stale "$o" "$f"; then
+    if [ -n "${BBB_BUILD_DRY_RUN:-}" ]; then echo "stale: $o"; continue; fi     # tests/test_host_cpu.py: what WOULD be rebuilt
+    rm -f "$o" "${o%.o}.d"           # a failed compile must not leave a stale object for the link step
+    "$HIPCC" $FLAGS -MMD -MF "${o%.o}.d" -c "$f" -o "$o" &
     pids+=($!)
   fi
   objs+=("$o")
 done
+[ -n "${BBB_BUILD_DRY_RUN:-}" ] && exit 0
 for p in "${pids[@]:-}"; do
   [ -n "$p" ] && { wait "$p" || { echo "build.sh: a hipcc job failed" >&2; exit 1; }; }
 done

@@ -178,9 +178,12 @@ __global__ __launch_bounds__(64) void uncertainty_kernel(const float* __restrict
 }
 
 // [R][Ccols] -> [Ccols][R] through a padded 32x32 LDS tile (NCHW batch -> batch-innermost: R = B, Ccols = C*H*W).
-__global__ __launch_bounds__(256) void transpose2d_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int Cc) {
+// The tile grid is flattened into blockIdx.x (gx column tiles per row of tiles): neither extent meets the 65535 limit of
+// gridDim.y, so an output map of any size transposes (64 channels x 224 x 224 per image: 100 352 row tiles).
+__global__ __launch_bounds__(256) void transpose2d_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int Cc, unsigned gx) {
     __shared__ float tile[32][33];
-    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const unsigned ty_tile = blockIdx.x / gx;
+    const int c0 = (int)(blockIdx.x - ty_tile * gx) * 32, r0 = (int)ty_tile * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -383,9 +386,9 @@ extern "C" int bbb_transpose2d(const float* in, float* out, int64_t rows, int64_
     if (in == nullptr || out == nullptr || rows <= 0 || cols <= 0 || rows > 0x7fffffffLL || cols > 0x7fffffffLL) return BBB_EINVAL;
     if ((((uintptr_t)in | (uintptr_t)out) & 3u) != 0) return BBB_EALIGN;
     const int64_t gx = (cols + 31) / 32, gy = (rows + 31) / 32;
-    if (gy > 65535) return BBB_ESHAPE;
-    hipLaunchKernelGGL(transpose2d_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, (hipStream_t)stream, in, out, (int)rows,
-                       (int)cols);
+    if (gx * gy > 0x7fffffffLL) return BBB_ESHAPE;
+    hipLaunchKernelGGL(transpose2d_kernel, dim3((unsigned)(gx * gy)), dim3(256), 0, (hipStream_t)stream, in, out, (int)rows,
+                       (int)cols, (unsigned)gx);
     return (int)hipGetLastError();
 }
 

@@ -349,6 +349,20 @@ def test_to_batch_innermost(ops, shape):
     assert torch.equal(ops.to_batch_innermost(x), x.permute(1, 2, 3, 0).contiguous())
 
 
+def test_layout_transposes_of_a_large_feature_map(ops):
+    """More than 65535 x 32 elements per image (64 channels x 224 x 224: the per-layer path of a 224 x 224 model): the row-tile
+    count used to sit on gridDim.y and the call failed with BBB_ESHAPE."""
+    x = torch.randn(4, 64, 224, 224, device="cuda")
+    t = ops.to_batch_innermost(x)
+    assert torch.equal(t, x.permute(1, 2, 3, 0).contiguous())
+    assert torch.equal(ops.from_batch_innermost(t), x)
+    w = torch.randn(1, 8, 64, 3, 3, device="cuda") * 0.05
+    with torch.no_grad():
+        y = ops.conv2d_layer(x, w, None, 1, 1, 1)                      # the per-layer fast path: transpose, conv, transpose back
+    ref = torch.nn.functional.conv2d(x.double(), w[0].double(), None, 1, 1, 1)
+    assert float((y.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 2e-5
+
+
 # ---------------------------------------------------------------- backward on the same GEMM kernel (training extension)
 @pytest.mark.parametrize("case", [
     # B, Cin, H, W, Cout, kh, kw, stride, pad, dil, E, w_shared

@@ -26,6 +26,24 @@ def built():
     return so
 
 
+def test_build_script_follows_included_headers(built):
+    """build.sh rebuilds an object when ANY file its last compile included is newer (hipcc -MMD dependency files), not only a
+    fixed list of headers: editing csrc/pconv_body.cuh -- the dominant kernel's body -- must make pconv_gemm.o stale."""
+    hdr = os.path.join(PKG, "csrc", "pconv_body.cuh")
+    run = lambda: subprocess.run(["bash", os.path.join(ROOT, "build.sh")], check=True, capture_output=True, text=True,
+                                 env=dict(os.environ, BBB_BUILD_DRY_RUN="1")).stdout
+    before = run()
+    st = os.stat(hdr)
+    try:
+        os.utime(hdr, None)                                  # "edited just now"
+        after = run()
+    finally:
+        os.utime(hdr, ns=(st.st_atime_ns, st.st_mtime_ns))
+    assert "stale: build/pconv_gemm.o" in after and "pconv_gemm" not in before, (before, after)
+    assert "reparam_kl" not in after                         # a source that does not include it stays as it is
+    assert run() == before
+
+
 def test_library_exports_every_declared_symbol(built):
     from bbb_hip import _lib
     decl = set(re.findall(r"^\s*(?:int|int64_t|const char\*)\s+(bbb_\w+)\s*\(", open(HEADER).read(), flags=re.M))
