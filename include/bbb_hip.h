@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define BBB_ABI_VERSION 10
+#define BBB_ABI_VERSION 11
 #define BBB_MAX_SEGMENTS 16
 
 #define BBB_EINVAL (-1)   /* bad argument (null pointer, non-positive size, too many segments) */
@@ -234,6 +234,29 @@ int bbb_conv2d_chwn_bf16x3_fwd(const bbb_conv_desc_t* d, const void* x, const fl
 int bbb_maxpool_chwn_s3(const void* x, void* y, int64_t slabs, int channels, int h, int w, int batch, int k, int s, void* stream);
 /* fp32 [slabs][n] -> S3 [slabs][3][n] (to_s3 != 0) or back (to_s3 == 0); n % 8 == 0; exact in both directions. */
 int bbb_s3_convert(const void* src, void* dst, int64_t slabs, int64_t n, int to_s3, void* stream);
+/*
+ * The split-bf16 contraction over MFMA-READY operands (ABI 11): same arithmetic as bbb_conv2d_chwn_bf16x3_fwd (three bf16 pieces per
+ * fp32 element, six products per fp32 product, fp32 accumulation, in-bounds taps only), with both operands laid out the way
+ * v_mfma_f32_32x32x16_bf16 wants them, so that the k loop holds no operand arithmetic, no transposing LDS reads and no LDS traffic
+ * on the image side:
+ *   x: "c8 S3" activations, bf16 [draws|1][3][cin / 8][h][w][B][8] -- the hi / mid / lo pieces (exact: hi + mid + lo is the fp32
+ *      value) of the 8 channels 8g .. 8g + 7 of an image are 16 adjacent bytes of a plane = one lane's B operand.  cin % 32 == 0,
+ *      B % 4 == 0, 16-byte aligned; d->x_draw_stride counts bf16 elements (3 * cin * h * w * B per slab, or 0 = shared).
+ *   w: fp32, TAP-MAJOR rows [draws|1][cout][kh * kw][cin] -- what bbb_reparam_kl_fwd writes for a segment with w_tm_cin = cin,
+ *      w_taps = kh * kw (bbb_w_tap_major converts a dense tensor); 16-byte aligned, draw strides multiples of 4 elements.
+ *   y: c8 S3 [draws][3][cout / 8][ho][wo][B][8] (cout % 8 == 0), or with BBB_C8X3_OUT_F32 the fp32 batch-innermost tensor
+ *      [draws][cout][ho][wo][B] of bbb_conv2d_chwn_fwd (the logits layer).
+ * Work units / x_unit_div as in bbb_conv2d_chwn_fwd; d->pool and d->w_row_pitch must be 0.  bbb_maxpool_chwn_s3 pools c8 S3 tensors
+ * (channels = cin / 8, batch = 8 * B: the window maximum is element-wise on 16-byte vectors); bbb_c8s3_convert converts
+ * fp32 batch-innermost [slabs][channels][positions][batch] <-> c8 S3 (exact both ways).  Replaces F.conv2d / F.linear of
+ * layers/BBB/BBBConv.py:77, layers/BBB/BBBLinear.py:70; every slab (three planes) must stay below 1 GiB.
+ */
+#define BBB_C8X3_OUT_F32 1u
+int bbb_conv2d_c8x3_fwd(const bbb_conv_desc_t* d, const void* x, const float* w, const float* bias, void* y, uint32_t flags,
+                        void* stream);
+int bbb_c8s3_convert(const void* src, void* dst, int64_t slabs, int channels, int64_t positions, int batch, int to_c8s3, void* stream);
+/* w [rows][cin][taps] -> out [rows][taps][cin] (rows = draws * cout): the tap-major weight layout from the reference's. */
+int bbb_w_tap_major(const float* w, float* out, int64_t rows, int cin, int taps, void* stream);
 int bbb_lrt_conv2d_chwn_fwd(const bbb_conv_desc_t* d, const float* x, const float* w_mu, const float* w_var,
                             const float* b_mu, const float* b_var, float* y,
                             float* act_mu_out, float* act_var_out, const float* eps_ext,

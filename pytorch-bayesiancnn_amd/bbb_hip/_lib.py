@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede CDLL: shares torch's HIP runtime)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BBB_HIP_LIB") or os.path.join(_HERE, "libbbb_hip.so")   # env override: experiments only
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 MAX_SEGMENTS = 16
 SIGMA_SQUARED = 1
 KL_TEXTBOOK = 2
@@ -24,7 +24,7 @@ c_u64, c_u32, c_i64, c_i32 = ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int64, c
 
 class Segment(ctypes.Structure):
     _fields_ = [("mu", c_void_p), ("rho", c_void_p), ("w", c_void_p), ("sigma", c_void_p), ("eps", c_void_p),
-                ("n", c_i64), ("draw_stride", c_i64), ("stream_id", c_u32), ("w_row_len", c_u32), ("w_taps", c_u32), ("reserved", c_u32)]
+                ("n", c_i64), ("draw_stride", c_i64), ("stream_id", c_u32), ("w_row_len", c_u32), ("w_taps", c_u32), ("w_tm_cin", c_u32)]
 
 
 class AdamSegment(ctypes.Structure):
@@ -56,6 +56,9 @@ _SIGNATURES = {
     "bbb_conv2d_chwn_bf16x3_fwd": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_u32, c_void_p]),
     "bbb_maxpool_chwn_s3": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "bbb_s3_convert": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_int, c_void_p]),
+    "bbb_conv2d_c8x3_fwd": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_u32, c_void_p]),
+    "bbb_c8s3_convert": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_i64, c_int, c_int, c_void_p]),
+    "bbb_w_tap_major": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p]),
     "bbb_lrt_conv2d_chwn_fwd": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_u64, c_u32, c_u32, c_int, c_void_p, c_void_p]),
     "bbb_lrt_sample_chwn": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_u64, c_u32, c_u32, c_void_p,

@@ -595,6 +595,116 @@ def maxpool_chwn_s3(x, k, s):
     return y
 
 
+# ---- split-bf16 contraction over MFMA-ready operands (csrc/pconv_c8x3.hip): channel-interleaved split activations + tap-major weights
+def c8s3_from_f32(x):
+    """fp32 batch-innermost [E, C, H, W, B] (C % 8 == 0) -> "c8 S3": bf16 [E, 3, C / 8, H, W, B, 8], the hi / mid / lo pieces
+    (exact: hi + mid + lo is the fp32 value) of the 8 channels 8g .. 8g + 7 of an image adjacent in memory."""
+    require_device(x)
+    x = x.contiguous()
+    E, C, H, W, B = x.shape
+    if C % 8:
+        raise _lib.BBBHipError("c8 S3 needs a multiple of 8 channels")
+    y = torch.empty((E, 3, C // 8, H, W, B, 8), dtype=torch.bfloat16, device=x.device)
+    with on_device(x.device):
+        check(_lib.lib().bbb_c8s3_convert(x.data_ptr(), y.data_ptr(), E, C, H * W, B, 1, cur_stream(x.device)), "bbb_c8s3_convert")
+    return y
+
+
+def c8s3_to_f32(x):
+    """c8 S3 [E, 3, C / 8, H, W, B, 8] -> the fp32 batch-innermost tensor [E, C, H, W, B] it stores (exact)."""
+    require_device(x, dtype=torch.bfloat16)
+    x = x.contiguous()
+    E, three, CG, H, W, B, eight = x.shape
+    y = torch.empty((E, CG * 8, H, W, B), dtype=torch.float32, device=x.device)
+    with on_device(x.device):
+        check(_lib.lib().bbb_c8s3_convert(x.data_ptr(), y.data_ptr(), E, CG * 8, H * W, B, 0, cur_stream(x.device)), "bbb_c8s3_convert")
+    return y
+
+
+def w_tap_major(w):
+    """[E, Cout, Cin, kh, kw] -> the tap-major rows [E, Cout, kh * kw, Cin] (what the parameter pass writes directly for a
+    segment with w_tm_cin set: sample_weights_tm)."""
+    require_device(w)
+    w = w.contiguous()
+    E, Cout, Cin, kh, kw = w.shape
+    y = torch.empty((E, Cout, kh * kw, Cin), dtype=torch.float32, device=w.device)
+    with on_device(w.device):
+        check(_lib.lib().bbb_w_tap_major(w.data_ptr(), y.data_ptr(), E * Cout, Cin, kh * kw, cur_stream(w.device)), "bbb_w_tap_major")
+    return y
+
+
+def c8x3_layer_ok(cin, cout, is_logits=False):
+    """May a BBB layer with these channel counts run on bbb_conv2d_c8x3_fwd?  (32-channel k tiles inside one tap; the output is
+    written in groups of 8 channels unless it is the fp32 logits tensor.)"""
+    return cin % 32 == 0 and (is_logits or cout % 8 == 0)
+
+
+def conv2d_c8x3_forward(x, w_tm, bias, kernel_size, stride=1, padding=0, dilation=1, act=None, out_f32=False, out=None, units=None,
+                        n_units=None, x_div=1, x_off=0):
+    """The split-bf16 contraction over MFMA-ready operands (bbb_conv2d_c8x3_fwd).  x: c8 S3 [E|1, 3, Cin / 8, H, W, B, 8];
+    w_tm: fp32 tap-major [E|1, Cout, kh * kw, Cin]; bias [E|1, Cout] | None -> c8 S3 [E, 3, Cout / 8, Ho, Wo, B, 8], or with
+    out_f32 the fp32 batch-innermost [E, Cout, Ho, Wo, B] (the logits layer).  Work units / x_div / x_off as conv2d_chwn_forward."""
+    require_device(w_tm, bias)
+    require_device(x, dtype=torch.bfloat16)
+    x, w_tm = x.contiguous(), w_tm.contiguous()
+    bias = None if bias is None else bias.contiguous()
+    if x.dim() != 7 or x.shape[1] != 3 or x.shape[6] != 8 or w_tm.dim() != 4:
+        raise _lib.BBBHipError("c8 S3 input [E|1, 3, Cin / 8, H, W, B, 8] and tap-major weights [E|1, Cout, kh * kw, Cin] expected")
+    kh, kw = _pair(kernel_size)
+    Ex, _, CG, H, W, B, _ = x.shape
+    Ew, Cout, T, Cin = w_tm.shape
+    if T != kh * kw or Cin != CG * 8:
+        raise _lib.BBBHipError(f"weights [{Cout}, {T}, {Cin}] do not match a {kh} x {kw} layer on {CG * 8} channels")
+    x5 = x.new_empty((Ex, Cin, H, W, B), dtype=torch.float32, device="meta")
+    w5 = w_tm.new_empty((Ew, Cout, Cin, kh, kw), device="meta")
+    if units is not None and units[0] > 1:
+        E = int(n_units)
+        if Ex != E:
+            raise _lib.BBBHipError("work units: x must hold one slab per unit")
+        d, ho, wo = _desc_chwn(x5, w5, stride, padding, dilation, E, False, False, act)
+        _apply_units(d, units, False)
+    elif int(x_div) > 1:
+        E = Ew
+        if not 0 <= int(x_off) < int(x_div) or Ex != -(-(E + int(x_off)) // int(x_div)):
+            raise _lib.BBBHipError("x_div: x must hold ceil((E + x_off) / x_div) input slabs for the E weight sets")
+        d, ho, wo = _desc_chwn(x5, w5, stride, padding, dilation, E, False, False, act)
+        d.x_unit_div, d.x_unit_off = int(x_div), int(x_off)
+    else:
+        E = max(Ex, Ew)
+        if Ex not in (1, E) or Ew not in (1, E):
+            raise _lib.BBBHipError("leading (draw) dims of x and w must be 1 or equal")
+        d, ho, wo = _desc_chwn(x5, w5, stride, padding, dilation, E, Ex == 1 and E > 1, Ew == 1 and E > 1, act)
+    d.x_draw_stride *= 3                                       # bf16 elements per slab of three planes
+    if out_f32:
+        shape, odt = (E, Cout, ho, wo, B), torch.float32
+    else:
+        if Cout % 8:
+            raise _lib.BBBHipError("a c8 S3 output needs a multiple of 8 output channels")
+        shape, odt = (E, 3, Cout // 8, ho, wo, B, 8), torch.bfloat16
+    if out is None:
+        y = torch.empty(shape, dtype=odt, device=x.device)
+    else:
+        n = 1
+        for v in shape:
+            n *= v
+        if out.numel() != n or not out.is_contiguous() or out.dtype != odt:
+            raise _lib.BBBHipError("out= must be a contiguous tensor of the output's size and dtype")
+        y = out.view(shape)
+    with on_device(x.device):
+        check(_lib.lib().bbb_conv2d_c8x3_fwd(ctypes.byref(d), x.data_ptr(), w_tm.data_ptr(), ptr(bias), y.data_ptr(),
+                                             1 if out_f32 else 0, cur_stream(x.device)), "bbb_conv2d_c8x3_fwd")
+    return y
+
+
+def maxpool_c8s3(x, k, s):
+    """MaxPool2d(k, s) on a c8 S3 tensor [E, 3, C / 8, H, W, B, 8] (element-wise on the 16-byte channel vectors)."""
+    require_device(x, dtype=torch.bfloat16)
+    x = x.contiguous()
+    E, three, CG, H, W, B, eight = x.shape
+    y = maxpool_chwn_s3(x.view(E, 3, CG, H, W, B * 8), k, s)
+    return y.view(E, 3, CG, y.shape[3], y.shape[4], B, 8)
+
+
 def lrt_conv2d_chwn_forward(x, w_mu, w_var, b_mu, b_var, seed, call0, stream_id, stride=1, padding=0, dilation=1,
                             sample=True, eps=None, want_moments=False, act=None, units=None, n_units=None, b_offset=0,
                             x_per_slice=False, x_div=1, x_off=0, n_slabs=None, pool=False):

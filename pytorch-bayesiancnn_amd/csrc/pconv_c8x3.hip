@@ -1,0 +1,402 @@
+// Split-bf16 contraction over MFMA-READY operands (round 6): the pixel-major implicit GEMM of pconv_bf16x3.cuh -- fp32 accuracy on
+// v_mfma_f32_32x32x16_bf16 through a = hi + mid + lo, six products per fp32 product, fp32 accumulation, small terms first -- with
+// both operands laid out in memory the way the matrix instruction wants them, so that the k loop holds no operand arithmetic, no
+// transposing LDS reads and no LDS traffic at all on the image side:
+//   * activations travel between the layers channel-interleaved AND already split ("c8 S3"): three bf16 planes per slab,
+//     [slab][3][C / 8][H][W][B][8] -- the 8 channels 8g .. 8g + 7 of an image are 16 adjacent bytes of a plane, which is exactly
+//     one lane's B operand (8 consecutive k of one column): ONE 16-byte load per plane, 32 images = 512 contiguous bytes;
+//   * sampled weights come TAP-MAJOR from the parameter pass (bbb_segment_t::w_tm_cin: fp32 [draw][cout][kh*kw][cin]), so that the
+//     in-bounds taps of a pixel are runs of cin consecutive k -- padding taps are skipped exactly as in the fp32 kernel -- and a
+//     32-k tile of 64 channels is 64 runs of 128 contiguous bytes; the tile is cut into its three bf16 pieces ONCE per workgroup
+//     while it is staged (8 elements per thread and tile against 48 matrix instructions per wave) and lands in LDS as [n][k] rows
+//     of 80 bytes: the A operand of a lane is one conflict-free ds_read_b128.
+// Workgroup = one output pixel x 64 channels x 128 * MT images; every wave owns 64 channels x 32 * MT images (2 x MT accumulator
+// tiles), so a 16-byte image fragment feeds 12 / 8 / 4 (hi / mid / lo plane) of the step's 24 * MT matrix instructions and a
+// weight fragment 3 * MT of them.  Per k16 step and wave (MT = 2): 6 ds_read_b128 + 6 global 16-byte loads for 24 MFMAs (768 pipe
+// cycles); pconv_bf16x3_kernel needed 18 transposing LDS reads, 9 LDS writes and the split arithmetic for 12.
+// Replaces F.conv2d / F.linear of layers/BBB/BBBConv.py:77, layers/BBB/BBBLinear.py:70 (same contraction; not bit-identical to the
+// fp32 fmaf chain: a mode, ops.gemm_mode = "bf16x3").
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/bbb_hip.h"
+#include "bbb_common.cuh"
+#include "pconv_args.h"
+#include "pconv_bf16x3.cuh"
+
+namespace pconv {
+
+constexpr int C8_LDA = 40;               // bf16 elements per LDS weight row: 32 k + 8 pad = 80 bytes (16-lane groups hit 64 distinct banks)
+constexpr int C8_PLANE = 64 * C8_LDA;    // one plane of one stage: 64 channel rows
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+template <int MT, bool OUTF32>
+__global__ __launch_bounds__(kThreads) void pconv_c8x3_kernel(const PConvArgs p) {
+    constexpr int BMW = 32 * MT, BM = 4 * BMW;
+    __shared__ __attribute__((aligned(16))) unsigned short Wp[2 * 3 * C8_PLANE];      // [stage][plane][n][k]: 30 KB
+
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7;
+    const int64_t item = (int64_t)xcd * p.per_xcd + (bid >> 3);
+    const int64_t item_end = (int64_t)(xcd + 1) * p.per_xcd;
+    if (item >= item_end || item >= (int64_t)p.G * p.Mtiles) return;
+    const int g = (int)(item / p.Mtiles);
+    const int j = (int)(item - (int64_t)g * p.Mtiles);
+    const int e = g / p.Ntiles;
+    const int ue = p.unit_off + e;
+    const int ew = p.unit_div > 1 ? ue / p.unit_div : e;
+    const int ex = p.x_div > 1 ? (e + p.x_off) / p.x_div : (p.x_mod > 0 ? ue % p.x_mod : e);
+    const int n0 = (g - e * p.Ntiles) * BN;
+    const int pix = j / p.nbt;
+    const int b0 = (j - pix * p.nbt) * BM;
+    const int oh = pix / p.Wo, ow = pix - oh * p.Wo;
+    const int ihb = oh * p.sh - p.ph, iwb = ow * p.sw - p.pw;
+    int r_lo = ihb < 0 ? (-ihb + p.dh - 1) / p.dh : 0;
+    int q_lo = iwb < 0 ? (-iwb + p.dw - 1) / p.dw : 0;
+    int r_hi = (p.H - 1 - ihb) >= 0 ? (p.H - 1 - ihb) / p.dh + 1 : 0;
+    int q_hi = (p.W - 1 - iwb) >= 0 ? (p.W - 1 - iwb) / p.dw + 1 : 0;
+    r_hi = r_hi < p.kh ? r_hi : p.kh;
+    q_hi = q_hi < p.kw ? q_hi : p.kw;
+    const int nr = r_hi > r_lo ? r_hi - r_lo : 0;
+    const int nq = q_hi > q_lo ? q_hi - q_lo : 0;
+    const int cpt = p.Cin >> 5;                                      // 32-channel tiles per tap
+    const int ntiles = nr * nq * cpt;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane & 31, lk = lane >> 5;
+
+    constexpr uint32_t kOOB = 0xFFFFFFF0u;
+    // weights: fp32, tap-major rows of Kp elements; thread (channel row tid / 4, 8 consecutive k of the tile)
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.w + (int64_t)ew * p.w_ds), 0, (int)((int64_t)p.Cout * p.Kp * 4), 0x00020000);
+    const int wn = tid >> 2, wk = (tid & 3) * 8;
+    const uint32_t wrow = ((uint32_t)(n0 + wn) * (uint32_t)p.Kp + (uint32_t)wk) * 4u;       // rows >= Cout: out of range, read as 0
+    // images: one descriptor over the slab's three planes; lane (image lrow of the wave's block, k half lk)
+    const unsigned short* const xb16 = reinterpret_cast<const unsigned short*>(p.x) + (int64_t)ex * p.x_ds;
+    const uint32_t xplane = (uint32_t)(p.x_ps * 2);                  // bytes per plane
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(xb16), 0, (int)(3u * xplane), 0x00020000);
+    const uint32_t img_b = (uint32_t)p.B * 16u;                      // bytes per (channel group, position)
+    const uint32_t grp_b = (uint32_t)(p.H * p.W) * img_b;            // bytes per channel group of 8
+    // Out-of-range addressing without selects: every slab is < 1 GiB (checked by the launcher), an image column past the batch
+    // carries 0x80000000 in its lane offset and a step past the last tile 0x40000000 in its uniform offset -- any sum holding one
+    // of the two lies in [0x40000000, 2^32) and reads zeros (no wrap: the in-range parts stay below 0x40000000).
+    constexpr uint32_t kLaneInv = 0x80000000u, kStepInv = 0x40000000u;
+    uint32_t xlane[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int b = b0 + wave * BMW + mt * 32 + lrow;
+        xlane[mt] = b < p.B ? (uint32_t)b * 16u + (uint32_t)lk * grp_b : kLaneInv;
+    }
+
+    // the tile AHEAD of the one being multiplied: tap (rr, qq) of the pixel's in-bounds rectangle, 32-channel block c32
+    int nx_rr = 0, nx_qq = 0, nx_c32 = 0;
+    uint32_t nx_w = 0, nx_x = 0;                                     // uniform byte offsets of that tile (weights / images)
+    auto cursor_offsets = [&]() {
+        const int r = r_lo + nx_rr, q = q_lo + nx_qq;
+        nx_w = (uint32_t)((r * p.kw + q) * p.Cin + nx_c32 * 32) * 4u;
+        nx_x = (uint32_t)(nx_c32 * 4) * grp_b + (uint32_t)((ihb + r * p.dh) * p.W + iwb + q * p.dw) * img_b;
+    };
+    auto cursor_advance = [&]() {
+        if (++nx_c32 == cpt) {
+            nx_c32 = 0;
+            if (++nx_qq == nq) { nx_qq = 0; ++nx_rr; }
+        }
+        cursor_offsets();
+    };
+
+    f32x4 wreg[2];
+    bf16x8 bfr[2][MT][3];
+    // (unconditional loads with out-of-range offsets instead of branches: with branches around them the compiler drains every
+    // outstanding load at every step)
+    auto wload = [&](bool ok) {
+        const uint32_t o = wrow + (ok ? nx_w : kStepInv);
+        wreg[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, o, 0, 0));
+        wreg[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, o + 16u, 0, 0));
+    };
+    auto bload = [&](int s, bool ok) {
+        const uint32_t u = ok ? nx_x + (uint32_t)(2 * s) * grp_b : kStepInv;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                bfr[s][mt][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xrs, xlane[mt] + u + (uint32_t)pl * xplane, 0, 0));
+    };
+    auto wstore = [&](int stage) {
+        u32x4 h, m, l;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint32_t a0, a1, a2;
+            const f32x4 v = wreg[i >> 1];
+            split3_pair((i & 1) ? f32x2{v[2], v[3]} : f32x2{v[0], v[1]}, a0, a1, a2);
+            h[i] = a0; m[i] = a1; l[i] = a2;
+        }
+        unsigned short* const base = Wp + stage * (3 * C8_PLANE) + wn * C8_LDA + wk;
+        *reinterpret_cast<u32x4*>(base) = h;
+        *reinterpret_cast<u32x4*>(base + C8_PLANE) = m;
+        *reinterpret_cast<u32x4*>(base + 2 * C8_PLANE) = l;
+    };
+
+    f32x16 acc[2][MT];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < MT; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.0f;
+
+    auto step = [&](int stage, int s) {
+        bf16x8 a[2][3];
+        const unsigned short* const base = Wp + stage * (3 * C8_PLANE) + lrow * C8_LDA + s * 16 + lk * 8;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                a[nt][pl] = *reinterpret_cast<const bf16x8*>(base + pl * C8_PLANE + nt * 32 * C8_LDA);
+        // small terms first; the 2 * MT accumulators take turns, so consecutive matrix instructions are independent
+#define C8X3_TERM(PA, PB)                                                                                           \
+        _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                            \
+            _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                       \
+                acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[nt][PA], bfr[s][mt][PB], acc[nt][mt], 0, 0, 0);
+        C8X3_TERM(2, 0)
+        C8X3_TERM(0, 2)
+        C8X3_TERM(1, 1)
+        C8X3_TERM(1, 0)
+        C8X3_TERM(0, 1)
+        C8X3_TERM(0, 0)
+#undef C8X3_TERM
+    };
+
+    if (ntiles > 0) {
+        cursor_offsets();
+        wload(true);
+        bload(0, true);
+        bload(1, true);
+        wstore(0);
+        cursor_advance();
+        __syncthreads();
+        for (int t = 0; t < ntiles; ++t) {
+            const bool more = (t + 1) < ntiles;
+            const int stage = t & 1;
+            // issue order pinned with scheduling barriers: left alone, the compiler sinks every load below the step's matrix
+            // instructions (right in front of its first use), i.e. out of their shadow
+            wload(more);
+            __builtin_amdgcn_sched_barrier(0);
+            step(stage, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            bload(0, more);
+            __builtin_amdgcn_sched_barrier(0);
+            step(stage, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            bload(1, more);
+            __builtin_amdgcn_sched_barrier(0);
+            wstore(stage ^ 1);                                       // (after the last tile: zeros into a stage nobody reads)
+            cursor_advance();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue ----
+    const int HoWo = p.Ho * p.Wo;
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.bias ? p.bias + (int64_t)ew * p.b_ds : p.w), 0, p.bias ? p.Cout * 4 : 0, 0x00020000);
+    if constexpr (OUTF32) {
+        // fp32 batch-innermost output [slab][cout][ho][wo][B] (the logits layer): a lane's accumulator registers are channels of ONE
+        // image, a wave-store is 32 consecutive images of a channel row
+        const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
+            p.y + (int64_t)e * p.y_ds, 0, (int)((int64_t)p.Cout * HoWo * p.B * 4), 0x00020000);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                const float bv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brs, (uint32_t)n * 4u, 0, 0));
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int b = b0 + wave * BMW + mt * 32 + lrow;
+                    const float o = bbb::apply_act(acc[nt][mt][r] + bv, p.act);
+                    const uint32_t off = ((b < p.B) & (n < p.Cout)) ? (uint32_t)(((int64_t)n * HoWo + pix) * p.B + b) * 4u : kOOB;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, o), yrs, off, 0, 0);
+                }
+            }
+    } else {
+        // c8 S3 output [slab][3][cout / 8][ho][wo][B][8]: a lane holds four consecutive channels of its image = 8 adjacent bytes of
+        // each plane; a wave-store covers 32 images x 16 bytes = 512 contiguous bytes.  The next layer's operand pieces are cut
+        // here, once per element.
+        unsigned short* const yb16 = reinterpret_cast<unsigned short*>(p.y) + (int64_t)e * p.y_ds;
+        const uint32_t yplane = (uint32_t)(p.y_ps * 2);
+        const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(yb16, 0, (int)(3u * yplane), 0x00020000);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int n = n0 + nt * 32 + 8 * r4;                     // first channel of the group of 8 (this lane: + 4 lk .. + 3)
+                const f32x4 bq = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, (uint32_t)(n + 4 * lk) * 4u, 0, 0));
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int b = b0 + wave * BMW + mt * 32 + lrow;
+                    float o[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) o[c] = bbb::apply_act(acc[nt][mt][4 * r4 + c] + bq[c], p.act);
+                    uint32_t h0, m0, l0, h1, m1, l1;
+                    split3_pair(f32x2{o[0], o[1]}, h0, m0, l0);
+                    split3_pair(f32x2{o[2], o[3]}, h1, m1, l1);
+                    const uint32_t off = ((b < p.B) & (n < p.Cout))
+                        ? (uint32_t)((((int64_t)(n >> 3) * HoWo + pix) * p.B + b) * 16 + lk * 8) : kOOB;
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{h0, h1}, yrs, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{m0, m1}, yrs, off == kOOB ? kOOB : off + yplane, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{l0, l1}, yrs, off == kOOB ? kOOB : off + 2u * yplane, 0, 0);
+                }
+            }
+    }
+}
+
+// fp32 batch-innermost [slabs][C][HW][B] <-> c8 S3 [slabs][3][C / 8][HW][B][8] (exact in both directions): the boundary of a chain of
+// pconv_c8x3 launches (the first layer's fp32 output; a flatten that has to pass through the reference's NCHW order).  One thread
+// per (slab, channel group, position, image): 8 coalesced 4-byte accesses on the fp32 side, one 16-byte vector per plane.
+// pv = vectors per plane = (C / 8) * HW * B.
+__global__ __launch_bounds__(256) void c8s3_from_chwn_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, int64_t total,
+                                                             int64_t pv, int64_t HW, int B) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int64_t slab = i / pv, in = i - slab * pv;
+    const int b = (int)(in % B);
+    const int64_t t = in / B;
+    const int64_t pos = t % HW, grp = t / HW;
+    const float* xp = x + slab * pv * 8 + ((grp * 8) * HW + pos) * B + b;
+    u32x4 h, m, l;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        uint32_t a0, a1, a2;
+        split3_pair(f32x2{xp[(int64_t)(2 * c) * HW * B], xp[(int64_t)(2 * c + 1) * HW * B]}, a0, a1, a2);
+        h[c] = a0; m[c] = a1; l[c] = a2;
+    }
+    u32x4* yp = reinterpret_cast<u32x4*>(y) + slab * 3 * pv + in;
+    yp[0] = h; yp[pv] = m; yp[2 * pv] = l;
+}
+
+__global__ __launch_bounds__(256) void c8s3_to_chwn_kernel(const unsigned short* __restrict__ x, float* __restrict__ y, int64_t total,
+                                                           int64_t pv, int64_t HW, int B) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int64_t slab = i / pv, in = i - slab * pv;
+    const int b = (int)(in % B);
+    const int64_t t = in / B;
+    const int64_t pos = t % HW, grp = t / HW;
+    const u32x4* xp = reinterpret_cast<const u32x4*>(x) + slab * 3 * pv + in;
+    const u32x4 h = xp[0], m = xp[pv], l = xp[2 * pv];
+    float* yp = y + slab * pv * 8 + ((grp * 8) * HW + pos) * B + b;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {        // hi + mid is exact (16 significant bits), + lo gives back the fp32 value exactly
+        yp[(int64_t)(2 * c) * HW * B] = (__builtin_bit_cast(float, h[c] << 16) + __builtin_bit_cast(float, m[c] << 16)) + __builtin_bit_cast(float, l[c] << 16);
+        yp[(int64_t)(2 * c + 1) * HW * B] = (__builtin_bit_cast(float, h[c] & 0xFFFF0000u) + __builtin_bit_cast(float, m[c] & 0xFFFF0000u)) +
+                                           __builtin_bit_cast(float, l[c] & 0xFFFF0000u);
+    }
+}
+
+// [slabs][rows][cin][taps] -> [slabs][rows][taps][cin]: the tap-major weight layout from a dense one (test / boundary helper; the
+// product path gets tap-major rows straight from the parameter pass, bbb_segment_t::w_tm_cin)
+__global__ __launch_bounds__(256) void w_tap_major_kernel(const float* __restrict__ w, float* __restrict__ out, int64_t total, int cin, int taps) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // output index
+    if (i >= total) return;
+    const int ci = (int)(i % cin);
+    const int64_t t = i / cin;
+    const int tp = (int)(t % taps);
+    const int64_t row = t / taps;
+    out[i] = w[(row * cin + ci) * taps + tp];
+}
+
+}  // namespace pconv
+
+using namespace pconv;
+
+extern "C" int bbb_conv2d_c8x3_fwd(const bbb_conv_desc_t* d, const void* x, const float* w, const float* bias, void* y, uint32_t flags,
+                                   void* stream) {
+    if (d == nullptr || x == nullptr || w == nullptr || y == nullptr || (flags & ~BBB_C8X3_OUT_F32) != 0) return BBB_EINVAL;
+    if (d->batch <= 0 || d->cin <= 0 || d->h <= 0 || d->w <= 0 || d->cout <= 0 || d->kh <= 0 || d->kw <= 0 || d->stride_h <= 0 ||
+        d->stride_w <= 0 || d->pad_h < 0 || d->pad_w < 0 || d->dil_h <= 0 || d->dil_w <= 0 || d->draws <= 0 || d->act < 0 || d->act > 2 ||
+        d->pool != 0 || d->w_row_pitch != 0)
+        return BBB_EINVAL;
+    const bool of32 = (flags & BBB_C8X3_OUT_F32) != 0;
+    if (d->cin % 32 != 0 || d->batch % 4 != 0 || (!of32 && d->cout % 8 != 0)) return BBB_ESHAPE;
+    const int ho = (d->h + 2 * d->pad_h - d->dil_h * (d->kh - 1) - 1) / d->stride_h + 1;
+    const int wo = (d->w + 2 * d->pad_w - d->dil_w * (d->kw - 1) - 1) / d->stride_w + 1;
+    if (ho <= 0 || wo <= 0) return BBB_ESHAPE;
+    if ((((uintptr_t)x | (uintptr_t)y) & 15u) != 0 || (((uintptr_t)w) & 15u) != 0 || (((uintptr_t)bias) & (of32 ? 3u : 15u)) != 0) return BBB_EALIGN;
+    PConvArgs a = {};
+    a.B = d->batch; a.Cin = d->cin; a.H = d->h; a.W = d->w; a.Cout = d->cout; a.kh = d->kh; a.kw = d->kw;
+    a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w; a.dh = d->dil_h; a.dw = d->dil_w;
+    a.Ho = ho; a.Wo = wo; a.K = d->cin * d->kh * d->kw; a.Kp = a.K; a.khkw = d->kh * d->kw; a.act = d->act;
+    a.x_ps = (int64_t)a.Cin * a.H * a.W * a.B;
+    a.y_ps = (int64_t)a.Cout * ho * wo * a.B;
+    // slabs are addressed through 32-bit buffer offsets (three planes of 2-byte elements, or fp32 outputs)
+    if (6 * a.x_ps >= 0x3FFF0000LL || 6 * a.y_ps >= 0x3FFF0000LL || ((int64_t)a.Cout + 64) * a.K * 4 >= 0x3FFF0000LL) return BBB_ESHAPE;
+    if (d->x_draw_stride != 0 && d->x_draw_stride < 3 * a.x_ps) return BBB_EINVAL;
+    if (d->w_draw_stride % 4 != 0 || (!of32 && d->b_draw_stride % 4 != 0) || d->x_draw_stride % 8 != 0) return BBB_EALIGN;
+    a.x_ds = d->x_draw_stride; a.w_ds = d->w_draw_stride; a.b_ds = d->b_draw_stride;
+    a.y_ds = of32 ? a.y_ps : 3 * a.y_ps;
+    if (d->unit_div < 0 || d->unit_off < 0 || d->x_unit_mod < 0) return BBB_EINVAL;
+    if (d->unit_div > 1 && d->unit_off >= d->unit_div) return BBB_EINVAL;
+    if (d->x_unit_mod > 0 && d->x_unit_mod != d->unit_div) return BBB_EINVAL;
+    if (d->x_unit_div < 0 || d->x_unit_off < 0 || (d->x_unit_div > 1 && (d->unit_div > 1 || d->x_unit_off >= d->x_unit_div)) ||
+        (d->x_unit_div <= 1 && d->x_unit_off != 0))
+        return BBB_EINVAL;
+    a.unit_div = d->unit_div; a.unit_off = d->unit_div > 1 ? d->unit_off : 0; a.x_mod = d->x_unit_mod;
+    a.x_div = d->x_unit_div; a.x_off = d->x_unit_off;
+    a.x = static_cast<const float*>(x); a.w = w; a.bias = bias; a.y = static_cast<float*>(y);
+    a.Ntiles = (a.Cout + BN - 1) / BN;
+    a.G = a.Ntiles * d->draws;
+    const int64_t pixels = (int64_t)ho * wo;
+    // 256 images per workgroup (a wave's image fragments feed two channel tiles AND its weight fragments two image tiles) when that
+    // still leaves the chip two rounds of workgroups; 128 otherwise.  Same MFMA sequence per output element either way.
+    int mt = 2;
+    {
+        const int64_t items256 = (int64_t)a.G * pixels * ((a.B + 255) / 256);
+        static const int force = [] { const char* s = getenv("BBB_C8X3_MT"); return s ? atoi(s) : 0; }();
+        if (force == 1 || force == 2) mt = force;
+        else if (a.B <= 128 || items256 < 1024) mt = 1;
+    }
+    a.nbt = (a.B + 128 * mt - 1) / (128 * mt);
+    const int64_t mtiles = pixels * a.nbt;
+    if (mtiles > 0x7fffffffLL) return BBB_ESHAPE;
+    a.Mtiles = (int)mtiles;
+    const int64_t per = ((int64_t)a.G * mtiles + 7) / 8;
+    if (8 * per > 0x7fffffffLL) return BBB_ESHAPE;
+    a.per_xcd = (int32_t)per;
+    const dim3 grid((unsigned)(8 * per)), block(kThreads);
+    hipStream_t st = (hipStream_t)stream;
+    if (mt == 2) {
+        if (of32) hipLaunchKernelGGL((pconv_c8x3_kernel<2, true>), grid, block, 0, st, a);
+        else      hipLaunchKernelGGL((pconv_c8x3_kernel<2, false>), grid, block, 0, st, a);
+    } else {
+        if (of32) hipLaunchKernelGGL((pconv_c8x3_kernel<1, true>), grid, block, 0, st, a);
+        else      hipLaunchKernelGGL((pconv_c8x3_kernel<1, false>), grid, block, 0, st, a);
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int bbb_c8s3_convert(const void* src, void* dst, int64_t slabs, int channels, int64_t positions, int batch, int to_c8s3,
+                                void* stream) {
+    if (src == nullptr || dst == nullptr || slabs <= 0 || channels <= 0 || positions <= 0 || batch <= 0) return BBB_EINVAL;
+    if (channels % 8 != 0) return BBB_ESHAPE;
+    if ((((uintptr_t)src | (uintptr_t)dst) & 15u) != 0) return BBB_EALIGN;
+    const int64_t pv = (int64_t)(channels / 8) * positions * batch, total = slabs * pv;
+    const int64_t blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffffLL) return BBB_ESHAPE;
+    if (to_c8s3) hipLaunchKernelGGL(c8s3_from_chwn_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                                    static_cast<const float*>(src), static_cast<unsigned short*>(dst), total, pv, positions, batch);
+    else         hipLaunchKernelGGL(c8s3_to_chwn_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                                    static_cast<const unsigned short*>(src), static_cast<float*>(dst), total, pv, positions, batch);
+    return (int)hipGetLastError();
+}
+
+extern "C" int bbb_w_tap_major(const float* w, float* out, int64_t rows, int cin, int taps, void* stream) {
+    if (w == nullptr || out == nullptr || rows <= 0 || cin <= 0 || taps <= 0) return BBB_EINVAL;
+    if ((((uintptr_t)w | (uintptr_t)out) & 3u) != 0) return BBB_EALIGN;
+    const int64_t total = rows * cin * taps;
+    const int64_t blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffffLL) return BBB_ESHAPE;
+    hipLaunchKernelGGL(w_tap_major_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, out, total, cin, taps);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,128 @@
+"""Split-bf16 contraction over MFMA-ready operands (bbb_conv2d_c8x3_fwd, csrc/pconv_c8x3.hip): channel-interleaved split
+activations ("c8 S3") + tap-major fp32 weights.  Same arithmetic as bbb_conv2d_chwn_bf16x3_fwd, held to the SAME bound as the fp32
+kernel against the float64 oracle (4e-6 of sum_k |w||x|) on every operand scale.  Run with -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+import bbb_numpy as O
+
+pytestmark = pytest.mark.gpu
+TOL = 4e-6
+
+
+@pytest.fixture(scope="module")
+def env():
+    import layers  # noqa: F401
+    from bbb_hip import ops, rng, ensemble, zoo
+    return dict(ops=ops, rng=rng, ens=ensemble, zoo=zoo)
+
+
+def test_c8s3_layout_round_trip_and_definition(env):
+    """c8 S3 is a storage format of the same fp32 values: [E, 3, C/8, H, W, B, 8] holds bf16(a), bf16(a - hi), bf16(a - hi - mid)
+    of channel 8g + i of image b at [e, :, g, h, w, b, i]; the round trip is exact on every scale."""
+    ops = env["ops"]
+    torch.manual_seed(0)
+    x = (torch.randn(2, 24, 3, 5, 12, device="cuda") * torch.logspace(-12, 12, 24, device="cuda").view(1, 24, 1, 1, 1)).contiguous()
+    c = ops.c8s3_from_f32(x)
+    assert c.shape == (2, 3, 3, 3, 5, 12, 8) and c.dtype == torch.bfloat16
+    assert torch.equal(ops.c8s3_to_f32(c), x)
+    xr = x.view(2, 3, 8, 3, 5, 12).permute(0, 1, 3, 4, 5, 2)                 # [E, G, H, W, B, 8]
+    hi = xr.to(torch.bfloat16)
+    mid = (xr - hi.float()).to(torch.bfloat16)
+    lo = (xr - hi.float() - mid.float()).to(torch.bfloat16)
+    assert torch.equal(c[:, 0], hi) and torch.equal(c[:, 1], mid) and torch.equal(c[:, 2], lo)
+    # pooling acts element-wise on the 16-byte channel vectors
+    p = ops.c8s3_to_f32(ops.maxpool_c8s3(ops.c8s3_from_f32(x[:, :, :3, :4]), 2, 1))
+    assert torch.equal(p, ops.maxpool_chwn(x[:, :, :3, :4].contiguous(), 2, 1))
+
+
+def test_tap_major_weights(env):
+    ops = env["ops"]
+    w = torch.randn(3, 5, 8, 3, 2, device="cuda")
+    assert torch.equal(ops.w_tap_major(w), w.permute(0, 1, 3, 4, 2).reshape(3, 5, 6, 8).contiguous())
+
+
+CASES = [
+    # B, Cin, H, W, Cout, k, stride, pad, dil, E, x_shared
+    (512, 64, 4, 4, 192, 5, 1, 2, 1, 2, False),      # AlexNet conv2: most taps of border pixels out of bounds; 256-image tiles
+    (256, 192, 2, 2, 384, 3, 1, 1, 1, 2, False),     # AlexNet conv3
+    (132, 32, 9, 7, 72, 3, 1, 1, 1, 2, False),       # ragged image tile, ragged channel tile
+    (8, 64, 6, 6, 136, 3, 2, 1, 2, 3, False),        # stride + dilation
+    (40, 512, 1, 1, 16, 1, 1, 0, 1, 2, False),       # linear, K = 512
+    (64, 256, 2, 2, 256, 3, 1, 1, 1, 1, True),       # AlexNet conv4 shape, one draw
+    (300, 32, 5, 5, 8, 5, 1, 0, 1, 2, True),         # input shared by the draws, a single output pixel, 8 output channels
+]
+
+
+@pytest.mark.parametrize("B,Cin,H,W,Cout,k,s,p,d,E,xs", CASES)
+@pytest.mark.parametrize("xscale,wscale", [(3.0, 0.2), (0.004, 0.0003), (1e-6, 1e-9), (1e6, 1e-12)])
+@pytest.mark.parametrize("out_f32", [False, True])
+def test_c8x3_launch_vs_oracle_and_fp32_kernel(env, B, Cin, H, W, Cout, k, s, p, d, E, xs, xscale, wscale, out_f32):
+    ops = env["ops"]
+    if out_f32 and xscale != 3.0:
+        pytest.skip("the fp32 output form shares everything but the store: one operand scale")
+    torch.manual_seed(B + Cout)
+    x = torch.randn(1 if xs else E, Cin, H, W, B, device="cuda") * xscale
+    w = torch.randn(E, Cout, Cin, k, k, device="cuda") * wscale
+    bias = torch.randn(E, Cout, device="cuda") * (xscale * wscale)
+    y = ops.conv2d_c8x3_forward(ops.c8s3_from_f32(x), ops.w_tap_major(w), bias, k, s, p, d, act=None, out_f32=out_f32)
+    if not out_f32:
+        y = ops.c8s3_to_f32(y)
+    y32 = ops.conv2d_chwn_forward(x, w, bias, s, p, d, act=None, bf16x3=False)
+    assert y.shape == y32.shape
+    worst = worst32 = 0.0
+    for e in range(E):
+        xe = x[0 if xs else e].permute(3, 0, 1, 2).double().cpu().numpy()            # [B, C, H, W]
+        we, be = w[e].double().cpu().numpy(), bias[e].double().cpu().numpy()
+        want = O.conv2d(xe, we, be, s, p, d)
+        mag = O.conv2d(np.abs(xe), np.abs(we), np.abs(be), s, p, d)
+        got = y[e].permute(3, 0, 1, 2).double().cpu().numpy()
+        got32 = y32[e].permute(3, 0, 1, 2).double().cpu().numpy()
+        worst = max(worst, float((np.abs(got - want) / mag).max()))
+        worst32 = max(worst32, float((np.abs(got32 - want) / mag).max()))
+    print(f"relative to sum|w||x|: c8x3 {worst:.2e}, fp32 kernel {worst32:.2e}")
+    assert worst <= TOL, (worst, worst32)
+    assert worst <= max(4e-7, 3.0 * worst32)
+
+
+@pytest.mark.parametrize("act", ["relu", "softplus"])
+def test_c8x3_fused_activation_and_tile_shapes(env, act, monkeypatch):
+    """Bias + activation in the epilogue = the fp32 kernel's epilogue on the contraction result; the 128- and 256-image workgroup
+    tiles run the same MFMA sequence per output element: bit-identical outputs."""
+    import os
+    ops = env["ops"]
+    torch.manual_seed(5)
+    x = torch.randn(2, 64, 4, 4, 512, device="cuda")
+    w = torch.randn(2, 72, 64, 3, 3, device="cuda") * 0.05
+    bias = torch.randn(2, 72, device="cuda")
+    xc, wt = ops.c8s3_from_f32(x), ops.w_tap_major(w)
+    y = ops.c8s3_to_f32(ops.conv2d_c8x3_forward(xc, wt, bias, 3, 1, 1, 1, act=act))
+    y32 = ops.conv2d_chwn_forward(x, w, bias, 1, 1, 1, act=act, bf16x3=False)
+    assert float((y - y32).abs().max()) <= 2e-5 * float(y32.abs().max())
+    pre = ops.c8s3_to_f32(ops.conv2d_c8x3_forward(xc, wt, bias, 3, 1, 1, 1, act=None))
+    ref = torch.relu(pre) if act == "relu" else torch.nn.functional.softplus(pre)
+    assert float((y - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+
+
+def test_c8x3_is_exact_on_one_hot_weights(env):
+    """hi + mid + lo == a exactly, through the c8 layout: a 1 x 1 convolution with a one-hot weight matrix returns its input bit
+    for bit on channel scales 1e-20 .. 1e20."""
+    ops = env["ops"]
+    torch.manual_seed(3)
+    C, B = 64, 256
+    x = (torch.randn(1, C, 3, 3, B, device="cuda") * torch.logspace(-20, 20, C, device="cuda").view(1, C, 1, 1, 1)).contiguous()
+    w = torch.eye(C, device="cuda").view(1, C, C, 1, 1).contiguous()
+    y = ops.conv2d_c8x3_forward(ops.c8s3_from_f32(x), ops.w_tap_major(w), None, 1, 1, 0, 1)
+    assert torch.equal(ops.c8s3_to_f32(y), x)
+
+
+def test_c8x3_argument_errors(env):
+    ops, L = env["ops"], __import__("bbb_hip")._lib
+    x = ops.c8s3_from_f32(torch.randn(1, 32, 2, 2, 8, device="cuda"))
+    with pytest.raises(L.BBBHipError):                       # 16 input channels: no 32-channel k tile
+        ops.conv2d_c8x3_forward(ops.c8s3_from_f32(torch.randn(1, 16, 2, 2, 8, device="cuda")), torch.randn(1, 8, 1, 16, device="cuda"), None, 1)
+    with pytest.raises(L.BBBHipError):                       # 12 output channels in c8 form
+        ops.conv2d_c8x3_forward(x, torch.randn(1, 12, 1, 32, device="cuda"), None, 1)
+    y = ops.conv2d_c8x3_forward(x, torch.randn(1, 12, 1, 32, device="cuda"), None, 1, out_f32=True)
+    assert y.shape == (1, 12, 2, 2, 8)
