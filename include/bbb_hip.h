@@ -56,7 +56,10 @@ typedef struct bbb_segment {
     uint32_t w_taps;      /* bf16 rows only.  0 / 1: row elements keep the tensor's own order ([cin][kh][kw]).  T > 1: the
                              row is a [cin][T] matrix (T = kh*kw) and is written TRANSPOSED, [T][cin] ("tap-major":
                              element (ci, t) lands at column t*cin + ci), the BBB_BF16_W_TAP_MAJOR operand layout */
-    uint32_t reserved;
+    uint32_t w_tm_cin;    /* fp32 w only (w_row_len == 0; ABI 11).  C > 0: the tensor is [rows][C][T] with T = w_taps (2..128), C % 8 == 0,
+                             and w is written TAP-MAJOR, fp32 [draws][rows][T][C] -- the weight operand of bbb_conv2d_c8x3_fwd.  Noise
+                             elements, sigma and KL are those of the dense launch (the noise of a weight is keyed by its index in
+                             the tensor's own order); mu, rho and w 16-byte aligned, draw_stride % 4 == 0, on-chip noise only. */
 } bbb_segment_t;
 
 #define BBB_SIGMA_SQUARED 1u   /* flags: write sigma^2 (the LRT variance operand) instead of sigma */
@@ -250,8 +253,12 @@ int bbb_s3_convert(const void* src, void* dst, int64_t slabs, int64_t n, int to_
  * (channels = cin / 8, batch = 8 * B: the window maximum is element-wise on 16-byte vectors); bbb_c8s3_convert converts
  * fp32 batch-innermost [slabs][channels][positions][batch] <-> c8 S3 (exact both ways).  Replaces F.conv2d / F.linear of
  * layers/BBB/BBBConv.py:77, layers/BBB/BBBLinear.py:70; every slab (three planes) must stay below 1 GiB.
+ * BBB_C8X3_TILE128 / _TILE256 force the images per workgroup (default: by launch size); the MFMA sequence per output element, hence
+ * every output bit, is the same for both.
  */
 #define BBB_C8X3_OUT_F32 1u
+#define BBB_C8X3_TILE128 2u
+#define BBB_C8X3_TILE256 4u
 int bbb_conv2d_c8x3_fwd(const bbb_conv_desc_t* d, const void* x, const float* w, const float* bias, void* y, uint32_t flags,
                         void* stream);
 int bbb_c8s3_convert(const void* src, void* dst, int64_t slabs, int channels, int64_t positions, int batch, int to_c8s3, void* stream);

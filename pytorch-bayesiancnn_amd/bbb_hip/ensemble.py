@@ -193,15 +193,17 @@ def _run(timers, tag, info, fn):
     return timers.bracket(tag, info, fn) if timers is not None else fn()
 
 
-def _sample_all(layers, draws, seed, call0, timers=None, eps=None):
-    """One fused launch (per <=16 tensors) for every BBB layer: -> ({layer: (w, b)}, kl)."""
-    mus, rhos, ids, owners = [], [], [], []
+def _sample_all(layers, draws, seed, call0, timers=None, eps=None, tm=()):
+    """One fused launch (per <=16 tensors) for every BBB layer: -> ({layer: (w, b)}, kl).  tm: layers whose conv weights come out
+    TAP-MAJOR, [draws, Cout, kh * kw, Cin] (ops.sample_weights_tm: the operand layout of ops.conv2d_c8x3_forward; inference)."""
+    mus, rhos, ids, owners, tmf = [], [], [], [], []
     for l in layers:
         m, r, i = l._param_lists()
         mus += m
         rhos += r
         ids += i
         owners += [l] * len(m)
+        tmf += [l in tm and t.dim() == 4 and t.shape[2] * t.shape[3] > 1 for t in m]
     pri = {(l.prior_mu, l.prior_sigma) for l in layers}
     out, kl_total = {}, None
     ws_all = []
@@ -210,17 +212,24 @@ def _sample_all(layers, draws, seed, call0, timers=None, eps=None):
         for s in range(0, len(mus), _lib.MAX_SEGMENTS):
             sl = slice(s, s + _lib.MAX_SEGMENTS)
             n_el = sum(m.numel() for m in mus[sl])
-            kl, ws = _run(timers, "reparam_kl", n_el,
-                          lambda: ops.sample_weights(mus[sl], rhos[sl], pm, ps, ids[sl], seed, call0, draws,
-                                                     eps=None if eps is None else eps[sl]))
+            if any(tmf[sl]):
+                kl, ws = _run(timers, "reparam_kl", n_el,
+                              lambda: ops.sample_weights_tm(mus[sl], rhos[sl], pm, ps, ids[sl], seed, call0, draws, tmf[sl]))
+            else:
+                kl, ws = _run(timers, "reparam_kl", n_el,
+                              lambda: ops.sample_weights(mus[sl], rhos[sl], pm, ps, ids[sl], seed, call0, draws,
+                                                         eps=None if eps is None else eps[sl]))
             kl_total = kl if kl_total is None else kl_total + kl
             ws_all += ws
     else:  # layers with different priors: one launch per layer
         k = 0
         for l in layers:
             m, r, i = l._param_lists()
-            kl, ws = ops.sample_weights(m, r, l.prior_mu, l.prior_sigma, i, seed, call0, draws,
-                                        eps=None if eps is None else eps[k:k + len(m)])
+            if any(tmf[k:k + len(m)]):
+                kl, ws = ops.sample_weights_tm(m, r, l.prior_mu, l.prior_sigma, i, seed, call0, draws, tmf[k:k + len(m)])
+            else:
+                kl, ws = ops.sample_weights(m, r, l.prior_mu, l.prior_sigma, i, seed, call0, draws,
+                                            eps=None if eps is None else eps[k:k + len(m)])
             k += len(m)
             kl_total = kl if kl_total is None else kl_total + kl
             ws_all += ws
@@ -414,8 +423,22 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
         S, n_draws = 1, E
     if bf16 and (lrt or B % 8 != 0):
         raise _lib.BBBHipError("the bf16 path covers BBB (non-LRT) layers and batch sizes that are multiples of 8")
+    # split-bf16 mode, steps of >= s3_min_images rows: BBB layers with Cin % 32 == 0 (never the first one: its input is the caller's
+    # fp32 batch) run on the MFMA-ready-operand kernel (ops.conv2d_c8x3_forward) -- their input travels channel-interleaved and
+    # already split ("c8 S3"), their weights come tap-major from the parameter pass
+    children = flat_children(net)
+    last_bayes = max((i for i, m in enumerate(children) if isinstance(m, (_BBBLayer, _LRTLayer))), default=-1)
+    tail_is_last = last_bayes == len(children) - 1
+    split_mode = (precision == "bf16x3" or ops.current_config().gemm_mode == "bf16x3") and not bf16 and not lrt and bool(bbb) and tail_is_last
+    c8_set = set()
+    if split_mode and ops.current_config().c8x3 and E * B >= ops.current_config().s3_min_images:
+        for l in bbb[1:]:
+            cin = l.in_channels if isinstance(l, _BBBConv) else l.in_features
+            cout = l.out_channels if isinstance(l, _BBBConv) else l.out_features
+            if ops.c8x3_layer_ok(cin, cout, is_logits=(l is children[last_bayes])):
+                c8_set.add(l)
     if bbb:
-        sampled, kl = _sample_all_bf16(bbb, n_draws, seed, call0, timers) if bf16 else _sample_all(bbb, n_draws, seed, call0, timers)
+        sampled, kl = _sample_all_bf16(bbb, n_draws, seed, call0, timers) if bf16 else _sample_all(bbb, n_draws, seed, call0, timers, tm=c8_set)
     if lrt:
         variances, k2 = _variances_all(lrt, timers)
         kl = k2 if kl is None else kl + k2
@@ -425,9 +448,6 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
         xt = ops.to_batch_innermost_bf16_slices(x, nblk) if bf16 else ops.to_batch_innermost_slices(x, nblk)
     else:
         xt = to_cb(x).unsqueeze(0)                              # [1, C, H, W, B], shared by all draws
-    children = flat_children(net)
-    last_bayes = max((i for i, m in enumerate(children) if isinstance(m, (_BBBLayer, _LRTLayer))), default=-1)
-    tail_is_last = last_bayes == len(children) - 1
     n_out = getattr(children[last_bayes], "out_features", None) if tail_is_last else None
     logits_buf = torch.empty((E, n_out, B), dtype=torch.float32, device=x.device) if n_out is not None else None
 
@@ -435,8 +455,7 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
     # split-bf16 mode, steps large enough that every conv launch takes that kernel: the activations between the layers travel in
     # the split format S3 (three bf16 planes holding the exact fp32 values; ops.conv2d_chwn_forward x_s3 / out_s3) -- each
     # element is cut into its pieces ONCE, by the launch that produces it, instead of by every workgroup that stages it
-    s3_chain = ((precision == "bf16x3" or ops.current_config().gemm_mode == "bf16x3") and not bf16 and not lrt and bool(bbb) and B % 8 == 0
-                and E * B >= ops.current_config().s3_min_images and tail_is_last)
+    s3_chain = split_mode and not c8_set and B % 8 == 0 and E * B >= ops.current_config().s3_min_images
 
     def run(e0, e1):
         """Layers for draws [e0, e1) on the current stream -> logits [e1-e0, C, B] (or None: fall back)."""
@@ -445,6 +464,7 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
         Es = e1 - e0
         h = xt
         s3 = False                     # h is an S3 tensor [E, 3, C, H, W, B] (split-bf16 chain)
+        c8s3 = False                   # h is a c8 S3 tensor [E, 3, C / 8, H, W, B, 8] (split-bf16 chain over MFMA-ready operands)
         boff = int(b_offset)           # global index of the first local "image" (rows multiply at a flatten that cuts images up)
         per_slice = bool(ukw)          # work units: until the first Bayesian layer, h is one block per batch slice
         x_div, x_off = x_div0, x_off0  # several steps per launch: the first layer's slab e reads batch (e + x_off) // x_div
@@ -456,12 +476,25 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
             if isinstance(mod, (_BBBLayer, _LRTLayer)):
                 is_conv = isinstance(mod, (_BBBConv, _LRTConv))
                 geom = (mod.stride, mod.padding, mod.dilation) if is_conv else (1, 0, 1)
-                if s3:
+                use_c8 = mod in c8_set
+                if c8s3 and not use_c8:
+                    h, c8s3 = ops.c8s3_to_f32(h), False
+                if use_c8 and not c8s3:
+                    hf = h if is_conv else h.reshape(h.shape[0], mod.in_features, 1, 1, -1)
+                    if hf.dim() != 5 or hf.shape[-1] != B:
+                        return None
+                    h = _run(timers, "layout", None, lambda hf=hf: ops.c8s3_from_f32(hf))
+                    c8s3 = True
+                if c8s3:
+                    h5 = h if is_conv else h.reshape(h.shape[0], 3, mod.in_features // 8, 1, 1, h.shape[5], 8)
+                    if h5.shape[5] != B or h5.shape[2] * 8 != (mod.in_channels if is_conv else mod.in_features):
+                        return None
+                elif s3:
                     h5 = h if is_conv else h.reshape(h.shape[0], 3, mod.in_features, 1, 1, -1)
                 else:
                     h5 = h if is_conv else h.reshape(h.shape[0], mod.in_features, 1, 1, -1)
                 c8 = bf16 and h5.dim() == 6                      # channel-interleaved [E, C / 8, H, W, B, 8] (ops.to_c8), written by the layer before
-                if h5.dim() != (6 if (s3 or c8) else 5) or h5.shape[4 if c8 else -1] != B:
+                if not c8s3 and (h5.dim() != (6 if (s3 or c8) else 5) or h5.shape[4 if c8 else -1] != B):
                     return None                                  # flatten quirk etc.: caller falls back
                 ukw2 = dict(ukw, x_per_slice=per_slice) if ukw else ({"x_div": x_div, "x_off": x_off} if x_div > 1 else {})
                 per_slice = False
@@ -501,6 +534,21 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
                                                           pool=pool_ks, out_c8=out_c8, **ukw2))
                     if fuse_pool:
                         i += 1                                   # the pooling module is done too
+                elif use_c8:
+                    w, b = sampled[mod]
+                    if not ukw:
+                        w = w[e0:e1]
+                        b = None if b is None else b[e0:e1]
+                    ks = mod.kernel_size if is_conv else (1, 1)
+                    w = w.reshape(w.shape[0], w.shape[1], ks[0] * ks[1], -1)      # tap-major rows (a linear layer's rows as they are)
+                    fl = conv_flops(B, h5.shape[2] * 8, h5.shape[3], h5.shape[4], w.shape[1], ks[0], ks[1], *geom, Es) if timers is not None else None
+                    is_logits = logits_buf is not None and i == last_bayes and not is_conv
+                    of32 = i == last_bayes
+                    dst = logits_buf[e0:e1] if is_logits else None
+                    ukw3 = {k: v for k, v in ukw2.items() if k != "x_per_slice"}
+                    y = _run(timers, "conv_gemm", fl, lambda h5=h5, w=w, b=b, ks=ks, geom=geom, act=act, dst=dst, ukw3=ukw3, of32=of32:
+                             ops.conv2d_c8x3_forward(h5, w, b, ks, *geom, act=act, out_f32=of32, out=dst, **ukw3))
+                    c8s3 = not of32
                 elif isinstance(mod, _BBBLayer):
                     w, b = sampled[mod]
                     if not ukw:
@@ -515,10 +563,12 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
                     # (ops.pool_fusion_ok; same bits as the separate pooling launch)
                     pool_at = i + (2 if act is not None else 1)
                     pool_mod = children[pool_at] if pool_at < len(children) and isinstance(children[pool_at], nn.MaxPool2d) else None
-                    fuse_pool = (pool_mod is not None and is_conv and not s3 and not o_s3 and bf16x3 is None and
-                                 ops.pool_fusion_ok(tuple(h5.shape), tuple(w.shape), *geom, Es, pool_mod))
-                    y = _run(timers, "conv_gemm", fl, lambda h5=h5, w=w, b=b, geom=geom, act=act, dst=dst, ukw2=ukw2, s3=s3, o_s3=o_s3, fuse_pool=fuse_pool:
-                             ops.conv2d_chwn_forward(h5, w, b, *geom, act=act, out=dst, bf16x3=bf16x3, x_s3=s3, out_s3=o_s3,
+                    # (a chain over MFMA-ready operands: the layers outside it -- the first one -- take the fp32 kernel, pooled form included)
+                    bx3 = False if c8_set else bf16x3
+                    fuse_pool = (pool_mod is not None and is_conv and not s3 and not o_s3 and (bf16x3 is None or bool(c8_set)) and
+                                 ops.pool_fusion_ok(tuple(h5.shape), tuple(w.shape), *geom, Es, pool_mod, fp32_kernel=bool(c8_set)))
+                    y = _run(timers, "conv_gemm", fl, lambda h5=h5, w=w, b=b, geom=geom, act=act, dst=dst, ukw2=ukw2, s3=s3, o_s3=o_s3, fuse_pool=fuse_pool, bx3=bx3:
+                             ops.conv2d_chwn_forward(h5, w, b, *geom, act=act, out=dst, bf16x3=bx3, x_s3=s3, out_s3=o_s3,
                                                      pool=fuse_pool, **ukw2))
                     s3 = o_s3
                     if fuse_pool:
@@ -553,6 +603,11 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
                 if act is not None:
                     i += 1
             elif isinstance(mod, FlattenLayer):
+                if c8s3:
+                    if h.shape[3] * h.shape[4] == 1 and h.shape[2] * 8 == mod.num_features:
+                        i += 1                                   # [E, 3, F / 8, 1, 1, B, 8] already is the flattened feature order
+                        continue
+                    h, c8s3 = ops.c8s3_to_f32(h), False
                 if s3 and h.shape[2] * h.shape[3] * h.shape[4] != mod.num_features:
                     h, s3 = ops.s3_to_f32(h), False              # the flatten quirk below works on the fp32 tensor
                 if h.dim() != (6 if s3 else 5):
@@ -577,19 +632,25 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
                     if logits_buf is not None and logits_buf.shape[2] != B:
                         logits_buf = torch.empty((E, n_out, B), dtype=torch.float32, device=x.device)
             elif isinstance(mod, nn.MaxPool2d):
-                pool = ops.maxpool_chwn_s3 if s3 else (ops.maxpool_chwn_bf16 if bf16 else ops.maxpool_chwn)
+                pool = ops.maxpool_c8s3 if c8s3 else ops.maxpool_chwn_s3 if s3 else (ops.maxpool_chwn_bf16 if bf16 else ops.maxpool_chwn)
                 h = _run(timers, "maxpool", None, lambda: pool(h, mod.kernel_size, mod.stride))
             elif isinstance(mod, nn.ReLU):
                 if s3:
                     h, s3 = ops.s3_to_f32(h), False
+                if c8s3:
+                    h, c8s3 = ops.c8s3_to_f32(h), False
                 h = torch.relu(h)
             else:
                 if s3:
                     h, s3 = ops.s3_to_f32(h), False
+                if c8s3:
+                    h, c8s3 = ops.c8s3_to_f32(h), False
                 h = F.softplus(h)
             i += 1
         if s3:
             h, s3 = ops.s3_to_f32(h), False
+        if c8s3:
+            h, c8s3 = ops.c8s3_to_f32(h), False
         if h.shape[0] == 1 and Es > 1:
             h = h.expand(Es, *h.shape[1:])
         h = h.reshape(Es, -1, B)

@@ -298,10 +298,12 @@ class LaunchConfig:
     launches_overlap   the caller enqueues work that runs beside other lanes' kernels: the under-filled tail of a fused launch is
                 then filled by them, and fusing pays from ~2 items per CU on (measured, profiles/r04_notes.md section 7: -2 to
                 -3 % per step at 10 draws x 3 lanes, +4.5 % with one lane; at 5 draws per launch it no longer does)
-    pool_fuse_weight_budget   bytes of weight tiles concurrently live per XCD that a fused launch may have (see pool_fusion_ok)"""
+    pool_fuse_weight_budget   bytes of weight tiles concurrently live per XCD that a fused launch may have (see pool_fusion_ok)
+    c8x3        split-bf16 mode: layers with Cin % 32 == 0 take the MFMA-ready-operand kernel (csrc/pconv_c8x3.hip) in chains of
+                >= s3_min_images rows"""
     FIELDS = ("gemm_mode", "bf16x3_min_workgroups", "s3_min_images", "split_k", "pool_fusion", "pool_fuse_min_items",
               "pool_fuse_imbalance", "launches_overlap", "pool_fuse_min_items_overlapped", "pool_fuse_weight_budget",
-              "bf16_pool_fuse_min_rows", "bf16_pool_fuse_min_rows_overlapped", "bf16_c8", "bf16_c8_min_items")
+              "bf16_pool_fuse_min_rows", "bf16_pool_fuse_min_rows_overlapped", "bf16_c8", "bf16_c8_min_items", "c8x3")
     __slots__ = FIELDS
 
     def __init__(self, **kw):
@@ -321,6 +323,10 @@ class LaunchConfig:
         self.bf16_c8 = True                            # (bf16_c8_input_ok) channel-interleaved activations between a pooled first layer and a
         self.bf16_c8_min_items = 0                     # layer that has the strip form over them, for launches of at least this many strip
                                                        # workgroups (0: always -- measured faster from one step per launch on); False: never
+        self.c8x3 = True                               # split-bf16 mode, steps of >= s3_min_images rows: layers with Cin % 32 == 0 run on the
+                                                       # MFMA-ready-operand kernel (conv2d_c8x3_forward: channel-interleaved split
+                                                       # activations + tap-major weights from the parameter pass); False: round 4's
+                                                       # kernel (split while staging / planar S3) everywhere
         for k, v in kw.items():
             setattr(self, k, v)              # (unknown names raise: __slots__)
 
@@ -423,14 +429,14 @@ class overlapped_launches(use_config):
         super().__init__(launches_overlap=bool(on))
 
 
-def pool_fusion_ok(x_shape, w_shape, stride, padding, dilation, draws, pool_module=None):
+def pool_fusion_ok(x_shape, w_shape, stride, padding, dilation, draws, pool_module=None, fp32_kernel=False):
     """Should conv2d_chwn_forward(..., pool=True) replace conv + maxpool_chwn(2, 2) for this launch?  Same bits either way; the
     fused launch saves the pooling launch and 3/4 of the layer's output traffic, but its items are four times fewer and four
     times longer: chosen when other lanes' kernels run beside it (launches_overlap), else only when its items still fill the chip
     evenly (measured: profiles/r04_notes.md section 7).
     x_shape [*, Cin, H, W, B], w_shape [*, Cout, Cin, kh, kw]; pool_module: the nn.MaxPool2d that follows (checked for 2 / 2)."""
     cfg = current_config()
-    if not cfg.pool_fusion or cfg.gemm_mode != "fp32":
+    if not cfg.pool_fusion or (cfg.gemm_mode != "fp32" and not fp32_kernel):       # (fp32_kernel: the caller runs THIS launch on the fp32 kernel)
         return False
     key = (tuple(x_shape[-4:]), tuple(w_shape[-4:]), _pair(stride), _pair(padding), _pair(dilation), int(draws), cfg.launches_overlap,
            cfg.pool_fuse_min_items, cfg.pool_fuse_imbalance, cfg.pool_fuse_min_items_overlapped, cfg.pool_fuse_weight_budget,
@@ -640,10 +646,11 @@ def c8x3_layer_ok(cin, cout, is_logits=False):
 
 
 def conv2d_c8x3_forward(x, w_tm, bias, kernel_size, stride=1, padding=0, dilation=1, act=None, out_f32=False, out=None, units=None,
-                        n_units=None, x_div=1, x_off=0):
+                        n_units=None, x_div=1, x_off=0, tile=None):
     """The split-bf16 contraction over MFMA-ready operands (bbb_conv2d_c8x3_fwd).  x: c8 S3 [E|1, 3, Cin / 8, H, W, B, 8];
     w_tm: fp32 tap-major [E|1, Cout, kh * kw, Cin]; bias [E|1, Cout] | None -> c8 S3 [E, 3, Cout / 8, Ho, Wo, B, 8], or with
-    out_f32 the fp32 batch-innermost [E, Cout, Ho, Wo, B] (the logits layer).  Work units / x_div / x_off as conv2d_chwn_forward."""
+    out_f32 the fp32 batch-innermost [E, Cout, Ho, Wo, B] (the logits layer).  Work units / x_div / x_off as conv2d_chwn_forward.
+    tile = 128 | 256: images per workgroup (None: the library picks by launch size; same bits either way)."""
     require_device(w_tm, bias)
     require_device(x, dtype=torch.bfloat16)
     x, w_tm = x.contiguous(), w_tm.contiguous()
@@ -692,7 +699,8 @@ def conv2d_c8x3_forward(x, w_tm, bias, kernel_size, stride=1, padding=0, dilatio
         y = out.view(shape)
     with on_device(x.device):
         check(_lib.lib().bbb_conv2d_c8x3_fwd(ctypes.byref(d), x.data_ptr(), w_tm.data_ptr(), ptr(bias), y.data_ptr(),
-                                             1 if out_f32 else 0, cur_stream(x.device)), "bbb_conv2d_c8x3_fwd")
+                                             (1 if out_f32 else 0) | {None: 0, 128: 2, 256: 4}[tile], cur_stream(x.device)),
+              "bbb_conv2d_c8x3_fwd")
     return y
 
 
@@ -824,6 +832,40 @@ def sample_weights_bf16(mus, rhos, prior_mu, prior_sigma, stream_ids, seed, call
             segs[i].w_row_len = rl
             segs[i].w_taps = tp
             segs[i].draw_stride = o.shape[1] * o.shape[2]
+    kl = torch.empty((), dtype=torch.float32, device=dev)
+    L = _lib.lib()
+    parts = _partials(dev, L.bbb_reparam_partials(segs, len(mus)))
+    with on_device(dev):
+        rc = L.bbb_reparam_kl_fwd(segs, len(mus), draws, float(prior_mu), float(prior_sigma), seed, call0 & 0xFFFFFFFF,
+                                  0, ptr(parts), ptr(kl), 0, rng.call_dev_ptr(dev), cur_stream(dev))
+    check(rc, "bbb_reparam_kl_fwd")
+    return kl, outs
+
+
+def sample_weights_tm(mus, rhos, prior_mu, prior_sigma, stream_ids, seed, call0, draws, tap_major):
+    """The fused reparam + KL pass with the conv weights flagged in `tap_major` (one bool per tensor) written TAP-MAJOR, fp32
+    [draws, Cout, kh * kw, Cin] (bbb_segment_t::w_tm_cin: the weight operand of conv2d_c8x3_forward), every other tensor dense
+    [draws, *shape].  Same noise elements, same KL bits as the dense launch (w_tap_major(dense) == this, bit for bit).
+    Inference only.  Returns (kl, [tensors])."""
+    if len(mus) == 0 or len(mus) > _lib.MAX_SEGMENTS:
+        raise _lib.BBBHipError(f"1..{_lib.MAX_SEGMENTS} tensors per launch, got {len(mus)}")
+    require_device(*mus, *rhos)
+    dev = mus[0].device
+    mus = [m.detach().contiguous() for m in mus]
+    rhos = [r.detach().contiguous() for r in rhos]
+    outs = []
+    for m, tm in zip(mus, tap_major):
+        if tm:
+            if m.dim() != 4 or m.shape[1] % 8 or m.shape[2] * m.shape[3] < 2:
+                raise _lib.BBBHipError("tap-major output: conv weights [Cout, Cin, kh, kw] with Cin % 8 == 0 and more than one tap")
+            outs.append(torch.empty((draws, m.shape[0], m.shape[2] * m.shape[3], m.shape[1]), dtype=torch.float32, device=dev))
+        else:
+            outs.append(torch.empty((draws,) + tuple(m.shape), dtype=torch.float32, device=dev))
+    segs = _segments(mus, rhos, outs, None, None, stream_ids, draws)
+    for i, (m, tm) in enumerate(zip(mus, tap_major)):
+        if tm:
+            segs[i].w_taps = m.shape[2] * m.shape[3]
+            segs[i].w_tm_cin = m.shape[1]
     kl = torch.empty((), dtype=torch.float32, device=dev)
     L = _lib.lib()
     parts = _partials(dev, L.bbb_reparam_partials(segs, len(mus)))

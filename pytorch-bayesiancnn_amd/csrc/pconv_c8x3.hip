@@ -313,7 +313,9 @@ using namespace pconv;
 
 extern "C" int bbb_conv2d_c8x3_fwd(const bbb_conv_desc_t* d, const void* x, const float* w, const float* bias, void* y, uint32_t flags,
                                    void* stream) {
-    if (d == nullptr || x == nullptr || w == nullptr || y == nullptr || (flags & ~BBB_C8X3_OUT_F32) != 0) return BBB_EINVAL;
+    if (d == nullptr || x == nullptr || w == nullptr || y == nullptr || (flags & ~(BBB_C8X3_OUT_F32 | BBB_C8X3_TILE128 | BBB_C8X3_TILE256)) != 0 ||
+        ((flags & BBB_C8X3_TILE128) && (flags & BBB_C8X3_TILE256)))
+        return BBB_EINVAL;
     if (d->batch <= 0 || d->cin <= 0 || d->h <= 0 || d->w <= 0 || d->cout <= 0 || d->kh <= 0 || d->kw <= 0 || d->stride_h <= 0 ||
         d->stride_w <= 0 || d->pad_h < 0 || d->pad_w < 0 || d->dil_h <= 0 || d->dil_w <= 0 || d->draws <= 0 || d->act < 0 || d->act > 2 ||
         d->pool != 0 || d->w_row_pitch != 0)
@@ -353,8 +355,8 @@ extern "C" int bbb_conv2d_c8x3_fwd(const bbb_conv_desc_t* d, const void* x, cons
     int mt = 2;
     {
         const int64_t items256 = (int64_t)a.G * pixels * ((a.B + 255) / 256);
-        static const int force = [] { const char* s = getenv("BBB_C8X3_MT"); return s ? atoi(s) : 0; }();
-        if (force == 1 || force == 2) mt = force;
+        if (flags & BBB_C8X3_TILE128) mt = 1;
+        else if (flags & BBB_C8X3_TILE256) mt = 2;
         else if (a.B <= 128 || items256 < 1024) mt = 1;
     }
     a.nbt = (a.B + 128 * mt - 1) / (128 * mt);

@@ -47,6 +47,11 @@ struct ReparamArgs {
     int32_t small_chunk0;  // first chunk handled by small blocks
     const float* gkl;
     const uint32_t* call_dev;
+    // tap-major fp32 outputs (bbb_segment_t::w_tm_cin): the draws of such a segment are produced by `tm_blocks` extra blocks at the
+    // FRONT of the grid, each owning tm_cg (row, input channel) pairs = tm_cg * taps consecutive source elements
+    int32_t tm_begin[BBB_MAX_SEGMENTS + 1];
+    int32_t tm_cg[BBB_MAX_SEGMENTS];
+    int32_t tm_blocks;
 };
 
 // KL term in the reference's form (metrics.py:28 with the call-site argument order):
@@ -165,6 +170,66 @@ __device__ __forceinline__ void sum_partials(const ReparamArgs& a, double* sm /*
     }
 }
 
+// Tap-major fp32 weights for bbb_conv2d_c8x3_fwd (segment field w_tm_cin = C, w_taps = T): w[draw][row][tap][ci] instead of the
+// tensor's own [row][ci][tap].  The noise element of a weight is its index in the tensor's OWN order and one Philox call covers
+// four consecutive ones, so a thread still owns 4 consecutive SOURCE elements; the block owns `cg` consecutive (row, ci) pairs =
+// cg * T consecutive source elements (cg % 8 == 0, cg * T <= 1024: 40 channels of a 5 x 5 layer, 112 of a 3 x 3 one), every
+// draw goes through LDS once -- written in source order (one 16-byte write per thread), read with stride T (odd: conflict-light)
+// as 4 consecutive channels of one tap -- and leaves as 16-byte stores, runs of cg * 4 contiguous bytes per tap.  Double-buffered:
+// one barrier per draw.  Sigma / KL of these elements are NOT computed here: the segment's ordinary 1024-element chunks do that
+// (and skip the draws), so the KL partials, their slots and the summation order are exactly those of a dense launch.
+template <bool NT>
+__device__ __forceinline__ void tm_block(const ReparamArgs& a, int tb, float* lds /* [2][kChunk] */) {
+    int s = 0;
+    while (s + 1 < a.nseg && tb >= a.tm_begin[s + 1]) ++s;
+    const bbb_segment_t sg = a.seg[s];
+    const int T = (int)sg.w_taps, C = (int)sg.w_tm_cin, cg = a.tm_cg[s];
+    const int64_t rc_total = sg.n / T;                           // rows * C
+    const int64_t rc0 = (int64_t)(tb - a.tm_begin[s]) * cg;
+    const int nrc = (rc_total - rc0) < cg ? (int)(rc_total - rc0) : cg;
+    const int cnt = nrc * T;                                     // source elements of this block (multiple of 8)
+    const int64_t i0 = rc0 * T;
+    const int tid = threadIdx.x, j = 4 * tid;
+    const bool active = j < cnt;                                 // cnt / 4 threads: one source group AND one destination quad each
+    const uint32_t call0 = a.call0 + (a.call_dev ? *a.call_dev : 0u);
+    f32x4 m4 = {0.f, 0.f, 0.f, 0.f}, r4 = m4;
+    if (active) {
+        m4 = *reinterpret_cast<const f32x4*>(sg.mu + i0 + j);
+        r4 = *reinterpret_cast<const f32x4*>(sg.rho + i0 + j);
+    }
+    const uint64_t g = (uint64_t)(i0 + j) >> 2;
+    float z[4];
+    bbb::normal4(g, sg.stream_id, call0, a.k0, a.k1, z);         // first draw's noise while the loads are in flight
+    __builtin_amdgcn_sched_barrier(0);
+    const f32x4 sig = bbb::softplus_ref4(r4);
+    // destination quad of this thread: tap-slowest, so that consecutive lanes store consecutive 16-byte pieces
+    const int nq4 = nrc >> 2;
+    const int tap = active ? tid / nq4 : 0, quad = active ? tid - tap * nq4 : 0;
+    const int64_t rc = rc0 + 4 * quad;
+    const int64_t row = rc / C;
+    const int ci = (int)(rc - row * C);
+    float* wp = sg.w + row * (int64_t)T * C + (int64_t)tap * C + ci;
+    const int src = 4 * quad * T + tap;
+    for (int e = 0;;) {
+        float* buf = lds + (e & 1) * kChunk;
+        if (active) {
+            f32x4 w4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) w4[c] = sample_w(m4[c], z[c], sig[c]);
+            *reinterpret_cast<f32x4*>(buf + j) = w4;
+        }
+        __syncthreads();
+        if (active) {
+            const f32x4 o = {buf[src], buf[src + T], buf[src + 2 * T], buf[src + 3 * T]};
+            if (NT) __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(wp));
+            else    *reinterpret_cast<f32x4*>(wp) = o;
+        }
+        if (++e >= a.draws) break;
+        wp += sg.draw_stride;
+        bbb::normal4(g, sg.stream_id, call0 + (uint32_t)e, a.k0, a.k1, z);
+    }
+}
+
 // The hot instantiation: on-chip noise, dense fp32 outputs.  Straight-line draw loop: no loads, no waits -- a thread's (mu, rho) vectors are loaded
 // once, sigma and the KL term are computed once (and published), and every draw is one Philox call, two Box-Muller pairs,
 // four FMAs and one 16-byte store; a thread may have all of its draws' stores in flight at once.  The tail of an aligned tensor (n % 4 != 0) still LOADS a full
@@ -177,7 +242,9 @@ __device__ __forceinline__ void sum_partials(const ReparamArgs& a, double* sm /*
 template <int GPT, bool NT>
 __global__ __launch_bounds__(kThreads) void reparam_kl_fast_kernel(const ReparamArgs a) {
     __shared__ double sm[kThreads];
-    const int b = blockIdx.x;
+    __shared__ __attribute__((aligned(16))) float tm_lds[2 * kChunk];
+    if ((int)blockIdx.x < a.tm_blocks) { tm_block<NT>(a, (int)blockIdx.x, tm_lds); return; }
+    const int b = (int)blockIdx.x - a.tm_blocks;
     if (b == a.sum_block) { sum_partials(a, sm); return; }
     int chunk, e_lo, e_hi;
     if (b < a.n_small) {
@@ -256,7 +323,7 @@ __global__ __launch_bounds__(kThreads) void reparam_kl_fast_kernel(const Reparam
         }
     }
     if (a.partials != nullptr && first) publish_partial(a, chunk, kl_acc, sm);     // block-uniform condition
-    if (sg.w == nullptr) return;
+    if (sg.w == nullptr || sg.w_tm_cin != 0) return;                               // (tap-major outputs: the tm blocks draw them)
 #pragma unroll
     for (int it = 0; it < GPT; ++it) {
         const int c = cnt[it];
@@ -528,7 +595,12 @@ int fill_args(ReparamArgs& a, const bbb_segment_t* segs, int nseg, int draws, bo
         if ((((uintptr_t)g.mu | (uintptr_t)g.rho | (g.w_row_len ? 0 : (uintptr_t)g.w) | (uintptr_t)g.sigma | (uintptr_t)g.eps) & 3u) != 0)
             return BBB_EALIGN;
         if (g.w_row_len != 0 && (bwd || g.w == nullptr || g.n % g.w_row_len != 0 || ((uintptr_t)g.w & 1u))) return BBB_EINVAL;
-        if (g.w_taps > 1 && (g.w_row_len == 0 || g.w_row_len % g.w_taps != 0)) return BBB_EINVAL;
+        if (g.w_tm_cin != 0) {      // fp32 tap-major output: dense Philox-sampled fp32 segment, [rows][C][T] with C % 8 == 0, 16-byte aligned
+            if (bwd || g.w_row_len != 0 || g.w_taps < 2 || g.w_taps > 128 || g.w_tm_cin % 8 != 0 || g.w == nullptr || g.eps != nullptr ||
+                g.n % ((int64_t)g.w_tm_cin * g.w_taps) != 0)
+                return BBB_EINVAL;
+            if ((((uintptr_t)g.mu | (uintptr_t)g.rho | (uintptr_t)g.w) & 15u) != 0 || (g.draw_stride & 3) != 0) return BBB_EALIGN;
+        } else if (g.w_taps > 1 && (g.w_row_len == 0 || g.w_row_len % g.w_taps != 0)) return BBB_EINVAL;
         a.seg[s] = g;
         a.chunk_begin[s] = chunks;
         chunks += (int)((g.n + (int64_t)kChunk * gpt - 1) / ((int64_t)kChunk * gpt));
@@ -602,6 +674,23 @@ extern "C" int bbb_reparam_kl_fwd(const bbb_segment_t* segs, int nseg, int draws
     const bool fast = fast_path_ok(segs, nseg);
 #endif
     if (fast) {
+        // tap-major segments: their draws come from extra blocks at the front of the grid (tm_block)
+        int tmb = 0;
+        for (int s = 0; s < nseg; ++s) {
+            a.tm_begin[s] = tmb;
+            a.tm_cg[s] = 0;
+            if (segs[s].w_tm_cin != 0) {
+                const int64_t rc_total = segs[s].n / segs[s].w_taps;
+                int64_t cg = (kChunk / (int)segs[s].w_taps) & ~7;
+                if (cg > rc_total) cg = rc_total;
+                a.tm_cg[s] = (int)cg;
+                const int64_t nb = (rc_total + cg - 1) / cg;
+                if (tmb + nb > 0x3fffffffLL) return BBB_ESHAPE;
+                tmb += (int)nb;
+            }
+        }
+        for (int s = nseg; s <= BBB_MAX_SEGMENTS; ++s) a.tm_begin[s] = tmb;
+        a.tm_blocks = tmb;
         // A launch a little larger than one round of resident blocks (the model-sized case: 2137 chunks on 2048 slots) would
         // run its excess blocks alone at the end, one wave per SIMD, for a whole 10-draw block time.  Instead the LAST
         // `excess` chunks are cut into one block per draw and put FIRST in the grid: they finish early, the whole-chunk
@@ -609,12 +698,12 @@ extern "C" int bbb_reparam_kl_fwd(const bbb_segment_t* segs, int nseg, int draws
         // draw 0 owns the chunk's KL partial and sigma output; partial indices = chunk indices, so the KL sum is unchanged.)
         const int slots = resident_blocks();
         int excess = 0;
-        if (gpt == 1 && draws > 1 && chunks > slots && chunks <= 3 * slots) excess = chunks % slots;
+        if (gpt == 1 && draws > 1 && chunks > slots && chunks <= 3 * slots && tmb == 0) excess = chunks % slots;
         a.n_small = excess * draws;
         a.small_chunk0 = chunks - excess;
         const int blocks = a.n_small + (chunks - excess);
         a.sum_block = want_kl ? blocks : -1;
-        const dim3 grid(blocks + (want_kl ? 1 : 0));
+        const dim3 grid(tmb + blocks + (want_kl ? 1 : 0));
         // Store flavour of w (measured, AlexNet's 12 tensors, us per launch, plain / non-temporal): E=4 14.6 / 12.2, E=10
         // 21.7 / 19.2, E=25 40.0 / 42.5 -- with plain stores the launch ends with up to 32 MB of dirty L2 lines to write back
         // at the kernel boundary; streaming them out as they are produced wins until the launch is long enough to hide that.
@@ -623,6 +712,8 @@ extern "C" int bbb_reparam_kl_fwd(const bbb_segment_t* segs, int nseg, int draws
         else if (nt) hipLaunchKernelGGL((reparam_kl_fast_kernel<1, true>), grid, block, 0, st, a);
         else         hipLaunchKernelGGL((reparam_kl_fast_kernel<1, false>), grid, block, 0, st, a);
     } else {
+        for (int s = 0; s < nseg; ++s)
+            if (segs[s].w_tm_cin != 0) return BBB_EINVAL;                 // tap-major outputs: Philox-sampled dense launches only
         a.sum_block = want_kl ? chunks : -1;
         const dim3 grid(chunks + (want_kl ? 1 : 0));
         if (big) hipLaunchKernelGGL(reparam_kl_fwd_kernel<4>, grid, block, 0, st, a);

@@ -126,3 +126,93 @@ def test_c8x3_argument_errors(env):
         ops.conv2d_c8x3_forward(x, torch.randn(1, 12, 1, 32, device="cuda"), None, 1)
     y = ops.conv2d_c8x3_forward(x, torch.randn(1, 12, 1, 32, device="cuda"), None, 1, out_f32=True)
     assert y.shape == (1, 12, 2, 2, 8)
+
+
+@pytest.mark.parametrize("draws", [1, 3, 17])
+def test_parameter_pass_writes_tap_major_rows(env, draws):
+    """bbb_segment_t::w_tm_cin: the sampled weights of flagged conv tensors come out tap-major, bit for bit the transposition of
+    what the dense launch writes (the noise of a weight is keyed by its index in the tensor's OWN order), dense tensors and the KL
+    scalar are untouched -- for 5 x 5, 3 x 3 and rectangular taps, row counts that leave a ragged last block, and enough elements
+    that a block's (row, channel) range straddles rows."""
+    ops = env["ops"]
+    torch.manual_seed(draws)
+    shapes = [(24, 64, 5, 5), (7,), (40, 192, 3, 3), (40,), (9, 8, 2, 3), (10, 128), (3, 16, 1, 7)]
+    mus = [torch.randn(*s, device="cuda") * 0.1 for s in shapes]
+    rhos = [torch.randn(*s, device="cuda") * 0.1 - 5.0 for s in shapes]
+    ids = list(range(len(shapes)))
+    tm = [len(s) == 4 for s in shapes]
+    kl_d, ws_d = ops.sample_weights(mus, rhos, 0.0, 0.1, ids, 11, 5, draws)
+    kl_t, ws_t = ops.sample_weights_tm(mus, rhos, 0.0, 0.1, ids, 11, 5, draws, tm)
+    assert torch.equal(kl_d, kl_t)
+    for wd, wt, flag in zip(ws_d, ws_t, tm):
+        if flag:
+            assert torch.equal(wt, ops.w_tap_major(wd))
+        else:
+            assert torch.equal(wt, wd)
+
+
+import ref_port_torch as P
+
+
+@pytest.mark.parametrize("model,shape,classes", [("alexnet", (512, 3, 32, 32), 10), ("3conv3fc", (256, 3, 32, 32), 10),
+                                                 ("lenet", (512, 1, 32, 32), 10)])
+def test_c8_chain_model_step(env, model, shape, classes):
+    """The whole Monte-Carlo step in split-bf16 mode with the layers behind the first one on the MFMA-ready-operand kernel
+    (LaunchConfig.c8x3, the default) against the same mode on round 4's kernel and against the fp32 path, same noise: KL bit for
+    bit (the tap-major parameter pass leaves sigma / KL to the ordinary chunks), log-probabilities within 1e-5 of their largest
+    magnitude; eager = hipGraph replay bit for bit.  3Conv3FC: its flatten cuts 2 x 2 maps into features (the chain passes through
+    fp32 there); LeNet: no layer qualifies (6 / 16 channels) -- the mode must not change a thing."""
+    ens, ops = env["ens"], env["ops"]
+    torch.manual_seed(0)
+    net = env["zoo"].getModel(model, shape[1], classes, P.CONFIG_PRIORS, "bbb", "softplus").cuda()
+    env["rng"].assign_stream_ids(net)
+    x = torch.rand(*shape, device="cuda")
+    E = 10
+    with torch.no_grad():
+        env["rng"].manual_seed(3, call=0)
+        lo32, kl32 = ens.mc_forward(net, x, E)
+        with ops.use_config(gemm_mode="bf16x3", c8x3=False):
+            env["rng"].manual_seed(3, call=0)
+            lo_old, kl_old = ens.mc_forward(net, x, E)
+        with ops.use_config(gemm_mode="bf16x3"):
+            assert ops.current_config().c8x3
+            env["rng"].manual_seed(3, call=0)
+            lo, kl = ens.mc_forward(net, x, E)
+            env["rng"].manual_seed(3, call=0)
+            g = ens.GraphedMC(net, x, E)
+            lo_g, kl_g = g.step()
+            torch.cuda.synchronize()
+    assert torch.equal(kl, kl32) and torch.equal(kl, kl_old) and torch.equal(kl_g, kl)
+    assert torch.equal(lo_g, lo)
+    scale = float(lo32.abs().max())
+    assert float((lo - lo32).abs().max()) <= 1e-5 * scale and float((lo - lo_old).abs().max()) <= 1e-5 * scale
+    if model == "lenet":
+        assert torch.equal(lo, lo_old)
+    else:
+        assert not torch.equal(lo, lo_old)                  # the new kernel really ran
+
+
+def test_c8_chain_partitions_are_the_whole_step(env):
+    """Work units of a sharded step and several steps per launch on the c8 chain: bit for bit the corresponding slices of the whole
+    step (same MFMA sequence per output element whatever the launch holds; the first layer runs the fp32 kernel, whose split
+    contraction is a property of the layer)."""
+    ens, ops = env["ens"], env["ops"]
+    torch.manual_seed(0)
+    net = env["zoo"].getModel("alexnet", 3, 10, P.CONFIG_PRIORS, "bbb", "softplus").cuda()
+    env["rng"].assign_stream_ids(net)
+    x = torch.rand(512, 3, 32, 32, device="cuda")
+    E, S = 10, 2
+    with torch.no_grad(), ops.use_config(gemm_mode="bf16x3", s3_min_images=0):   # (no launch-size policy: a rank's few units stay on the chain)
+        full, kl = ens._mc_logits_chwn(net, x, E, 7, 3)                          # [E, C, B]
+        for rank in (0, 3):
+            lo, hi = ens.unit_range(E, S, rank, 4)
+            part, klp = ens._mc_logits_chwn(net, x, E, 7, 3, units=(S, lo, hi))  # [hi-lo, C, B/S]
+            assert torch.equal(klp, kl)
+            for i, u in enumerate(range(lo, hi)):
+                j, sl = divmod(u, S)
+                assert torch.equal(part[i], full[j][:, sl * 256:(sl + 1) * 256])
+        x2 = torch.cat([x, torch.rand(512, 3, 32, 32, device="cuda")])
+        two, _ = ens._mc_logits_chwn(net, x2, E, 7, 3, groups=2)                # [2 E, C, B]: step 1 under calls 3 + E ..
+        assert torch.equal(two[:E], full)
+        second, _ = ens._mc_logits_chwn(net, x2[512:], E, 7, 3 + E)
+        assert torch.equal(two[E:], second)
