@@ -243,7 +243,7 @@ int bbb_s3_convert(const void* src, void* dst, int64_t slabs, int64_t n, int to_
  * v_mfma_f32_32x32x16_bf16 wants them, so that the k loop holds no operand arithmetic, no transposing LDS reads and no LDS traffic
  * on the image side:
  *   x: "c8 S3" activations, bf16 [draws|1][3][cin / 8][h][w][B][8] -- the hi / mid / lo pieces (exact: hi + mid + lo is the fp32
- *      value) of the 8 channels 8g .. 8g + 7 of an image are 16 adjacent bytes of a plane = one lane's B operand.  cin % 32 == 0,
+ *      value) of the 8 channels 8g .. 8g + 7 of an image are 16 adjacent bytes of a plane = one lane's B operand.  cin % 16 == 0,
  *      B % 4 == 0, 16-byte aligned; d->x_draw_stride counts bf16 elements (3 * cin * h * w * B per slab, or 0 = shared).
  *   w: fp32, TAP-MAJOR rows [draws|1][cout][kh * kw][cin] -- what bbb_reparam_kl_fwd writes for a segment with w_tm_cin = cin,
  *      w_taps = kh * kw (bbb_w_tap_major converts a dense tensor); 16-byte aligned, draw strides multiples of 4 elements.
@@ -253,12 +253,18 @@ int bbb_s3_convert(const void* src, void* dst, int64_t slabs, int64_t n, int to_
  * (channels = cin / 8, batch = 8 * B: the window maximum is element-wise on 16-byte vectors); bbb_c8s3_convert converts
  * fp32 batch-innermost [slabs][channels][positions][batch] <-> c8 S3 (exact both ways).  Replaces F.conv2d / F.linear of
  * layers/BBB/BBBConv.py:77, layers/BBB/BBBLinear.py:70; every slab (three planes) must stay below 1 GiB.
- * BBB_C8X3_TILE128 / _TILE256 force the images per workgroup (default: by launch size); the MFMA sequence per output element, hence
- * every output bit, is the same for both.
+ * BBB_C8X3_TILE128 / _TILE256 force the images per workgroup and the BBB_C8X3_NT bits the channels per workgroup (default: by layer
+ * and launch size); the MFMA sequence per output element, hence every output bit, is the same for all of them.
  */
 #define BBB_C8X3_OUT_F32 1u
 #define BBB_C8X3_TILE128 2u
 #define BBB_C8X3_TILE256 4u
+#define BBB_C8X3_POOL 8u          /* the launch also applies MaxPool2d(2, 2) to the activated output ("parallel window": the four waves of a
+                                     workgroup own the four pixels of a window).  pad == 0, even ho and wo, c8 S3 output
+                                     [draws][3][cout / 8][ho / 2][wo / 2][B][8]; bit for bit the plain launch + bbb_maxpool_chwn_s3(2, 2).
+                                     TILE128 / TILE256 then mean 32 / 64 images per workgroup. */
+#define BBB_C8X3_NT_SHIFT 4       /* bits 4..6: force the channels per workgroup, 32 * NT with NT = 2, 3 or 4 (0: by layer and launch size) */
+#define BBB_C8X3_NT_MASK 0x70u
 int bbb_conv2d_c8x3_fwd(const bbb_conv_desc_t* d, const void* x, const float* w, const float* bias, void* y, uint32_t flags,
                         void* stream);
 int bbb_c8s3_convert(const void* src, void* dst, int64_t slabs, int channels, int64_t positions, int batch, int to_c8s3, void* stream);

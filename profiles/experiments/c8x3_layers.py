@@ -53,10 +53,18 @@ for E in [int(a) for a in sys.argv[1:]] or [40, 10]:
             ref = f32()
             got = new() if of32 else ops.c8s3_to_f32(new())
             err = float((got - ref).abs().max() / ref.abs().max())
-            t32, told, tnew = hot_us(f32), hot_us(old), hot_us(new)
+            quick = os.environ.get("C8X3_ONLY") == "1"
+            t32, told, tnew = (0.0, 0.0, hot_us(new)) if quick else (hot_us(f32), hot_us(old), hot_us(new))
             rows[name] = dict(fp32_us=round(t32, 1), bf16x3_us=round(told, 1), c8x3_us=round(tnew, 1), rel_diff_vs_fp32=float(f"{err:.2e}"))
+            if os.environ.get("C8X3_SWEEP") == "1" and not of32:
+                sw = {}
+                for nt in (2, 3, 4):
+                    for tile in (128, 256):
+                        fn = lambda nt=nt, tile=tile: ops.conv2d_c8x3_forward(xc, wt, b, (kh, kw), 1, pad, 1, act="softplus", nt=nt, tile=tile)
+                        sw[f"nt{nt}_t{tile}"] = round(hot_us(fn), 1)
+                rows[name]["sweep_us"] = sw
             if fl:
                 rows[name]["c8x3_frac_of_bf16_peak"] = round(6 * fl / (tnew * 1e-6) / 2.5e15, 3)
-                rows[name]["fp32_frac"] = round(fl / (t32 * 1e-6) / 157.3e12, 3)
+                rows[name]["fp32_frac"] = round(fl / (t32 * 1e-6) / 157.3e12, 3) if t32 else None
     tot = {k: round(sum(r[k] for r in rows.values()), 1) for k in ("fp32_us", "bf16x3_us", "c8x3_us")}
     print(json.dumps({"E": E, "mt": os.environ.get("BBB_C8X3_MT", "auto"), "layers": rows, "total": tot}), flush=True)

@@ -423,15 +423,16 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
         S, n_draws = 1, E
     if bf16 and (lrt or B % 8 != 0):
         raise _lib.BBBHipError("the bf16 path covers BBB (non-LRT) layers and batch sizes that are multiples of 8")
-    # split-bf16 mode, steps of >= s3_min_images rows: BBB layers with Cin % 32 == 0 (never the first one: its input is the caller's
-    # fp32 batch) run on the MFMA-ready-operand kernel (ops.conv2d_c8x3_forward) -- their input travels channel-interleaved and
-    # already split ("c8 S3"), their weights come tap-major from the parameter pass
+    # split-bf16 mode: BBB layers with Cin % 32 == 0 (never the first one: its input is the caller's fp32 batch) run on the
+    # MFMA-ready-operand kernel (ops.conv2d_c8x3_forward) -- their input travels channel-interleaved and already split ("c8 S3"),
+    # their weights come tap-major from the parameter pass.  Which kernel a layer takes is a property of the LAYER (not of the
+    # launch size), so that a work unit, a share of a group of steps and the whole step are the same bits.
     children = flat_children(net)
     last_bayes = max((i for i, m in enumerate(children) if isinstance(m, (_BBBLayer, _LRTLayer))), default=-1)
     tail_is_last = last_bayes == len(children) - 1
     split_mode = (precision == "bf16x3" or ops.current_config().gemm_mode == "bf16x3") and not bf16 and not lrt and bool(bbb) and tail_is_last
     c8_set = set()
-    if split_mode and ops.current_config().c8x3 and E * B >= ops.current_config().s3_min_images:
+    if split_mode and ops.current_config().c8x3:
         for l in bbb[1:]:
             cin = l.in_channels if isinstance(l, _BBBConv) else l.in_features
             cout = l.out_channels if isinstance(l, _BBBConv) else l.out_features

@@ -299,8 +299,8 @@ class LaunchConfig:
                 then filled by them, and fusing pays from ~2 items per CU on (measured, profiles/r04_notes.md section 7: -2 to
                 -3 % per step at 10 draws x 3 lanes, +4.5 % with one lane; at 5 draws per launch it no longer does)
     pool_fuse_weight_budget   bytes of weight tiles concurrently live per XCD that a fused launch may have (see pool_fusion_ok)
-    c8x3        split-bf16 mode: layers with Cin % 32 == 0 take the MFMA-ready-operand kernel (csrc/pconv_c8x3.hip) in chains of
-                >= s3_min_images rows"""
+    c8x3        split-bf16 mode: layers with Cin % 32 == 0 take the MFMA-ready-operand kernel (csrc/pconv_c8x3.hip), whatever the
+                launch size (a property of the layer: partitions of a step keep its bits)"""
     FIELDS = ("gemm_mode", "bf16x3_min_workgroups", "s3_min_images", "split_k", "pool_fusion", "pool_fuse_min_items",
               "pool_fuse_imbalance", "launches_overlap", "pool_fuse_min_items_overlapped", "pool_fuse_weight_budget",
               "bf16_pool_fuse_min_rows", "bf16_pool_fuse_min_rows_overlapped", "bf16_c8", "bf16_c8_min_items", "c8x3")
@@ -323,7 +323,7 @@ class LaunchConfig:
         self.bf16_c8 = True                            # (bf16_c8_input_ok) channel-interleaved activations between a pooled first layer and a
         self.bf16_c8_min_items = 0                     # layer that has the strip form over them, for launches of at least this many strip
                                                        # workgroups (0: always -- measured faster from one step per launch on); False: never
-        self.c8x3 = True                               # split-bf16 mode, steps of >= s3_min_images rows: layers with Cin % 32 == 0 run on the
+        self.c8x3 = True                               # split-bf16 mode: layers (behind the first) with Cin % 32 == 0 run on the
                                                        # MFMA-ready-operand kernel (conv2d_c8x3_forward: channel-interleaved split
                                                        # activations + tap-major weights from the parameter pass); False: round 4's
                                                        # kernel (split while staging / planar S3) everywhere
@@ -640,17 +640,21 @@ def w_tap_major(w):
 
 
 def c8x3_layer_ok(cin, cout, is_logits=False):
-    """May a BBB layer with these channel counts run on bbb_conv2d_c8x3_fwd?  (32-channel k tiles inside one tap; the output is
+    """May a BBB layer with these channel counts run on bbb_conv2d_c8x3_fwd?  (16-channel k steps inside one tap; the output is
     written in groups of 8 channels unless it is the fp32 logits tensor.)"""
-    return cin % 32 == 0 and (is_logits or cout % 8 == 0)
+    return cin % 16 == 0 and (is_logits or cout % 8 == 0)
 
 
 def conv2d_c8x3_forward(x, w_tm, bias, kernel_size, stride=1, padding=0, dilation=1, act=None, out_f32=False, out=None, units=None,
-                        n_units=None, x_div=1, x_off=0, tile=None):
+                        n_units=None, x_div=1, x_off=0, tile=None, nt=None, pool=False):
     """The split-bf16 contraction over MFMA-ready operands (bbb_conv2d_c8x3_fwd).  x: c8 S3 [E|1, 3, Cin / 8, H, W, B, 8];
     w_tm: fp32 tap-major [E|1, Cout, kh * kw, Cin]; bias [E|1, Cout] | None -> c8 S3 [E, 3, Cout / 8, Ho, Wo, B, 8], or with
     out_f32 the fp32 batch-innermost [E, Cout, Ho, Wo, B] (the logits layer).  Work units / x_div / x_off as conv2d_chwn_forward.
-    tile = 128 | 256: images per workgroup (None: the library picks by launch size; same bits either way)."""
+    tile = 128 | 256: images per workgroup, nt = 2 | 3 | 4: 32-channel tiles per workgroup (None: the library picks by layer and
+    launch size; same bits whatever the choice).
+    pool = True (padding 0, even Ho and Wo, c8 S3 output): the launch also applies MaxPool2d(2, 2) to the activated output ->
+    [E, 3, Cout / 8, Ho / 2, Wo / 2, B, 8], bit for bit maxpool_c8s3(conv2d_c8x3_forward(...), 2, 2); tile then means 32 | 64
+    images per workgroup (its four waves own the four pixels of a window)."""
     require_device(w_tm, bias)
     require_device(x, dtype=torch.bfloat16)
     x, w_tm = x.contiguous(), w_tm.contiguous()
@@ -682,6 +686,10 @@ def conv2d_c8x3_forward(x, w_tm, bias, kernel_size, stride=1, padding=0, dilatio
             raise _lib.BBBHipError("leading (draw) dims of x and w must be 1 or equal")
         d, ho, wo = _desc_chwn(x5, w5, stride, padding, dilation, E, Ex == 1 and E > 1, Ew == 1 and E > 1, act)
     d.x_draw_stride *= 3                                       # bf16 elements per slab of three planes
+    if pool:
+        if out_f32 or ho % 2 or wo % 2 or _pair(padding) != (0, 0):
+            raise _lib.BBBHipError("pool=True: c8 S3 output, no padding, even output height and width")
+        ho, wo = ho // 2, wo // 2
     if out_f32:
         shape, odt = (E, Cout, ho, wo, B), torch.float32
     else:
@@ -699,7 +707,8 @@ def conv2d_c8x3_forward(x, w_tm, bias, kernel_size, stride=1, padding=0, dilatio
         y = out.view(shape)
     with on_device(x.device):
         check(_lib.lib().bbb_conv2d_c8x3_fwd(ctypes.byref(d), x.data_ptr(), w_tm.data_ptr(), ptr(bias), y.data_ptr(),
-                                             (1 if out_f32 else 0) | {None: 0, 128: 2, 256: 4}[tile], cur_stream(x.device)),
+                                             (1 if out_f32 else 0) | {None: 0, 128: 2, 256: 4, 32: 2, 64: 4}[tile] | (8 if pool else 0) |
+                                             ({None: 0, 2: 2, 3: 3, 4: 4}[nt] << 4), cur_stream(x.device)),
               "bbb_conv2d_c8x3_fwd")
     return y
 

@@ -26,14 +26,33 @@
 
 namespace pconv {
 
+#ifndef C8X3_ABLATE
+#define C8X3_ABLATE 0            // experiments only (profiles/experiments/c8x3_ablate.sh): 1 no epilogue math, 2 no barriers, 3 no image loads,
+#endif                           // 4 no weight staging, 5 no matrix instructions in the k loop -- timing of what is left; results are garbage
 constexpr int C8_LDA = 40;               // bf16 elements per LDS weight row: 32 k + 8 pad = 80 bytes (16-lane groups hit 64 distinct banks)
-constexpr int C8_PLANE = 64 * C8_LDA;    // one plane of one stage: 64 channel rows
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
-template <int MT, bool OUTF32>
-__global__ __launch_bounds__(kThreads) void pconv_c8x3_kernel(const PConvArgs p) {
-    constexpr int BMW = 32 * MT, BM = 4 * BMW;
-    __shared__ __attribute__((aligned(16))) unsigned short Wp[2 * 3 * C8_PLANE];      // [stage][plane][n][k]: 30 KB
+// NT x MT: 32-channel x 32-image accumulator tiles per wave.  The workgroup's weight tile is 32 * NT channel rows; its four waves own
+//   * (plain form) 32 * MT images each of one output pixel: 128 * MT images per workgroup;
+//   * (POOLP, "parallel window") one pixel each of a 2 x 2 pooling window, the SAME 32 * MT images: the launch also applies the
+//     activation and MaxPool2d(2, 2) -- the four waves' activated tiles meet in LDS, the element-wise maximum is cut into its
+//     three pieces and stored.  For layers without padding (all four pixels walk the same taps, so the weight tile serves all of
+//     them); bit for bit the plain launch followed by bbb_maxpool_c8s3(2, 2).
+// The contraction walks the in-bounds taps in (r, q) order and the channels of a tap in 16-channel steps, two steps (32 k) per
+// weight tile; Cin % 16 == 0 (a tile may straddle two taps: the k runs of a tap are adjacent in a tap-major row, and a thread's
+// 8-k piece never straddles).  Every output element sees the same sequence of matrix instructions whatever NT, MT and the form.
+template <int NT, int MT, bool OUTF32, bool POOLP>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(NT * MT >= 8 ? 2 : 1)))      // (8 tiles: 128 + 128 registers)
+void pconv_c8x3_kernel(const PConvArgs p) {
+    constexpr int BNW = 32 * NT;                                     // channels per workgroup
+    constexpr int BMW = 32 * MT;                                     // images per wave
+    constexpr int BM = POOLP ? BMW : 4 * BMW;                        // images per workgroup
+    constexpr int PLANE = BNW * C8_LDA;                              // one plane of one stage
+    constexpr int WPASS = (BNW + 63) / 64;                           // 64 channel rows per staging pass
+    static_assert(!(OUTF32 && POOLP), "the pooled form writes c8 S3");
+    constexpr int kWpBytes = 2 * 3 * PLANE * 2;
+    constexpr int kLdsBytes = (POOLP && kWpBytes < 16384) ? 16384 : kWpBytes;       // (POOLP: the window exchange needs 16 KB)
+    __shared__ __attribute__((aligned(16))) unsigned short Wp[kLdsBytes / 2];        // [stage][plane][n][k]
 
     const int bid = blockIdx.x;
     const int xcd = bid & 7;
@@ -46,10 +65,25 @@ __global__ __launch_bounds__(kThreads) void pconv_c8x3_kernel(const PConvArgs p)
     const int ue = p.unit_off + e;
     const int ew = p.unit_div > 1 ? ue / p.unit_div : e;
     const int ex = p.x_div > 1 ? (e + p.x_off) / p.x_div : (p.x_mod > 0 ? ue % p.x_mod : e);
-    const int n0 = (g - e * p.Ntiles) * BN;
-    const int pix = j / p.nbt;
+    const int n0 = (g - e * p.Ntiles) * BNW;
+    const int pix = j / p.nbt;                                       // output pixel (POOLP: pooled pixel)
     const int b0 = (j - pix * p.nbt) * BM;
-    const int oh = pix / p.Wo, ow = pix - oh * p.Wo;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane & 31, lk = lane >> 5;
+
+    int oh, ow;
+    if constexpr (POOLP) {
+        const int pw2 = p.Wo >> 1;
+        const int poh = pix / pw2, pow_ = pix - poh * pw2;
+        oh = 2 * poh + (wave >> 1);
+        ow = 2 * pow_ + (wave & 1);
+    } else {
+        oh = pix / p.Wo;
+        ow = pix - oh * p.Wo;
+    }
     const int ihb = oh * p.sh - p.ph, iwb = ow * p.sw - p.pw;
     int r_lo = ihb < 0 ? (-ihb + p.dh - 1) / p.dh : 0;
     int q_lo = iwb < 0 ? (-iwb + p.dw - 1) / p.dw : 0;
@@ -58,21 +92,18 @@ __global__ __launch_bounds__(kThreads) void pconv_c8x3_kernel(const PConvArgs p)
     r_hi = r_hi < p.kh ? r_hi : p.kh;
     q_hi = q_hi < p.kw ? q_hi : p.kw;
     const int nr = r_hi > r_lo ? r_hi - r_lo : 0;
-    const int nq = q_hi > q_lo ? q_hi - q_lo : 0;
-    const int cpt = p.Cin >> 5;                                      // 32-channel tiles per tap
-    const int ntiles = nr * nq * cpt;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lrow = lane & 31, lk = lane >> 5;
+    const int nq = q_hi > q_lo ? q_hi - q_lo : 0;                    // (POOLP: no padding -- the same for the four waves)
+    const int n16 = p.Cin >> 4;                                      // 16-channel steps per tap
+    const int nsteps = nr * nq * n16;
+    const int ntiles = (nsteps + 1) >> 1;
 
     constexpr uint32_t kOOB = 0xFFFFFFF0u;
-    // weights: fp32, tap-major rows of Kp elements; thread (channel row tid / 4, 8 consecutive k of the tile)
+    // weights: fp32, tap-major rows of Kp elements; thread (channel row tid / 4 [+ 64 per pass], 8 consecutive k of the tile)
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.w + (int64_t)ew * p.w_ds), 0, (int)((int64_t)p.Cout * p.Kp * 4), 0x00020000);
     const int wn = tid >> 2, wk = (tid & 3) * 8;
-    const uint32_t wrow = ((uint32_t)(n0 + wn) * (uint32_t)p.Kp + (uint32_t)wk) * 4u;       // rows >= Cout: out of range, read as 0
+    const uint32_t wrow = ((uint32_t)(n0 + wn) * (uint32_t)p.Kp) * 4u;                      // rows >= Cout: out of range, read as 0
+    const uint32_t wpass = 64u * (uint32_t)p.Kp * 4u;
     // images: one descriptor over the slab's three planes; lane (image lrow of the wave's block, k half lk)
     const unsigned short* const xb16 = reinterpret_cast<const unsigned short*>(p.x) + (int64_t)ex * p.x_ds;
     const uint32_t xplane = (uint32_t)(p.x_ps * 2);                  // bytes per plane
@@ -80,43 +111,62 @@ __global__ __launch_bounds__(kThreads) void pconv_c8x3_kernel(const PConvArgs p)
     const uint32_t img_b = (uint32_t)p.B * 16u;                      // bytes per (channel group, position)
     const uint32_t grp_b = (uint32_t)(p.H * p.W) * img_b;            // bytes per channel group of 8
     // Out-of-range addressing without selects: every slab is < 1 GiB (checked by the launcher), an image column past the batch
-    // carries 0x80000000 in its lane offset and a step past the last tile 0x40000000 in its uniform offset -- any sum holding one
+    // carries 0x80000000 in its lane offset and a step past the last one 0x40000000 in its uniform offset -- any sum holding one
     // of the two lies in [0x40000000, 2^32) and reads zeros (no wrap: the in-range parts stay below 0x40000000).
     constexpr uint32_t kLaneInv = 0x80000000u, kStepInv = 0x40000000u;
     uint32_t xlane[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        const int b = b0 + wave * BMW + mt * 32 + lrow;
+        const int b = b0 + (POOLP ? 0 : wave * BMW) + mt * 32 + lrow;
         xlane[mt] = b < p.B ? (uint32_t)b * 16u + (uint32_t)lk * grp_b : kLaneInv;
     }
 
-    // the tile AHEAD of the one being multiplied: tap (rr, qq) of the pixel's in-bounds rectangle, 32-channel block c32
-    int nx_rr = 0, nx_qq = 0, nx_c32 = 0;
-    uint32_t nx_w = 0, nx_x = 0;                                     // uniform byte offsets of that tile (weights / images)
-    auto cursor_offsets = [&]() {
-        const int r = r_lo + nx_rr, q = q_lo + nx_qq;
-        nx_w = (uint32_t)((r * p.kw + q) * p.Cin + nx_c32 * 32) * 4u;
-        nx_x = (uint32_t)(nx_c32 * 4) * grp_b + (uint32_t)((ihb + r * p.dh) * p.W + iwb + q * p.dw) * img_b;
-    };
-    auto cursor_advance = [&]() {
-        if (++nx_c32 == cpt) {
-            nx_c32 = 0;
-            if (++nx_qq == nq) { nx_qq = 0; ++nx_rr; }
+    // image-side cursor (wave-uniform): the 16-channel step AHEAD of the ones being multiplied -- tap (rr, qq) of the pixel's
+    // in-bounds rectangle, 16-channel block c16
+    int sx_rr = 0, sx_qq = 0, sx_c16 = 0, sx_left = nsteps;
+    auto next_step_offset = [&]() -> uint32_t {
+        if (sx_left <= 0) return kStepInv;
+        const int r = r_lo + sx_rr, q = q_lo + sx_qq;
+        const uint32_t o = (uint32_t)(sx_c16 * 2) * grp_b + (uint32_t)((ihb + r * p.dh) * p.W + iwb + q * p.dw) * img_b;
+        --sx_left;
+        if (++sx_c16 == n16) {
+            sx_c16 = 0;
+            if (++sx_qq == nq) { sx_qq = 0; ++sx_rr; }
         }
-        cursor_offsets();
+        return o;
+    };
+    // weight-side cursor (per thread: the four 8-k pieces of a tile may lie in two taps): piece (tid & 3) of the tile ahead
+    int wc_rr, wc_qq, wc_ch;
+    {
+        const int tapi = wk / p.Cin;                                 // Cin >= 16: 0 or 1
+        wc_ch = wk - tapi * p.Cin;
+        wc_rr = nq > 0 ? tapi / nq : 0;
+        wc_qq = nq > 0 ? tapi - wc_rr * nq : 0;
+    }
+    auto next_piece_offset = [&]() -> uint32_t {
+        const uint32_t o = wc_rr < nr ? (uint32_t)(((r_lo + wc_rr) * p.kw + q_lo + wc_qq) * p.Cin + wc_ch) * 4u : kStepInv;
+        wc_ch += 32;
+        while (wc_ch >= p.Cin) {
+            wc_ch -= p.Cin;
+            if (++wc_qq >= nq) { wc_qq = 0; ++wc_rr; }
+        }
+        return o;
     };
 
-    f32x4 wreg[2];
+    f32x4 wreg[WPASS][2];
     bf16x8 bfr[2][MT][3];
     // (unconditional loads with out-of-range offsets instead of branches: with branches around them the compiler drains every
     // outstanding load at every step)
-    auto wload = [&](bool ok) {
-        const uint32_t o = wrow + (ok ? nx_w : kStepInv);
-        wreg[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, o, 0, 0));
-        wreg[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, o + 16u, 0, 0));
+    auto wload = [&]() {
+        const uint32_t o = wrow + next_piece_offset();
+#pragma unroll
+        for (int ps = 0; ps < WPASS; ++ps) {
+            wreg[ps][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, o + (uint32_t)ps * wpass, 0, 0));
+            wreg[ps][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, o + (uint32_t)ps * wpass + 16u, 0, 0));
+        }
     };
-    auto bload = [&](int s, bool ok) {
-        const uint32_t u = ok ? nx_x + (uint32_t)(2 * s) * grp_b : kStepInv;
+    auto bload = [&](int s) {
+        const uint32_t u = next_step_offset();
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -124,76 +174,82 @@ __global__ __launch_bounds__(kThreads) void pconv_c8x3_kernel(const PConvArgs p)
                 bfr[s][mt][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xrs, xlane[mt] + u + (uint32_t)pl * xplane, 0, 0));
     };
     auto wstore = [&](int stage) {
-        u32x4 h, m, l;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            uint32_t a0, a1, a2;
-            const f32x4 v = wreg[i >> 1];
-            split3_pair((i & 1) ? f32x2{v[2], v[3]} : f32x2{v[0], v[1]}, a0, a1, a2);
-            h[i] = a0; m[i] = a1; l[i] = a2;
+        for (int ps = 0; ps < WPASS; ++ps) {
+            if ((BNW % 64) != 0 && ps == WPASS - 1 && wn >= (BNW % 64)) break;      // 96-row tiles: the last pass holds 32 rows
+            u32x4 h, m, l;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uint32_t a0, a1, a2;
+                const f32x4 v = wreg[ps][i >> 1];
+                split3_pair((i & 1) ? f32x2{v[2], v[3]} : f32x2{v[0], v[1]}, a0, a1, a2);
+                h[i] = a0; m[i] = a1; l[i] = a2;
+            }
+            unsigned short* const base = Wp + stage * (3 * PLANE) + (wn + 64 * ps) * C8_LDA + wk;
+            *reinterpret_cast<u32x4*>(base) = h;
+            *reinterpret_cast<u32x4*>(base + PLANE) = m;
+            *reinterpret_cast<u32x4*>(base + 2 * PLANE) = l;
         }
-        unsigned short* const base = Wp + stage * (3 * C8_PLANE) + wn * C8_LDA + wk;
-        *reinterpret_cast<u32x4*>(base) = h;
-        *reinterpret_cast<u32x4*>(base + C8_PLANE) = m;
-        *reinterpret_cast<u32x4*>(base + 2 * C8_PLANE) = l;
     };
 
-    f32x16 acc[2][MT];
+    f32x16 acc[NT][MT];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int u = 0; u < MT; ++u)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.0f;
 
     auto step = [&](int stage, int s) {
-        bf16x8 a[2][3];
-        const unsigned short* const base = Wp + stage * (3 * C8_PLANE) + lrow * C8_LDA + s * 16 + lk * 8;
+        const unsigned short* const base = Wp + stage * (3 * PLANE) + lrow * C8_LDA + s * 16 + lk * 8;
+        // channel tiles in pairs (a pair's 6 operand fragments live at a time); small terms first; the accumulators of a pair
+        // take turns, so consecutive matrix instructions are independent
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int n2 = 0; n2 < NT; n2 += 2) {
+            constexpr int kPairMax = 2;
+            bf16x8 a[kPairMax][3];
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-                a[nt][pl] = *reinterpret_cast<const bf16x8*>(base + pl * C8_PLANE + nt * 32 * C8_LDA);
-        // small terms first; the 2 * MT accumulators take turns, so consecutive matrix instructions are independent
+            for (int nt = 0; nt < kPairMax; ++nt)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    if (n2 + nt < NT) a[nt][pl] = *reinterpret_cast<const bf16x8*>(base + pl * PLANE + (n2 + nt) * 32 * C8_LDA);
 #define C8X3_TERM(PA, PB)                                                                                           \
-        _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                            \
-            _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                       \
-                acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[nt][PA], bfr[s][mt][PB], acc[nt][mt], 0, 0, 0);
-        C8X3_TERM(2, 0)
-        C8X3_TERM(0, 2)
-        C8X3_TERM(1, 1)
-        C8X3_TERM(1, 0)
-        C8X3_TERM(0, 1)
-        C8X3_TERM(0, 0)
+            _Pragma("unroll") for (int nt = 0; nt < kPairMax; ++nt)                                                 \
+                _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                   \
+                    if (n2 + nt < NT)                                                                               \
+                        acc[n2 + nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[nt][PA], bfr[s][mt][PB], acc[n2 + nt][mt], 0, 0, 0);
+            C8X3_TERM(2, 0)
+            C8X3_TERM(0, 2)
+            C8X3_TERM(1, 1)
+            C8X3_TERM(1, 0)
+            C8X3_TERM(0, 1)
+            C8X3_TERM(0, 0)
 #undef C8X3_TERM
+        }
     };
 
     if (ntiles > 0) {
-        cursor_offsets();
-        wload(true);
-        bload(0, true);
-        bload(1, true);
+        wload();
+        bload(0);
+        bload(1);
         wstore(0);
-        cursor_advance();
         __syncthreads();
         for (int t = 0; t < ntiles; ++t) {
-            const bool more = (t + 1) < ntiles;
             const int stage = t & 1;
             // issue order pinned with scheduling barriers: left alone, the compiler sinks every load below the step's matrix
             // instructions (right in front of its first use), i.e. out of their shadow
-            wload(more);
+            if (C8X3_ABLATE != 4) wload();                           // (past the last tile: out-of-range offsets, zeros)
             __builtin_amdgcn_sched_barrier(0);
-            step(stage, 0);
+            if (C8X3_ABLATE != 5) step(stage, 0);
             __builtin_amdgcn_sched_barrier(0);
-            bload(0, more);
+            if (C8X3_ABLATE != 3) bload(0);
             __builtin_amdgcn_sched_barrier(0);
-            step(stage, 1);
+            if (C8X3_ABLATE != 5) step(stage, 1);
             __builtin_amdgcn_sched_barrier(0);
-            bload(1, more);
+            if (C8X3_ABLATE != 3) bload(1);
             __builtin_amdgcn_sched_barrier(0);
-            wstore(stage ^ 1);                                       // (after the last tile: zeros into a stage nobody reads)
-            cursor_advance();
-            __syncthreads();
+            if (C8X3_ABLATE != 4) wstore(stage ^ 1);                 // (after the last tile: zeros into a stage nobody reads)
+            if (C8X3_ABLATE != 2) __syncthreads();
         }
     }
 
@@ -207,7 +263,7 @@ __global__ __launch_bounds__(kThreads) void pconv_c8x3_kernel(const PConvArgs p)
         const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
             p.y + (int64_t)e * p.y_ds, 0, (int)((int64_t)p.Cout * HoWo * p.B * 4), 0x00020000);
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
@@ -227,28 +283,68 @@ __global__ __launch_bounds__(kThreads) void pconv_c8x3_kernel(const PConvArgs p)
         unsigned short* const yb16 = reinterpret_cast<unsigned short*>(p.y) + (int64_t)e * p.y_ds;
         const uint32_t yplane = (uint32_t)(p.y_ps * 2);
         const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(yb16, 0, (int)(3u * yplane), 0x00020000);
+        auto store4 = [&](const float (&o)[4], int n, int b, int opix, int opixels) {       // channels n + 4 lk .. + 3 of image b
+            uint32_t h0, m0, l0, h1, m1, l1;
+            if (C8X3_ABLATE == 1) {
+                h0 = m0 = l0 = __builtin_bit_cast(uint32_t, o[0] + o[1]); h1 = m1 = l1 = __builtin_bit_cast(uint32_t, o[2] + o[3]);
+            } else {
+                split3_pair(f32x2{o[0], o[1]}, h0, m0, l0);
+                split3_pair(f32x2{o[2], o[3]}, h1, m1, l1);
+            }
+            const uint32_t off = ((b < p.B) & (n < p.Cout))
+                ? (uint32_t)((((int64_t)(n >> 3) * opixels + opix) * p.B + b) * 16 + lk * 8) : kOOB;
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2{h0, h1}, yrs, off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2{m0, m1}, yrs, off == kOOB ? kOOB : off + yplane, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2{l0, l1}, yrs, off == kOOB ? kOOB : off + 2u * yplane, 0, 0);
+        };
+        if constexpr (!POOLP) {
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const int n = n0 + nt * 32 + 8 * r4;                     // first channel of the group of 8 (this lane: + 4 lk .. + 3)
-                const f32x4 bq = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, (uint32_t)(n + 4 * lk) * 4u, 0, 0));
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int n = n0 + nt * 32 + 8 * r4;                 // first channel of the group of 8 (this lane: + 4 lk .. + 3)
+                    const f32x4 bq = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, (uint32_t)(n + 4 * lk) * 4u, 0, 0));
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const int b = b0 + wave * BMW + mt * 32 + lrow;
+                        float o[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) o[c] = C8X3_ABLATE == 1 ? acc[nt][mt][4 * r4 + c] : bbb::apply_act(acc[nt][mt][4 * r4 + c] + bq[c], p.act);
+                        store4(o, n, b, pix, HoWo);
+                    }
+                }
+        } else {
+            // 2 x 2 window: every wave activates its pixel's tile; per (channel tile, image tile) the four waves' 16 registers meet
+            // in LDS ([wave][r4][lane] 16-byte vectors: conflict-free both ways) and wave w finishes channel group r4 = w
+            f32x4* const ex4 = reinterpret_cast<f32x4*>(Wp);             // (the k loop's last barrier is behind every wave)
+            const int opixels = HoWo >> 2;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
-                    const int b = b0 + wave * BMW + mt * 32 + lrow;
-                    float o[4];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) o[c] = bbb::apply_act(acc[nt][mt][4 * r4 + c] + bq[c], p.act);
-                    uint32_t h0, m0, l0, h1, m1, l1;
-                    split3_pair(f32x2{o[0], o[1]}, h0, m0, l0);
-                    split3_pair(f32x2{o[2], o[3]}, h1, m1, l1);
-                    const uint32_t off = ((b < p.B) & (n < p.Cout))
-                        ? (uint32_t)((((int64_t)(n >> 3) * HoWo + pix) * p.B + b) * 16 + lk * 8) : kOOB;
-                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{h0, h1}, yrs, off, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{m0, m1}, yrs, off == kOOB ? kOOB : off + yplane, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{l0, l1}, yrs, off == kOOB ? kOOB : off + 2u * yplane, 0, 0);
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const int n = n0 + nt * 32 + 8 * r4;
+                        const f32x4 bq = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, (uint32_t)(n + 4 * lk) * 4u, 0, 0));
+                        f32x4 o;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) o[c] = bbb::apply_act(acc[nt][mt][4 * r4 + c] + bq[c], p.act);
+                        ex4[(wave * 4 + r4) * 64 + lane] = o;
+                    }
+                    __syncthreads();
+                    f32x4 v = ex4[(0 * 4 + wave) * 64 + lane];
+#pragma unroll
+                    for (int w2 = 1; w2 < 4; ++w2) {
+                        const f32x4 u = ex4[(w2 * 4 + wave) * 64 + lane];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], u[c]);
+                    }
+                    const float o4[4] = {v[0], v[1], v[2], v[3]};
+                    store4(o4, n0 + nt * 32 + 8 * wave, b0 + mt * 32 + lrow, pix, opixels);
+                    __syncthreads();
                 }
             }
+        }
     }
 }
 
@@ -311,9 +407,20 @@ __global__ __launch_bounds__(256) void w_tap_major_kernel(const float* __restric
 
 using namespace pconv;
 
+namespace {
+template <int NT, int MT>
+void launch_c8x3(bool of32, bool poolp, dim3 grid, hipStream_t st, const PConvArgs& a) {
+    const dim3 block(kThreads);
+    if (poolp)     hipLaunchKernelGGL((pconv_c8x3_kernel<NT, MT, false, true>), grid, block, 0, st, a);
+    else if (of32) hipLaunchKernelGGL((pconv_c8x3_kernel<NT, MT, true, false>), grid, block, 0, st, a);
+    else           hipLaunchKernelGGL((pconv_c8x3_kernel<NT, MT, false, false>), grid, block, 0, st, a);
+}
+}  // namespace
+
 extern "C" int bbb_conv2d_c8x3_fwd(const bbb_conv_desc_t* d, const void* x, const float* w, const float* bias, void* y, uint32_t flags,
                                    void* stream) {
-    if (d == nullptr || x == nullptr || w == nullptr || y == nullptr || (flags & ~(BBB_C8X3_OUT_F32 | BBB_C8X3_TILE128 | BBB_C8X3_TILE256)) != 0 ||
+    constexpr uint32_t kKnown = BBB_C8X3_OUT_F32 | BBB_C8X3_TILE128 | BBB_C8X3_TILE256 | BBB_C8X3_POOL | BBB_C8X3_NT_MASK;
+    if (d == nullptr || x == nullptr || w == nullptr || y == nullptr || (flags & ~kKnown) != 0 ||
         ((flags & BBB_C8X3_TILE128) && (flags & BBB_C8X3_TILE256)))
         return BBB_EINVAL;
     if (d->batch <= 0 || d->cin <= 0 || d->h <= 0 || d->w <= 0 || d->cout <= 0 || d->kh <= 0 || d->kw <= 0 || d->stride_h <= 0 ||
@@ -321,19 +428,25 @@ extern "C" int bbb_conv2d_c8x3_fwd(const bbb_conv_desc_t* d, const void* x, cons
         d->pool != 0 || d->w_row_pitch != 0)
         return BBB_EINVAL;
     const bool of32 = (flags & BBB_C8X3_OUT_F32) != 0;
-    if (d->cin % 32 != 0 || d->batch % 4 != 0 || (!of32 && d->cout % 8 != 0)) return BBB_ESHAPE;
+    const bool poolp = (flags & BBB_C8X3_POOL) != 0;
+    const int nt_force = (int)((flags & BBB_C8X3_NT_MASK) >> BBB_C8X3_NT_SHIFT);
+    if (nt_force == 1 || nt_force > 4 || (poolp && of32)) return BBB_EINVAL;
+    if (d->cin % 16 != 0 || d->batch % 4 != 0 || (!of32 && d->cout % 8 != 0)) return BBB_ESHAPE;
     const int ho = (d->h + 2 * d->pad_h - d->dil_h * (d->kh - 1) - 1) / d->stride_h + 1;
     const int wo = (d->w + 2 * d->pad_w - d->dil_w * (d->kw - 1) - 1) / d->stride_w + 1;
     if (ho <= 0 || wo <= 0) return BBB_ESHAPE;
+    // the pooled form: no padding (the four pixels of a window walk the same taps), even output height and width
+    if (poolp && (d->pad_h != 0 || d->pad_w != 0 || ho % 2 != 0 || wo % 2 != 0)) return BBB_ESHAPE;
     if ((((uintptr_t)x | (uintptr_t)y) & 15u) != 0 || (((uintptr_t)w) & 15u) != 0 || (((uintptr_t)bias) & (of32 ? 3u : 15u)) != 0) return BBB_EALIGN;
     PConvArgs a = {};
     a.B = d->batch; a.Cin = d->cin; a.H = d->h; a.W = d->w; a.Cout = d->cout; a.kh = d->kh; a.kw = d->kw;
     a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w; a.dh = d->dil_h; a.dw = d->dil_w;
     a.Ho = ho; a.Wo = wo; a.K = d->cin * d->kh * d->kw; a.Kp = a.K; a.khkw = d->kh * d->kw; a.act = d->act;
+    a.pool = poolp ? 1 : 0;
     a.x_ps = (int64_t)a.Cin * a.H * a.W * a.B;
-    a.y_ps = (int64_t)a.Cout * ho * wo * a.B;
+    a.y_ps = (int64_t)a.Cout * ho * wo * a.B / (poolp ? 4 : 1);
     // slabs are addressed through 32-bit buffer offsets (three planes of 2-byte elements, or fp32 outputs)
-    if (6 * a.x_ps >= 0x3FFF0000LL || 6 * a.y_ps >= 0x3FFF0000LL || ((int64_t)a.Cout + 64) * a.K * 4 >= 0x3FFF0000LL) return BBB_ESHAPE;
+    if (6 * a.x_ps >= 0x3FFF0000LL || 6 * a.y_ps >= 0x3FFF0000LL || ((int64_t)a.Cout + 128) * a.K * 4 >= 0x3FFF0000LL) return BBB_ESHAPE;
     if (d->x_draw_stride != 0 && d->x_draw_stride < 3 * a.x_ps) return BBB_EINVAL;
     if (d->w_draw_stride % 4 != 0 || (!of32 && d->b_draw_stride % 4 != 0) || d->x_draw_stride % 8 != 0) return BBB_EALIGN;
     a.x_ds = d->x_draw_stride; a.w_ds = d->w_draw_stride; a.b_ds = d->b_draw_stride;
@@ -347,33 +460,56 @@ extern "C" int bbb_conv2d_c8x3_fwd(const bbb_conv_desc_t* d, const void* x, cons
     a.unit_div = d->unit_div; a.unit_off = d->unit_div > 1 ? d->unit_off : 0; a.x_mod = d->x_unit_mod;
     a.x_div = d->x_unit_div; a.x_off = d->x_unit_off;
     a.x = static_cast<const float*>(x); a.w = w; a.bias = bias; a.y = static_cast<float*>(y);
-    a.Ntiles = (a.Cout + BN - 1) / BN;
-    a.G = a.Ntiles * d->draws;
-    const int64_t pixels = (int64_t)ho * wo;
-    // 256 images per workgroup (a wave's image fragments feed two channel tiles AND its weight fragments two image tiles) when that
-    // still leaves the chip two rounds of workgroups; 128 otherwise.  Same MFMA sequence per output element either way.
-    int mt = 2;
+    const int64_t pixels = (int64_t)ho * wo / (poolp ? 4 : 1);
+    // Tile shape (the MFMA sequence per output element, hence every output bit, does not depend on it).  Channels per workgroup
+    // 32 * NT: the fewer channel tiles share an image fragment's trip from L2, the better -- 128 (NT = 4) when the layer's channels
+    // fill such tiles, 96 (NT = 3) for multiples of 96, else 64; images per wave 32 * MT: 64, or 32 when the launch would otherwise
+    // leave the chip less than ~two rounds of workgroups (small launches step down NT as well).
+    int nt = 2, mt = 2;
     {
-        const int64_t items256 = (int64_t)a.G * pixels * ((a.B + 255) / 256);
+        static const int env_nt = [] { const char* s = getenv("BBB_C8X3_NT"); return s ? atoi(s) : 0; }();   // (experiments)
+        const int wg_per_cu4 = 2, wg_per_cu2 = 3;                // resident workgroups per CU: NT = 4 / 3 (registers), NT = 2
+        auto items = [&](int n, int m) {
+            return (int64_t)d->draws * ((a.Cout + 32 * n - 1) / (32 * n)) * pixels * ((a.B + (poolp ? 32 : 128) * m - 1) / ((poolp ? 32 : 128) * m));
+        };
+        auto waste = [&](int n) { return (double)((a.Cout + 32 * n - 1) / (32 * n) * 32 * n) / (double)a.Cout; };
         if (flags & BBB_C8X3_TILE128) mt = 1;
         else if (flags & BBB_C8X3_TILE256) mt = 2;
-        else if (a.B <= 128 || items256 < 1024) mt = 1;
+        int want_nt = nt_force ? nt_force : (env_nt >= 2 && env_nt <= 4 ? env_nt : 0);
+        if (want_nt == 0) {
+            // candidates in order of preference; a candidate qualifies when its padding waste is no larger than NT = 2's and the launch
+            // still holds two rounds of its resident workgroups
+            want_nt = 2;
+            for (int n : {4, 3}) {
+                if (waste(n) > waste(2) + 1e-9) continue;
+                if (items(n, 1) >= 2 * 256 * wg_per_cu4) { want_nt = n; break; }
+            }
+        }
+        nt = want_nt;
+        if (!(flags & (BBB_C8X3_TILE128 | BBB_C8X3_TILE256))) {
+            const int64_t slots = 256 * (nt == 2 ? wg_per_cu2 : wg_per_cu4);
+            mt = (a.B <= (poolp ? 32 : 128) || items(nt, 2) < 2 * slots) ? 1 : 2;
+        }
     }
-    a.nbt = (a.B + 128 * mt - 1) / (128 * mt);
+    const int bnw = 32 * nt, bm = (poolp ? 32 : 128) * mt;
+    a.Ntiles = (a.Cout + bnw - 1) / bnw;
+    a.G = a.Ntiles * d->draws;
+    a.nbt = (a.B + bm - 1) / bm;
     const int64_t mtiles = pixels * a.nbt;
     if (mtiles > 0x7fffffffLL) return BBB_ESHAPE;
     a.Mtiles = (int)mtiles;
     const int64_t per = ((int64_t)a.G * mtiles + 7) / 8;
     if (8 * per > 0x7fffffffLL) return BBB_ESHAPE;
     a.per_xcd = (int32_t)per;
-    const dim3 grid((unsigned)(8 * per)), block(kThreads);
+    const dim3 grid((unsigned)(8 * per));
     hipStream_t st = (hipStream_t)stream;
-    if (mt == 2) {
-        if (of32) hipLaunchKernelGGL((pconv_c8x3_kernel<2, true>), grid, block, 0, st, a);
-        else      hipLaunchKernelGGL((pconv_c8x3_kernel<2, false>), grid, block, 0, st, a);
-    } else {
-        if (of32) hipLaunchKernelGGL((pconv_c8x3_kernel<1, true>), grid, block, 0, st, a);
-        else      hipLaunchKernelGGL((pconv_c8x3_kernel<1, false>), grid, block, 0, st, a);
+    switch (nt * 10 + mt) {
+        case 21: launch_c8x3<2, 1>(of32, poolp, grid, st, a); break;
+        case 22: launch_c8x3<2, 2>(of32, poolp, grid, st, a); break;
+        case 31: launch_c8x3<3, 1>(of32, poolp, grid, st, a); break;
+        case 32: launch_c8x3<3, 2>(of32, poolp, grid, st, a); break;
+        case 41: launch_c8x3<4, 1>(of32, poolp, grid, st, a); break;
+        default: launch_c8x3<4, 2>(of32, poolp, grid, st, a); break;
     }
     return (int)hipGetLastError();
 }
