@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define BBB_ABI_VERSION 11
+#define BBB_ABI_VERSION 12
 #define BBB_MAX_SEGMENTS 16
 
 #define BBB_EINVAL (-1)   /* bad argument (null pointer, non-positive size, too many segments) */
@@ -268,6 +268,17 @@ int bbb_s3_convert(const void* src, void* dst, int64_t slabs, int64_t n, int to_
 int bbb_conv2d_c8x3_fwd(const bbb_conv_desc_t* d, const void* x, const float* w, const float* bias, void* y, uint32_t flags,
                         void* stream);
 int bbb_c8s3_convert(const void* src, void* dst, int64_t slabs, int channels, int64_t positions, int batch, int to_c8s3, void* stream);
+/*
+ * Space-to-depth operands (ABI 12): a strided layer with few input channels (AlexNet conv1: 3 channels, 11 x 11, stride 4, padding 5 --
+ * models/BayesianModels/BayesianAlexNet.py:33) as a layer bbb_conv2d_c8x3_fwd can take.  With m = ceil(k / stride) it is the m x m
+ * convolution, stride 1, no padding, of the block image x'[(c s + dy) s + dx][bh][bw] = xpad[c][s bh + dy][s bw + dx] with weights
+ * w'[(mr, mq)][(c s + dy) s + dx] = w[c][s mr + dy][s mq + dx] (zero outside the k x k taps); C' = channels * stride^2 rounded up to a
+ * multiple of 16.  Same products as F.conv2d(x, w, stride, padding) of layers/BBB/BBBConv.py:77 plus exact zeros.
+ * bbb_s2d_c8s3: the caller's NCHW fp32 batch [blocks * batch][channels][h][w] -> c8 S3 [blocks][3][C' / 8][ho + m - 1][wo + m - 1][batch][8]
+ * (one block per batch slice / per step of a launch); bbb_w_s2d_tap_major: w [rows][channels][k][k] -> [rows][m * m][C'].
+ */
+int bbb_s2d_c8s3(const float* x, void* y, int64_t blocks, int batch, int channels, int h, int w, int k, int stride, int pad, void* stream);
+int bbb_w_s2d_tap_major(const float* w, float* out, int64_t rows, int channels, int k, int stride, void* stream);
 /* w [rows][cin][taps] -> out [rows][taps][cin] (rows = draws * cout): the tap-major weight layout from the reference's. */
 int bbb_w_tap_major(const float* w, float* out, int64_t rows, int cin, int taps, void* stream);
 int bbb_lrt_conv2d_chwn_fwd(const bbb_conv_desc_t* d, const float* x, const float* w_mu, const float* w_var,

@@ -438,14 +438,28 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
             cout = l.out_channels if isinstance(l, _BBBConv) else l.out_features
             if ops.c8x3_layer_ok(cin, cout, is_logits=(l is children[last_bayes])):
                 c8_set.add(l)
+    # ... and a strided first layer on few channels (AlexNet conv1) joins the chain in space-to-depth form (ops.s2d_layer_ok): its block
+    # image is cut from the caller's NCHW batch in c8 S3 directly, its dense weight draws are rearranged by one small launch
+    s2d_first = None
+    if split_mode and ops.current_config().c8x3 and ops.current_config().c8x3_s2d and children and children[0] is bbb[0] and \
+            isinstance(bbb[0], _BBBConv) and bbb[0] not in c8_set and x.dim() == 4 and last_bayes != 0:
+        l0 = bbb[0]
+        if ops.s2d_layer_ok(l0.in_channels, l0.out_channels, l0.kernel_size, l0.stride, l0.padding, l0.dilation, x.shape[2], x.shape[3]):
+            s2d_first = l0
     if bbb:
         sampled, kl = _sample_all_bf16(bbb, n_draws, seed, call0, timers) if bf16 else _sample_all(bbb, n_draws, seed, call0, timers, tm=c8_set)
     if lrt:
         variances, k2 = _variances_all(lrt, timers)
         kl = k2 if kl is None else kl + k2
     to_cb = ops.to_batch_innermost_bf16 if bf16 else ops.to_batch_innermost
-    if S > 1 or G > 1 or share is not None:                     # [S, C, H, W, B/S]: one batch-innermost block per slice / per step
-        nblk = S if S > 1 else nb
+    nblk = (S if S > 1 else nb) if (S > 1 or G > 1 or share is not None) else 1
+    xs2d = w_s2d = None
+    if s2d_first is not None:
+        l0 = s2d_first
+        xt = None
+        xs2d = _run(timers, "layout", None, lambda: ops.s2d_c8s3(x, nblk, l0.kernel_size, l0.stride, l0.padding))   # [nblk, 3, C'/8, Hb, Wb, B, 8]
+        w_s2d = _run(timers, "layout", None, lambda: ops.w_s2d_tap_major(sampled[l0][0], l0.stride))                  # [n_draws, Cout, m*m, C']
+    elif nblk > 1 or S > 1 or G > 1 or share is not None:       # [S, C, H, W, B/S]: one batch-innermost block per slice / per step
         xt = ops.to_batch_innermost_bf16_slices(x, nblk) if bf16 else ops.to_batch_innermost_slices(x, nblk)
     else:
         xt = to_cb(x).unsqueeze(0)                              # [1, C, H, W, B], shared by all draws
@@ -461,7 +475,7 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
     def run(e0, e1):
         """Layers for draws [e0, e1) on the current stream -> logits [e1-e0, C, B] (or None: fall back)."""
         nonlocal logits_buf
-        B = xt.shape[-1]
+        B = xs2d.shape[5] if xs2d is not None else xt.shape[-1]
         Es = e1 - e0
         h = xt
         s3 = False                     # h is an S3 tensor [E, 3, C, H, W, B] (split-bf16 chain)
@@ -474,6 +488,28 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
             mod = children[i]
             nxt = children[i + 1] if i + 1 < len(children) else None
             act = _act_name(nxt) if nxt is not None else None
+            if mod is s2d_first and i == 0:
+                # the first layer in space-to-depth form: an m x m layer, stride 1, no padding, on the block image; [activation ->]
+                # MaxPool2d(2, 2) inside the launch (every window walks the same taps: the parallel-window form)
+                w, b = w_s2d, sampled[mod][1]
+                if not ukw:
+                    w = w[e0:e1]
+                    b = None if b is None else b[e0:e1]
+                m_ = int(round(w.shape[2] ** 0.5))
+                g_ = ops.s2d_geometry(mod.in_channels, mod.kernel_size, mod.stride, mod.padding, mod.dilation, x.shape[2], x.shape[3])
+                pool_at = i + (2 if act is not None else 1)
+                pool_mod = children[pool_at] if pool_at < len(children) and isinstance(children[pool_at], nn.MaxPool2d) else None
+                fuse_pool = pool_mod is not None and g_[4] % 2 == 0 and g_[5] % 2 == 0 and ops.is_pool_2x2(pool_mod)
+                ukw3 = dict(ukw, x_per_slice=True) if ukw else ({"x_div": x_div, "x_off": x_off} if x_div > 1 else {})
+                x_div = 1
+                per_slice = False
+                fl = conv_flops(B, mod.in_channels, x.shape[2], x.shape[3], w.shape[1], *mod.kernel_size, mod.stride, mod.padding, mod.dilation, Es) \
+                    if timers is not None else None
+                h = _run(timers, "conv_gemm", fl, lambda w=w, b=b, m_=m_, act=act, ukw3=ukw3, fuse_pool=fuse_pool:
+                         ops.conv2d_c8x3_forward(xs2d, w, b, (m_, m_), 1, 0, 1, act=act, pool=fuse_pool, **ukw3))
+                c8s3 = True
+                i += (1 if act is not None else 0) + (1 if fuse_pool else 0) + 1
+                continue
             if isinstance(mod, (_BBBLayer, _LRTLayer)):
                 is_conv = isinstance(mod, (_BBBConv, _LRTConv))
                 geom = (mod.stride, mod.padding, mod.dilation) if is_conv else (1, 0, 1)

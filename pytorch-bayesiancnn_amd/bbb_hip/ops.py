@@ -299,11 +299,12 @@ class LaunchConfig:
                 then filled by them, and fusing pays from ~2 items per CU on (measured, profiles/r04_notes.md section 7: -2 to
                 -3 % per step at 10 draws x 3 lanes, +4.5 % with one lane; at 5 draws per launch it no longer does)
     pool_fuse_weight_budget   bytes of weight tiles concurrently live per XCD that a fused launch may have (see pool_fusion_ok)
-    c8x3        split-bf16 mode: layers with Cin % 32 == 0 take the MFMA-ready-operand kernel (csrc/pconv_c8x3.hip), whatever the
-                launch size (a property of the layer: partitions of a step keep its bits)"""
+    c8x3        split-bf16 mode: layers with Cin % 16 == 0 take the MFMA-ready-operand kernel (csrc/pconv_c8x3.hip), whatever the
+                launch size (a property of the layer: partitions of a step keep its bits)
+    c8x3_s2d    ... and a strided first layer on few channels (s2d_layer_ok: AlexNet conv1) joins them in space-to-depth form"""
     FIELDS = ("gemm_mode", "bf16x3_min_workgroups", "s3_min_images", "split_k", "pool_fusion", "pool_fuse_min_items",
               "pool_fuse_imbalance", "launches_overlap", "pool_fuse_min_items_overlapped", "pool_fuse_weight_budget",
-              "bf16_pool_fuse_min_rows", "bf16_pool_fuse_min_rows_overlapped", "bf16_c8", "bf16_c8_min_items", "c8x3")
+              "bf16_pool_fuse_min_rows", "bf16_pool_fuse_min_rows_overlapped", "bf16_c8", "bf16_c8_min_items", "c8x3", "c8x3_s2d")
     __slots__ = FIELDS
 
     def __init__(self, **kw):
@@ -327,6 +328,8 @@ class LaunchConfig:
                                                        # MFMA-ready-operand kernel (conv2d_c8x3_forward: channel-interleaved split
                                                        # activations + tap-major weights from the parameter pass); False: round 4's
                                                        # kernel (split while staging / planar S3) everywhere
+        self.c8x3_s2d = True                           # ... and a strided first layer on few channels joins that chain in space-to-depth form
+                                                       # (s2d_layer_ok: AlexNet conv1), pooling inside its launch; False: fp32 kernel
         for k, v in kw.items():
             setattr(self, k, v)              # (unknown names raise: __slots__)
 
@@ -454,14 +457,18 @@ def pool_fusion_ok(x_shape, w_shape, stride, padding, dilation, draws, pool_modu
 _pool_rule_cache = {}
 
 
+def is_pool_2x2(pool_module):
+    """Is this nn.MaxPool2d the plain 2 x 2 / stride 2 window (what the fused launches implement)?"""
+    pr = lambda v: (v, v) if isinstance(v, int) else tuple(v)
+    return not (pr(pool_module.kernel_size) != (2, 2) or pr(pool_module.stride if pool_module.stride is not None else 2) != (2, 2) or
+                pr(pool_module.padding) != (0, 0) or pr(pool_module.dilation) != (1, 1) or pool_module.ceil_mode or
+                getattr(pool_module, "return_indices", False))
+
+
 def _pool_fusion_rule(x_shape, w_shape, stride, padding, dilation, draws, pool_module):
     cfg = current_config()
-    if pool_module is not None:
-        pr = lambda v: (v, v) if isinstance(v, int) else tuple(v)
-        if pr(pool_module.kernel_size) != (2, 2) or pr(pool_module.stride if pool_module.stride is not None else 2) != (2, 2) or \
-                pr(pool_module.padding) != (0, 0) or pr(pool_module.dilation) != (1, 1) or pool_module.ceil_mode or \
-                getattr(pool_module, "return_indices", False):
-            return False
+    if pool_module is not None and not is_pool_2x2(pool_module):
+        return False
     B = x_shape[-1]
     xm = torch.empty((1,) + tuple(x_shape[-4:]), device="meta")
     wm = torch.empty((1,) + tuple(w_shape[-4:]), device="meta")
@@ -639,6 +646,64 @@ def w_tap_major(w):
     return y
 
 
+def s2d_geometry(cin, kernel_size, stride, padding, dilation, h, w):
+    """Space-to-depth form of a strided square layer (bbb_s2d_c8s3 / bbb_w_s2d_tap_major): None, or (m, C', Hb, Wb, Ho, Wo) -- the
+    layer as an m x m convolution, stride 1, no padding, over a block image of C' channels and Hb x Wb positions."""
+    (kh, kw), (sh, sw), (ph, pw), (dh, dw) = _pair(kernel_size), _pair(stride), _pair(padding), _pair(dilation)
+    if kh != kw or sh != sw or ph != pw or (dh, dw) != (1, 1):
+        return None
+    ho, wo = (h + 2 * ph - kh) // sh + 1, (w + 2 * pw - kw) // sw + 1
+    if ho <= 0 or wo <= 0:
+        return None
+    m = -(-kh // sh)
+    cp = -(-(cin * sh * sh) // 16) * 16
+    return m, cp, ho + m - 1, wo + m - 1, ho, wo
+
+
+def s2d_layer_ok(cin, cout, kernel_size, stride, padding, dilation, h, w, max_waste=1.5):
+    """Should a layer that bbb_conv2d_c8x3_fwd cannot take directly (few input channels) run on it in space-to-depth form?  Yes when
+    the block form's contraction (m * m * C' products per output) is at most max_waste times the layer's own (kh * kw * Cin): AlexNet
+    conv1 (3 channels, 11 x 11, stride 4: 9 x 48 = 432 against 363, 1.19); not a 5 x 5 stride-1 layer on 3 channels (25 x 16 against
+    75)."""
+    g = s2d_geometry(cin, kernel_size, stride, padding, dilation, h, w)
+    if g is None or cout % 8:
+        return False
+    kh, kw = _pair(kernel_size)
+    return g[0] * g[0] * g[1] <= max_waste * kh * kw * cin
+
+
+def s2d_c8s3(x, blocks, kernel_size, stride, padding):
+    """The caller's NCHW fp32 batch [blocks * Bs, C, H, W] -> the c8 S3 block image [blocks, 3, C' / 8, Hb, Wb, Bs, 8] of the layer
+    (kernel_size, stride, padding): see s2d_geometry."""
+    require_device(x)
+    x = x.contiguous()
+    N, C, H, W = x.shape
+    k, st, pd = _pair(kernel_size)[0], _pair(stride)[0], _pair(padding)[0]
+    g = s2d_geometry(C, kernel_size, stride, padding, 1, H, W)
+    if g is None or N % blocks:
+        raise _lib.BBBHipError("space-to-depth form: square kernel / stride / padding, no dilation, the batch a multiple of `blocks`")
+    m, cp, hb, wb, _, _ = g
+    y = torch.empty((blocks, 3, cp // 8, hb, wb, N // blocks, 8), dtype=torch.bfloat16, device=x.device)
+    with on_device(x.device):
+        check(_lib.lib().bbb_s2d_c8s3(x.data_ptr(), y.data_ptr(), blocks, N // blocks, C, H, W, k, st, pd, cur_stream(x.device)), "bbb_s2d_c8s3")
+    return y
+
+
+def w_s2d_tap_major(w, stride):
+    """[E, Cout, Cin, k, k] -> the tap-major rows [E, Cout, m * m, C'] of the space-to-depth layer (zeros outside the k x k taps and in
+    the padding channels)."""
+    require_device(w)
+    w = w.contiguous()
+    E, Cout, Cin, kh, kw = w.shape
+    st = _pair(stride)[0]
+    m = -(-kh // st)
+    cp = -(-(Cin * st * st) // 16) * 16
+    y = torch.empty((E, Cout, m * m, cp), dtype=torch.float32, device=w.device)
+    with on_device(w.device):
+        check(_lib.lib().bbb_w_s2d_tap_major(w.data_ptr(), y.data_ptr(), E * Cout, Cin, kh, st, cur_stream(w.device)), "bbb_w_s2d_tap_major")
+    return y
+
+
 def c8x3_layer_ok(cin, cout, is_logits=False):
     """May a BBB layer with these channel counts run on bbb_conv2d_c8x3_fwd?  (16-channel k steps inside one tap; the output is
     written in groups of 8 channels unless it is the fp32 logits tensor.)"""
@@ -646,7 +711,7 @@ def c8x3_layer_ok(cin, cout, is_logits=False):
 
 
 def conv2d_c8x3_forward(x, w_tm, bias, kernel_size, stride=1, padding=0, dilation=1, act=None, out_f32=False, out=None, units=None,
-                        n_units=None, x_div=1, x_off=0, tile=None, nt=None, pool=False):
+                        n_units=None, x_div=1, x_off=0, tile=None, nt=None, pool=False, x_per_slice=False):
     """The split-bf16 contraction over MFMA-ready operands (bbb_conv2d_c8x3_fwd).  x: c8 S3 [E|1, 3, Cin / 8, H, W, B, 8];
     w_tm: fp32 tap-major [E|1, Cout, kh * kw, Cin]; bias [E|1, Cout] | None -> c8 S3 [E, 3, Cout / 8, Ho, Wo, B, 8], or with
     out_f32 the fp32 batch-innermost [E, Cout, Ho, Wo, B] (the logits layer).  Work units / x_div / x_off as conv2d_chwn_forward.
@@ -670,10 +735,10 @@ def conv2d_c8x3_forward(x, w_tm, bias, kernel_size, stride=1, padding=0, dilatio
     w5 = w_tm.new_empty((Ew, Cout, Cin, kh, kw), device="meta")
     if units is not None and units[0] > 1:
         E = int(n_units)
-        if Ex != E:
-            raise _lib.BBBHipError("work units: x must hold one slab per unit")
+        if Ex != (units[0] if x_per_slice else E):
+            raise _lib.BBBHipError("work units: x must hold one slab per unit, or one per batch slice with x_per_slice")
         d, ho, wo = _desc_chwn(x5, w5, stride, padding, dilation, E, False, False, act)
-        _apply_units(d, units, False)
+        _apply_units(d, units, x_per_slice)
     elif int(x_div) > 1:
         E = Ew
         if not 0 <= int(x_off) < int(x_div) or Ex != -(-(E + int(x_off)) // int(x_div)):

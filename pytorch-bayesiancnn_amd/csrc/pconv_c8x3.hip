@@ -403,6 +403,60 @@ __global__ __launch_bounds__(256) void w_tap_major_kernel(const float* __restric
     out[i] = w[(row * cin + ci) * taps + tp];
 }
 
+// Space-to-depth forms of a strided layer's operands, so that a layer the c8x3 kernel cannot take directly (AlexNet conv1: 3
+// channels, 11 x 11 taps, stride 4, padding 5) becomes one it can: with m = ceil(k / s) the layer is an m x m convolution of stride 1
+// without padding over the block image
+//     x'[(c s + dy) s + dx][bh][bw] = xpad[c][s bh + dy][s bw + dx]          (xpad: the input behind `pad` zero rows / columns)
+// with weights w'[(mr, mq)][(c s + dy) s + dx] = w[c][s mr + dy][s mq + dx] (zero where s mr + dy >= k or s mq + dx >= k) and
+// C' = C s^2 rounded up to a multiple of 16 (zero channels): the same products as the strided layer plus exact zeros.  The zeros
+// of the padding are materialised here, so every window walks the same taps -- which is what the pooled form needs.
+// s2d_c8s3_kernel: caller's NCHW fp32 batch [nblk * Bs][C][H][W] -> c8 S3 [nblk][3][C' / 8][Hb][Wb][Bs][8]; one thread per 16-byte
+// vector (8 channels of one image at one block position), image index fastest.
+__global__ __launch_bounds__(256) void s2d_c8s3_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, int64_t total, int64_t pv,
+                                                      int C, int H, int W, int s, int pad, int Hb, int Wb, int Bs) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int64_t blk = i / pv, in = i - blk * pv;
+    const int b = (int)(in % Bs);
+    int64_t t = in / Bs;
+    const int bw = (int)(t % Wb); t /= Wb;
+    const int bh = (int)(t % Hb);
+    const int grp = (int)(t / Hb);
+    const float* xi = x + (blk * Bs + b) * (int64_t)C * H * W;
+    float v[8];
+#pragma unroll
+    for (int c8 = 0; c8 < 8; ++c8) {
+        const int cp = grp * 8 + c8;
+        const int dx = cp % s, dy = (cp / s) % s, c = cp / (s * s);
+        const int ih = s * bh + dy - pad, iw = s * bw + dx - pad;
+        v[c8] = (c < C && ih >= 0 && ih < H && iw >= 0 && iw < W) ? xi[((int64_t)c * H + ih) * W + iw] : 0.0f;
+    }
+    u32x4 h, m, l;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        uint32_t a0, a1, a2;
+        split3_pair(f32x2{v[2 * c], v[2 * c + 1]}, a0, a1, a2);
+        h[c] = a0; m[c] = a1; l[c] = a2;
+    }
+    u32x4* yp = reinterpret_cast<u32x4*>(y) + blk * 3 * pv + in;
+    yp[0] = h; yp[pv] = m; yp[2 * pv] = l;
+}
+
+// w [rows][C][k][k] -> out [rows][m * m][Cp] (tap-major rows of the space-to-depth layer); one thread per output element
+__global__ __launch_bounds__(256) void w_s2d_tap_major_kernel(const float* __restrict__ w, float* __restrict__ out, int64_t total, int C, int k,
+                                                             int s, int m, int Cp) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int cp = (int)(i % Cp);
+    int64_t t = i / Cp;
+    const int mq = (int)(t % m); t /= m;
+    const int mr = (int)(t % m);
+    const int64_t row = t / m;
+    const int dx = cp % s, dy = (cp / s) % s, c = cp / (s * s);
+    const int r = s * mr + dy, q = s * mq + dx;
+    out[i] = (c < C && r < k && q < k) ? w[((row * C + c) * k + r) * k + q] : 0.0f;
+}
+
 }  // namespace pconv
 
 using namespace pconv;
@@ -526,6 +580,36 @@ extern "C" int bbb_c8s3_convert(const void* src, void* dst, int64_t slabs, int c
                                     static_cast<const float*>(src), static_cast<unsigned short*>(dst), total, pv, positions, batch);
     else         hipLaunchKernelGGL(c8s3_to_chwn_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                                     static_cast<const unsigned short*>(src), static_cast<float*>(dst), total, pv, positions, batch);
+    return (int)hipGetLastError();
+}
+
+extern "C" int bbb_s2d_c8s3(const float* x, void* y, int64_t blocks, int batch, int channels, int h, int w, int k, int stride, int pad,
+                            void* stream) {
+    if (x == nullptr || y == nullptr || blocks <= 0 || batch <= 0 || channels <= 0 || h <= 0 || w <= 0 || k <= 0 || stride <= 0 || pad < 0)
+        return BBB_EINVAL;
+    if ((((uintptr_t)x) & 3u) != 0 || (((uintptr_t)y) & 15u) != 0) return BBB_EALIGN;
+    const int ho = (h + 2 * pad - k) / stride + 1, wo = (w + 2 * pad - k) / stride + 1;
+    if (ho <= 0 || wo <= 0) return BBB_ESHAPE;
+    const int m = (k + stride - 1) / stride;
+    const int hb = ho + m - 1, wb = wo + m - 1;
+    const int cp = (channels * stride * stride + 15) / 16 * 16;
+    const int64_t pv = (int64_t)(cp / 8) * hb * wb * batch, total = blocks * pv;
+    const int64_t nb = (total + 255) / 256;
+    if (nb > 0x7fffffffLL) return BBB_ESHAPE;
+    hipLaunchKernelGGL(s2d_c8s3_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, static_cast<unsigned short*>(y), total, pv,
+                       channels, h, w, stride, pad, hb, wb, batch);
+    return (int)hipGetLastError();
+}
+
+extern "C" int bbb_w_s2d_tap_major(const float* w, float* out, int64_t rows, int channels, int k, int stride, void* stream) {
+    if (w == nullptr || out == nullptr || rows <= 0 || channels <= 0 || k <= 0 || stride <= 0) return BBB_EINVAL;
+    if ((((uintptr_t)w | (uintptr_t)out) & 3u) != 0) return BBB_EALIGN;
+    const int m = (k + stride - 1) / stride;
+    const int cp = (channels * stride * stride + 15) / 16 * 16;
+    const int64_t total = rows * m * m * cp;
+    const int64_t nb = (total + 255) / 256;
+    if (nb > 0x7fffffffLL) return BBB_ESHAPE;
+    hipLaunchKernelGGL(w_s2d_tap_major_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, w, out, total, channels, k, stride, m, cp);
     return (int)hipGetLastError();
 }
 

@@ -151,6 +151,55 @@ def test_c8x3_pooled_launch_is_the_launch_then_the_pooling(env, B, Cin, H, W, Co
             assert torch.equal(ops.conv2d_c8x3_forward(x, w, bias, k, s, 0, d, act=act, pool=True, nt=nt, tile=tile), want), (nt, tile)
 
 
+@pytest.mark.parametrize("N,C,H,W,Cout,k,s,p,blocks", [(64, 3, 32, 32, 64, 11, 4, 5, 1), (24, 3, 32, 32, 16, 11, 4, 5, 3),
+                                                       (16, 1, 17, 21, 8, 5, 2, 1, 2), (8, 5, 12, 12, 24, 3, 3, 0, 1)])
+def test_space_to_depth_operands_and_layer(env, N, C, H, W, Cout, k, s, p, blocks):
+    """bbb_s2d_c8s3 / bbb_w_s2d_tap_major against their definition (include/bbb_hip.h) built with torch indexing, and the strided
+    layer computed as the m x m stride-1 layer on them against the float64 oracle (bound of the fp32 kernel) -- plain and with the
+    activation and the 2 x 2 pooling inside the launch."""
+    ops = env["ops"]
+    torch.manual_seed(N + k)
+    x = torch.randn(N, C, H, W, device="cuda")
+    w = torch.randn(2, Cout, C, k, k, device="cuda") * 0.1
+    bias = torch.randn(2, Cout, device="cuda")
+    m, cp, hb, wb, ho, wo = ops.s2d_geometry(C, k, s, p, 1, H, W)
+    xs = ops.s2d_c8s3(x, blocks, k, s, p)
+    assert xs.shape == (blocks, 3, cp // 8, hb, wb, N // blocks, 8)
+    xf = ops.c8s3_to_f32(xs)                                                     # [blocks, C', Hb, Wb, Bs]
+    xpad = torch.zeros(N, C, s * hb + s, s * wb + s, device="cuda")
+    xpad[:, :, p:p + H, p:p + W] = x
+    want = torch.zeros(N, cp, hb, wb, device="cuda")
+    for c in range(C):
+        for dy in range(s):
+            for dx in range(s):
+                want[:, (c * s + dy) * s + dx] = xpad[:, c, dy:dy + s * hb:s, dx:dx + s * wb:s]
+    assert torch.equal(xf, want.view(blocks, N // blocks, cp, hb, wb).permute(0, 2, 3, 4, 1).contiguous())
+    ws = ops.w_s2d_tap_major(w, s)
+    assert ws.shape == (2, Cout, m * m, cp)
+    wpad = torch.zeros(2, Cout, C, s * m, s * m, device="cuda")
+    wpad[..., :k, :k] = w
+    wwant = torch.zeros(2, Cout, m, m, cp, device="cuda")
+    for c in range(C):
+        for dy in range(s):
+            for dx in range(s):
+                wwant[..., (c * s + dy) * s + dx] = wpad[:, :, c, dy::s, dx::s]
+    assert torch.equal(ws, wwant.view(2, Cout, m * m, cp))
+    # the layer: every block's images against all draws' weights (input shared by the draws when blocks == 1)
+    if blocks == 1:
+        y = ops.c8s3_to_f32(ops.conv2d_c8x3_forward(xs, ws, bias, m, 1, 0, 1))   # [2, Cout, ho, wo, N]
+        for e in range(2):
+            xe, we, be = x.double().cpu().numpy(), w[e].double().cpu().numpy(), bias[e].double().cpu().numpy()
+            ref = O.conv2d(xe, we, be, s, p, 1)
+            mag = O.conv2d(np.abs(xe), np.abs(we), np.abs(be), s, p, 1)
+            got = y[e].permute(3, 0, 1, 2).double().cpu().numpy()
+            assert float((np.abs(got - ref) / mag).max()) <= TOL
+        if ho % 2 == 0 and wo % 2 == 0:
+            for act in (None, "softplus"):
+                full = ops.conv2d_c8x3_forward(xs, ws, bias, m, 1, 0, 1, act=act)
+                assert torch.equal(ops.conv2d_c8x3_forward(xs, ws, bias, m, 1, 0, 1, act=act, pool=True), ops.maxpool_c8s3(full, 2, 2))
+    assert ops.s2d_layer_ok(3, 64, 11, 4, 5, 1, 32, 32) and not ops.s2d_layer_ok(3, 32, 5, 1, 2, 1, 32, 32)
+
+
 def test_c8x3_is_exact_on_one_hot_weights(env):
     """hi + mid + lo == a exactly, through the c8 layout: a 1 x 1 convolution with a one-hot weight matrix returns its input bit
     for bit on channel scales 1e-20 .. 1e20."""
@@ -239,8 +288,8 @@ def test_c8_chain_model_step(env, model, shape, classes):
 
 def test_c8_chain_partitions_are_the_whole_step(env):
     """Work units of a sharded step and several steps per launch on the c8 chain: bit for bit the corresponding slices of the whole
-    step (same MFMA sequence per output element whatever the launch holds; the first layer runs the fp32 kernel, whose split
-    contraction is a property of the layer)."""
+    step (same MFMA sequence per output element whatever the launch holds; the first layer runs in space-to-depth form, its
+    block image cut per batch slice / per step)."""
     ens, ops = env["ens"], env["ops"]
     torch.manual_seed(0)
     net = env["zoo"].getModel("alexnet", 3, 10, P.CONFIG_PRIORS, "bbb", "softplus").cuda()
