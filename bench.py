@@ -751,6 +751,9 @@ def slow_paths(dev, steps):
     return out
 
 
+SPLIT_STEPS_PER_LAUNCH = 4
+
+
 def split_bf16(dev, steps, pipeline):
     """The metric step with the GEMM launches on the 16-bit matrix pipe at fp32 accuracy, range-free (ops.gemm_mode = "bf16x3",
     bbb_conv2d_chwn_bf16x3_fwd: every operand element split into three bf16 pieces while staged, six products per fp32 product,
@@ -770,27 +773,53 @@ def split_bf16(dev, steps, pipeline):
             lo = ensemble.mc_forward(net, x, E)[0]
             out["max_abs_diff_of_log_probs_vs_fp32_path"] = float((lo - ref_lo).abs().max())
             out["max_abs_log_prob"] = float(ref_lo.abs().max())
-            for name, depth in (("steps_in_flight_%d" % pipeline, pipeline), ("one_step_in_flight", 1)):
-                pipe = ensemble.GraphedPipeline(net, x, E, depth=depth)
-                preheat(pipe.step, 0.2, dev)
-                pipe.sync()
-                t0 = time.perf_counter()
-                for _ in range(steps):
+            # the headline's launch geometry (G steps per launch x 2 lanes) first, then one step per launch x `pipeline` lanes and x 1
+            G = SPLIT_STEPS_PER_LAUNCH
+            for name, depth, spl in (("steps_per_launch_%d_x_2_lanes" % G, 2, G), ("steps_in_flight_%d" % pipeline, pipeline, 1),
+                                     ("one_step_in_flight", 1, 1)):
+                pipe = ensemble.GraphedPipeline(net, x, E, depth=depth, steps_per_launch=spl)
+                n = -(-steps // spl) * spl
+                for _ in range(depth * spl):
                     pipe.step()
                 pipe.sync()
-                dt = (time.perf_counter() - t0) / steps
+                t_heat = time.perf_counter()
+                while time.perf_counter() - t_heat < 0.2:
+                    for _ in range(depth * spl * 2):
+                        pipe.step()
+                    pipe.sync()
+                vals = []
+                for _ in range(5 if spl > 1 else 1):
+                    torch.cuda.synchronize(dev)
+                    t0 = time.perf_counter()
+                    for _ in range(n):
+                        pipe.step()
+                    pipe.sync()
+                    torch.cuda.synchronize(dev)
+                    vals.append((time.perf_counter() - t0) / n)
+                dt = statistics.median(vals)
                 out[name] = {"ms_per_step": round(1e3 * dt, 4), "value": round(cfg["B"] * E / dt, 1)}
+                if len(vals) > 1:
+                    out[name]["blocks"] = len(vals)
+                    out[name]["best_ms_per_step"] = round(1e3 * min(vals), 4)
                 del pipe
-            rec = LaunchRecorder()
-            ensemble.mc_forward(net, x, E, timers=rec)
-            torch.cuda.synchronize(dev)
-            ing = rec.time_in_graphs(dev)
-            g = ing.get("conv_gemm")
-            if g:
-                tf = g["work"] / (g["ms"] * 1e-3) / 1e12
-                out["gemm_launches"] = {"per_launch_us": rec.per_launch_us, "fp32_equivalent_TFLOPs": round(tf, 1),
-                                        "bf16_mfma_TFLOPs": round(6 * tf, 1), "frac_of_bf16_peak": round(6 * tf / PEAK_BF16_MFMA_TFLOPS, 4),
-                                        "frac_of_fp32_matrix_peak": round(tf / PEAK_F32_MFMA_TFLOPS, 4)}
+            for tag, g_ in (("gemm_launches", G), ("gemm_launches_one_step", 1)):
+                rec = LaunchRecorder()
+                if g_ > 1:
+                    seed, call0 = rng.next_calls(g_ * E)
+                    ensemble._local_lse(net, x.repeat(g_, 1, 1, 1), E, seed, call0, E, timers=rec, groups=g_)
+                else:
+                    ensemble.mc_forward(net, x, E, timers=rec)
+                torch.cuda.synchronize(dev)
+                ing = rec.time_in_graphs(dev)
+                g = ing.get("conv_gemm")
+                if g:
+                    tf = g["work"] / (g["ms"] * 1e-3) / 1e12
+                    out[tag] = {"per_launch_us": rec.per_launch_us, "slabs_per_launch": g_ * E, "fp32_equivalent_TFLOPs": round(tf, 1),
+                                "bf16_mfma_TFLOPs": round(6 * tf, 1), "frac_of_bf16_peak": round(6 * tf / PEAK_BF16_MFMA_TFLOPS, 4),
+                                "frac_of_fp32_matrix_peak": round(tf / PEAK_F32_MFMA_TFLOPS, 4),
+                                "what": "executed (in-bounds) fp32-equivalent FLOPs of the layers x 6 bf16 products, over the summed hot per-launch "
+                                        "times; conv1 runs in space-to-depth form (432 products per output against the layer's <= 363: the extra "
+                                        "ones are not counted)"}
         # the mode also covers the role-swapped gradient GEMMs of the training step (range-free: 1e-6-sized operands are fine)
         try:
             from bbb_hip import train
@@ -1160,8 +1189,15 @@ def main():
                 try:
                     if args.gemm_mode == "fp32":
                         second["split_bf16"] = split_bf16(dev, max(20, args.steps // 2), 3)
-                        if out["roofline"] is not None and "steps_in_flight_3" in second["split_bf16"]:
-                            out["roofline"]["split_bf16_value"] = second["split_bf16"]["steps_in_flight_3"]["value"]
+                        sb = second["split_bf16"]
+                        key = "steps_per_launch_%d_x_2_lanes" % SPLIT_STEPS_PER_LAUNCH
+                        if out["roofline"] is not None and key in sb:
+                            out["roofline"]["split_bf16_value"] = sb[key]["value"]
+                            out["roofline"]["split_bf16_ms_per_step"] = sb[key]["ms_per_step"]
+                            if "gemm_launches" in sb:
+                                out["roofline"]["split_bf16_frac_of_bf16_peak"] = sb["gemm_launches"]["frac_of_bf16_peak"]
+                                out["roofline"]["split_bf16_per_launch_us"] = "/".join("%.1f" % v for v in sb["gemm_launches"]["per_launch_us"])
+                            out["roofline"]["split_bf16_max_abs_diff_vs_fp32"] = sb.get("max_abs_diff_of_log_probs_vs_fp32_path")
                 except Exception as exc:
                     second["split_bf16"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:160])}
             try:

@@ -265,6 +265,14 @@ int bbb_s3_convert(const void* src, void* dst, int64_t slabs, int64_t n, int to_
                                      TILE128 / TILE256 then mean 32 / 64 images per workgroup. */
 #define BBB_C8X3_NT_SHIFT 4       /* bits 4..6: force the channels per workgroup, 32 * NT with NT = 2, 3 or 4 (0: by layer and launch size) */
 #define BBB_C8X3_NT_MASK 0x70u
+/* bits 8..23: four nibbles = leading rows, leading columns, trailing rows, trailing columns of the INPUT map that are all zero (the
+ * materialised padding of a bbb_s2d_c8s3 block image): their products are exact zeros and are not computed -- same result as
+ * computing them, less work.  A promise of the caller: non-zero data there is silently ignored. */
+#define BBB_C8X3_ZERO_LEAD_H(n) (((uint32_t)(n) & 15u) << 8)
+#define BBB_C8X3_ZERO_LEAD_W(n) (((uint32_t)(n) & 15u) << 12)
+#define BBB_C8X3_ZERO_TRAIL_H(n) (((uint32_t)(n) & 15u) << 16)
+#define BBB_C8X3_ZERO_TRAIL_W(n) (((uint32_t)(n) & 15u) << 20)
+#define BBB_C8X3_ZERO_MASK 0x00FFFF00u
 int bbb_conv2d_c8x3_fwd(const bbb_conv_desc_t* d, const void* x, const float* w, const float* bias, void* y, uint32_t flags,
                         void* stream);
 int bbb_c8s3_convert(const void* src, void* dst, int64_t slabs, int channels, int64_t positions, int batch, int to_c8s3, void* stream);

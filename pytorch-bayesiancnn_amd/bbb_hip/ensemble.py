@@ -505,8 +505,9 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
                 per_slice = False
                 fl = conv_flops(B, mod.in_channels, x.shape[2], x.shape[3], w.shape[1], *mod.kernel_size, mod.stride, mod.padding, mod.dilation, Es) \
                     if timers is not None else None
-                h = _run(timers, "conv_gemm", fl, lambda w=w, b=b, m_=m_, act=act, ukw3=ukw3, fuse_pool=fuse_pool:
-                         ops.conv2d_c8x3_forward(xs2d, w, b, (m_, m_), 1, 0, 1, act=act, pool=fuse_pool, **ukw3))
+                zb = ops.s2d_zero_border(mod.in_channels, mod.kernel_size, mod.stride, mod.padding, x.shape[2], x.shape[3])
+                h = _run(timers, "conv_gemm", fl, lambda w=w, b=b, m_=m_, act=act, ukw3=ukw3, fuse_pool=fuse_pool, zb=zb:
+                         ops.conv2d_c8x3_forward(xs2d, w, b, (m_, m_), 1, 0, 1, act=act, pool=fuse_pool, zero_border=zb, **ukw3))
                 c8s3 = True
                 i += (1 if act is not None else 0) + (1 if fuse_pool else 0) + 1
                 continue

@@ -660,6 +660,13 @@ def s2d_geometry(cin, kernel_size, stride, padding, dilation, h, w):
     return m, cp, ho + m - 1, wo + m - 1, ho, wo
 
 
+def s2d_zero_border(cin, kernel_size, stride, padding, h, w):
+    """Block rows / columns of the layer's space-to-depth image that lie entirely in the padding: (lead_h, lead_w, trail_h, trail_w)."""
+    g = s2d_geometry(cin, kernel_size, stride, padding, 1, h, w)
+    s, p = _pair(stride)[0], _pair(padding)[0]
+    return (p // s, p // s, max(0, g[2] - -(-(p + h) // s)), max(0, g[3] - -(-(p + w) // s)))
+
+
 def s2d_layer_ok(cin, cout, kernel_size, stride, padding, dilation, h, w, max_waste=1.5):
     """Should a layer that bbb_conv2d_c8x3_fwd cannot take directly (few input channels) run on it in space-to-depth form?  Yes when
     the block form's contraction (m * m * C' products per output) is at most max_waste times the layer's own (kh * kw * Cin): AlexNet
@@ -711,7 +718,7 @@ def c8x3_layer_ok(cin, cout, is_logits=False):
 
 
 def conv2d_c8x3_forward(x, w_tm, bias, kernel_size, stride=1, padding=0, dilation=1, act=None, out_f32=False, out=None, units=None,
-                        n_units=None, x_div=1, x_off=0, tile=None, nt=None, pool=False, x_per_slice=False):
+                        n_units=None, x_div=1, x_off=0, tile=None, nt=None, pool=False, x_per_slice=False, zero_border=(0, 0, 0, 0)):
     """The split-bf16 contraction over MFMA-ready operands (bbb_conv2d_c8x3_fwd).  x: c8 S3 [E|1, 3, Cin / 8, H, W, B, 8];
     w_tm: fp32 tap-major [E|1, Cout, kh * kw, Cin]; bias [E|1, Cout] | None -> c8 S3 [E, 3, Cout / 8, Ho, Wo, B, 8], or with
     out_f32 the fp32 batch-innermost [E, Cout, Ho, Wo, B] (the logits layer).  Work units / x_div / x_off as conv2d_chwn_forward.
@@ -719,7 +726,9 @@ def conv2d_c8x3_forward(x, w_tm, bias, kernel_size, stride=1, padding=0, dilatio
     launch size; same bits whatever the choice).
     pool = True (padding 0, even Ho and Wo, c8 S3 output): the launch also applies MaxPool2d(2, 2) to the activated output ->
     [E, 3, Cout / 8, Ho / 2, Wo / 2, B, 8], bit for bit maxpool_c8s3(conv2d_c8x3_forward(...), 2, 2); tile then means 32 | 64
-    images per workgroup (its four waves own the four pixels of a window)."""
+    images per workgroup (its four waves own the four pixels of a window).
+    zero_border = (leading rows, leading columns, trailing rows, trailing columns) of the input map that hold nothing but zeros (a
+    space-to-depth block image's materialised padding, s2d_zero_border): their products are skipped -- same result, less work."""
     require_device(w_tm, bias)
     require_device(x, dtype=torch.bfloat16)
     x, w_tm = x.contiguous(), w_tm.contiguous()
@@ -773,7 +782,9 @@ def conv2d_c8x3_forward(x, w_tm, bias, kernel_size, stride=1, padding=0, dilatio
     with on_device(x.device):
         check(_lib.lib().bbb_conv2d_c8x3_fwd(ctypes.byref(d), x.data_ptr(), w_tm.data_ptr(), ptr(bias), y.data_ptr(),
                                              (1 if out_f32 else 0) | {None: 0, 128: 2, 256: 4, 32: 2, 64: 4}[tile] | (8 if pool else 0) |
-                                             ({None: 0, 2: 2, 3: 3, 4: 4}[nt] << 4), cur_stream(x.device)),
+                                             ({None: 0, 2: 2, 3: 3, 4: 4}[nt] << 4) | (min(15, zero_border[0]) << 8) |
+                                             (min(15, zero_border[1]) << 12) | (min(15, zero_border[2]) << 16) | (min(15, zero_border[3]) << 20),
+                                             cur_stream(x.device)),
               "bbb_conv2d_c8x3_fwd")
     return y
 

@@ -29,5 +29,6 @@ struct PConvArgs {
     int32_t pool;        // bbb_conv_desc_t::pool: the launch also applies MaxPool2d(2, 2) to the activated output (pconv_body.cuh, POOL)
     int32_t x_div, x_off; // bbb_conv_desc_t::x_unit_div / x_unit_off: output slab e reads input slab (e + x_off) / x_div (x_div <= 1: slab e)
     int32_t y_f32;       // pconv_bf16_fewout_kernel: y is fp32 (the logits layer) instead of bf16
+    int32_t vh0, vh1, vw0, vw1;   // pconv_c8x3: input rows [vh0, vh1) x columns [vw0, vw1) may hold non-zero data (the rest is declared zero)
     int32_t y_c8;        // pconv_bf16.hip: y is written channel-interleaved, [cout / 8][ho][wo][B][8] (BBB_BF16_OUT_C8)
 };

@@ -27,8 +27,8 @@
 namespace pconv {
 
 #ifndef C8X3_ABLATE
-#define C8X3_ABLATE 0            // experiments only (profiles/experiments/c8x3_ablate.sh): 1 no epilogue math, 2 no barriers, 3 no image loads,
-#endif                           // 4 no weight staging, 5 no matrix instructions in the k loop -- timing of what is left; results are garbage
+#define C8X3_ABLATE 0            // experiments only (profiles/experiments/c8x3_ablate.sh, on the generic k loop: BBB_C8X3_NT=3): 1 no epilogue math,
+#endif                           // 2 no barriers, 3 no image loads, 4 no weight staging, 5 no matrix instructions -- timing of what is left
 constexpr int C8_LDA = 40;               // bf16 elements per LDS weight row: 32 k + 8 pad = 80 bytes (16-lane groups hit 64 distinct banks)
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
@@ -91,6 +91,21 @@ void pconv_c8x3_kernel(const PConvArgs p) {
     int q_hi = (p.W - 1 - iwb) >= 0 ? (p.W - 1 - iwb) / p.dw + 1 : 0;
     r_hi = r_hi < p.kh ? r_hi : p.kh;
     q_hi = q_hi < p.kw ? q_hi : p.kw;
+    // Input rows / columns the caller declares all-zero (PConvArgs::vh0 .. vw1: the materialised padding of a space-to-depth block
+    // image): their taps are exact zeros and are left out.  Plain form: they leave the walk.  POOLP: the four waves share one walk
+    // (the weight tile is the workgroup's), so a wave only skips the loads and matrix instructions of the steps that are zero for
+    // ITS pixel.
+    int my_r_lo = r_lo, my_r_hi = r_hi, my_q_lo = q_lo, my_q_hi = q_hi;
+    {
+        const int a0 = p.vh0 - ihb, a1 = p.vh1 - 1 - ihb, c0 = p.vw0 - iwb, c1 = p.vw1 - 1 - iwb;
+        const int rl = a0 > 0 ? (a0 + p.dh - 1) / p.dh : 0, rh = a1 >= 0 ? a1 / p.dh + 1 : 0;
+        const int ql = c0 > 0 ? (c0 + p.dw - 1) / p.dw : 0, qh = c1 >= 0 ? c1 / p.dw + 1 : 0;
+        my_r_lo = rl > my_r_lo ? rl : my_r_lo;
+        my_r_hi = rh < my_r_hi ? rh : my_r_hi;
+        my_q_lo = ql > my_q_lo ? ql : my_q_lo;
+        my_q_hi = qh < my_q_hi ? qh : my_q_hi;
+    }
+    if constexpr (!POOLP) { r_lo = my_r_lo; r_hi = my_r_hi; q_lo = my_q_lo; q_hi = my_q_hi; }
     const int nr = r_hi > r_lo ? r_hi - r_lo : 0;
     const int nq = q_hi > q_lo ? q_hi - q_lo : 0;                    // (POOLP: no padding -- the same for the four waves)
     const int n16 = p.Cin >> 4;                                      // 16-channel steps per tap
@@ -124,10 +139,14 @@ void pconv_c8x3_kernel(const PConvArgs p) {
     // image-side cursor (wave-uniform): the 16-channel step AHEAD of the ones being multiplied -- tap (rr, qq) of the pixel's
     // in-bounds rectangle, 16-channel block c16
     int sx_rr = 0, sx_qq = 0, sx_c16 = 0, sx_left = nsteps;
+    bool sx_live = false;                                            // the step the last call described holds non-zero products
     auto next_step_offset = [&]() -> uint32_t {
+        sx_live = false;
         if (sx_left <= 0) return kStepInv;
         const int r = r_lo + sx_rr, q = q_lo + sx_qq;
-        const uint32_t o = (uint32_t)(sx_c16 * 2) * grp_b + (uint32_t)((ihb + r * p.dh) * p.W + iwb + q * p.dw) * img_b;
+        uint32_t o = (uint32_t)(sx_c16 * 2) * grp_b + (uint32_t)((ihb + r * p.dh) * p.W + iwb + q * p.dw) * img_b;
+        sx_live = !POOLP || ((r >= my_r_lo) & (r < my_r_hi) & (q >= my_q_lo) & (q < my_q_hi));
+        if (!sx_live) o = kStepInv;
         --sx_left;
         if (++sx_c16 == n16) {
             sx_c16 = 0;
@@ -165,8 +184,10 @@ void pconv_c8x3_kernel(const PConvArgs p) {
             wreg[ps][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, o + (uint32_t)ps * wpass + 16u, 0, 0));
         }
     };
+    bool live_next[2] = {false, false};
     auto bload = [&](int s) {
         const uint32_t u = next_step_offset();
+        live_next[s] = sx_live;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -228,7 +249,22 @@ void pconv_c8x3_kernel(const PConvArgs p) {
         }
     };
 
-    if (ntiles > 0) {
+    // NT = 2, plain form: the weight fragments of a step are fetched from LDS while the step before is multiplied -- a plane's
+    // registers are free as soon as its last term is issued (lo after the first term, mid after the fourth, hi after the sixth), so
+    // the six 16-byte reads of step 1 ride under step 0's matrix instructions and only a tile's first reads are waited for
+    // (measured -1.2 % per launch, profiles/r06_notes.md).
+    if constexpr (NT == 2 && !POOLP) {
+      if (ntiles > 0) {
+        bf16x8 af[2][3];                                             // the step's weight fragments: [channel tile][plane]
+        auto aread = [&](int stage, int s, int pl) {
+            const unsigned short* const base = Wp + stage * (3 * PLANE) + lrow * C8_LDA + s * 16 + lk * 8 + pl * PLANE;
+            af[0][pl] = *reinterpret_cast<const bf16x8*>(base);
+            af[1][pl] = *reinterpret_cast<const bf16x8*>(base + 32 * C8_LDA);
+        };
+#define C8X3_T(PA, PB, S)                                                                                            \
+        _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                             \
+            _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                        \
+                acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[nt][PA], bfr[S][mt][PB], acc[nt][mt], 0, 0, 0);
         wload();
         bload(0);
         bload(1);
@@ -236,17 +272,51 @@ void pconv_c8x3_kernel(const PConvArgs p) {
         __syncthreads();
         for (int t = 0; t < ntiles; ++t) {
             const int stage = t & 1;
+            aread(stage, 0, 2); aread(stage, 0, 0); aread(stage, 0, 1);
+            wload();
+            __builtin_amdgcn_sched_barrier(0);
+            C8X3_T(2, 0, 0)
+            __builtin_amdgcn_sched_barrier(0);
+            aread(stage, 1, 2);                                      // step 1's lo fragments: their registers are free
+            __builtin_amdgcn_sched_barrier(0);
+            C8X3_T(0, 2, 0) C8X3_T(1, 1, 0) C8X3_T(1, 0, 0)
+            __builtin_amdgcn_sched_barrier(0);
+            aread(stage, 1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            C8X3_T(0, 1, 0) C8X3_T(0, 0, 0)
+            __builtin_amdgcn_sched_barrier(0);
+            aread(stage, 1, 0);
+            bload(0);
+            __builtin_amdgcn_sched_barrier(0);
+            C8X3_T(2, 0, 1) C8X3_T(0, 2, 1) C8X3_T(1, 1, 1) C8X3_T(1, 0, 1) C8X3_T(0, 1, 1) C8X3_T(0, 0, 1)
+            __builtin_amdgcn_sched_barrier(0);
+            bload(1);
+            __builtin_amdgcn_sched_barrier(0);
+            wstore(stage ^ 1);
+            __syncthreads();
+        }
+#undef C8X3_T
+      }
+    } else if (ntiles > 0) {
+        wload();
+        bload(0);
+        bload(1);
+        wstore(0);
+        __syncthreads();
+        bool live0 = live_next[0], live1 = live_next[1];
+        for (int t = 0; t < ntiles; ++t) {
+            const int stage = t & 1;
             // issue order pinned with scheduling barriers: left alone, the compiler sinks every load below the step's matrix
             // instructions (right in front of its first use), i.e. out of their shadow
             if (C8X3_ABLATE != 4) wload();                           // (past the last tile: out-of-range offsets, zeros)
             __builtin_amdgcn_sched_barrier(0);
-            if (C8X3_ABLATE != 5) step(stage, 0);
+            if (C8X3_ABLATE != 5 && live0) step(stage, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (C8X3_ABLATE != 3) bload(0);
+            if (C8X3_ABLATE != 3) { bload(0); live0 = live_next[0]; }
             __builtin_amdgcn_sched_barrier(0);
-            if (C8X3_ABLATE != 5) step(stage, 1);
+            if (C8X3_ABLATE != 5 && live1) step(stage, 1);
             __builtin_amdgcn_sched_barrier(0);
-            if (C8X3_ABLATE != 3) bload(1);
+            if (C8X3_ABLATE != 3) { bload(1); live1 = live_next[1]; }
             __builtin_amdgcn_sched_barrier(0);
             if (C8X3_ABLATE != 4) wstore(stage ^ 1);                 // (after the last tile: zeros into a stage nobody reads)
             if (C8X3_ABLATE != 2) __syncthreads();
@@ -473,7 +543,7 @@ void launch_c8x3(bool of32, bool poolp, dim3 grid, hipStream_t st, const PConvAr
 
 extern "C" int bbb_conv2d_c8x3_fwd(const bbb_conv_desc_t* d, const void* x, const float* w, const float* bias, void* y, uint32_t flags,
                                    void* stream) {
-    constexpr uint32_t kKnown = BBB_C8X3_OUT_F32 | BBB_C8X3_TILE128 | BBB_C8X3_TILE256 | BBB_C8X3_POOL | BBB_C8X3_NT_MASK;
+    constexpr uint32_t kKnown = BBB_C8X3_OUT_F32 | BBB_C8X3_TILE128 | BBB_C8X3_TILE256 | BBB_C8X3_POOL | BBB_C8X3_NT_MASK | BBB_C8X3_ZERO_MASK;
     if (d == nullptr || x == nullptr || w == nullptr || y == nullptr || (flags & ~kKnown) != 0 ||
         ((flags & BBB_C8X3_TILE128) && (flags & BBB_C8X3_TILE256)))
         return BBB_EINVAL;
@@ -497,6 +567,11 @@ extern "C" int bbb_conv2d_c8x3_fwd(const bbb_conv_desc_t* d, const void* x, cons
     a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w; a.dh = d->dil_h; a.dw = d->dil_w;
     a.Ho = ho; a.Wo = wo; a.K = d->cin * d->kh * d->kw; a.Kp = a.K; a.khkw = d->kh * d->kw; a.act = d->act;
     a.pool = poolp ? 1 : 0;
+    {   // rows / columns of the input the caller declares all-zero (BBB_C8X3_ZERO_* nibbles of flags)
+        const int lh = (int)((flags >> 8) & 15u), lw = (int)((flags >> 12) & 15u), th = (int)((flags >> 16) & 15u), tw = (int)((flags >> 20) & 15u);
+        if (lh + th >= a.H || lw + tw >= a.W) return BBB_EINVAL;
+        a.vh0 = lh; a.vh1 = a.H - th; a.vw0 = lw; a.vw1 = a.W - tw;
+    }
     a.x_ps = (int64_t)a.Cin * a.H * a.W * a.B;
     a.y_ps = (int64_t)a.Cout * ho * wo * a.B / (poolp ? 4 : 1);
     // slabs are addressed through 32-bit buffer offsets (three planes of 2-byte elements, or fp32 outputs)
@@ -516,34 +591,20 @@ extern "C" int bbb_conv2d_c8x3_fwd(const bbb_conv_desc_t* d, const void* x, cons
     a.x = static_cast<const float*>(x); a.w = w; a.bias = bias; a.y = static_cast<float*>(y);
     const int64_t pixels = (int64_t)ho * wo / (poolp ? 4 : 1);
     // Tile shape (the MFMA sequence per output element, hence every output bit, does not depend on it).  Channels per workgroup
-    // 32 * NT: the fewer channel tiles share an image fragment's trip from L2, the better -- 128 (NT = 4) when the layer's channels
-    // fill such tiles, 96 (NT = 3) for multiples of 96, else 64; images per wave 32 * MT: 64, or 32 when the launch would otherwise
-    // leave the chip less than ~two rounds of workgroups (small launches step down NT as well).
+    // 32 * NT: NT = 2 unless forced -- wider tiles halve the image fragments' trips through the vector memory path per matrix
+    // instruction but hold 96 / 128 accumulation registers (two waves per SIMD instead of three), and measured slower on every
+    // AlexNet layer but conv3 (profiles/r06_notes.md: conv2 504 / 515 / 603 us for NT = 2 / 3 / 4 at 40 slabs).  Images per wave
+    // 32 * MT: 64, or 32 when the launch would otherwise leave the chip less than ~two rounds of workgroups.
     int nt = 2, mt = 2;
     {
         static const int env_nt = [] { const char* s = getenv("BBB_C8X3_NT"); return s ? atoi(s) : 0; }();   // (experiments)
-        const int wg_per_cu4 = 2, wg_per_cu2 = 3;                // resident workgroups per CU: NT = 4 / 3 (registers), NT = 2
-        auto items = [&](int n, int m) {
-            return (int64_t)d->draws * ((a.Cout + 32 * n - 1) / (32 * n)) * pixels * ((a.B + (poolp ? 32 : 128) * m - 1) / ((poolp ? 32 : 128) * m));
-        };
-        auto waste = [&](int n) { return (double)((a.Cout + 32 * n - 1) / (32 * n) * 32 * n) / (double)a.Cout; };
+        if (nt_force) nt = nt_force;
+        else if (env_nt >= 2 && env_nt <= 4) nt = env_nt;
+        const int64_t bm2 = (poolp ? 32 : 128) * 2;
+        const int64_t items2 = (int64_t)d->draws * ((a.Cout + 32 * nt - 1) / (32 * nt)) * pixels * ((a.B + bm2 - 1) / bm2);
         if (flags & BBB_C8X3_TILE128) mt = 1;
         else if (flags & BBB_C8X3_TILE256) mt = 2;
-        int want_nt = nt_force ? nt_force : (env_nt >= 2 && env_nt <= 4 ? env_nt : 0);
-        if (want_nt == 0) {
-            // candidates in order of preference; a candidate qualifies when its padding waste is no larger than NT = 2's and the launch
-            // still holds two rounds of its resident workgroups
-            want_nt = 2;
-            for (int n : {4, 3}) {
-                if (waste(n) > waste(2) + 1e-9) continue;
-                if (items(n, 1) >= 2 * 256 * wg_per_cu4) { want_nt = n; break; }
-            }
-        }
-        nt = want_nt;
-        if (!(flags & (BBB_C8X3_TILE128 | BBB_C8X3_TILE256))) {
-            const int64_t slots = 256 * (nt == 2 ? wg_per_cu2 : wg_per_cu4);
-            mt = (a.B <= (poolp ? 32 : 128) || items(nt, 2) < 2 * slots) ? 1 : 2;
-        }
+        else if (a.B <= bm2 / 2 || items2 < 1024) mt = 1;
     }
     const int bnw = 32 * nt, bm = (poolp ? 32 : 128) * mt;
     a.Ntiles = (a.Cout + bnw - 1) / bnw;

@@ -197,6 +197,14 @@ def test_space_to_depth_operands_and_layer(env, N, C, H, W, Cout, k, s, p, block
             for act in (None, "softplus"):
                 full = ops.conv2d_c8x3_forward(xs, ws, bias, m, 1, 0, 1, act=act)
                 assert torch.equal(ops.conv2d_c8x3_forward(xs, ws, bias, m, 1, 0, 1, act=act, pool=True), ops.maxpool_c8s3(full, 2, 2))
+        # block rows / columns that are all padding: declared to the launch, skipped, same bits (plain and pooled, every tile shape)
+        zb = ops.s2d_zero_border(C, k, s, p, H, W)
+        assert torch.equal(ops.conv2d_c8x3_forward(xs, ws, bias, m, 1, 0, 1, zero_border=zb), ops.conv2d_c8x3_forward(xs, ws, bias, m, 1, 0, 1))
+        if ho % 2 == 0 and wo % 2 == 0:
+            want = ops.conv2d_c8x3_forward(xs, ws, bias, m, 1, 0, 1, act="softplus", pool=True)
+            for nt in (None, 3):
+                assert torch.equal(ops.conv2d_c8x3_forward(xs, ws, bias, m, 1, 0, 1, act="softplus", pool=True, zero_border=zb, nt=nt), want)
+    assert ops.s2d_zero_border(3, 11, 4, 5, 32, 32) == (1, 1, 0, 0)
     assert ops.s2d_layer_ok(3, 64, 11, 4, 5, 1, 32, 32) and not ops.s2d_layer_ok(3, 32, 5, 1, 2, 1, 32, 32)
 
 
