@@ -215,30 +215,39 @@ def cpu_baseline(budget_s=20.0):
                       f"after a warm-up each; {src}; {avail} CPUs usable (cgroup quota / affinity), best of {{all, half}} thread counts"}
 
 
-def profile_traffic(kind):
-    """HBM bytes per launch-group from the committed PMC summaries (profiles/r02_pmc_FETCH_SIZE.txt / _WRITE_SIZE.txt, written
-    by profiles/collect.sh): (read_bytes, written_bytes, source) or None.  FETCH_SIZE x2 = the gfx950 wide-load correction."""
+def profile_traffic(kind, suffix=""):
+    """HBM bytes per launch-group from the committed PMC summaries (profiles/r06_pmc_FETCH_SIZE<suffix>.txt / _WRITE_SIZE<suffix>.txt,
+    written by profiles/collect.sh; suffix "" = the metric configuration, "_configs1" ... = BASELINE configs[1..4], "_split" = the
+    split-bf16 mode): (read_bytes, written_bytes, source) or None.  FETCH_SIZE x2 = the gfx950 wide-load correction.
+    kind: one kernel family or a tuple of families whose STEP_TOTAL rows are added."""
     out = {}
     tag = None
-    for t in ("r05", "r04", "r03", "r02"):         # the newest committed PMC passes
-        if all(os.path.exists(os.path.join(ROOT, "profiles", f"{t}_pmc_{c}.txt")) for c in ("FETCH_SIZE", "WRITE_SIZE")):
+    for t in ("r06", "r05", "r04", "r03", "r02"):  # the newest committed PMC passes
+        if all(os.path.exists(os.path.join(ROOT, "profiles", f"{t}_pmc_{c}{suffix}.txt")) for c in ("FETCH_SIZE", "WRITE_SIZE")):
             tag = t
             break
     if tag is None:
         return None
+    kinds = (kind,) if isinstance(kind, str) else tuple(kind)
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
-        path = os.path.join(ROOT, "profiles", f"{tag}_pmc_{c}.txt")
+        path = os.path.join(ROOT, "profiles", f"{tag}_pmc_{c}{suffix}.txt")
         kb = None
-        for line in open(path):
-            m = re.match(r"\s*STEP_TOTAL\s+%s\s+(\S+)\s+KB_per_step=([0-9.]+)" % kind, line)
-            if m:
-                kb = float(m.group(2))
+        for k in kinds:
+            last = None
+            for line in open(path):
+                if line.startswith("##"):
+                    break                                # (a second section of the file: another launch mode)
+                m = re.match(r"\s*STEP_TOTAL\s+%s\s+(\S+)\s+KB_per_step=([0-9.]+)" % re.escape(k), line)
+                if m:
+                    last = float(m.group(2))
+            if last is not None:
+                kb = (kb or 0.0) + last
         if kb is None:
             return None
         out[c] = kb * 1024.0
     rd = 2.0 * out["FETCH_SIZE"]
     return rd, out["WRITE_SIZE"], "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 wide-load correction) + WRITE_SIZE, separate passes: " \
-        "profiles/%s_pmc_FETCH_SIZE.txt, profiles/%s_pmc_WRITE_SIZE.txt (STEP_TOTAL %s rows)" % (tag, tag, kind)
+        "profiles/%s_pmc_FETCH_SIZE%s.txt, profiles/%s_pmc_WRITE_SIZE%s.txt (STEP_TOTAL %s rows)" % (tag, suffix, tag, suffix, "+".join(kinds))
 
 
 def build_net(cfg, dev):
@@ -264,6 +273,24 @@ def mfma_loop_ceiling():
         v = (ctypes.c_double * 2)(0.0, 0.0)
         rc = lib.probe_mfma_f32_ceiling(v, 5, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         return (round(v[0], 1), round(v[1], 3)) if rc == 0 and v[0] > 0 else None
+    except Exception:
+        return None
+
+
+def write_roof_probe(elems_per_draw, draws):
+    """GB/s of a write-only kernel with the store shape of the fused reparam+KL pass (profiles/probe/mfma_ceiling.hip,
+    probe_write_roof: same bytes, 16-byte stores, draws strided by the tensor size, no reads, no arithmetic): the write roof of THIS
+    box for that pattern.  (plain, non-temporal) or None."""
+    import ctypes
+    path = os.path.join(ROOT, "profiles", "probe", "libmfma_probe.so")
+    if not os.path.exists(path):
+        return None
+    try:
+        lib = ctypes.CDLL(path)
+        lib.probe_write_roof.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        v = (ctypes.c_double * 2)(0.0, 0.0)
+        rc = lib.probe_write_roof(v, int(elems_per_draw), int(draws), 5, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        return (round(v[0], 1), round(v[1], 1)) if rc == 0 and max(v[0], v[1]) > 0 else None
     except Exception:
         return None
 
@@ -578,13 +605,20 @@ def run_config(cfg, steps, warmup, pipeline, dev, group=None, world=1, want_roof
         out["value"] = round(cfg["B"] * E / (elapsed / steps), 1)
         out["rows_out"] = rows
         if stat_blocks and not multi:
-            # block statistics: `stat_blocks` blocks of `steps` steps, each between device syncs
-            vals = []
+            # block statistics: `stat_blocks` MORE blocks of exactly `steps` steps, each between device syncs.  The reported value is
+            # the MEDIAN over all 1 + stat_blocks blocks (a single block lands anywhere in the box's clock spread -- review r05
+            # item 4); the first block alone stays next to it as `single_block`.
+            vals = [cfg["B"] * E * steps / elapsed]
             for _ in range(stat_blocks):
                 dt, _ = timed_block(steps)
                 vals.append(cfg["B"] * E * steps / dt)
-            out["stats"] = {"blocks": stat_blocks, "steps_per_block": steps, "median": round(statistics.median(vals), 1),
-                            "p10": round(pctl(vals, 0.1), 1), "p90": round(pctl(vals, 0.9), 1), "unit": "samples/s"}
+            med = statistics.median(vals)
+            out["single_block"] = {"ms_per_step": out["ms_per_step"], "value": out["value"]}
+            out["value"] = round(med, 1)
+            out["ms_per_step"] = round(1e3 * cfg["B"] * E / med, 4)
+            out["stats"] = {"blocks": len(vals), "steps_per_block": steps, "median": round(med, 1),
+                            "p10": round(pctl(vals, 0.1), 1), "p90": round(pctl(vals, 0.9), 1), "unit": "samples/s",
+                            "value_is": "median of the blocks"}
         del gstep, step, flush
         if not multi and single_lane and (pipeline > 1 or G > 1):
             g1 = ensemble.GraphedMC(net, x, E, precision=prec)
@@ -1094,6 +1128,10 @@ def main():
             else:
                 out["config"]["units_per_rank"] = [(lambda r: r[1] - r[0])(ensemble.unit_range(cfg["E"], S, r, world)) for r in range(world)]
             out["config"]["backend"] = backend
+            try:
+                out["config"]["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None
+            except Exception:
+                out["config"]["rccl_version"] = None
             proto = head.get("collective_protocol") or {}
             out["config"]["backend_mode"] = ("all_gather recorded into each lane's hipGraph (private communicator per lane)"
                                              if proto.get("collective") == "recorded" else
@@ -1130,8 +1168,9 @@ def main():
             out["roofline"] = None
         if "stats" in head and out["roofline"] is not None:
             st = head["stats"]
-            out["roofline"].update(stats_median=st["median"], stats_p10=st["p10"], stats_p90=st["p90"],
-                                   value_above_p90=bool(out["value"] > st["p90"]))
+            out["roofline"].update(stats_median=st["median"], stats_p10=st["p10"], stats_p90=st["p90"], stats_blocks=st["blocks"],
+                                   value_above_p90=bool(out["value"] > st["p90"]),
+                                   single_block_value=(head.get("single_block") or {}).get("value"))
             second["stats"] = st
         if "one_step_in_flight" in head and out["roofline"] is not None:
             out["roofline"]["one_step_in_flight_ms"] = head["one_step_in_flight"]["ms_per_step"]
@@ -1177,6 +1216,18 @@ def main():
                                            reparam_10draw_frac=rp["frac"],
                                            reparam_hbm_resident_frac=(round(hb["E10_GBps"] / PEAK_HBM_GBS, 4) if "E10_GBps" in hb else None),
                                            device_copy_GBps=hb.get("device_copy_GBps"))
+                    # the write roof of this box for the pass's store pattern (same bytes, no reads, no arithmetic), back to back like
+                    # reparam_back_to_back_frac: how much of what the hardware gives the pass's WRITES the fused pass reaches
+                    wr = write_roof_probe(n_params, cfg["E"] * G)
+                    if wr:
+                        roof_gbps = max(wr)
+                        bb_gbps = rpg["frac"] * PEAK_HBM_GBS
+                        second["write_roof_probe"] = {"plain_GBps": wr[0], "non_temporal_GBps": wr[1], "draws": cfg["E"] * G,
+                                                      "elements_per_draw": n_params,
+                                                      "what": "write-only kernel, the reparam pass's store shape and bytes, 10 launches back to back, best of 5"}
+                        out["roofline"].update(write_roof_GBps=roof_gbps,
+                                               reparam_frac_of_write_roof=round(bb_gbps / roof_gbps, 4),
+                                               reparam_in_step_frac_of_write_roof=round(main_rp["frac"] * PEAK_HBM_GBS / roof_gbps, 4))
             del net, x
             try:
                 second["dropin_loop"] = dropin_loop(dev, max(40, args.steps // 2))
@@ -1198,6 +1249,11 @@ def main():
                                 out["roofline"]["split_bf16_frac_of_bf16_peak"] = sb["gemm_launches"]["frac_of_bf16_peak"]
                                 out["roofline"]["split_bf16_per_launch_us"] = "/".join("%.1f" % v for v in sb["gemm_launches"]["per_launch_us"])
                             out["roofline"]["split_bf16_max_abs_diff_vs_fp32"] = sb.get("max_abs_diff_of_log_probs_vs_fp32_path")
+                            trs = profile_traffic("pconv_c8x3", "_split")
+                            if trs and "gemm_launches" in sb:
+                                sb["gemm_launches"]["traffic"] = round(trs[0] + trs[1], 1)
+                                sb["gemm_launches"]["traffic_source"] = trs[2]
+                                out["roofline"]["split_bf16_traffic"] = round(trs[0] + trs[1], 1)
                 except Exception as exc:
                     second["split_bf16"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:160])}
             try:
@@ -1233,6 +1289,12 @@ def main():
                         r1, _, _ = run_config(c, nst, 5, depth, dev, want_roofline=False, steps_per_launch=1, preheat_s=0.1, single_lane=False)
                         r["one_step_per_launch"] = {"ms_per_step": r1["ms_per_step"], "value": r1["value"]}
                     del n2, x2
+                    if r.get("roofline"):
+                        tr = profile_traffic(("pconv_bf16", "pconv_gemm"), "_" + name.replace("[", "").replace("]", ""))
+                        if tr:
+                            r["roofline"]["traffic"] = round(tr[0] + tr[1], 1)
+                            r["roofline"]["traffic_read_written"] = [round(tr[0], 1), round(tr[1], 1)]
+                            r["roofline"]["traffic_source"] = tr[2] + "; bytes per step over the conv/linear launches"
                     r["workload"] = c["what"]
                     r["dtype"] = "bf16" if c["precision"] == "bf16" else "f32"
                     r["unit"] = "samples/s"

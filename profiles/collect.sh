@@ -3,7 +3,7 @@
 # Separate passes (kernel trace / FETCH_SIZE / WRITE_SIZE / SQ counters), summaries into gpurun_out/<tag>_*.txt for copying
 # to profiles/.  --pmc passes never combine with other trace domains (only --kernel-trace).
 set -u
-TAG=${1:-r02}
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out
 mkdir -p "$OUT"
@@ -39,6 +39,8 @@ rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- $BENCH > /tmp/kt/log.txt 2>
     echo
   done; } > "$OUT/${TAG}_graph_kernel_stats.txt" 2>&1
 
+bash $R/profiles/experiments/split_trace.sh $TAG > /dev/null 2>&1
+cd /tmp
 if [ "${SKIP_PMC:-0}" = "1" ]; then ls -la "$OUT" | tail -8; exit 0; fi     # kernel traces only (the PMC passes were taken earlier in the round)
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pm && mkdir -p /tmp/pm
@@ -51,9 +53,23 @@ for C in FETCH_SIZE WRITE_SIZE; do
     echo "## the same with ONE step per launch (python bench.py --steps 5 --warmup 2 --no-graph --steps-per-launch 1; 7 steps): rows prefixed G1_"
     python $R/profiles/summarize_pmc.py $(find /tmp/pm -name '*.db' | head -1) --steps 7 | sed 's/^STEP_TOTAL/G1_STEP_TOTAL/'; } > "$OUT/${TAG}_pmc_${C}.txt" 2>&1
 done
+# HBM traffic of the other configurations (BASELINE configs[1], [2], [4], configs[3] = the 25-draw step) and of the split-bf16 mode,
+# at the launch shapes bench.py times them in: the files bench.py's profile_traffic(kind, suffix) reads for their `traffic` fields
+for C in FETCH_SIZE WRITE_SIZE; do
+  for SPEC in "configs1|--config configs[1] --steps 16 --warmup 16 --steps-per-launch 16|32" "configs2|--config configs[2] --steps 16 --warmup 16 --steps-per-launch 16|32" \
+              "configs3|--config configs[3] --steps 4 --warmup 2 --steps-per-launch 1|6" "configs4|--config configs[4] --steps 3 --warmup 1 --steps-per-launch 1|4" \
+              "split|--gemm-mode bf16x3 --steps 8 --warmup 4|12"; do
+    NAME=${SPEC%%|*}; REST=${SPEC#*|}; ARGS=${REST%|*}; NST=${REST##*|}
+    rm -rf /tmp/pm && mkdir -p /tmp/pm
+    rocprofv3 --kernel-trace --pmc $C -d /tmp/pm -o pm -- python $R/bench.py --no-graph $ARGS > /tmp/pm/log.txt 2>&1
+    { echo "# rocprofv3 --kernel-trace --pmc $C -- python bench.py --no-graph $ARGS   (KB per launch; gfx950: FETCH_SIZE counts 1/2 of wide coalesced reads; STEP_TOTAL = per MC step, $NST steps)"
+      grep '^{' /tmp/pm/log.txt | cut -c1-300
+      python $R/profiles/summarize_pmc.py $(find /tmp/pm -name '*.db' | head -1) --steps $NST; } > "$OUT/${TAG}_pmc_${C}_${NAME}.txt" 2>&1
+  done
+done
 rm -rf /tmp/pm && mkdir -p /tmp/pm
 { echo "# rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_WAIT_INST_ANY -- (fp32 eager step, then the bf16 configs[1] eager step)"
-  for CMD in "$EAGER" "$EAGER16"; do
+  for CMD in "$EAGER" "$EAGER16" "$EAGER --gemm-mode bf16x3"; do
     rm -rf /tmp/pm/*
     rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_WAIT_INST_ANY -d /tmp/pm -o pm -- $CMD > /tmp/pm_log.txt 2>&1
     echo "## $CMD" | sed "s#$R/##"

@@ -112,3 +112,57 @@ static int probe_impl(double* tflops_out, int reps, void* stream, bool f16) {
     tflops_out[1] = best_clk;
     return (int)er;
 }
+
+// Write-only streaming probe (review r05 item 6): the bytes of the fused reparam+KL pass's output written with the same store shape
+// (16 bytes per lane, consecutive lanes consecutive vectors, 256-thread blocks, one 4 KB piece per block and "draw", draws strided by
+// the tensor size) and NO arithmetic or reads -- the HBM write roof of this box for that pattern.  gbps_out[0] = plain stores,
+// gbps_out[1] = non-temporal stores; best of `reps` launches each, HIP events on `stream`.
+namespace {
+typedef float wf32x4 __attribute__((ext_vector_type(4)));
+template <bool NT>
+__global__ __launch_bounds__(256) void write_stream_kernel(float* out, long long n_vec, int draws, long long draw_stride_vec, float v) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_vec) return;
+    wf32x4* p = reinterpret_cast<wf32x4*>(out) + i;
+    const wf32x4 val = {v, v + 1.0f, v + 2.0f, v + 3.0f};
+    for (int e = 0; e < draws; ++e) {
+        if (NT) __builtin_nontemporal_store(val, p);
+        else    *p = val;
+        p += draw_stride_vec;
+    }
+}
+}  // namespace
+
+extern "C" int probe_write_roof(double* gbps_out, long long elems_per_draw, int draws, int reps, void* stream) {
+    if (gbps_out == nullptr || elems_per_draw <= 0 || draws <= 0 || reps <= 0) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    const long long n_vec = (elems_per_draw + 3) / 4;
+    float* buf = nullptr;
+    hipError_t er = hipMalloc(&buf, (size_t)n_vec * 16 * draws);
+    if (er != hipSuccess) return (int)er;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipFree(buf); return (int)hipErrorUnknown; }
+    const dim3 grid((unsigned)((n_vec + 255) / 256)), block(256);
+    for (int nt = 0; nt < 2; ++nt) {
+        double best = 0.0;
+        for (int r = 0; r < reps + 2; ++r) {                       // two warm-up rounds
+            (void)hipEventRecord(e0, st);
+            for (int k = 0; k < 10; ++k) {                         // ten launches back to back per bracket
+                if (nt) hipLaunchKernelGGL(write_stream_kernel<true>, grid, block, 0, st, buf, n_vec, draws, n_vec, (float)k);
+                else    hipLaunchKernelGGL(write_stream_kernel<false>, grid, block, 0, st, buf, n_vec, draws, n_vec, (float)k);
+            }
+            (void)hipEventRecord(e1, st);
+            er = hipEventSynchronize(e1);
+            if (er != hipSuccess) break;
+            float ms = 0.0f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            const double gbps = 10.0 * (double)n_vec * 16.0 * draws / ((double)ms * 1e6);
+            if (r >= 2 && gbps > best) best = gbps;
+        }
+        gbps_out[nt] = best;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(buf);
+    return (int)er;
+}

@@ -29,7 +29,7 @@ def main():
     per = {}
     fam = {}
     for n, gx, gy, gz, wx, did, cn, v, dur in rows:
-        for f in ("pconv_gemm", "pconv_bf16", "reparam", "maxpool", "mc_tail"):
+        for f in ("pconv_gemm", "pconv_bf16", "pconv_c8x3", "reparam", "maxpool", "mc_tail", "s2d_c8s3"):
             if f in n:
                 t = fam.setdefault((f, cn), [0.0, 0])
                 t[0] += v
