@@ -1316,6 +1316,23 @@ def main():
                 out["cpu_baseline"]["reference_gpu_value"] = rg["no_grad"]["samples_per_s"]
                 out["speedup_vs_reference_gpu"] = round(out["value"] / rg["no_grad"]["samples_per_s"], 1)
             out["speedup_vs_cpu"] = round(out["value"] / cpu["value"], 1)
+        # the judged line must stay under 2000 characters (the driver's record keeps a 2000-character tail): scalars that only
+        # repeat or qualify another one ride on the SECONDARY line instead (second["main_line_extras"])
+        extras_moved = {}
+        if isinstance(out.get("roofline"), dict):
+            for k in ("reparam_traffic", "device_copy_GBps", "one_step_per_launch_frac", "sustained_TFLOPs", "dropin_loop_autograd_value",
+                      "split_bf16_per_launch_us", "stats_blocks", "reparam_in_step_frac_of_write_roof", "split_bf16_max_abs_diff_vs_fp32"):
+                if k in out["roofline"]:
+                    extras_moved["roofline." + k] = out["roofline"].pop(k)
+        if isinstance(out.get("cpu_baseline"), dict):
+            for k in ("p10", "p90", "autograd_value"):
+                if k in out["cpu_baseline"]:
+                    extras_moved["cpu_baseline." + k] = out["cpu_baseline"].pop(k)
+        for k in ("speedup_vs_reference_gpu", "speedup_vs_cpu"):
+            if k in out:
+                extras_moved[k] = out.pop(k)
+        if extras_moved:
+            second["main_line_extras"] = extras_moved
         final_lines = (["SECONDARY " + json.dumps(second)] if second else []) + [json.dumps(compact(out))]
     def flush_c_stdio():
         # RCCL writes a version banner through C stdio, which sits in libc's buffer until exit when stdout is a pipe -- it would
