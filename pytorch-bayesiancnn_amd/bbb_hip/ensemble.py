@@ -1264,6 +1264,20 @@ def collective_capture_ok(group, device, _force_probe=False, _stall_s=0.0):
         ok = False
         why = ("the capture probe did not finish within %.0f s (a rank is missing or stalled)" % capture_probe_timeout_s) if res is None \
             else "probe raised %s: %s" % (type(res).__name__, str(res)[:120])
+    # Confirmation (advisor r05): the decision above is LOCAL where a watchdog fired -- a rank whose watchdog expires just as the last
+    # agreement completes on its peers would cache "eager" while they cache "recorded", and the next step would hang on mismatched
+    # protocols.  So every rank enters one more MIN agreement, on the caller's own group (the private agreement communicator may
+    # hold an abandoned thread), again under the watchdog: "recorded" only if every rank says so and the round itself completes.
+    def confirm():
+        flag = torch.tensor([1.0 if ok else 0.0], device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        return bool(flag.item() > 0.5)
+
+    done2, res2 = _with_watchdog(confirm, capture_probe_timeout_s)
+    if not done2:
+        ok, why = False, why or "the confirmation round did not finish within %.0f s" % capture_probe_timeout_s
+    elif ok and not res2:
+        ok, why = False, "another rank fell back to the eager protocol (its probe timed out)"
     _capture_probe[group] = ok
     last_protocol.update(collective="recorded" if ok else "eager", reason=None if ok else why)
     return ok

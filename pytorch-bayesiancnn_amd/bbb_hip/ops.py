@@ -20,9 +20,10 @@ from . import _lib, rng
 from ._lib import Segment, ConvDesc, check, ptr, require_device, cur_stream, on_device
 
 _scratch = {}
-_retired = []     # outgrown scratch buffers: a captured hipGraph may have their address baked in, so they are NEVER freed (a
-                  # second pipeline / a larger model captured on the same stream must not pull the first graph's tickets or KL
-                  # slots out from under it).  Sizes at least double, so a stream retires < its final size in total.
+_retired = []     # (key, buffer) of outgrown scratch buffers: a captured hipGraph may have their address baked in, so a per-stream
+                  # one is NEVER freed (a second pipeline / a larger model captured on the same stream must not pull the first
+                  # graph's tickets or KL slots out from under it); a scope's go when its owner dies (_release_scope).  Sizes at
+                  # least double, so a key retires < its final size in total.
 
 
 _scope_tls = threading.local()
@@ -47,7 +48,9 @@ class scratch_scope:
                 owner._bbb_scratch_token = tok
                 weakref.finalize(owner, _release_scope, tok)
             except (AttributeError, TypeError):
-                pass
+                # an owner that can carry neither the token nor a finaliser: a fresh token per call would leave a scratch set behind
+                # every time and nothing would ever release it -- fall back to the per-(device, stream) set
+                tok = None
         self.tok = tok
 
     def __enter__(self):
@@ -65,8 +68,10 @@ def current_scratch_token():
 
 
 def _release_scope(tok):
-    for k in [k for k in _scratch if isinstance(k[2], tuple) and k[2][:2] == ("scope", tok)]:
+    mine = lambda k: isinstance(k[2], tuple) and k[2][:2] == ("scope", tok)
+    for k in [k for k in _scratch if mine(k)]:
         del _scratch[k]
+    _retired[:] = [(k, b) for k, b in _retired if not mine(k)]          # the scope's outgrown buffers: its graphs are gone too
 
 
 def _scratch_key(device, kind):
@@ -80,7 +85,7 @@ def _grow(key, need, make):
     buf = _scratch.get(key)
     if buf is None or buf.numel() < need:
         if buf is not None:
-            _retired.append(buf)
+            _retired.append((key, buf))
             need = max(int(need), 2 * buf.numel())
         buf = _scratch[key] = make(int(need))
     return buf

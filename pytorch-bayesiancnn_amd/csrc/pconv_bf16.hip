@@ -22,6 +22,7 @@
 // LDS pitches: image rows 320 B (= 64 B mod 256: the four rows of a transpose read and the two 16-column halves of a
 // 32-lane group land on disjoint banks), weight rows 144 B (conflict-free for the 16-byte reads).
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdlib.h>
 #include <stdint.h>
 
@@ -1362,28 +1363,36 @@ __global__ __launch_bounds__(256) void pconv_bf16_fewout_kernel(const PConvArgs 
     }
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: `state` (one array per kernel instantiation)
+// remembers the bytes granted on each device, so that a process driving several GPUs -- or several threads (relaxed atomics: a
+// duplicated call is harmless) -- sets it wherever a launch needs it.
+constexpr int kMaxDevices = 64;
+struct SmemAttrState { std::atomic<int> bytes[kMaxDevices]; };
+inline int ensure_dynamic_smem(const void* fn, int bytes, SmemAttrState& state) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+        return (int)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);       // (unknown device: every time)
+    }
+    if (state.bytes[dev].load(std::memory_order_relaxed) >= bytes) return 0;
+    const hipError_t er = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (er != hipSuccess) return (int)er;
+    state.bytes[dev].store(bytes, std::memory_order_relaxed);
+    return 0;
+}
+
 template <int NP>
 int launch_fewout(const PConvArgs& a, int64_t blocks, hipStream_t st) {
     constexpr int kSmem = 64 * NP * 32 * 4;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(&pconv_bf16_fewout_kernel<NP>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmem);
-        if (er != hipSuccess) return (int)er;
-        attr_done = true;
-    }
+    static SmemAttrState attr_state;
+    if (const int rc = ensure_dynamic_smem(reinterpret_cast<const void*>(&pconv_bf16_fewout_kernel<NP>), kSmem, attr_state)) return rc;
     hipLaunchKernelGGL((pconv_bf16_fewout_kernel<NP>), dim3((unsigned)blocks), dim3(256), kSmem, st, a);
     return (int)hipGetLastError();
 }
 
 template <int KS, bool C8>
 int launch_smallk_poolwin_c(const PConvArgs& a, int64_t blocks, int smem_bytes, hipStream_t st) {
-    static int attr_bytes = 0;
-    if (smem_bytes > attr_bytes) {
-        hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(&pconv_bf16_smallk_poolwin_kernel<KS, C8>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
-        if (er != hipSuccess) return (int)er;
-        attr_bytes = smem_bytes;
-    }
+    static SmemAttrState attr_state;
+    if (const int rc = ensure_dynamic_smem(reinterpret_cast<const void*>(&pconv_bf16_smallk_poolwin_kernel<KS, C8>), smem_bytes, attr_state)) return rc;
     hipLaunchKernelGGL((pconv_bf16_smallk_poolwin_kernel<KS, C8>), dim3((unsigned)blocks), dim3(256), smem_bytes, st, a);
     return (int)hipGetLastError();
 }
@@ -1399,13 +1408,8 @@ template <int NT, int KS, bool C8>
 int launch_smallk_pool_c(const PConvArgs& a, int64_t blocks, hipStream_t st) {
     constexpr int kSmem = (KS * 16 * (256 + 32) + 4 * 32 * NT * 72) * 2 + 2 * 3 * KS * 16 * 4;
     static_assert(kSmem <= 160 * 1024, "LDS");
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(&pconv_bf16_smallk_pool_kernel<NT, KS, C8>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, kSmem);
-        if (er != hipSuccess) return (int)er;
-        attr_done = true;
-    }
+    static SmemAttrState attr_state;
+    if (const int rc = ensure_dynamic_smem(reinterpret_cast<const void*>(&pconv_bf16_smallk_pool_kernel<NT, KS, C8>), kSmem, attr_state)) return rc;
     hipLaunchKernelGGL((pconv_bf16_smallk_pool_kernel<NT, KS, C8>), dim3((unsigned)blocks), dim3(256), kSmem, st, a);
     return (int)hipGetLastError();
 }
@@ -1419,13 +1423,8 @@ template <int NT, int KS>
 int launch_smallk(const PConvArgs& a, int64_t blocks, hipStream_t st) {
     constexpr int kSmem = (KS * 16 * (256 + 32) + 4 * 32 * NT * 72) * 2 + 16 * KS * 16 * 4;      // px_run <= 16
     static_assert(kSmem <= 160 * 1024, "LDS");
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(&pconv_bf16_smallk_kernel<NT, KS>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, kSmem);
-        if (er != hipSuccess) return (int)er;
-        attr_done = true;
-    }
+    static SmemAttrState attr_state;
+    if (const int rc = ensure_dynamic_smem(reinterpret_cast<const void*>(&pconv_bf16_smallk_kernel<NT, KS>), kSmem, attr_state)) return rc;
     hipLaunchKernelGGL((pconv_bf16_smallk_kernel<NT, KS>), dim3((unsigned)blocks), dim3(256), kSmem, st, a);
     return (int)hipGetLastError();
 }
@@ -1438,13 +1437,8 @@ int launch_cfg(const PConvArgs& a, int64_t blocks, hipStream_t st) {
     static_assert(kRed <= KG * kStageB, "reduction buffer must fit in the stage memory");
     static_assert(kSmem <= 160 * 1024, "LDS");
     static_assert(WN * WM * 64 * 72 * 2 <= kStageB, "epilogue staging must fit in one stage");
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(&pconv_bf16_kernel<OUT_F32, WN, WM, KG, WS>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, kSmem);
-        if (er != hipSuccess) return (int)er;
-        attr_done = true;
-    }
+    static SmemAttrState attr_state;
+    if (const int rc = ensure_dynamic_smem(reinterpret_cast<const void*>(&pconv_bf16_kernel<OUT_F32, WN, WM, KG, WS>), kSmem, attr_state)) return rc;
     hipLaunchKernelGGL((pconv_bf16_kernel<OUT_F32, WN, WM, KG, WS>), dim3((unsigned)blocks),
                        dim3(64 * WN * WM * KG + (WS ? 256 : 0)), kSmem, st, a);
     return (int)hipGetLastError();

@@ -58,21 +58,19 @@ class BayesianLayer(ModuleWrapper):
             self.bias_rho.data.normal_(*self.posterior_rho_initial)
 
     # -- compat: the reference caches W_sigma / bias_sigma as plain attributes during forward -----------
-    # (layers/BBB/BBBConv.py:64,69).  Here they are read-only views of the parameters: without autograd the sigma the fused
-    # parameter pass computes (bbb_reparam_kl_fwd's sigma output: the value every sampled weight of a forward was built from),
-    # cached until rho changes; with autograd enabled on a trainable rho the differentiable torch expression, as upstream.
+    # (layers/BBB/BBBConv.py:64,69).  Here they are read-only views of the parameters, computed on every read (nothing in this
+    # package reads them; upstream recomputes them every forward too): without autograd the sigma of the fused parameter pass
+    # (bbb_reparam_kl_fwd's sigma output: the value every sampled weight of a forward is built from) -- NOT cached: writes
+    # through `.data` (reset_parameters, a user's p.data.copy_) do not bump the version counter a cache could be keyed on --
+    # with autograd enabled on a trainable rho the differentiable torch expression, as upstream.
     def _sigma_of(self, mu, rho, slot):
         if rho is None:
             return None
         if not rho.is_cuda or (torch.is_grad_enabled() and rho.requires_grad):
             return torch.log1p(torch.exp(rho))
-        key = (rho.data_ptr(), rho._version, rho.device)
-        hit = self.__dict__.get(slot)
-        if hit is None or hit[0] != key:
-            _, sig, _ = ops.reparam_kl_forward([mu.detach()], [rho.detach()], self.prior_mu, self.prior_sigma, [0], 0, 0, draws=1,
-                                               sample=False, want_sigma=True, want_kl=False)
-            hit = self.__dict__[slot] = (key, sig[0])
-        return hit[1]
+        _, sig, _ = ops.reparam_kl_forward([mu.detach()], [rho.detach()], self.prior_mu, self.prior_sigma, [0], 0, 0, draws=1,
+                                           sample=False, want_sigma=True, want_kl=False)
+        return sig[0]
 
     @property
     def W_sigma(self):

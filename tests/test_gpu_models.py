@@ -455,7 +455,8 @@ def test_pipeline_lanes_own_their_input_buffers(env):
 
 def test_sigma_attributes_come_from_the_fused_pass_and_follow_rho():
     """W_sigma / bias_sigma (readable after forward upstream: layers/BBB/BBBConv.py:64,69): without autograd the fused parameter
-    pass's own sigma output, cached until rho changes; with autograd on a trainable rho the differentiable expression."""
+    pass's own sigma output, computed on every read -- writes through `.data` (reset_parameters, p.data.copy_) never bump the version
+    counter a cache could be keyed on --; with autograd on a trainable rho the differentiable expression."""
     import copy
     import layers
     from bbb_hip import ops
@@ -463,7 +464,7 @@ def test_sigma_attributes_come_from_the_fused_pass_and_follow_rho():
     l = layers.BBB_Conv2d(3, 8, 3, priors=None).cuda()
     with torch.no_grad():
         s1 = l.W_sigma
-        assert s1 is l.W_sigma and not s1.requires_grad                       # cached
+        assert torch.equal(s1, l.W_sigma) and not s1.requires_grad
         _, sig, _ = ops.reparam_kl_forward([l.W_mu.detach()], [l.W_rho.detach()], 0, 0.1, [0], 0, 0, draws=1, sample=False,
                                            want_sigma=True, want_kl=False)
         assert torch.equal(s1, sig[0])
@@ -471,6 +472,10 @@ def test_sigma_attributes_come_from_the_fused_pass_and_follow_rho():
         l.W_rho.add_(0.5)                                                     # an optimizer step
         s2 = l.W_sigma
         assert s2 is not s1 and float((s2 - s1).abs().min()) > 0
+        l.W_rho.data.fill_(-3.0)                                              # a write the version counter does not see
+        assert float((l.W_sigma - 0.048587).abs().max()) < 1e-6
+        l.reset_parameters()
+        np.testing.assert_allclose(l.W_sigma.cpu().numpy(), torch.log1p(torch.exp(l.W_rho)).cpu().numpy(), rtol=3e-7)
         assert l.bias_sigma.shape == (8,) and layers.BBB_Linear(4, 2, bias=False).cuda().bias_sigma is None
     s3 = l.W_sigma                                                            # autograd on: connected to rho
     assert s3.requires_grad

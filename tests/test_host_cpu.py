@@ -878,8 +878,24 @@ def test_outgrown_scratch_buffers_are_retired_not_freed():
     a = ops._grow(key, 100, make)
     assert ops._grow(key, 50, make) is a and ops._grow(key, 100, make) is a
     b = ops._grow(key, 101, make)
-    assert b is not a and b.numel() >= 200 and ops._retired[n_ret] is a       # doubled, the old one kept
+    assert b is not a and b.numel() >= 200 and ops._retired[n_ret] == (key, a) and ops._retired[n_ret][1] is a   # doubled, the old one kept
     assert ops._grow(key, 150, make) is b
     assert made == [100, 200]
     ops._scratch.pop(key)
     del ops._retired[n_ret:]
+    # ... a scope's outgrown buffers go with the scope (its graphs died with the owner), and an owner that can carry neither the
+    # token nor a finaliser does not get a scope of its own (it would never be released): the per-stream set instead
+    class Owner:
+        pass
+    o = Owner()
+    with ops.scratch_scope(o) as sc:
+        tok = sc.tok
+    sk = (0, "kl", ("scope", tok, 0))
+    ops._grow(sk, 10, make)
+    ops._grow(sk, 100, make)
+    assert any(k == sk for k, _ in ops._retired) and sk in ops._scratch
+    del o
+    import gc
+    gc.collect()
+    assert sk not in ops._scratch and not any(k == sk for k, _ in ops._retired)
+    assert ops.scratch_scope(object()).tok is None
