@@ -788,6 +788,65 @@ def slow_paths(dev, steps):
 SPLIT_STEPS_PER_LAUNCH = 4
 
 
+def hot_us(fn, dev, reps=10, heat_s=0.03):
+    """us per call of fn: `reps` calls back to back inside one hipGraph, pre-heated, HIP events around 3 replays, median of 3."""
+    from bbb_hip import ops
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize(dev)
+    g = torch.cuda.CUDAGraph()
+    with ops.graph_capture(g):
+        for _ in range(reps):
+            fn()
+    preheat(g.replay, heat_s, dev)
+    ts = []
+    for _ in range(3):
+        s0, e0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s0.record()
+        for _ in range(3):
+            g.replay()
+        e0.record()
+        torch.cuda.synchronize(dev)
+        ts.append(s0.elapsed_time(e0) / (3 * reps))
+    return round(statistics.median(ts) * 1e3, 1)
+
+
+def fusion_ab(dev, slabs=40, B=512):
+    """SURVEY section 8(f) N3 on the split-bf16 chain (review r05 item 7): per pooling layer of BayesianAlexNet either the fused launch
+    that ships (A/B measured here, us per 40-slab launch) or the separate pooling launch's cost next to the extra matrix work its
+    fusion would need.  pool1: conv1 in space-to-depth form has no padding, every window walks the same taps -> the parallel-window
+    form (four waves = four pixels) fuses it at no extra matrix work.  pool2 / pool3 follow PADDED layers: the four pixels of a
+    window walk different in-bounds tap sets, a shared weight tile means the union (conv2: 64 taps for 49 = +31 %; conv5 on a 2 x 2
+    map: 36 for 16 = +125 %), and the serial-window form quarters the workgroup count at 4x their length (measured slower on the
+    fp32 kernel, profiles/r04_notes.md section 7, r05_notes.md section 4)."""
+    from bbb_hip import ops
+    out = {}
+    with torch.no_grad():
+        torch.manual_seed(0)
+        x = torch.rand(4 * B, 3, 32, 32, device=dev)
+        xs = ops.s2d_c8s3(x, 4, 11, 4, 5)                                     # four steps' batches
+        w = ops.w_s2d_tap_major(torch.randn(slabs, 64, 3, 11, 11, device=dev) * 0.05, 4)
+        b = torch.randn(slabs, 64, device=dev) * 0.1
+        zb = ops.s2d_zero_border(3, 11, 4, 5, 32, 32)
+        kw = dict(act="softplus", zero_border=zb, x_div=slabs // 4)
+        fused = hot_us(lambda: ops.conv2d_c8x3_forward(xs, w, b, 3, 1, 0, 1, pool=True, **kw), dev)
+        conv = hot_us(lambda: ops.conv2d_c8x3_forward(xs, w, b, 3, 1, 0, 1, **kw), dev)
+        y = ops.conv2d_c8x3_forward(xs, w, b, 3, 1, 0, 1, **kw)
+        pool = hot_us(lambda: ops.maxpool_c8s3(y, 2, 2), dev)
+        assert torch.equal(ops.maxpool_c8s3(y, 2, 2), ops.conv2d_c8x3_forward(xs, w, b, 3, 1, 0, 1, pool=True, **kw))
+        out["pool1"] = {"fused_us": fused, "conv_us": conv, "pool_us": pool, "shipped": "fused (bit for bit the two launches)",
+                        "saved_us": round(conv + pool - fused, 1)}
+        del y
+        for name, (C, H), extra in (("pool2", (192, 4), "+31 % matrix work (union of the window's tap sets: 64 for 49)"),
+                                    ("pool3", (128, 2), "+125 % matrix work (36 taps for 16)")):
+            t = ops.c8s3_from_f32(torch.rand(slabs, C, H, H, B, device=dev))
+            out[name] = {"pool_us": hot_us(lambda t=t: ops.maxpool_c8s3(t, 2, 2), dev), "shipped": "separate launch",
+                         "fused_form_would_need": extra}
+            del t
+    out["unit"] = "us per launch of %d slabs x %d images" % (slabs, B)
+    return out
+
+
 def split_bf16(dev, steps, pipeline):
     """The metric step with the GEMM launches on the 16-bit matrix pipe at fp32 accuracy, range-free (ops.gemm_mode = "bf16x3",
     bbb_conv2d_chwn_bf16x3_fwd: every operand element split into three bf16 pieces while staged, six products per fp32 product,
@@ -877,14 +936,36 @@ def split_bf16(dev, steps, pipeline):
                                        "what": "forward + backward + Adam, bs=512 num_ens=10, launch by launch; forward, wgrad and dgrad GEMMs in the mode"}
         except Exception as exc:
             out["training_step_ms"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:160])}
+        try:
+            out["fusion_ab"] = fusion_ab(dev)
+        except Exception as exc:
+            out["fusion_ab"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:160])}
+        # the other BBB configurations of BASELINE.json in the mode (same launch shapes as their fp32 rows in SECONDARY.configs)
+        oc = {}
+        for name in ("configs[3]", "configs[4]"):
+            try:
+                r, n2, x2 = run_config(CONFIGS[name], 12, 3, 3, dev, want_roofline=False, preheat_s=0.15, single_lane=False)
+                oc[name] = {"value": r["value"], "ms_per_step": r["ms_per_step"]}
+                del n2, x2
+            except Exception as exc:
+                oc[name] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:160])}
+            torch.cuda.empty_cache()
+        out["other_configs"] = oc
         out["unit"] = "samples/s"
-        out["note"] = ("opt-in precision mode, range-free: fp32 tensors in HBM, every GEMM operand element split into hi = bf16(a), "
-                       "mid = bf16(a - hi), lo = bf16(a - hi - mid) while its tile is staged (exact), six products on "
-                       "v_mfma_f32_32x32x16_bf16, fp32 accumulation; against the float64 oracle 2.5-3.2e-7 of sum|w||x| on every operand "
-                       "scale (the fp32 kernel: 2.8-3.7e-7), tests/test_gpu_bf16x3.py")
+        out["note"] = ("opt-in precision mode, range-free: every GEMM operand element is the sum of hi = bf16(a), mid = bf16(a - hi), "
+                       "lo = bf16(a - hi - mid) (exact), six products on v_mfma_f32_32x32x16_bf16, fp32 accumulation.  Round 6: both "
+                       "operands MFMA-ready in memory (csrc/pconv_c8x3.hip) -- activations travel channel-interleaved and already split "
+                       "(c8 S3, cut once by the producing epilogue), weights come tap-major from the parameter pass, conv1 runs in "
+                       "space-to-depth form with its pooling inside the launch.  Against the float64 oracle 2.5-3.2e-7 of sum|w||x| on "
+                       "every operand scale (the fp32 kernel: 2.8-3.7e-7); held to the SAME bounds as the fp32 path at every full-size "
+                       "configuration (tests/test_gpu_parity_fullsize.py[bf16x3], tests/test_gpu_c8x3.py)")
     finally:
         ops.gemm_mode = "fp32"
     return out
+
+
+def ops_pair(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
 
 
 def training_step(dev, steps):
@@ -909,7 +990,33 @@ def training_step(dev, steps):
         torch.cuda.synchronize(dev)
         res[mode] = (time.perf_counter() - t0) / steps
     dt = res["default"]
+    # executed matrix work of the step: forward (in-bounds taps) + weight gradients (the same products, every layer) + input gradients
+    # (the same products, every layer but the first) -- over the whole step's time: how much of the fp32 matrix peak a training
+    # step sustains (layout shuffles, pooling / activation backward, parameter passes and Adam included in the time)
+    fwd = first = 0.0
+    shape = (cfg["hw"], cfg["hw"])
+    import torch.nn as nn
+    from layers.misc import FlattenLayer
+    for m in ensemble.flat_children(net):
+        if hasattr(m, "W_mu"):
+            if m.W_mu.dim() == 4:
+                f = ensemble.conv_flops(cfg["B"], m.in_channels, shape[0], shape[1], m.out_channels, *m.kernel_size, m.stride, m.padding,
+                                        m.dilation, cfg["E"])[0]
+                sh, ph, dh = ops_pair(m.stride), ops_pair(m.padding), ops_pair(m.dilation)
+                shape = tuple((shape[a] + 2 * ph[a] - dh[a] * (m.kernel_size[a] - 1) - 1) // sh[a] + 1 for a in (0, 1))
+            else:
+                f = 2.0 * cfg["E"] * cfg["B"] * m.in_features * m.out_features
+            first = first or f
+            fwd += f
+        elif isinstance(m, nn.MaxPool2d):
+            k, st = m.kernel_size, (m.stride if m.stride is not None else m.kernel_size)
+            shape = tuple((v - k) // st + 1 for v in shape)
+    flop = 3.0 * fwd - first
     out = {"ms_per_step": round(1e3 * dt, 4), "value": round(cfg["B"] * cfg["E"] / dt, 1), "unit": "samples/s (forward + backward + Adam)",
+           "roofline": {"bound": "mfma", "achieved": round(flop / dt / 1e12, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(flop / dt / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), "flop_per_step": flop,
+                        "what": "executed FLOPs of forward + wgrad + dgrad (in-bounds taps; 3 x forward - the first layer's dgrad) over the "
+                                "whole step's wall time"},
            "launch_by_launch_ms_per_step": round(1e3 * res["launch_by_launch"], 4), "path": path,
            "note": "BayesianAlexNet bs=512 num_ens=10, fp32, train.train_step as called (it captures itself as one hipGraph after 3 "
                    "identical calls; graph=False = launch_by_launch); round 1 (reference-layout autograd path): 8.3 ms"}
@@ -1265,6 +1372,10 @@ def main():
                 second["slow_paths"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:160])}
             try:
                 second["training_step"] = training_step(dev, max(5, args.steps // 5))
+                ts = second["training_step"]
+                if out["roofline"] is not None and "roofline" in ts:
+                    out["roofline"]["training_step_ms"] = ts["ms_per_step"]
+                    out["roofline"]["training_step_frac"] = ts["roofline"]["frac"]
             except Exception as exc:
                 second["training_step"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:160])}
             torch.cuda.empty_cache()
@@ -1321,7 +1432,8 @@ def main():
         extras_moved = {}
         if isinstance(out.get("roofline"), dict):
             for k in ("reparam_traffic", "device_copy_GBps", "one_step_per_launch_frac", "sustained_TFLOPs", "dropin_loop_autograd_value",
-                      "split_bf16_per_launch_us", "stats_blocks", "reparam_in_step_frac_of_write_roof", "split_bf16_max_abs_diff_vs_fp32"):
+                      "split_bf16_per_launch_us", "stats_blocks", "reparam_in_step_frac_of_write_roof", "split_bf16_max_abs_diff_vs_fp32",
+                      "one_step_per_launch_ms", "reparam_10draw_frac", "reparam_hbm_resident_frac"):
                 if k in out["roofline"]:
                     extras_moved["roofline." + k] = out["roofline"].pop(k)
         if isinstance(out.get("cpu_baseline"), dict):

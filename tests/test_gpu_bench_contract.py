@@ -51,9 +51,11 @@ def test_bench_json_contract_default():
     _check_roofline(r, 157.3)
     # every judged number is a first-level scalar of `roofline` (what the driver's record keeps), the reparam pass also nested
     for k in ("per_launch_us", "slabs_per_launch", "sustained_frac", "stats_median", "stats_p10", "stats_p90", "one_step_in_flight_ms",
-              "one_step_per_launch_ms", "reparam_frac", "reparam_avg_us", "reparam_draws", "reparam_10draw_frac", "reparam_back_to_back_frac",
-              "reparam_hbm_resident_frac", "dropin_loop_value", "timed_by", "value_above_p90", "odd_batch_510_value", "hooked_loop_value"):
+              "reparam_frac", "reparam_avg_us", "reparam_draws", "reparam_back_to_back_frac", "training_step_ms", "training_step_frac",
+              "dropin_loop_value", "timed_by", "value_above_p90", "odd_batch_510_value", "hooked_loop_value"):
         assert k in r and not isinstance(r[k], (dict, list)), k
+    for k in ("one_step_per_launch_ms", "reparam_10draw_frac", "reparam_hbm_resident_frac"):        # (round 6: on the SECONDARY line)
+        assert ("roofline." + k) in sec["main_line_extras"], k
     assert r["slabs_per_launch"] == 40 and len(r["per_launch_us"].split("/")) == 6
     assert r["stats_p10"] <= r["stats_median"] <= r["stats_p90"]
     # reparam_frac is the launch shape the timed region runs: 4 steps x 10 draws per launch (review r04: "make the judged line say
@@ -65,7 +67,12 @@ def test_bench_json_contract_default():
     assert "error" not in reg and reg["draws_per_launch"] == 40 and reg["frac"] == r["reparam_frac"]
     assert abs(reg["avg_us"] - (reg["pair_us"] - reg["gemm_alone_us"])) < 0.02
     assert 0.3 < r["reparam_back_to_back_frac"] < 1.0 and r["reparam_back_to_back_frac"] == sec["roofline_reparam_steps_per_launch"]["frac"]
-    assert 0 < r["reparam_hbm_resident_frac"] < 1 and 0 < r["reparam_10draw_frac"] < 1.2
+    mx = sec["main_line_extras"]
+    assert 0 < mx["roofline.reparam_hbm_resident_frac"] < 1 and 0 < mx["roofline.reparam_10draw_frac"] < 1.2
+    ts = sec["training_step"]["roofline"]                # executed FLOPs of forward + wgrad + dgrad over the step's wall time
+    assert ts["bound"] == "mfma" and ts["peak"] == 157.3 and 0.05 < ts["frac"] < 1 and r["training_step_frac"] == ts["frac"]
+    fa = sec["split_bf16"]["fusion_ab"]                  # N3 closed with numbers: pool1 fused and shipped, pool2 / pool3 priced
+    assert "error" not in fa and fa["pool1"]["fused_us"] < fa["pool1"]["conv_us"] + fa["pool1"]["pool_us"] and fa["pool2"]["pool_us"] > 0
     assert r["value_above_p90"] == (j["value"] > r["stats_p90"]) and "hipGraph" in r["timed_by"]
     # the secondary line: the objects of rounds 1-3, unabridged
     for k in ("roofline_detail", "roofline_reparam", "stats", "one_step_in_flight", "one_step_per_launch", "dropin_loop", "configs",

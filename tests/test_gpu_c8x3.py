@@ -152,7 +152,8 @@ def test_c8x3_pooled_launch_is_the_launch_then_the_pooling(env, B, Cin, H, W, Co
 
 
 @pytest.mark.parametrize("N,C,H,W,Cout,k,s,p,blocks", [(64, 3, 32, 32, 64, 11, 4, 5, 1), (24, 3, 32, 32, 16, 11, 4, 5, 3),
-                                                       (16, 1, 17, 21, 8, 5, 2, 1, 2), (8, 5, 12, 12, 24, 3, 3, 0, 1)])
+                                                       (16, 1, 17, 21, 8, 5, 2, 1, 2), (8, 5, 12, 12, 24, 3, 3, 0, 1),
+                                                       (20, 3, 20, 70, 16, 11, 4, 5, 1)])      # two column tiles, ragged image tile
 def test_space_to_depth_operands_and_layer(env, N, C, H, W, Cout, k, s, p, blocks):
     """bbb_s2d_c8s3 / bbb_w_s2d_tap_major against their definition (include/bbb_hip.h) built with torch indexing, and the strided
     layer computed as the m x m stride-1 layer on them against the float64 oracle (bound of the fp32 kernel) -- plain and with the
