@@ -275,7 +275,28 @@ int bbb_s3_convert(const void* src, void* dst, int64_t slabs, int64_t n, int to_
 #define BBB_C8X3_ZERO_MASK 0x00FFFF00u
 int bbb_conv2d_c8x3_fwd(const bbb_conv_desc_t* d, const void* x, const float* w, const float* bias, void* y, uint32_t flags,
                         void* stream);
+/* to_c8s3: 1 = fp32 -> c8 S3, 0 = back; 2 = fp32 -> six planes (values + squares), 3 = six planes -> fp32 (the LRT chain's slabs) */
 int bbb_c8s3_convert(const void* src, void* dst, int64_t slabs, int channels, int64_t positions, int batch, int to_c8s3, void* stream);
+/*
+ * The LRT form of the same contraction (ABI 12; layers/BBB_LRT/BBBConv.py:62-87, BBBLinear.py:56-79 in the split-bf16 mode):
+ *   act_mu = conv(x, w_mu) + b_mu,  act_var = 1e-16 + conv(x^2, w_var) + b_var,  y = act(act_mu + sqrt(act_var) * eps)
+ * with both contractions on v_mfma_f32_32x32x16_bf16 (two weight tiles, two sets of image fragments and accumulators per
+ * workgroup) and eps drawn in the epilogue exactly as bbb_lrt_conv2d_chwn_fwd draws it (element index of the output's canonical
+ * [B][cout][ho][wo] slab, stream (seed, call0 + draw, stream_id); d->b_offset and work units key the GLOBAL image index).
+ *   x, y: SIX-plane c8 S3 slabs [draws|1][6][c / 8][h][w][B][8] -- the three pieces of the values, then the three pieces of their
+ *      squares (squared in fp32 by whoever writes the slab: this launch's epilogue, bbb_maxpool_chwn_s3sq, bbb_s2d_c8s3sq,
+ *      bbb_c8s3_convert mode 2); d->x_draw_stride counts bf16 elements (6 * cin * h * w * B per slab, or 0 = shared).
+ *      With BBB_C8X3_OUT_F32, y is the fp32 tensor [draws][cout][ho][wo][B] (the logits layer).
+ *   w_mu, w_var: fp32 tap-major [cout][kh * kw][cin], shared by the slabs (d->w_draw_stride == d->b_draw_stride == 0).
+ * flags: BBB_C8X3_OUT_F32, BBB_C8X3_TILE128 / _TILE256, BBB_C8X3_ZERO_*; no pooled form.  sample == 0: y = act(act_mu).
+ * bbb_maxpool_chwn_s3sq pools six-plane slabs (maximum over the values; the squares are those of the pooled values);
+ * bbb_s2d_c8s3sq is bbb_s2d_c8s3 with the squares' planes behind; bbb_c8s3_convert modes 2 / 3 convert fp32 <-> six planes.
+ */
+int bbb_lrt_conv2d_c8x3_fwd(const bbb_conv_desc_t* d, const void* x, const float* w_mu, const float* w_var, const float* b_mu,
+                            const float* b_var, void* y, uint64_t seed, uint32_t call0, uint32_t stream_id, int sample,
+                            const uint32_t* call_dev, uint32_t flags, void* stream);
+int bbb_maxpool_chwn_s3sq(const void* x, void* y, int64_t slabs, int channels, int h, int w, int batch, int k, int s, void* stream);
+int bbb_s2d_c8s3sq(const float* x, void* y, int64_t blocks, int batch, int channels, int h, int w, int k, int stride, int pad, void* stream);
 /*
  * Space-to-depth operands (ABI 12): a strided layer with few input channels (AlexNet conv1: 3 channels, 11 x 11, stride 4, padding 5 --
  * models/BayesianModels/BayesianAlexNet.py:33) as a layer bbb_conv2d_c8x3_fwd can take.  With m = ceil(k / stride) it is the m x m

@@ -60,6 +60,10 @@ _SIGNATURES = {
     "bbb_c8s3_convert": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_i64, c_int, c_int, c_void_p]),
     "bbb_w_tap_major": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p]),
     "bbb_s2d_c8s3": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "bbb_s2d_c8s3sq": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "bbb_lrt_conv2d_c8x3_fwd": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_u64, c_u32,
+                                        c_u32, c_int, c_void_p, c_u32, c_void_p]),
+    "bbb_maxpool_chwn_s3sq": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "bbb_w_s2d_tap_major": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_void_p]),
     "bbb_lrt_conv2d_chwn_fwd": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_u64, c_u32, c_u32, c_int, c_void_p, c_void_p]),

@@ -430,8 +430,18 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
     children = flat_children(net)
     last_bayes = max((i for i, m in enumerate(children) if isinstance(m, (_BBBLayer, _LRTLayer))), default=-1)
     tail_is_last = last_bayes == len(children) - 1
-    split_mode = (precision == "bf16x3" or ops.current_config().gemm_mode == "bf16x3") and not bf16 and not lrt and bool(bbb) and tail_is_last
+    split_any = (precision == "bf16x3" or ops.current_config().gemm_mode == "bf16x3") and not bf16 and tail_is_last
+    split_mode = split_any and not lrt and bool(bbb)
+    # ... LRT models (every Bayesian layer local-reparameterisation) the same way, on the kernel's LRT form: six-plane slabs (values +
+    # squares), W_mu / W_sigma^2 tap-major (rearranged once per launch: LRT weights do not depend on the draw)
+    lrt_mode = split_any and bool(lrt) and not bbb and ops.current_config().c8x3
     c8_set = set()
+    if lrt_mode:
+        for l in lrt[1:]:
+            cin = l.in_channels if isinstance(l, _LRTConv) else l.in_features
+            cout = l.out_channels if isinstance(l, _LRTConv) else l.out_features
+            if ops.c8x3_layer_ok(cin, cout, is_logits=(l is children[last_bayes])):
+                c8_set.add(l)
     if split_mode and ops.current_config().c8x3:
         for l in bbb[1:]:
             cin = l.in_channels if isinstance(l, _BBBConv) else l.in_features
@@ -441,9 +451,10 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
     # ... and a strided first layer on few channels (AlexNet conv1) joins the chain in space-to-depth form (ops.s2d_layer_ok): its block
     # image is cut from the caller's NCHW batch in c8 S3 directly, its dense weight draws are rearranged by one small launch
     s2d_first = None
-    if split_mode and ops.current_config().c8x3 and ops.current_config().c8x3_s2d and children and children[0] is bbb[0] and \
-            isinstance(bbb[0], _BBBConv) and bbb[0] not in c8_set and x.dim() == 4 and last_bayes != 0:
-        l0 = bbb[0]
+    first_l = bbb[0] if (split_mode and bbb) else (lrt[0] if (lrt_mode and lrt) else None)
+    if first_l is not None and ops.current_config().c8x3 and ops.current_config().c8x3_s2d and children and children[0] is first_l and \
+            isinstance(first_l, (_BBBConv, _LRTConv)) and first_l not in c8_set and x.dim() == 4 and last_bayes != 0:
+        l0 = first_l
         if ops.s2d_layer_ok(l0.in_channels, l0.out_channels, l0.kernel_size, l0.stride, l0.padding, l0.dilation, x.shape[2], x.shape[3]):
             s2d_first = l0
     if bbb:
@@ -454,11 +465,24 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
     to_cb = ops.to_batch_innermost_bf16 if bf16 else ops.to_batch_innermost
     nblk = (S if S > 1 else nb) if (S > 1 or G > 1 or share is not None) else 1
     xs2d = w_s2d = None
+    lrt_tm = {}                                                   # LRT layer -> (W_mu, W_sigma^2) tap-major [Cout, taps, Cin]
+    for l in (c8_set if lrt_mode else ()):
+        wm = l.W_mu.detach()
+        wv = variances[l][0]
+        if wm.dim() == 2:
+            lrt_tm[l] = (wm.reshape(wm.shape[0], 1, wm.shape[1]), wv.reshape(wv.shape[0], 1, wv.shape[1]))
+        else:
+            lrt_tm[l] = (_run(timers, "layout", None, lambda wm=wm: ops.w_tap_major(wm.unsqueeze(0))[0]),
+                         _run(timers, "layout", None, lambda wv=wv: ops.w_tap_major(wv.unsqueeze(0))[0]))
     if s2d_first is not None:
         l0 = s2d_first
         xt = None
-        xs2d = _run(timers, "layout", None, lambda: ops.s2d_c8s3(x, nblk, l0.kernel_size, l0.stride, l0.padding))   # [nblk, 3, C'/8, Hb, Wb, B, 8]
-        w_s2d = _run(timers, "layout", None, lambda: ops.w_s2d_tap_major(sampled[l0][0], l0.stride))                  # [n_draws, Cout, m*m, C']
+        xs2d = _run(timers, "layout", None, lambda: ops.s2d_c8s3(x, nblk, l0.kernel_size, l0.stride, l0.padding, squares=lrt_mode))   # [nblk, 3|6, C'/8, Hb, Wb, B, 8]
+        if lrt_mode:
+            w_s2d = (_run(timers, "layout", None, lambda: ops.w_s2d_tap_major(l0.W_mu.detach().unsqueeze(0), l0.stride)[0]),
+                     _run(timers, "layout", None, lambda: ops.w_s2d_tap_major(variances[l0][0].unsqueeze(0), l0.stride)[0]))
+        else:
+            w_s2d = _run(timers, "layout", None, lambda: ops.w_s2d_tap_major(sampled[l0][0], l0.stride))              # [n_draws, Cout, m*m, C']
     elif nblk > 1 or S > 1 or G > 1 or share is not None:       # [S, C, H, W, B/S]: one batch-innermost block per slice / per step
         xt = ops.to_batch_innermost_bf16_slices(x, nblk) if bf16 else ops.to_batch_innermost_slices(x, nblk)
     else:
@@ -488,6 +512,22 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
             mod = children[i]
             nxt = children[i + 1] if i + 1 < len(children) else None
             act = _act_name(nxt) if nxt is not None else None
+            if mod is s2d_first and i == 0 and lrt_mode:
+                # an LRT first layer in space-to-depth form (values and squares of the block image; no pooled form: the pool follows)
+                wm_, wv_ = w_s2d
+                m_ = int(round(wm_.shape[1] ** 0.5))
+                zb = ops.s2d_zero_border(mod.in_channels, mod.kernel_size, mod.stride, mod.padding, x.shape[2], x.shape[3])
+                ukw3 = dict(ukw, x_per_slice=True) if ukw else ({"x_div": x_div, "x_off": x_off, "n_slabs": Es} if x_div > 1 else {"n_slabs": Es})
+                x_div = 1
+                per_slice = False
+                fl = conv_flops(B, mod.in_channels, x.shape[2], x.shape[3], wm_.shape[0], *mod.kernel_size, mod.stride, mod.padding, mod.dilation, Es, 2) \
+                    if timers is not None else None
+                h = _run(timers, "lrt_gemm", fl, lambda wm_=wm_, wv_=wv_, m_=m_, act=act, ukw3=ukw3, zb=zb, mod=mod, boff=boff:
+                         ops.lrt_conv2d_c8x3_forward(xs2d, wm_, wv_, mod.bias_mu if mod.use_bias else None, variances[mod][1], (m_, m_), seed,
+                                                     call0 + e0, mod._stream_base + 2, 1, 0, 1, act=act, b_offset=boff, zero_border=zb, **ukw3))
+                c8s3 = True
+                i += (1 if act is not None else 0) + 1
+                continue
             if mod is s2d_first and i == 0:
                 # the first layer in space-to-depth form: an m x m layer, stride 1, no padding, on the block image; [activation ->]
                 # MaxPool2d(2, 2) inside the launch (every window walks the same taps: the parallel-window form)
@@ -521,10 +561,10 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
                     hf = h if is_conv else h.reshape(h.shape[0], mod.in_features, 1, 1, -1)
                     if hf.dim() != 5 or hf.shape[-1] != B:
                         return None
-                    h = _run(timers, "layout", None, lambda hf=hf: ops.c8s3_from_f32(hf))
+                    h = _run(timers, "layout", None, lambda hf=hf: ops.c8s3_from_f32(hf, squares=lrt_mode))
                     c8s3 = True
                 if c8s3:
-                    h5 = h if is_conv else h.reshape(h.shape[0], 3, mod.in_features // 8, 1, 1, h.shape[5], 8)
+                    h5 = h if is_conv else h.reshape(h.shape[0], h.shape[1], mod.in_features // 8, 1, 1, h.shape[5], 8)
                     if h5.shape[5] != B or h5.shape[2] * 8 != (mod.in_channels if is_conv else mod.in_features):
                         return None
                 elif s3:
@@ -572,6 +612,21 @@ def _mc_logits_chwn(net, x, draws, seed, call0, timers=None, streams=1, precisio
                                                           pool=pool_ks, out_c8=out_c8, **ukw2))
                     if fuse_pool:
                         i += 1                                   # the pooling module is done too
+                elif use_c8 and lrt_mode:
+                    wm_, wv_ = lrt_tm[mod]
+                    ks = mod.kernel_size if is_conv else (1, 1)
+                    fl = conv_flops(B, h5.shape[2] * 8, h5.shape[3], h5.shape[4], wm_.shape[0], ks[0], ks[1], *geom, Es, 2) if timers is not None else None
+                    is_logits = logits_buf is not None and i == last_bayes and not is_conv
+                    of32 = i == last_bayes
+                    dst = logits_buf[e0:e1] if is_logits else None
+                    ukw3 = {k: v for k, v in ukw2.items() if k != "x_per_slice"}
+                    if not ukw:
+                        ukw3["n_slabs"] = Es
+                    y = _run(timers, "lrt_gemm", fl, lambda h5=h5, wm_=wm_, wv_=wv_, ks=ks, geom=geom, act=act, dst=dst, ukw3=ukw3, of32=of32, mod=mod, boff=boff:
+                             ops.lrt_conv2d_c8x3_forward(h5, wm_, wv_, mod.bias_mu if mod.use_bias else None, variances[mod][1], ks, seed,
+                                                         call0 + e0, mod._stream_base + 2, *geom, act=act, out_f32=of32, out=dst, b_offset=boff,
+                                                         **ukw3))
+                    c8s3 = not of32
                 elif use_c8:
                     w, b = sampled[mod]
                     if not ukw:

@@ -614,28 +614,32 @@ def maxpool_chwn_s3(x, k, s):
 
 
 # ---- split-bf16 contraction over MFMA-ready operands (csrc/pconv_c8x3.hip): channel-interleaved split activations + tap-major weights
-def c8s3_from_f32(x):
+def c8s3_from_f32(x, squares=False):
     """fp32 batch-innermost [E, C, H, W, B] (C % 8 == 0) -> "c8 S3": bf16 [E, 3, C / 8, H, W, B, 8], the hi / mid / lo pieces
-    (exact: hi + mid + lo is the fp32 value) of the 8 channels 8g .. 8g + 7 of an image adjacent in memory."""
+    (exact: hi + mid + lo is the fp32 value) of the 8 channels 8g .. 8g + 7 of an image adjacent in memory.
+    squares = True: SIX planes [E, 6, ...] -- the pieces of the values, then the pieces of their squares (fp32 products): the slabs
+    of the LRT chain (lrt_conv2d_c8x3_forward's second contraction reads the squares)."""
     require_device(x)
     x = x.contiguous()
     E, C, H, W, B = x.shape
     if C % 8:
         raise _lib.BBBHipError("c8 S3 needs a multiple of 8 channels")
-    y = torch.empty((E, 3, C // 8, H, W, B, 8), dtype=torch.bfloat16, device=x.device)
+    y = torch.empty((E, 6 if squares else 3, C // 8, H, W, B, 8), dtype=torch.bfloat16, device=x.device)
     with on_device(x.device):
-        check(_lib.lib().bbb_c8s3_convert(x.data_ptr(), y.data_ptr(), E, C, H * W, B, 1, cur_stream(x.device)), "bbb_c8s3_convert")
+        check(_lib.lib().bbb_c8s3_convert(x.data_ptr(), y.data_ptr(), E, C, H * W, B, 2 if squares else 1, cur_stream(x.device)), "bbb_c8s3_convert")
     return y
 
 
 def c8s3_to_f32(x):
-    """c8 S3 [E, 3, C / 8, H, W, B, 8] -> the fp32 batch-innermost tensor [E, C, H, W, B] it stores (exact)."""
+    """c8 S3 [E, 3 | 6, C / 8, H, W, B, 8] -> the fp32 batch-innermost tensor [E, C, H, W, B] it stores (exact; six-plane slabs: their
+    values)."""
     require_device(x, dtype=torch.bfloat16)
     x = x.contiguous()
-    E, three, CG, H, W, B, eight = x.shape
+    E, planes, CG, H, W, B, eight = x.shape
     y = torch.empty((E, CG * 8, H, W, B), dtype=torch.float32, device=x.device)
     with on_device(x.device):
-        check(_lib.lib().bbb_c8s3_convert(x.data_ptr(), y.data_ptr(), E, CG * 8, H * W, B, 0, cur_stream(x.device)), "bbb_c8s3_convert")
+        check(_lib.lib().bbb_c8s3_convert(x.data_ptr(), y.data_ptr(), E, CG * 8, H * W, B, 3 if planes == 6 else 0, cur_stream(x.device)),
+              "bbb_c8s3_convert")
     return y
 
 
@@ -684,9 +688,9 @@ def s2d_layer_ok(cin, cout, kernel_size, stride, padding, dilation, h, w, max_wa
     return g[0] * g[0] * g[1] <= max_waste * kh * kw * cin
 
 
-def s2d_c8s3(x, blocks, kernel_size, stride, padding):
+def s2d_c8s3(x, blocks, kernel_size, stride, padding, squares=False):
     """The caller's NCHW fp32 batch [blocks * Bs, C, H, W] -> the c8 S3 block image [blocks, 3, C' / 8, Hb, Wb, Bs, 8] of the layer
-    (kernel_size, stride, padding): see s2d_geometry."""
+    (kernel_size, stride, padding): see s2d_geometry.  squares = True: six planes (the squares' pieces behind: an LRT first layer)."""
     require_device(x)
     x = x.contiguous()
     N, C, H, W = x.shape
@@ -695,9 +699,10 @@ def s2d_c8s3(x, blocks, kernel_size, stride, padding):
     if g is None or N % blocks:
         raise _lib.BBBHipError("space-to-depth form: square kernel / stride / padding, no dilation, the batch a multiple of `blocks`")
     m, cp, hb, wb, _, _ = g
-    y = torch.empty((blocks, 3, cp // 8, hb, wb, N // blocks, 8), dtype=torch.bfloat16, device=x.device)
+    y = torch.empty((blocks, 6 if squares else 3, cp // 8, hb, wb, N // blocks, 8), dtype=torch.bfloat16, device=x.device)
     with on_device(x.device):
-        check(_lib.lib().bbb_s2d_c8s3(x.data_ptr(), y.data_ptr(), blocks, N // blocks, C, H, W, k, st, pd, cur_stream(x.device)), "bbb_s2d_c8s3")
+        fn = _lib.lib().bbb_s2d_c8s3sq if squares else _lib.lib().bbb_s2d_c8s3
+        check(fn(x.data_ptr(), y.data_ptr(), blocks, N // blocks, C, H, W, k, st, pd, cur_stream(x.device)), "bbb_s2d_c8s3")
     return y
 
 
@@ -795,12 +800,83 @@ def conv2d_c8x3_forward(x, w_tm, bias, kernel_size, stride=1, padding=0, dilatio
 
 
 def maxpool_c8s3(x, k, s):
-    """MaxPool2d(k, s) on a c8 S3 tensor [E, 3, C / 8, H, W, B, 8] (element-wise on the 16-byte channel vectors)."""
+    """MaxPool2d(k, s) on a c8 S3 tensor [E, 3, C / 8, H, W, B, 8] (element-wise on the 16-byte channel vectors); six-plane slabs
+    (the LRT chain): the maximum of the values, and the squares of the pooled values behind."""
     require_device(x, dtype=torch.bfloat16)
     x = x.contiguous()
-    E, three, CG, H, W, B, eight = x.shape
+    E, planes, CG, H, W, B, eight = x.shape
+    if planes == 6:
+        ho, wo = (H - k) // s + 1, (W - k) // s + 1
+        y = torch.empty((E, 6, CG, ho, wo, B, 8), dtype=torch.bfloat16, device=x.device)
+        with on_device(x.device):
+            check(_lib.lib().bbb_maxpool_chwn_s3sq(x.data_ptr(), y.data_ptr(), E, CG, H, W, B * 8, int(k), int(s), cur_stream(x.device)),
+                  "bbb_maxpool_chwn_s3sq")
+        return y
     y = maxpool_chwn_s3(x.view(E, 3, CG, H, W, B * 8), k, s)
     return y.view(E, 3, CG, y.shape[3], y.shape[4], B, 8)
+
+
+def lrt_conv2d_c8x3_forward(x, w_mu_tm, w_var_tm, b_mu, b_var, kernel_size, seed, call0, stream_id, stride=1, padding=0, dilation=1,
+                            sample=True, act=None, out_f32=False, out=None, units=None, n_units=None, b_offset=0, x_per_slice=False,
+                            x_div=1, x_off=0, n_slabs=None, tile=None, zero_border=(0, 0, 0, 0)):
+    """The LRT layer on the split-bf16 kernel over MFMA-ready operands (bbb_lrt_conv2d_c8x3_fwd): both contractions -- (x, W_mu) and
+    (x^2, W_sigma^2) -- on the 16-bit matrix pipe at fp32 accuracy, sampling epilogue as lrt_conv2d_chwn_forward's (same noise
+    elements).  x: six-plane c8 S3 [E|1|S, 6, Cin / 8, H, W, B, 8]; w_mu_tm / w_var_tm: fp32 tap-major [Cout, kh * kw, Cin];
+    -> six-plane c8 S3 [E, 6, Cout / 8, Ho, Wo, B, 8], or with out_f32 the fp32 [E, Cout, Ho, Wo, B].  Work units / x_div / x_off /
+    b_offset / n_slabs as lrt_conv2d_chwn_forward."""
+    require_device(w_mu_tm, w_var_tm, b_mu, b_var)
+    require_device(x, dtype=torch.bfloat16)
+    x, w_mu_tm, w_var_tm = x.contiguous(), w_mu_tm.contiguous(), w_var_tm.contiguous()
+    b_mu = None if b_mu is None else b_mu.contiguous()
+    b_var = None if b_var is None else b_var.contiguous()
+    if x.dim() != 7 or x.shape[1] != 6 or x.shape[6] != 8 or w_mu_tm.dim() != 3 or w_var_tm.shape != w_mu_tm.shape:
+        raise _lib.BBBHipError("six-plane c8 S3 input [E|1, 6, Cin / 8, H, W, B, 8] and tap-major weights [Cout, kh * kw, Cin] expected")
+    kh, kw = _pair(kernel_size)
+    Ex, _, CG, H, W, B, _ = x.shape
+    Cout, T, Cin = w_mu_tm.shape
+    if T != kh * kw or Cin != CG * 8:
+        raise _lib.BBBHipError(f"weights [{Cout}, {T}, {Cin}] do not match a {kh} x {kw} layer on {CG * 8} channels")
+    x5 = x.new_empty((Ex, Cin, H, W, B), dtype=torch.float32, device="meta")
+    w5 = w_mu_tm.new_empty((1, Cout, Cin, kh, kw), device="meta")
+    E = (int(n_slabs) if n_slabs is not None else Ex * int(x_div)) if (units is None or units[0] <= 1) else int(n_units)
+    d, ho, wo = _desc_chwn(x5, w5, stride, padding, dilation, E, Ex == 1 and E > 1 and int(x_div) <= 1 and (units is None or units[0] <= 1),
+                           True, act)
+    if units is not None and units[0] > 1:
+        if Ex != (units[0] if x_per_slice else E):
+            raise _lib.BBBHipError("work units: x must hold one slab per unit, or one per batch slice with x_per_slice")
+        _apply_units(d, units, x_per_slice)
+    elif int(x_div) > 1:
+        if not 0 <= int(x_off) < int(x_div) or Ex != -(-(E + int(x_off)) // int(x_div)):
+            raise _lib.BBBHipError("x_div: x must hold ceil((E + x_off) / x_div) input slabs for the E output slabs")
+        d.x_unit_div, d.x_unit_off = int(x_div), int(x_off)
+    elif Ex not in (1, E):
+        raise _lib.BBBHipError("x must hold one slab, or one per output slab")
+    d.b_offset = int(b_offset)
+    d.w_draw_stride = 0
+    d.b_draw_stride = 0
+    d.x_draw_stride *= 6                                       # bf16 elements per slab of six planes
+    if out_f32:
+        shape, odt = (E, Cout, ho, wo, B), torch.float32
+    else:
+        if Cout % 8:
+            raise _lib.BBBHipError("a c8 S3 output needs a multiple of 8 output channels")
+        shape, odt = (E, 6, Cout // 8, ho, wo, B, 8), torch.bfloat16
+    if out is None:
+        y = torch.empty(shape, dtype=odt, device=x.device)
+    else:
+        n = 1
+        for v in shape:
+            n *= v
+        if out.numel() != n or not out.is_contiguous() or out.dtype != odt:
+            raise _lib.BBBHipError("out= must be a contiguous tensor of the output's size and dtype")
+        y = out.view(shape)
+    flags = (1 if out_f32 else 0) | {None: 0, 128: 2, 256: 4}[tile] | (min(15, zero_border[0]) << 8) | (min(15, zero_border[1]) << 12) | \
+        (min(15, zero_border[2]) << 16) | (min(15, zero_border[3]) << 20)
+    with on_device(x.device):
+        check(_lib.lib().bbb_lrt_conv2d_c8x3_fwd(ctypes.byref(d), x.data_ptr(), w_mu_tm.data_ptr(), w_var_tm.data_ptr(), ptr(b_mu), ptr(b_var),
+                                                 y.data_ptr(), seed, call0 & 0xFFFFFFFF, stream_id, 1 if sample else 0,
+                                                 rng.call_dev_ptr(x.device), flags, cur_stream(x.device)), "bbb_lrt_conv2d_c8x3_fwd")
+    return y
 
 
 def lrt_conv2d_chwn_forward(x, w_mu, w_var, b_mu, b_var, seed, call0, stream_id, stride=1, padding=0, dilation=1,

@@ -133,6 +133,14 @@ __device__ __forceinline__ bbb_f32x4 softplus_ref4(bbb_f32x4 rho) {
 
 // Epilogue activations.  Softplus(beta=1, threshold=20) on the hardware exp2 / log2 units:
 // log(1 + e^v) = ln2 * log2(1 + 2^(v*log2 e)); absolute error <= ~1e-7 (v < -16.6 flushes to 0 instead of e^v < 6e-8).
+// a * b rounded to fp32, as an instruction of its own: hipcc contracts a product into a following add / subtract (fma) by default,
+// which is wrong wherever the ROUNDED product is the value (the squares of the LRT chain: their pieces must sum to the fp32 x * x the
+// fp32 path computes).  The pragma keeps the `contract` flag off this multiply, so no later pass may fuse it.
+__device__ __forceinline__ float mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == 1) return fmaxf(v, 0.0f);
     if (act == 2) {

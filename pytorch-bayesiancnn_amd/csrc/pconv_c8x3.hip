@@ -41,18 +41,26 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 // The contraction walks the in-bounds taps in (r, q) order and the channels of a tap in 16-channel steps, two steps (32 k) per
 // weight tile; Cin % 16 == 0 (a tile may straddle two taps: the k runs of a tap are adjacent in a tap-major row, and a thread's
 // 8-k piece never straddles).  Every output element sees the same sequence of matrix instructions whatever NT, MT and the form.
-template <int NT, int MT, bool OUTF32, bool POOLP>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(NT * MT >= 8 ? 2 : 1)))      // (8 tiles: 128 + 128 registers)
+// LRT (local reparameterisation, layers/BBB_LRT/BBBConv.py:62-87): TWO contractions per output element -- act_mu over (x, W_mu) and
+// act_var over (x^2, W_sigma^2) -- with two weight tiles, two sets of image fragments and two sets of accumulators walking the same
+// taps, and the sampling epilogue out = act(act_mu + b_mu + sqrt(1e-16 + act_var + b_var) * eps), eps = the noise element of the
+// output's canonical [B][Cout][Ho][Wo] index in stream (seed, call0 + draw, stream_id): exactly what pconv_gemm's LRT epilogue
+// draws.  Input and output slabs hold SIX planes: the three pieces of the values, then the three pieces of their squares (the
+// next layer's second operand, squared here in fp32, once per element).
+template <int NT, int MT, bool OUTF32, bool POOLP, bool LRT = false>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(NT * MT * (LRT ? 2 : 1) >= 8 ? 2 : 1)))      // (8 tiles: 128 + 128 registers)
 void pconv_c8x3_kernel(const PConvArgs p) {
+    constexpr int SETS = LRT ? 2 : 1;
+    static_assert(!(LRT && POOLP), "LRT layers pool in a launch of their own");
     constexpr int BNW = 32 * NT;                                     // channels per workgroup
     constexpr int BMW = 32 * MT;                                     // images per wave
     constexpr int BM = POOLP ? BMW : 4 * BMW;                        // images per workgroup
     constexpr int PLANE = BNW * C8_LDA;                              // one plane of one stage
     constexpr int WPASS = (BNW + 63) / 64;                           // 64 channel rows per staging pass
     static_assert(!(OUTF32 && POOLP), "the pooled form writes c8 S3");
-    constexpr int kWpBytes = 2 * 3 * PLANE * 2;
+    constexpr int kWpBytes = 2 * SETS * 3 * PLANE * 2;
     constexpr int kLdsBytes = (POOLP && kWpBytes < 16384) ? 16384 : kWpBytes;       // (POOLP: the window exchange needs 16 KB)
-    __shared__ __attribute__((aligned(16))) unsigned short Wp[kLdsBytes / 2];        // [stage][plane][n][k]
+    __shared__ __attribute__((aligned(16))) unsigned short Wp[kLdsBytes / 2];        // [stage][set][plane][n][k]
 
     const int bid = blockIdx.x;
     const int xcd = bid & 7;
@@ -116,13 +124,15 @@ void pconv_c8x3_kernel(const PConvArgs p) {
     // weights: fp32, tap-major rows of Kp elements; thread (channel row tid / 4 [+ 64 per pass], 8 consecutive k of the tile)
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.w + (int64_t)ew * p.w_ds), 0, (int)((int64_t)p.Cout * p.Kp * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(LRT ? p.w2 + (int64_t)ew * p.w_ds : p.w), 0, (int)((int64_t)p.Cout * p.Kp * 4), 0x00020000);
     const int wn = tid >> 2, wk = (tid & 3) * 8;
     const uint32_t wrow = ((uint32_t)(n0 + wn) * (uint32_t)p.Kp) * 4u;                      // rows >= Cout: out of range, read as 0
     const uint32_t wpass = 64u * (uint32_t)p.Kp * 4u;
     // images: one descriptor over the slab's three planes; lane (image lrow of the wave's block, k half lk)
     const unsigned short* const xb16 = reinterpret_cast<const unsigned short*>(p.x) + (int64_t)ex * p.x_ds;
     const uint32_t xplane = (uint32_t)(p.x_ps * 2);                  // bytes per plane
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(xb16), 0, (int)(3u * xplane), 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(xb16), 0, (int)((uint32_t)(3 * SETS) * xplane), 0x00020000);
     const uint32_t img_b = (uint32_t)p.B * 16u;                      // bytes per (channel group, position)
     const uint32_t grp_b = (uint32_t)(p.H * p.W) * img_b;            // bytes per channel group of 8
     // Out-of-range addressing without selects: every slab is < 1 GiB (checked by the launcher), an image column past the batch
@@ -172,61 +182,72 @@ void pconv_c8x3_kernel(const PConvArgs p) {
         return o;
     };
 
-    f32x4 wreg[WPASS][2];
-    bf16x8 bfr[2][MT][3];
+    f32x4 wreg[SETS][WPASS][2];
+    bf16x8 bfr[2][SETS][MT][3];
     // (unconditional loads with out-of-range offsets instead of branches: with branches around them the compiler drains every
     // outstanding load at every step)
     auto wload = [&]() {
         const uint32_t o = wrow + next_piece_offset();
 #pragma unroll
-        for (int ps = 0; ps < WPASS; ++ps) {
-            wreg[ps][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, o + (uint32_t)ps * wpass, 0, 0));
-            wreg[ps][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, o + (uint32_t)ps * wpass + 16u, 0, 0));
-        }
+        for (int st = 0; st < SETS; ++st)
+#pragma unroll
+            for (int ps = 0; ps < WPASS; ++ps) {
+                wreg[st][ps][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(st ? wrs2 : wrs, o + (uint32_t)ps * wpass, 0, 0));
+                wreg[st][ps][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(st ? wrs2 : wrs, o + (uint32_t)ps * wpass + 16u, 0, 0));
+            }
     };
     bool live_next[2] = {false, false};
     auto bload = [&](int s) {
         const uint32_t u = next_step_offset();
         live_next[s] = sx_live;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int st = 0; st < SETS; ++st)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-                bfr[s][mt][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xrs, xlane[mt] + u + (uint32_t)pl * xplane, 0, 0));
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    bfr[s][st][mt][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xrs, xlane[mt] + u + (uint32_t)(3 * st + pl) * xplane, 0, 0));
     };
+    constexpr int STAGE = SETS * 3 * PLANE;                          // 16-bit elements per stage
     auto wstore = [&](int stage) {
 #pragma unroll
+        for (int st = 0; st < SETS; ++st)
+#pragma unroll
         for (int ps = 0; ps < WPASS; ++ps) {
-            if ((BNW % 64) != 0 && ps == WPASS - 1 && wn >= (BNW % 64)) break;      // 96-row tiles: the last pass holds 32 rows
+            if ((BNW % 64) != 0 && ps == WPASS - 1 && wn >= (BNW % 64)) continue;   // 96-row tiles: the last pass holds 32 rows
             u32x4 h, m, l;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 uint32_t a0, a1, a2;
-                const f32x4 v = wreg[ps][i >> 1];
+                const f32x4 v = wreg[st][ps][i >> 1];
                 split3_pair((i & 1) ? f32x2{v[2], v[3]} : f32x2{v[0], v[1]}, a0, a1, a2);
                 h[i] = a0; m[i] = a1; l[i] = a2;
             }
-            unsigned short* const base = Wp + stage * (3 * PLANE) + (wn + 64 * ps) * C8_LDA + wk;
+            unsigned short* const base = Wp + stage * STAGE + st * (3 * PLANE) + (wn + 64 * ps) * C8_LDA + wk;
             *reinterpret_cast<u32x4*>(base) = h;
             *reinterpret_cast<u32x4*>(base + PLANE) = m;
             *reinterpret_cast<u32x4*>(base + 2 * PLANE) = l;
         }
     };
 
-    f32x16 acc[NT][MT];
+    f32x16 acc[SETS][NT][MT];
+#pragma unroll
+    for (int st = 0; st < SETS; ++st)
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int u = 0; u < MT; ++u)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.0f;
+            for (int r = 0; r < 16; ++r) acc[st][t][u][r] = 0.0f;
 
     auto step = [&](int stage, int s) {
-        const unsigned short* const base = Wp + stage * (3 * PLANE) + lrow * C8_LDA + s * 16 + lk * 8;
         // channel tiles in pairs (a pair's 6 operand fragments live at a time); small terms first; the accumulators of a pair
         // take turns, so consecutive matrix instructions are independent
 #pragma unroll
+        for (int st = 0; st < SETS; ++st)
+#pragma unroll
         for (int n2 = 0; n2 < NT; n2 += 2) {
+            const unsigned short* const base = Wp + stage * STAGE + st * (3 * PLANE) + lrow * C8_LDA + s * 16 + lk * 8;
             constexpr int kPairMax = 2;
             bf16x8 a[kPairMax][3];
 #pragma unroll
@@ -238,7 +259,7 @@ void pconv_c8x3_kernel(const PConvArgs p) {
             _Pragma("unroll") for (int nt = 0; nt < kPairMax; ++nt)                                                 \
                 _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                   \
                     if (n2 + nt < NT)                                                                               \
-                        acc[n2 + nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[nt][PA], bfr[s][mt][PB], acc[n2 + nt][mt], 0, 0, 0);
+                        acc[st][n2 + nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[nt][PA], bfr[s][st][mt][PB], acc[st][n2 + nt][mt], 0, 0, 0);
             C8X3_TERM(2, 0)
             C8X3_TERM(0, 2)
             C8X3_TERM(1, 1)
@@ -253,18 +274,18 @@ void pconv_c8x3_kernel(const PConvArgs p) {
     // registers are free as soon as its last term is issued (lo after the first term, mid after the fourth, hi after the sixth), so
     // the six 16-byte reads of step 1 ride under step 0's matrix instructions and only a tile's first reads are waited for
     // (measured -1.2 % per launch, profiles/r06_notes.md).
-    if constexpr (NT == 2 && !POOLP) {
+    if constexpr (NT == 2 && !POOLP && !LRT) {
       if (ntiles > 0) {
         bf16x8 af[2][3];                                             // the step's weight fragments: [channel tile][plane]
         auto aread = [&](int stage, int s, int pl) {
-            const unsigned short* const base = Wp + stage * (3 * PLANE) + lrow * C8_LDA + s * 16 + lk * 8 + pl * PLANE;
+            const unsigned short* const base = Wp + stage * STAGE + lrow * C8_LDA + s * 16 + lk * 8 + pl * PLANE;
             af[0][pl] = *reinterpret_cast<const bf16x8*>(base);
             af[1][pl] = *reinterpret_cast<const bf16x8*>(base + 32 * C8_LDA);
         };
 #define C8X3_T(PA, PB, S)                                                                                            \
         _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                             \
             _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                        \
-                acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[nt][PA], bfr[S][mt][PB], acc[nt][mt], 0, 0, 0);
+                acc[0][nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[nt][PA], bfr[S][0][mt][PB], acc[0][nt][mt], 0, 0, 0);
         wload();
         bload(0);
         bload(1);
@@ -327,6 +348,27 @@ void pconv_c8x3_kernel(const PConvArgs p) {
     const int HoWo = p.Ho * p.Wo;
     const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.bias ? p.bias + (int64_t)ew * p.b_ds : p.w), 0, p.bias ? p.Cout * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t brs2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>((LRT && p.bias2) ? p.bias2 + (int64_t)ew * p.b_ds : p.w), 0, (LRT && p.bias2) ? p.Cout * 4 : 0, 0x00020000);
+    // one output element from its contraction result(s): BBB = act(a + bias); LRT = act(a_mu + b_mu + sqrt(1e-16 + a_var + b_var) * eps)
+    // with eps the noise element of the output's canonical [B][Cout][Ho][Wo] index (pconv_body.cuh's LRT epilogue, same stream)
+    const uint32_t lrt_call = LRT ? p.call0 + (p.call_dev ? *p.call_dev : 0u) + (uint32_t)ew : 0u;
+    const int lrt_b0 = LRT ? p.b_off + (p.unit_div > 1 ? (ue % p.unit_div) * p.B : 0) : 0;
+    auto finish = [&](float a_mu, float a_var, float b_mu, float b_var, int n, int b) -> float {
+        float v = a_mu + b_mu;
+        if constexpr (LRT) {
+            const float var = 1e-16f + (a_var + b_var);
+            if (p.sample) {
+                const uint64_t idx = (uint64_t)(((int64_t)(b + lrt_b0) * p.Cout + n) * HoWo + pix);
+                float z4[4];
+                bbb::normal4(idx >> 2, p.stream_id, lrt_call, p.k0, p.k1, z4);
+                const int c = (int)(idx & 3);
+                const float z = c == 0 ? z4[0] : c == 1 ? z4[1] : c == 2 ? z4[2] : z4[3];
+                v = v + __builtin_amdgcn_sqrtf(var) * z;
+            }
+        }
+        return bbb::apply_act(v, p.act);
+    };
     if constexpr (OUTF32) {
         // fp32 batch-innermost output [slab][cout][ho][wo][B] (the logits layer): a lane's accumulator registers are channels of ONE
         // image, a wave-store is 32 consecutive images of a channel row
@@ -338,10 +380,11 @@ void pconv_c8x3_kernel(const PConvArgs p) {
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
                 const float bv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brs, (uint32_t)n * 4u, 0, 0));
+                const float bv2 = LRT ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brs2, (uint32_t)n * 4u, 0, 0)) : 0.0f;
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     const int b = b0 + wave * BMW + mt * 32 + lrow;
-                    const float o = bbb::apply_act(acc[nt][mt][r] + bv, p.act);
+                    const float o = finish(acc[0][nt][mt][r], acc[SETS - 1][nt][mt][r], bv, bv2, n, b);
                     const uint32_t off = ((b < p.B) & (n < p.Cout)) ? (uint32_t)(((int64_t)n * HoWo + pix) * p.B + b) * 4u : kOOB;
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, o), yrs, off, 0, 0);
                 }
@@ -352,8 +395,8 @@ void pconv_c8x3_kernel(const PConvArgs p) {
         // here, once per element.
         unsigned short* const yb16 = reinterpret_cast<unsigned short*>(p.y) + (int64_t)e * p.y_ds;
         const uint32_t yplane = (uint32_t)(p.y_ps * 2);
-        const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(yb16, 0, (int)(3u * yplane), 0x00020000);
-        auto store4 = [&](const float (&o)[4], int n, int b, int opix, int opixels) {       // channels n + 4 lk .. + 3 of image b
+        const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(yb16, 0, (int)((uint32_t)(3 * SETS) * yplane), 0x00020000);
+        auto store4 = [&](const float (&o)[4], int n, int b, int opix, int opixels, uint32_t plane0 = 0u) {   // channels n + 4 lk .. + 3 of image b
             uint32_t h0, m0, l0, h1, m1, l1;
             if (C8X3_ABLATE == 1) {
                 h0 = m0 = l0 = __builtin_bit_cast(uint32_t, o[0] + o[1]); h1 = m1 = l1 = __builtin_bit_cast(uint32_t, o[2] + o[3]);
@@ -362,7 +405,7 @@ void pconv_c8x3_kernel(const PConvArgs p) {
                 split3_pair(f32x2{o[2], o[3]}, h1, m1, l1);
             }
             const uint32_t off = ((b < p.B) & (n < p.Cout))
-                ? (uint32_t)((((int64_t)(n >> 3) * opixels + opix) * p.B + b) * 16 + lk * 8) : kOOB;
+                ? (uint32_t)((((int64_t)(n >> 3) * opixels + opix) * p.B + b) * 16 + lk * 8) + plane0 * yplane : kOOB;
             __builtin_amdgcn_raw_buffer_store_b64(u32x2{h0, h1}, yrs, off, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b64(u32x2{m0, m1}, yrs, off == kOOB ? kOOB : off + yplane, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b64(u32x2{l0, l1}, yrs, off == kOOB ? kOOB : off + 2u * yplane, 0, 0);
@@ -374,13 +417,23 @@ void pconv_c8x3_kernel(const PConvArgs p) {
                 for (int r4 = 0; r4 < 4; ++r4) {
                     const int n = n0 + nt * 32 + 8 * r4;                 // first channel of the group of 8 (this lane: + 4 lk .. + 3)
                     const f32x4 bq = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, (uint32_t)(n + 4 * lk) * 4u, 0, 0));
+                    f32x4 bq2 = {0.0f, 0.0f, 0.0f, 0.0f};
+                    if constexpr (LRT) bq2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs2, (uint32_t)(n + 4 * lk) * 4u, 0, 0));
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
                         const int b = b0 + wave * BMW + mt * 32 + lrow;
                         float o[4];
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) o[c] = C8X3_ABLATE == 1 ? acc[nt][mt][4 * r4 + c] : bbb::apply_act(acc[nt][mt][4 * r4 + c] + bq[c], p.act);
+                        for (int c = 0; c < 4; ++c)
+                            o[c] = C8X3_ABLATE == 1 ? acc[0][nt][mt][4 * r4 + c]
+                                                    : finish(acc[0][nt][mt][4 * r4 + c], acc[SETS - 1][nt][mt][4 * r4 + c], bq[c], bq2[c], n + 4 * lk + c, b);
                         store4(o, n, b, pix, HoWo);
+                        if constexpr (LRT) {                             // the next layer's second operand: the squares, once per element
+                            // (mul_rn: the ROUNDED fp32 square is what gets cut -- left to the compiler the product contracts into
+                            // the split's first subtraction as an fma and the pieces no longer sum to the fp32 square the fp32 path uses)
+                            const float q[4] = {bbb::mul_rn(o[0], o[0]), bbb::mul_rn(o[1], o[1]), bbb::mul_rn(o[2], o[2]), bbb::mul_rn(o[3], o[3])};
+                            store4(q, n, b, pix, HoWo, 3u);
+                        }
                     }
                 }
         } else {
@@ -398,7 +451,7 @@ void pconv_c8x3_kernel(const PConvArgs p) {
                         const f32x4 bq = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, (uint32_t)(n + 4 * lk) * 4u, 0, 0));
                         f32x4 o;
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) o[c] = bbb::apply_act(acc[nt][mt][4 * r4 + c] + bq[c], p.act);
+                        for (int c = 0; c < 4; ++c) o[c] = bbb::apply_act(acc[0][nt][mt][4 * r4 + c] + bq[c], p.act);
                         ex4[(wave * 4 + r4) * 64 + lane] = o;
                     }
                     __syncthreads();
@@ -422,6 +475,7 @@ void pconv_c8x3_kernel(const PConvArgs p) {
 // pconv_c8x3 launches (the first layer's fp32 output; a flatten that has to pass through the reference's NCHW order).  One thread
 // per (slab, channel group, position, image): 8 coalesced 4-byte accesses on the fp32 side, one 16-byte vector per plane.
 // pv = vectors per plane = (C / 8) * HW * B.
+template <bool SQ>
 __global__ __launch_bounds__(256) void c8s3_from_chwn_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, int64_t total,
                                                              int64_t pv, int64_t HW, int B) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -438,10 +492,21 @@ __global__ __launch_bounds__(256) void c8s3_from_chwn_kernel(const float* __rest
         split3_pair(f32x2{xp[(int64_t)(2 * c) * HW * B], xp[(int64_t)(2 * c + 1) * HW * B]}, a0, a1, a2);
         h[c] = a0; m[c] = a1; l[c] = a2;
     }
-    u32x4* yp = reinterpret_cast<u32x4*>(y) + slab * 3 * pv + in;
+    u32x4* yp = reinterpret_cast<u32x4*>(y) + slab * (SQ ? 6 : 3) * pv + in;
     yp[0] = h; yp[pv] = m; yp[2 * pv] = l;
+    if constexpr (SQ) {                                              // six-plane slabs of the LRT chain: the squares' pieces behind
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            uint32_t a0, a1, a2;
+            const float u0 = xp[(int64_t)(2 * c) * HW * B], u1 = xp[(int64_t)(2 * c + 1) * HW * B];
+            split3_pair(f32x2{bbb::mul_rn(u0, u0), bbb::mul_rn(u1, u1)}, a0, a1, a2);
+            h[c] = a0; m[c] = a1; l[c] = a2;
+        }
+        yp[3 * pv] = h; yp[4 * pv] = m; yp[5 * pv] = l;
+    }
 }
 
+template <int NPL>      // planes per slab: 3, or 6 (the LRT chain's slabs: the values are the first three)
 __global__ __launch_bounds__(256) void c8s3_to_chwn_kernel(const unsigned short* __restrict__ x, float* __restrict__ y, int64_t total,
                                                            int64_t pv, int64_t HW, int B) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -450,7 +515,7 @@ __global__ __launch_bounds__(256) void c8s3_to_chwn_kernel(const unsigned short*
     const int b = (int)(in % B);
     const int64_t t = in / B;
     const int64_t pos = t % HW, grp = t / HW;
-    const u32x4* xp = reinterpret_cast<const u32x4*>(x) + slab * 3 * pv + in;
+    const u32x4* xp = reinterpret_cast<const u32x4*>(x) + slab * NPL * pv + in;
     const u32x4 h = xp[0], m = xp[pv], l = xp[2 * pv];
     float* yp = y + slab * pv * 8 + ((grp * 8) * HW + pos) * B + b;
 #pragma unroll
@@ -485,6 +550,7 @@ __global__ __launch_bounds__(256) void w_tap_major_kernel(const float* __restric
 // channel group, block row): a wave reads 4 images x 16 columns -- per image a contiguous run of 16 * s floats per (channel, dy)
 // row instead of one 16-byte piece from each of 64 images (602 KB apart on 224 x 224 inputs) -- and stores 64 contiguous bytes
 // (4 images) per column and plane.
+template <bool SQ>
 __global__ __launch_bounds__(256) void s2d_c8s3_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, int64_t pv,
                                                       int C, int H, int W, int s, int pad, int Hb, int Wb, int Bs, int nbt) {
     const int bwt = blockIdx.x / nbt, bt = blockIdx.x - bwt * nbt;
@@ -509,8 +575,17 @@ __global__ __launch_bounds__(256) void s2d_c8s3_kernel(const float* __restrict__
         split3_pair(f32x2{v[2 * c], v[2 * c + 1]}, a0, a1, a2);
         h[c] = a0; m[c] = a1; l[c] = a2;
     }
-    u32x4* yp = reinterpret_cast<u32x4*>(y) + blk * 3 * pv + (((int64_t)grp * Hb + bh) * Wb + bw) * Bs + b;
+    u32x4* yp = reinterpret_cast<u32x4*>(y) + blk * (SQ ? 6 : 3) * pv + (((int64_t)grp * Hb + bh) * Wb + bw) * Bs + b;
     yp[0] = h; yp[pv] = m; yp[2 * pv] = l;
+    if constexpr (SQ) {                                              // LRT first layer: the squares' pieces behind the values'
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            uint32_t a0, a1, a2;
+            split3_pair(f32x2{bbb::mul_rn(v[2 * c], v[2 * c]), bbb::mul_rn(v[2 * c + 1], v[2 * c + 1])}, a0, a1, a2);
+            h[c] = a0; m[c] = a1; l[c] = a2;
+        }
+        yp[3 * pv] = h; yp[4 * pv] = m; yp[5 * pv] = l;
+    }
 }
 
 // w [rows][C][k][k] -> out [rows][m * m][Cp] (tap-major rows of the space-to-depth layer); one thread per output element
@@ -534,16 +609,26 @@ using namespace pconv;
 
 namespace {
 template <int NT, int MT>
-void launch_c8x3(bool of32, bool poolp, dim3 grid, hipStream_t st, const PConvArgs& a) {
+void launch_c8x3(bool of32, bool poolp, bool lrt, dim3 grid, hipStream_t st, const PConvArgs& a) {
     const dim3 block(kThreads);
+    if constexpr (NT == 2 && MT == 1) {        // (LRT: two accumulator sets -- 32 images per wave; 64 would spill)
+        if (lrt) {
+            if (of32) hipLaunchKernelGGL((pconv_c8x3_kernel<NT, MT, true, false, true>), grid, block, 0, st, a);
+            else      hipLaunchKernelGGL((pconv_c8x3_kernel<NT, MT, false, false, true>), grid, block, 0, st, a);
+            return;
+        }
+    }
     if (poolp)     hipLaunchKernelGGL((pconv_c8x3_kernel<NT, MT, false, true>), grid, block, 0, st, a);
     else if (of32) hipLaunchKernelGGL((pconv_c8x3_kernel<NT, MT, true, false>), grid, block, 0, st, a);
     else           hipLaunchKernelGGL((pconv_c8x3_kernel<NT, MT, false, false>), grid, block, 0, st, a);
 }
 }  // namespace
 
-extern "C" int bbb_conv2d_c8x3_fwd(const bbb_conv_desc_t* d, const void* x, const float* w, const float* bias, void* y, uint32_t flags,
-                                   void* stream) {
+namespace {
+struct LrtNoise { const float* w_var; const float* b_var; uint64_t seed; uint32_t call0, stream_id; int sample; const uint32_t* call_dev; };
+
+int c8x3_launch(const bbb_conv_desc_t* d, const void* x, const float* w, const float* bias, void* y, uint32_t flags, const LrtNoise* lrt,
+                void* stream) {
     constexpr uint32_t kKnown = BBB_C8X3_OUT_F32 | BBB_C8X3_TILE128 | BBB_C8X3_TILE256 | BBB_C8X3_POOL | BBB_C8X3_NT_MASK | BBB_C8X3_ZERO_MASK;
     if (d == nullptr || x == nullptr || w == nullptr || y == nullptr || (flags & ~kKnown) != 0 ||
         ((flags & BBB_C8X3_TILE128) && (flags & BBB_C8X3_TILE256)))
@@ -556,6 +641,14 @@ extern "C" int bbb_conv2d_c8x3_fwd(const bbb_conv_desc_t* d, const void* x, cons
     const bool poolp = (flags & BBB_C8X3_POOL) != 0;
     const int nt_force = (int)((flags & BBB_C8X3_NT_MASK) >> BBB_C8X3_NT_SHIFT);
     if (nt_force == 1 || nt_force > 4 || (poolp && of32)) return BBB_EINVAL;
+    if (lrt != nullptr) {
+        // LRT: one (mu, sigma^2) weight pair for every slab; 64-channel tiles; pooling is a launch of its own (bbb_maxpool_c8s3_sq)
+        if (lrt->w_var == nullptr || poolp || (nt_force != 0 && nt_force != 2) || d->w_draw_stride != 0 || d->b_draw_stride != 0 ||
+            ((bias == nullptr) != (lrt->b_var == nullptr)))
+            return BBB_EINVAL;
+        if ((((uintptr_t)lrt->w_var) & 15u) != 0 || (((uintptr_t)lrt->b_var) & (of32 ? 3u : 15u)) != 0) return BBB_EALIGN;
+    }
+    const int sets = lrt != nullptr ? 2 : 1;
     if (d->cin % 16 != 0 || d->batch % 4 != 0 || (!of32 && d->cout % 8 != 0)) return BBB_ESHAPE;
     const int ho = (d->h + 2 * d->pad_h - d->dil_h * (d->kh - 1) - 1) / d->stride_h + 1;
     const int wo = (d->w + 2 * d->pad_w - d->dil_w * (d->kw - 1) - 1) / d->stride_w + 1;
@@ -575,12 +668,12 @@ extern "C" int bbb_conv2d_c8x3_fwd(const bbb_conv_desc_t* d, const void* x, cons
     }
     a.x_ps = (int64_t)a.Cin * a.H * a.W * a.B;
     a.y_ps = (int64_t)a.Cout * ho * wo * a.B / (poolp ? 4 : 1);
-    // slabs are addressed through 32-bit buffer offsets (three planes of 2-byte elements, or fp32 outputs)
-    if (6 * a.x_ps >= 0x3FFF0000LL || 6 * a.y_ps >= 0x3FFF0000LL || ((int64_t)a.Cout + 128) * a.K * 4 >= 0x3FFF0000LL) return BBB_ESHAPE;
-    if (d->x_draw_stride != 0 && d->x_draw_stride < 3 * a.x_ps) return BBB_EINVAL;
+    // slabs are addressed through 32-bit buffer offsets (three -- LRT: six -- planes of 2-byte elements, or fp32 outputs)
+    if (6 * sets * a.x_ps >= 0x3FFF0000LL || 6 * sets * a.y_ps >= 0x3FFF0000LL || ((int64_t)a.Cout + 128) * a.K * 4 >= 0x3FFF0000LL) return BBB_ESHAPE;
+    if (d->x_draw_stride != 0 && d->x_draw_stride < 3 * sets * a.x_ps) return BBB_EINVAL;
     if (d->w_draw_stride % 4 != 0 || (!of32 && d->b_draw_stride % 4 != 0) || d->x_draw_stride % 8 != 0) return BBB_EALIGN;
     a.x_ds = d->x_draw_stride; a.w_ds = d->w_draw_stride; a.b_ds = d->b_draw_stride;
-    a.y_ds = of32 ? a.y_ps : 3 * a.y_ps;
+    a.y_ds = of32 ? a.y_ps : 3 * sets * a.y_ps;
     if (d->unit_div < 0 || d->unit_off < 0 || d->x_unit_mod < 0) return BBB_EINVAL;
     if (d->unit_div > 1 && d->unit_off >= d->unit_div) return BBB_EINVAL;
     if (d->x_unit_mod > 0 && d->x_unit_mod != d->unit_div) return BBB_EINVAL;
@@ -590,6 +683,11 @@ extern "C" int bbb_conv2d_c8x3_fwd(const bbb_conv_desc_t* d, const void* x, cons
     a.unit_div = d->unit_div; a.unit_off = d->unit_div > 1 ? d->unit_off : 0; a.x_mod = d->x_unit_mod;
     a.x_div = d->x_unit_div; a.x_off = d->x_unit_off;
     a.x = static_cast<const float*>(x); a.w = w; a.bias = bias; a.y = static_cast<float*>(y);
+    if (lrt != nullptr) {
+        a.w2 = lrt->w_var; a.bias2 = lrt->b_var;
+        a.k0 = (uint32_t)lrt->seed; a.k1 = (uint32_t)(lrt->seed >> 32); a.call0 = lrt->call0; a.stream_id = lrt->stream_id;
+        a.sample = lrt->sample ? 1 : 0; a.call_dev = lrt->call_dev; a.b_off = d->b_offset;
+    }
     const int64_t pixels = (int64_t)ho * wo / (poolp ? 4 : 1);
     // Tile shape (the MFMA sequence per output element, hence every output bit, does not depend on it).  Channels per workgroup
     // 32 * NT: NT = 2 unless forced -- wider tiles halve the image fragments' trips through the vector memory path per matrix
@@ -606,6 +704,7 @@ extern "C" int bbb_conv2d_c8x3_fwd(const bbb_conv_desc_t* d, const void* x, cons
         if (flags & BBB_C8X3_TILE128) mt = 1;
         else if (flags & BBB_C8X3_TILE256) mt = 2;
         else if (a.B <= bm2 / 2 || items2 < 1024) mt = 1;
+        if (lrt != nullptr) mt = 1;                                  // two accumulator sets: 32 images per wave
     }
     const int bnw = 32 * nt, bm = (poolp ? 32 : 128) * mt;
     a.Ntiles = (a.Cout + bnw - 1) / bnw;
@@ -619,15 +718,30 @@ extern "C" int bbb_conv2d_c8x3_fwd(const bbb_conv_desc_t* d, const void* x, cons
     a.per_xcd = (int32_t)per;
     const dim3 grid((unsigned)(8 * per));
     hipStream_t st = (hipStream_t)stream;
+    const bool is_lrt = lrt != nullptr;
     switch (nt * 10 + mt) {
-        case 21: launch_c8x3<2, 1>(of32, poolp, grid, st, a); break;
-        case 22: launch_c8x3<2, 2>(of32, poolp, grid, st, a); break;
-        case 31: launch_c8x3<3, 1>(of32, poolp, grid, st, a); break;
-        case 32: launch_c8x3<3, 2>(of32, poolp, grid, st, a); break;
-        case 41: launch_c8x3<4, 1>(of32, poolp, grid, st, a); break;
-        default: launch_c8x3<4, 2>(of32, poolp, grid, st, a); break;
+        case 21: launch_c8x3<2, 1>(of32, poolp, is_lrt, grid, st, a); break;
+        case 22: launch_c8x3<2, 2>(of32, poolp, is_lrt, grid, st, a); break;
+        case 31: launch_c8x3<3, 1>(of32, poolp, false, grid, st, a); break;
+        case 32: launch_c8x3<3, 2>(of32, poolp, false, grid, st, a); break;
+        case 41: launch_c8x3<4, 1>(of32, poolp, false, grid, st, a); break;
+        default: launch_c8x3<4, 2>(of32, poolp, false, grid, st, a); break;
     }
     return (int)hipGetLastError();
+}
+}  // namespace
+
+extern "C" int bbb_conv2d_c8x3_fwd(const bbb_conv_desc_t* d, const void* x, const float* w, const float* bias, void* y, uint32_t flags,
+                                   void* stream) {
+    return c8x3_launch(d, x, w, bias, y, flags, nullptr, stream);
+}
+
+extern "C" int bbb_lrt_conv2d_c8x3_fwd(const bbb_conv_desc_t* d, const void* x, const float* w_mu, const float* w_var, const float* b_mu,
+                                       const float* b_var, void* y, uint64_t seed, uint32_t call0, uint32_t stream_id, int sample,
+                                       const uint32_t* call_dev, uint32_t flags, void* stream) {
+    if (w_var == nullptr) return BBB_EINVAL;
+    const LrtNoise n = {w_var, b_var, seed, call0, stream_id, sample, call_dev};
+    return c8x3_launch(d, x, w_mu, b_mu, y, flags, &n, stream);
 }
 
 extern "C" int bbb_c8s3_convert(const void* src, void* dst, int64_t slabs, int channels, int64_t positions, int batch, int to_c8s3,
@@ -638,15 +752,21 @@ extern "C" int bbb_c8s3_convert(const void* src, void* dst, int64_t slabs, int c
     const int64_t pv = (int64_t)(channels / 8) * positions * batch, total = slabs * pv;
     const int64_t blocks = (total + 255) / 256;
     if (blocks > 0x7fffffffLL) return BBB_ESHAPE;
-    if (to_c8s3) hipLaunchKernelGGL(c8s3_from_chwn_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                                    static_cast<const float*>(src), static_cast<unsigned short*>(dst), total, pv, positions, batch);
-    else         hipLaunchKernelGGL(c8s3_to_chwn_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                                    static_cast<const unsigned short*>(src), static_cast<float*>(dst), total, pv, positions, batch);
+    // to_c8s3: 1 = fp32 -> three planes, 2 = fp32 -> six planes (values + squares: the LRT chain), 0 / 3 = three / six planes -> fp32
+    const dim3 grid((unsigned)blocks), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    const float* sf = static_cast<const float*>(src);
+    const unsigned short* su = static_cast<const unsigned short*>(src);
+    if (to_c8s3 == 1)      hipLaunchKernelGGL(c8s3_from_chwn_kernel<false>, grid, block, 0, st, sf, static_cast<unsigned short*>(dst), total, pv, positions, batch);
+    else if (to_c8s3 == 2) hipLaunchKernelGGL(c8s3_from_chwn_kernel<true>, grid, block, 0, st, sf, static_cast<unsigned short*>(dst), total, pv, positions, batch);
+    else if (to_c8s3 == 0) hipLaunchKernelGGL(c8s3_to_chwn_kernel<3>, grid, block, 0, st, su, static_cast<float*>(dst), total, pv, positions, batch);
+    else if (to_c8s3 == 3) hipLaunchKernelGGL(c8s3_to_chwn_kernel<6>, grid, block, 0, st, su, static_cast<float*>(dst), total, pv, positions, batch);
+    else return BBB_EINVAL;
     return (int)hipGetLastError();
 }
 
-extern "C" int bbb_s2d_c8s3(const float* x, void* y, int64_t blocks, int batch, int channels, int h, int w, int k, int stride, int pad,
-                            void* stream) {
+namespace {
+int s2d_launch(const float* x, void* y, int64_t blocks, int batch, int channels, int h, int w, int k, int stride, int pad, bool sq, void* stream) {
     if (x == nullptr || y == nullptr || blocks <= 0 || batch <= 0 || channels <= 0 || h <= 0 || w <= 0 || k <= 0 || stride <= 0 || pad < 0)
         return BBB_EINVAL;
     if ((((uintptr_t)x) & 3u) != 0 || (((uintptr_t)y) & 15u) != 0) return BBB_EALIGN;
@@ -659,9 +779,22 @@ extern "C" int bbb_s2d_c8s3(const float* x, void* y, int64_t blocks, int batch, 
     const int nbt = (batch + 15) / 16;
     const int64_t gx = (int64_t)((wb + 15) / 16) * nbt, gy = (int64_t)(cp / 8) * hb;
     if (gx > 0x7fffffffLL || gy > 65535 || blocks > 65535) return BBB_ESHAPE;
-    hipLaunchKernelGGL(s2d_c8s3_kernel, dim3((unsigned)gx, (unsigned)gy, (unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x,
-                       static_cast<unsigned short*>(y), pv, channels, h, w, stride, pad, hb, wb, batch, nbt);
+    if (sq) hipLaunchKernelGGL(s2d_c8s3_kernel<true>, dim3((unsigned)gx, (unsigned)gy, (unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x,
+                               static_cast<unsigned short*>(y), pv, channels, h, w, stride, pad, hb, wb, batch, nbt);
+    else    hipLaunchKernelGGL(s2d_c8s3_kernel<false>, dim3((unsigned)gx, (unsigned)gy, (unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x,
+                               static_cast<unsigned short*>(y), pv, channels, h, w, stride, pad, hb, wb, batch, nbt);
     return (int)hipGetLastError();
+}
+}  // namespace
+
+extern "C" int bbb_s2d_c8s3(const float* x, void* y, int64_t blocks, int batch, int channels, int h, int w, int k, int stride, int pad,
+                            void* stream) {
+    return s2d_launch(x, y, blocks, batch, channels, h, w, k, stride, pad, false, stream);
+}
+
+extern "C" int bbb_s2d_c8s3sq(const float* x, void* y, int64_t blocks, int batch, int channels, int h, int w, int k, int stride, int pad,
+                              void* stream) {
+    return s2d_launch(x, y, blocks, batch, channels, h, w, k, stride, pad, true, stream);
 }
 
 extern "C" int bbb_w_s2d_tap_major(const float* w, float* out, int64_t rows, int channels, int k, int stride, void* stream) {

@@ -462,8 +462,12 @@ __device__ __forceinline__ void s3_cut(const float (&v)[8], s3_u32x4& h, s3_u32x
 
 // MaxPool2d(k, s) on S3 planes: x [slabs][3][C][H][W][B] -> y [slabs][3][C][Ho][Wo][B]; values are joined (exact), compared as
 // fp32 and cut again (exact), so the result is the S3 form of what maxpool_chwn_kernel computes on the fp32 tensor.
+// SQ (the LRT chain of pconv_c8x3): slabs hold SIX planes -- the values' pieces, then the pieces of their squares; the maximum is
+// taken over the values and the squares are those of the pooled values (what the next LRT layer's second contraction reads).
+template <bool SQ>
 __global__ __launch_bounds__(256) void maxpool_s3_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ y,
                                                          int64_t total8, int C, int H, int W, int Ho, int Wo, int B8, int k, int s) {
+    constexpr int NPL = SQ ? 6 : 3;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total8) return;
     const int b8 = (int)(i % B8);
@@ -475,7 +479,7 @@ __global__ __launch_bounds__(256) void maxpool_s3_kernel(const unsigned short* _
     const int c = (int)(t % C);
     const int64_t slab = t / C;
     const int64_t xps = (int64_t)C * H * W * B8, yps = (int64_t)C * Ho * Wo * B8;     // plane strides in 16-byte units
-    const s3_u32x4* xp = reinterpret_cast<const s3_u32x4*>(x) + slab * 3 * xps + (((int64_t)c * H + (int64_t)oh * s) * W + (int64_t)ow * s) * B8 + b8;
+    const s3_u32x4* xp = reinterpret_cast<const s3_u32x4*>(x) + slab * NPL * xps + (((int64_t)c * H + (int64_t)oh * s) * W + (int64_t)ow * s) * B8 + b8;
     float best[8];
     for (int a = 0; a < k; ++a)
         for (int q = 0; q < k; ++q) {
@@ -487,8 +491,14 @@ __global__ __launch_bounds__(256) void maxpool_s3_kernel(const unsigned short* _
         }
     s3_u32x4 h, m, l;
     s3_cut(best, h, m, l);
-    s3_u32x4* yp = reinterpret_cast<s3_u32x4*>(y) + slab * 3 * yps + (((int64_t)c * Ho + oh) * Wo + ow) * B8 + b8;
+    s3_u32x4* yp = reinterpret_cast<s3_u32x4*>(y) + slab * NPL * yps + (((int64_t)c * Ho + oh) * Wo + ow) * B8 + b8;
     yp[0] = h; yp[yps] = m; yp[2 * yps] = l;
+    if constexpr (SQ) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) best[u] = bbb::mul_rn(best[u], best[u]);      // (the rounded fp32 square: no fma contraction into the cut)
+        s3_cut(best, h, m, l);
+        yp[3 * yps] = h; yp[4 * yps] = m; yp[5 * yps] = l;
+    }
 }
 
 // fp32 [slabs][n] <-> S3 [slabs][3][n] (n % 8 == 0): test / boundary helpers
@@ -518,7 +528,8 @@ __global__ __launch_bounds__(256) void s3_to_f32_kernel(const unsigned short* __
 }
 }  // namespace
 
-extern "C" int bbb_maxpool_chwn_s3(const void* x, void* y, int64_t slabs, int channels, int h, int w, int batch, int k, int s, void* stream) {
+namespace {
+int maxpool_s3_launch(const void* x, void* y, int64_t slabs, int channels, int h, int w, int batch, int k, int s, bool sq, void* stream) {
     if (x == nullptr || y == nullptr || slabs <= 0 || channels <= 0 || h <= 0 || w <= 0 || batch <= 0 || k <= 0 || s <= 0) return BBB_EINVAL;
     if (batch % 8 != 0 || h < k || w < k) return BBB_ESHAPE;
     if ((((uintptr_t)x | (uintptr_t)y) & 15u) != 0) return BBB_EALIGN;
@@ -526,9 +537,20 @@ extern "C" int bbb_maxpool_chwn_s3(const void* x, void* y, int64_t slabs, int ch
     const int64_t total8 = slabs * channels * ho * wo * (batch / 8);
     const int64_t blocks = (total8 + 255) / 256;
     if (blocks > 0x7fffffffLL) return BBB_ESHAPE;
-    hipLaunchKernelGGL(maxpool_s3_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, static_cast<const unsigned short*>(x),
-                       static_cast<unsigned short*>(y), total8, channels, h, w, ho, wo, batch / 8, k, s);
+    if (sq) hipLaunchKernelGGL(maxpool_s3_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, static_cast<const unsigned short*>(x),
+                               static_cast<unsigned short*>(y), total8, channels, h, w, ho, wo, batch / 8, k, s);
+    else    hipLaunchKernelGGL(maxpool_s3_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, static_cast<const unsigned short*>(x),
+                               static_cast<unsigned short*>(y), total8, channels, h, w, ho, wo, batch / 8, k, s);
     return (int)hipGetLastError();
+}
+}  // namespace
+
+extern "C" int bbb_maxpool_chwn_s3(const void* x, void* y, int64_t slabs, int channels, int h, int w, int batch, int k, int s, void* stream) {
+    return maxpool_s3_launch(x, y, slabs, channels, h, w, batch, k, s, false, stream);
+}
+
+extern "C" int bbb_maxpool_chwn_s3sq(const void* x, void* y, int64_t slabs, int channels, int h, int w, int batch, int k, int s, void* stream) {
+    return maxpool_s3_launch(x, y, slabs, channels, h, w, batch, k, s, true, stream);
 }
 
 extern "C" int bbb_s3_convert(const void* src, void* dst, int64_t slabs, int64_t n, int to_s3, void* stream) {

@@ -319,3 +319,116 @@ def test_c8_chain_partitions_are_the_whole_step(env):
         assert torch.equal(two[:E], full)
         second, _ = ens._mc_logits_chwn(net, x2[512:], E, 7, 3 + E)
         assert torch.equal(two[E:], second)
+
+
+# ---- the LRT form (bbb_lrt_conv2d_c8x3_fwd): both contractions on the 16-bit matrix pipe, the fp32 LRT kernel's noise ----
+LRT_CASES = [
+    # B, Cin, H, W, Cout, k, stride, pad, E, x_shared, act
+    (256, 64, 4, 4, 192, 5, 1, 2, 2, False, "softplus"),     # AlexNet conv2
+    (132, 32, 5, 7, 72, 3, 1, 1, 3, True, "relu"),           # ragged tiles, one input slab for three draws
+    (64, 128, 1, 1, 16, 1, 1, 0, 2, False, None),            # linear
+    (40, 48, 6, 6, 24, 3, 2, 0, 1, False, "softplus"),       # 48 channels, stride 2
+]
+
+
+@pytest.mark.parametrize("B,Cin,H,W,Cout,k,s,p,E,xs,act", LRT_CASES)
+@pytest.mark.parametrize("out_f32", [False, True])
+def test_lrt_c8x3_launch_vs_the_fp32_lrt_kernel(env, B, Cin, H, W, Cout, k, s, p, E, xs, act, out_f32):
+    """Same layer, same noise elements (stream (seed, call0 + draw, stream_id), canonical output index): the two kernels differ by
+    the rounding of two contractions only -- outputs within 2e-5 of the largest magnitude; the six-plane output's squares are the
+    fp32 squares of its values; sample=False returns act(act_mu)."""
+    ops = env["ops"]
+    torch.manual_seed(B + Cout)
+    x = torch.randn(1 if xs else E, Cin, H, W, B, device="cuda")
+    w_mu = torch.randn(Cout, Cin, k, k, device="cuda") * 0.1
+    w_var = torch.rand(Cout, Cin, k, k, device="cuda") * 0.01
+    b_mu = torch.randn(Cout, device="cuda") * 0.1
+    b_var = torch.rand(Cout, device="cuda") * 0.01
+    seed, call0, sid = 77, 5, 6
+    ref, _, _ = ops.lrt_conv2d_chwn_forward(x.expand(E, *x.shape[1:]).contiguous(), w_mu, w_var, b_mu, b_var, seed, call0, sid, s, p, 1, act=act)
+    x6 = ops.c8s3_from_f32(x, squares=True)
+    wm, wv = ops.w_tap_major(w_mu.unsqueeze(0))[0], ops.w_tap_major(w_var.unsqueeze(0))[0]
+    got6 = ops.lrt_conv2d_c8x3_forward(x6, wm, wv, b_mu, b_var, k, seed, call0, sid, s, p, 1, act=act, out_f32=out_f32, n_slabs=E)
+    got = got6 if out_f32 else ops.c8s3_to_f32(got6)
+    assert got.shape == ref.shape
+    assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    if not out_f32:
+        assert got6.shape[1] == 6
+        sq = ops.c8s3_to_f32(torch.cat([got6[:, 3:], got6[:, 3:]], dim=1))       # (the squares' planes read as values)
+        assert torch.equal(sq, got * got)
+        # pooling six-plane slabs: maximum of the values, squares of the pooled values
+        if got6.shape[3] >= 2 and got6.shape[4] >= 2:
+            pl = ops.maxpool_c8s3(got6, 2, 2)
+            pv = ops.maxpool_chwn(got, 2, 2)
+            assert torch.equal(ops.c8s3_to_f32(pl), pv)
+            assert torch.equal(ops.c8s3_to_f32(torch.cat([pl[:, 3:], pl[:, 3:]], dim=1)), pv * pv)
+    det, _, _ = ops.lrt_conv2d_chwn_forward(x.expand(E, *x.shape[1:]).contiguous(), w_mu, w_var, b_mu, b_var, seed, call0, sid, s, p, 1, act=act,
+                                            sample=False)
+    got_d = ops.lrt_conv2d_c8x3_forward(x6, wm, wv, b_mu, b_var, k, seed, call0, sid, s, p, 1, act=act, out_f32=True, n_slabs=E, sample=False)
+    assert float((got_d - det).abs().max()) <= 2e-5 * float(det.abs().max())
+
+
+def test_lrt_c8x3_noise_follows_the_global_image_index(env):
+    """b_offset (batch-parallel shards) and work units key the noise by the GLOBAL image: a shard's / a unit's launch is bit for bit
+    the corresponding slice of the whole launch."""
+    ops = env["ops"]
+    torch.manual_seed(2)
+    E, Cin, H, W, B, Cout = 2, 32, 3, 3, 64, 40
+    x = torch.randn(E, Cin, H, W, B, device="cuda")
+    wm = ops.w_tap_major(torch.randn(1, Cout, Cin, 3, 3, device="cuda") * 0.1)[0]
+    wv = ops.w_tap_major(torch.rand(1, Cout, Cin, 3, 3, device="cuda") * 0.01)[0]
+    b_mu, b_var = torch.randn(Cout, device="cuda") * 0.1, torch.rand(Cout, device="cuda") * 0.01
+    full = ops.c8s3_to_f32(ops.lrt_conv2d_c8x3_forward(ops.c8s3_from_f32(x, squares=True), wm, wv, b_mu, b_var, 3, 9, 4, 2, 1, 1, 1, act="softplus"))
+    half = ops.c8s3_to_f32(ops.lrt_conv2d_c8x3_forward(ops.c8s3_from_f32(x[..., 32:].contiguous(), squares=True), wm, wv, b_mu, b_var, 3, 9, 4, 2,
+                                                       1, 1, 1, act="softplus", b_offset=32))
+    assert torch.equal(half, full[..., 32:])
+    # units: S = 2 slices per draw, units 1..3 of the (draw, slice) grid = (0, 1), (1, 0), (1, 1)
+    xu = torch.stack([x[0][..., 32:], x[1][..., :32], x[1][..., 32:]]).contiguous()
+    un = ops.c8s3_to_f32(ops.lrt_conv2d_c8x3_forward(ops.c8s3_from_f32(xu, squares=True), wm, wv, b_mu, b_var, 3, 9, 4, 2, 1, 1, 1, act="softplus",
+                                                     units=(2, 1), n_units=3))
+    assert torch.equal(un[0], full[0][..., 32:]) and torch.equal(un[1], full[1][..., :32]) and torch.equal(un[2], full[1][..., 32:])
+
+
+@pytest.mark.parametrize("model,shape,classes,E", [("alexnet", (512, 3, 32, 32), 100, 1), ("alexnet", (256, 3, 32, 32), 10, 4),
+                                                   ("3conv3fc", (64, 3, 32, 32), 10, 2)])
+def test_c8_chain_lrt_model_step(env, model, shape, classes, E):
+    """LRT models in split-bf16 mode: every layer behind the first (and AlexNet's conv1 in space-to-depth form) on the LRT form of
+    the MFMA-ready-operand kernel, six-plane slabs between them -- against the fp32 LRT path under the same noise: KL bit for bit,
+    log-probabilities within 2e-5 of their largest magnitude; eager = hipGraph replay; a rank's work units and several steps per
+    launch are bit for bit the slices of the whole step."""
+    ens, ops = env["ens"], env["ops"]
+    torch.manual_seed(1)
+    net = env["zoo"].getModel(model, shape[1], classes, P.CONFIG_PRIORS, "lrt", "softplus").cuda()
+    env["rng"].assign_stream_ids(net)
+    x = torch.rand(*shape, device="cuda")
+    with torch.no_grad():
+        env["rng"].manual_seed(3, call=0)
+        lo32, kl32 = ens.mc_forward(net, x, E)
+        with ops.use_config(gemm_mode="bf16x3", c8x3=False):
+            env["rng"].manual_seed(3, call=0)
+            lo_old, _ = ens.mc_forward(net, x, E)
+        assert torch.equal(lo_old, lo32)                     # (without the chain LRT layers keep their fp32 kernel in the mode)
+        with ops.use_config(gemm_mode="bf16x3"):
+            env["rng"].manual_seed(3, call=0)
+            lo, kl = ens.mc_forward(net, x, E)
+            env["rng"].manual_seed(3, call=0)
+            g = ens.GraphedMC(net, x, E)
+            lo_g, kl_g = g.step()
+            torch.cuda.synchronize()
+            assert torch.equal(kl, kl32) and torch.equal(kl_g, kl) and torch.equal(lo_g, lo)
+            scale = float(lo32.abs().max())
+            assert float((lo - lo32).abs().max()) <= 2e-5 * scale and not torch.equal(lo, lo32)
+            # partitions: work units of a sharded step, several steps per launch
+            full, _ = ens._mc_logits_chwn(net, x, E, 7, 3)
+            S = 2
+            lo_u, hi_u = ens.unit_range(E, S, 1, 2)
+            part, _ = ens._mc_logits_chwn(net, x, E, 7, 3, units=(S, lo_u, hi_u))
+            for i, u in enumerate(range(lo_u, hi_u)):
+                j, sl = divmod(u, S)
+                bs = shape[0] // S
+                assert torch.equal(part[i], full[j][:, sl * bs:(sl + 1) * bs])
+            x2 = torch.cat([x, torch.rand(*shape, device="cuda")])
+            two, _ = ens._mc_logits_chwn(net, x2, E, 7, 3, groups=2)
+            assert torch.equal(two[:E], full)
+            second, _ = ens._mc_logits_chwn(net, x2[shape[0]:], E, 7, 3 + E)
+            assert torch.equal(two[E:], second)
