@@ -940,11 +940,14 @@ def split_bf16(dev, steps, pipeline):
             out["fusion_ab"] = fusion_ab(dev)
         except Exception as exc:
             out["fusion_ab"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:160])}
-        # the other BBB configurations of BASELINE.json in the mode (same launch shapes as their fp32 rows in SECONDARY.configs)
+        # the other fp32 configurations of BASELINE.json in the mode (same launch shapes as their fp32 rows in SECONDARY.configs;
+        # configs[2]: LRT layers on the kernel's LRT form)
         oc = {}
-        for name in ("configs[3]", "configs[4]"):
+        for name in ("configs[2]", "configs[3]", "configs[4]"):
             try:
-                r, n2, x2 = run_config(CONFIGS[name], 12, 3, 3, dev, want_roofline=False, preheat_s=0.15, single_lane=False)
+                small = CONFIGS[name]["E"] == 1 and CONFIGS[name]["hw"] == 32        # (the launch shapes of SECONDARY.configs)
+                r, n2, x2 = run_config(CONFIGS[name], 256 if small else 12, 16 if small else 3, 4 if small else 3, dev, want_roofline=False,
+                                       preheat_s=0.15, single_lane=False, steps_per_launch=16 if small else 1)
                 oc[name] = {"value": r["value"], "ms_per_step": r["ms_per_step"]}
                 del n2, x2
             except Exception as exc:

@@ -9,7 +9,7 @@
 //     in-bounds taps of a pixel are runs of cin consecutive k -- padding taps are skipped exactly as in the fp32 kernel -- and a
 //     32-k tile of 64 channels is 64 runs of 128 contiguous bytes; the tile is cut into its three bf16 pieces ONCE per workgroup
 //     while it is staged (8 elements per thread and tile against 48 matrix instructions per wave) and lands in LDS as [n][k] rows
-//     of 80 bytes: the A operand of a lane is one conflict-free ds_read_b128.
+//     of 64 bytes with their four 16-byte pieces XOR-swizzled by the row: the A operand of a lane is one conflict-free ds_read_b128.
 // Workgroup = one output pixel x 64 channels x 128 * MT images; every wave owns 64 channels x 32 * MT images (2 x MT accumulator
 // tiles), so a 16-byte image fragment feeds 12 / 8 / 4 (hi / mid / lo plane) of the step's 24 * MT matrix instructions and a
 // weight fragment 3 * MT of them.  Per k16 step and wave (MT = 2): 6 ds_read_b128 + 6 global 16-byte loads for 24 MFMAs (768 pipe
@@ -29,7 +29,9 @@ namespace pconv {
 #ifndef C8X3_ABLATE
 #define C8X3_ABLATE 0            // experiments only (profiles/experiments/c8x3_ablate.sh, on the generic k loop: BBB_C8X3_NT=3): 1 no epilogue math,
 #endif                           // 2 no barriers, 3 no image loads, 4 no weight staging, 5 no matrix instructions -- timing of what is left
-constexpr int C8_LDA = 40;               // bf16 elements per LDS weight row: 32 k + 8 pad = 80 bytes (16-lane groups hit 64 distinct banks)
+constexpr int C8_LDA = 32;               // bf16 elements per LDS weight row: 32 k = four 16-byte pieces, no padding -- piece c of row n sits
+                                         // at position c ^ ((n >> 2) & 3): the 16 lanes of a ds_read_b128 group (rows {0-3, 12-15, 20-27} ...,
+                                         // one piece index) then cover all 64 banks, and a writer's 8-lane group fills 128 contiguous bytes
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 // NT x MT: 32-channel x 32-image accumulator tiles per wave.  The workgroup's weight tile is 32 * NT channel rows; its four waves own
@@ -223,7 +225,7 @@ void pconv_c8x3_kernel(const PConvArgs p) {
                 split3_pair((i & 1) ? f32x2{v[2], v[3]} : f32x2{v[0], v[1]}, a0, a1, a2);
                 h[i] = a0; m[i] = a1; l[i] = a2;
             }
-            unsigned short* const base = Wp + stage * STAGE + st * (3 * PLANE) + (wn + 64 * ps) * C8_LDA + wk;
+            unsigned short* const base = Wp + stage * STAGE + st * (3 * PLANE) + (wn + 64 * ps) * C8_LDA + (((tid & 3) ^ ((wn >> 2) & 3)) << 3);
             *reinterpret_cast<u32x4*>(base) = h;
             *reinterpret_cast<u32x4*>(base + PLANE) = m;
             *reinterpret_cast<u32x4*>(base + 2 * PLANE) = l;
@@ -247,7 +249,7 @@ void pconv_c8x3_kernel(const PConvArgs p) {
         for (int st = 0; st < SETS; ++st)
 #pragma unroll
         for (int n2 = 0; n2 < NT; n2 += 2) {
-            const unsigned short* const base = Wp + stage * STAGE + st * (3 * PLANE) + lrow * C8_LDA + s * 16 + lk * 8;
+            const unsigned short* const base = Wp + stage * STAGE + st * (3 * PLANE) + lrow * C8_LDA + (((2 * s + lk) ^ ((lrow >> 2) & 3)) << 3);
             constexpr int kPairMax = 2;
             bf16x8 a[kPairMax][3];
 #pragma unroll
@@ -278,7 +280,7 @@ void pconv_c8x3_kernel(const PConvArgs p) {
       if (ntiles > 0) {
         bf16x8 af[2][3];                                             // the step's weight fragments: [channel tile][plane]
         auto aread = [&](int stage, int s, int pl) {
-            const unsigned short* const base = Wp + stage * STAGE + lrow * C8_LDA + s * 16 + lk * 8 + pl * PLANE;
+            const unsigned short* const base = Wp + stage * STAGE + lrow * C8_LDA + (((2 * s + lk) ^ ((lrow >> 2) & 3)) << 3) + pl * PLANE;
             af[0][pl] = *reinterpret_cast<const bf16x8*>(base);
             af[1][pl] = *reinterpret_cast<const bf16x8*>(base + 32 * C8_LDA);
         };
