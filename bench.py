@@ -1328,11 +1328,16 @@ def main():
                                            device_copy_GBps=hb.get("device_copy_GBps"))
                     # the write roof of this box for the pass's store pattern (same bytes, no reads, no arithmetic), back to back like
                     # reparam_back_to_back_frac: how much of what the hardware gives the pass's WRITES the fused pass reaches
+                    # (A-B-A, best brackets of both: the two probes must see the same clock state -- measured minutes apart the ratio
+                    # wandered 0.80-1.03 on one box)
+                    ra = reparam_probe(net, dev, n_params, cfg["E"] * G, hbm_probe=False)
                     wr = write_roof_probe(n_params, cfg["E"] * G)
+                    rb = reparam_probe(net, dev, n_params, cfg["E"] * G, hbm_probe=False)
                     if wr:
                         roof_gbps = max(wr)
-                        bb_gbps = rpg["frac"] * PEAK_HBM_GBS
+                        bb_gbps = max(p_["bytes_per_launch"] / (p_["min_us"] * 1e-6) / 1e9 for p_ in (ra, rb))
                         second["write_roof_probe"] = {"plain_GBps": wr[0], "non_temporal_GBps": wr[1], "draws": cfg["E"] * G,
+                                                      "reparam_best_GBps_before_after": [round(p_["bytes_per_launch"] / (p_["min_us"] * 1e-6) / 1e9, 1) for p_ in (ra, rb)],
                                                       "elements_per_draw": n_params,
                                                       "what": "write-only kernel, the reparam pass's store shape and bytes, 10 launches back to back, best of 5"}
                         out["roofline"].update(write_roof_GBps=roof_gbps,

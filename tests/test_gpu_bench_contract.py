@@ -117,7 +117,7 @@ def test_bench_driver_invocation_line_is_short_and_complete():
     # round 6: the split-bf16 chain and the reparam pass against the box's write roof, as first-level scalars
     for k in ("split_bf16_value", "split_bf16_frac_of_bf16_peak", "split_bf16_ms_per_step", "write_roof_GBps", "reparam_frac_of_write_roof"):
         assert k in r and not isinstance(r[k], (dict, list)), k
-    assert r["split_bf16_value"] > j["value"] and 0.3 < r["split_bf16_frac_of_bf16_peak"] < 1 and 0.8 < r["reparam_frac_of_write_roof"] < 1.2
+    assert r["split_bf16_value"] > j["value"] and 0.3 < r["split_bf16_frac_of_bf16_peak"] < 1 and 0.7 < r["reparam_frac_of_write_roof"] < 1.3
 
 
 def test_bench_json_contract_other_config_as_headline():
