@@ -27,8 +27,8 @@
 namespace pconv {
 
 #ifndef C8X3_ABLATE
-#define C8X3_ABLATE 0            // experiments only (profiles/experiments/c8x3_ablate.sh, on the generic k loop: BBB_C8X3_NT=3): 1 no epilogue math,
-#endif                           // 2 no barriers, 3 no image loads, 4 no weight staging, 5 no matrix instructions -- timing of what is left
+#define C8X3_ABLATE 0            // experiments only (profiles/experiments/c8x3_ablate.sh): 1 no epilogue math, 2 no barriers, 3 no image loads,
+#endif                           // 4 no weight staging, 5 no matrix instructions, 6 weight loads but no cut / LDS writes (1-3, 5: the generic loop)
 constexpr int C8_LDA = 32;               // bf16 elements per LDS weight row: 32 k = four 16-byte pieces, no padding -- piece c of row n sits
                                          // at position c ^ ((n >> 2) & 3): the 16 lanes of a ds_read_b128 group (rows {0-3, 12-15, 20-27} ...,
                                          // one piece index) then cover all 64 banks, and a writer's 8-lane group fills 128 contiguous bytes
@@ -296,7 +296,7 @@ void pconv_c8x3_kernel(const PConvArgs p) {
         for (int t = 0; t < ntiles; ++t) {
             const int stage = t & 1;
             aread(stage, 0, 2); aread(stage, 0, 0); aread(stage, 0, 1);
-            wload();
+            if (C8X3_ABLATE != 4) wload();
             __builtin_amdgcn_sched_barrier(0);
             C8X3_T(2, 0, 0)
             __builtin_amdgcn_sched_barrier(0);
@@ -315,7 +315,12 @@ void pconv_c8x3_kernel(const PConvArgs p) {
             __builtin_amdgcn_sched_barrier(0);
             bload(1);
             __builtin_amdgcn_sched_barrier(0);
-            wstore(stage ^ 1);
+            if (C8X3_ABLATE == 4) {
+            } else if (C8X3_ABLATE == 6) {                           // (experiment: the weight loads without the cut / the LDS writes)
+                asm volatile("" :: "v"(wreg[0][0][0]), "v"(wreg[0][0][1]));
+            } else {
+                wstore(stage ^ 1);
+            }
             __syncthreads();
         }
 #undef C8X3_T
