@@ -53,6 +53,12 @@ def manual_seed(seed, call=0):
     _state["pinned"] = True
 
 
+def use_device_generator():
+    """Undo manual_seed: (seed, call) come from torch's default generator of the current device again."""
+    _state["pinned"] = False
+    _state["torch_seed"] = None
+
+
 def get_state():
     _sync()
     g = None if _state["pinned"] else _device_generator()

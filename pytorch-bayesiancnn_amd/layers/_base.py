@@ -106,4 +106,4 @@ class BayesianLayer(ModuleWrapper):
         return self._kl
 
     def _take_kl(self, kl):
-        self._kl = kl
+        self.__dict__["_kl"] = kl                # (a plain attribute: nn.Module.__setattr__ would spend ~2.5 us on its checks)

@@ -14,7 +14,7 @@ class _BBBLayer(BayesianLayer):
         mus, rhos, ids = self._param_lists()
         if self._presampled is not None:
             w, b = self._presampled
-            self._presampled = None
+            self.__dict__["_presampled"] = None
             return w, b
         if self.training or sample:
             seed, call = rng.layer_call()

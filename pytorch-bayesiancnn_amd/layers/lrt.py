@@ -14,7 +14,7 @@ class _LRTLayer(BayesianLayer):
         mus, rhos, _ = self._param_lists()
         if self._presampled is not None:
             out = self._presampled
-            self._presampled = None
+            self.__dict__["_presampled"] = None
             return out
         kl, sig2 = ops.kl_only(mus, rhos, self.prior_mu, self.prior_sigma, want_sigma=True, sigma_squared=True)
         self._take_kl(kl)

@@ -42,8 +42,12 @@ class ModuleWrapper(nn.Module):
         scope = None
         try:
             scope = _fused.enter(self)      # one noise call index (and, when possible, ONE fused reparam+KL
-            for child in self.children():   # launch) for every Bayesian layer below this wrapper
-                x = child(x)
+            y = _fused.hooked_chain(self, x, scope) if (_fast_inference[0] and scope is not None) else None
+            if y is not None:               # children with forward hooks: the same kernels without the per-layer layout round trips
+                x = y
+            else:
+                for child in self.children():   # launch) for every Bayesian layer below this wrapper
+                    x = child(x)
             if scope is not None and scope.kl is not None:
                 return x, scope.kl          # KL of all layers, already reduced on the device
             kl = 0.0

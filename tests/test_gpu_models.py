@@ -483,3 +483,53 @@ def test_sigma_attributes_come_from_the_fused_pass_and_follow_rho():
     assert l.W_rho.grad is not None and torch.isfinite(l.W_rho.grad).all()
     l2 = copy.deepcopy(l)
     assert "_w_sigma_view" not in l2.__dict__ and torch.equal(l2.W_rho, l.W_rho)
+
+
+@pytest.mark.parametrize("net_type,lt,shape", [("alexnet", "bbb", (64, 3, 32, 32)), ("alexnet", "lrt", (32, 3, 32, 32)),
+                                               ("3conv3fc", "bbb", (16, 3, 32, 32)), ("lenet", "lrt", (8, 1, 32, 32))])
+def test_hooked_forward_keeps_the_layout_between_layers(net_type, lt, shape):
+    """Forward hooks on children (layers/_fused.hooked_chain): the per-layer path's own kernels without the layout round trip around
+    every layer -- logits, KL and every tensor a hook sees are bit for bit those of the module-by-module loop; hooks that REPLACE
+    an input (pre-hook) or an output are honoured; hooks on a conv, an activation, a pooling module, the flatten and the classifier."""
+    import layers
+    from layers import _fused
+    from bbb_hip import rng, zoo
+    import torch.nn as nn
+    torch.manual_seed(5)
+    net = zoo.getModel(net_type, shape[1], 10, P.CONFIG_PRIORS, lt, "softplus").cuda()
+    rng.assign_stream_ids(net)
+    x = torch.rand(*shape, device="cuda")
+    kids = list(net.children())
+    convs = [m for m in kids if hasattr(m, "kernel_size") and hasattr(m, "W_mu")]
+    acts = [m for m in kids if isinstance(m, nn.Softplus)]
+    pools = [m for m in kids if isinstance(m, nn.MaxPool2d)]
+    flat = [m for m in kids if isinstance(m, layers.FlattenLayer)][0]
+    last = kids[-1]
+
+    def run(enabled):
+        seen = []
+        hs = [convs[1].register_forward_hook(lambda m, i, o: seen.append(("conv", i[0].clone(), o.clone()))),
+              acts[0].register_forward_hook(lambda m, i, o: seen.append(("act", i[0].clone(), o.clone()))),
+              pools[-1].register_forward_hook(lambda m, i, o: o * 0.5),                      # replaces the output
+              flat.register_forward_hook(lambda m, i, o: seen.append(("flat", i[0].clone(), o.clone()))),
+              last.register_forward_pre_hook(lambda m, i: (i[0] + 1.0,)),                    # replaces the input
+              last.register_forward_hook(lambda m, i, o: seen.append(("fc", i[0].clone(), o.clone())))]
+        _fused.hooked_chain_enabled[0] = enabled
+        try:
+            with torch.no_grad():
+                rng.manual_seed(11, call=3)
+                out, kl = net(x)
+                out2, _ = net(x)                                                             # (a second call: the next call index)
+        finally:
+            _fused.hooked_chain_enabled[0] = True
+            rng.use_device_generator()                                                       # (un-pin: later tests seed torch's generator)
+            for h in hs:
+                h.remove()
+        return out, kl, out2, seen
+
+    a, kla, a2, sa = run(True)
+    b, klb, b2, sb = run(False)
+    assert torch.equal(a, b) and torch.equal(kla, klb) and torch.equal(a2, b2) and not torch.equal(a, a2)
+    assert len(sa) == len(sb) == 8
+    for (ta, ia, oa), (tb, ib, ob) in zip(sa, sb):
+        assert ta == tb and ia.shape == ib.shape and oa.shape == ob.shape and torch.equal(ia, ib) and torch.equal(oa, ob), ta
