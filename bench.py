@@ -811,6 +811,47 @@ def hot_us(fn, dev, reps=10, heat_s=0.03):
     return round(statistics.median(ts) * 1e3, 1)
 
 
+def fusion_ab_fp32(dev, slabs=40, B=512):
+    """N3 on the fp32-MFMA chain, every pooling layer of BayesianAlexNet (BBB at 40 slabs = the metric launch shape; LRT at 16 slabs =
+    configs[2]'s): us per launch of the conv launch + the pooling launch against the pooled launch (serial window: one workgroup
+    walks the window's four pixels, running maximum in accumulation registers; bit for bit the two launches), and what ships.
+    conv5 + pool3 has a split contraction (a second set of running registers): no pooled form."""
+    from bbb_hip import ops
+    out = {}
+    shapes = {"pool1": ((3, 32, 32), (64, 3, 11, 11), 4, 5), "pool2": ((64, 4, 4), (192, 64, 5, 5), 1, 2)}
+    with torch.no_grad():
+        torch.manual_seed(0)
+        for name, ((C, H, W), wshape, st, pd) in shapes.items():
+            x = torch.rand(1 if name == "pool1" else slabs, C, H, W, B, device=dev)
+            w = torch.randn(slabs, *wshape, device=dev) * 0.05
+            b = torch.randn(slabs, wshape[0], device=dev) * 0.1
+            conv = hot_us(lambda: ops.conv2d_chwn_forward(x, w, b, st, pd, 1, act="softplus", bf16x3=False), dev)
+            y = ops.conv2d_chwn_forward(x, w, b, st, pd, 1, act="softplus", bf16x3=False)
+            pool = hot_us(lambda: ops.maxpool_chwn(y, 2, 2), dev)
+            fused = hot_us(lambda: ops.conv2d_chwn_forward(x, w, b, st, pd, 1, act="softplus", bf16x3=False, pool=True), dev)
+            ships = ops.pool_fusion_ok(tuple(x.shape), tuple(w.shape), st, pd, 1, slabs)
+            out["bbb_" + name] = {"conv_us": conv, "pool_us": pool, "fused_us": fused, "saved_us": round(conv + pool - fused, 1),
+                                  "shipped": "fused" if ships else "separate launches"}
+            del x, w, b, y
+        ls = 16
+        for name, ((C, H, W), wshape, st, pd) in shapes.items():
+            x = torch.rand(ls, C, H, W, B, device=dev)
+            w_mu = torch.randn(*wshape, device=dev) * 0.05
+            w_var = torch.rand(*wshape, device=dev) * 1e-4
+            b_mu, b_var = torch.randn(wshape[0], device=dev) * 0.1, torch.rand(wshape[0], device=dev) * 1e-4
+            f = lambda pool: ops.lrt_conv2d_chwn_forward(x, w_mu, w_var, b_mu, b_var, 1, 0, 2, st, pd, 1, act="softplus", pool=pool)[0]
+            conv = hot_us(lambda: f(False), dev)
+            y = f(False)
+            pool = hot_us(lambda: ops.maxpool_chwn(y, 2, 2), dev)
+            fused = hot_us(lambda: f(True), dev)
+            out["lrt_" + name] = {"conv_us": conv, "pool_us": pool, "fused_us": fused, "saved_us": round(conv + pool - fused, 1),
+                                  "shipped": "separate launches", "slabs": ls}
+            del x, y
+    out["bbb_pool3"] = {"shipped": "separate launch", "why": "conv5's contraction is split (ops.split_k): no pooled form"}
+    out["unit"] = "us per launch (BBB: %d slabs, LRT: 16 slabs) x %d images" % (slabs, B)
+    return out
+
+
 def fusion_ab(dev, slabs=40, B=512):
     """SURVEY section 8(f) N3 on the split-bf16 chain (review r05 item 7): per pooling layer of BayesianAlexNet either the fused launch
     that ships (A/B measured here, us per 40-slab launch) or the separate pooling launch's cost next to the extra matrix work its
@@ -1378,6 +1419,11 @@ def main():
                     out["roofline"]["hooked_loop_value"] = second["slow_paths"]["forward_hook_dropin_loop"]["value"]
             except Exception as exc:
                 second["slow_paths"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:160])}
+            if cfg is CONFIGS["metric"]:
+                try:
+                    second["fusion_ab_fp32"] = fusion_ab_fp32(dev)
+                except Exception as exc:
+                    second["fusion_ab_fp32"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:160])}
             try:
                 second["training_step"] = training_step(dev, max(5, args.steps // 5))
                 ts = second["training_step"]

@@ -71,6 +71,8 @@ def test_bench_json_contract_default():
     assert 0 < mx["roofline.reparam_hbm_resident_frac"] < 1 and 0 < mx["roofline.reparam_10draw_frac"] < 1.2
     ts = sec["training_step"]["roofline"]                # executed FLOPs of forward + wgrad + dgrad over the step's wall time
     assert ts["bound"] == "mfma" and ts["peak"] == 157.3 and 0.05 < ts["frac"] < 1 and r["training_step_frac"] == ts["frac"]
+    f32 = sec["fusion_ab_fp32"]                          # ... and on the fp32 chain: every pool either fused or priced
+    assert "error" not in f32 and f32["bbb_pool1"]["shipped"] == "fused" and f32["bbb_pool2"]["fused_us"] > 0 and f32["lrt_pool1"]["fused_us"] > 0
     fa = sec["split_bf16"]["fusion_ab"]                  # N3 closed with numbers: pool1 fused and shipped, pool2 / pool3 priced
     assert "error" not in fa and fa["pool1"]["fused_us"] < fa["pool1"]["conv_us"] + fa["pool1"]["pool_us"] and fa["pool2"]["pool_us"] > 0
     assert r["value_above_p90"] == (j["value"] > r["stats_p90"]) and "hipGraph" in r["timed_by"]
