@@ -432,3 +432,50 @@ def test_c8_chain_lrt_model_step(env, model, shape, classes, E):
             assert torch.equal(two[:E], full)
             second, _ = ens._mc_logits_chwn(net, x2[shape[0]:], E, 7, 3 + E)
             assert torch.equal(two[E:], second)
+
+
+def test_c8x3_random_geometries(env):
+    """60 seeded random layer geometries (channels 16 .. 144, maps 1 .. 11, kernels 1 .. 5, stride / dilation 1 .. 3, padding 0 .. 3,
+    batches that leave ragged image tiles, shared and per-draw inputs): the BBB form against the fp32 kernel (2e-5 of the largest
+    magnitude), its pooled form against conv + pool (bit for bit) wherever it applies, the LRT form against the fp32 LRT kernel under
+    the same noise."""
+    ops = env["ops"]
+    rs = np.random.RandomState(2024)
+    done = pooled = 0
+    while done < 60:
+        Cin = int(rs.choice([16, 32, 48, 64, 80, 144]))
+        Cout = int(rs.choice([8, 24, 64, 72, 136]))
+        H, W = int(rs.randint(1, 12)), int(rs.randint(1, 12))
+        kh = int(rs.randint(1, 6))
+        k = (kh, kh)
+        s, d, p = int(rs.randint(1, 4)), int(rs.randint(1, 4)), int(rs.randint(0, 4))
+        ho = (H + 2 * p - d * (kh - 1) - 1) // s + 1
+        wo = (W + 2 * p - d * (kh - 1) - 1) // s + 1
+        if ho <= 0 or wo <= 0 or d * (kh - 1) < p:
+            continue
+        B = int(rs.choice([4, 36, 132, 260]))
+        E = int(rs.randint(1, 4))
+        xs = bool(rs.randint(0, 2))
+        torch.manual_seed(done)
+        x = torch.randn(1 if xs else E, Cin, H, W, B, device="cuda")
+        w = torch.randn(E, Cout, Cin, kh, kh, device="cuda") * (1.0 / (Cin * kh * kh) ** 0.5)
+        b = torch.randn(E, Cout, device="cuda") * 0.1
+        ref = ops.conv2d_chwn_forward(x, w, b, s, p, d, act="softplus", bf16x3=False)
+        xc, wt = ops.c8s3_from_f32(x), ops.w_tap_major(w)
+        got6 = ops.conv2d_c8x3_forward(xc, wt, b, k, s, p, d, act="softplus")
+        got = ops.c8s3_to_f32(got6)
+        assert got.shape == ref.shape and float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), (Cin, Cout, H, W, kh, s, d, p, B, E, xs)
+        if p == 0 and ho % 2 == 0 and wo % 2 == 0:
+            assert torch.equal(ops.conv2d_c8x3_forward(xc, wt, b, k, s, p, d, act="softplus", pool=True), ops.maxpool_c8s3(got6, 2, 2))
+            pooled += 1
+        # LRT form: one (mu, sigma^2) pair for all slabs
+        w_var = torch.rand(Cout, Cin, kh, kh, device="cuda") * (0.01 / (Cin * kh * kh))
+        b_var = torch.rand(Cout, device="cuda") * 1e-3
+        xe = x.expand(E, *x.shape[1:]).contiguous()
+        lref, _, _ = ops.lrt_conv2d_chwn_forward(xe, w[0], w_var, b[0], b_var, 5, 9, 6, s, p, d, act="relu")
+        lgot = ops.c8s3_to_f32(ops.lrt_conv2d_c8x3_forward(ops.c8s3_from_f32(x, squares=True), ops.w_tap_major(w[:1])[0],
+                                                           ops.w_tap_major(w_var.unsqueeze(0))[0], b[0], b_var, k, 5, 9, 6, s, p, d, act="relu",
+                                                           n_slabs=E))
+        assert float((lgot - lref).abs().max()) <= 2e-5 * max(float(lref.abs().max()), 1e-3), ("lrt", Cin, Cout, H, W, kh, s, d, p, B, E, xs)
+        done += 1
+    assert pooled >= 3
