@@ -1454,6 +1454,22 @@ def main():
                         r1, _, _ = run_config(c, nst, 5, depth, dev, want_roofline=False, steps_per_launch=1, preheat_s=0.1, single_lane=False)
                         r["one_step_per_launch"] = {"ms_per_step": r1["ms_per_step"], "value": r1["value"]}
                     del n2, x2
+                    if c["precision"] == "bf16":
+                        # what the bf16 storage path's numbers are held to (review r05): the project's own bf16 oracle states the
+                        # rounding points (tests: 1e-2 of max|logit|, a self-consistency bound -- the reference has no bf16); the
+                        # meaningful figure is the same draw against the fp32 path, measured here
+                        try:
+                            from bbb_hip import rng as _rng
+                            with torch.no_grad():
+                                sc = _rng.next_calls(0)
+                                a32 = ensemble.mc_forward(n2, x2, c["E"])[0].clone()
+                                _rng.rewind(sc)
+                                a16 = ensemble.mc_forward(n2, x2, c["E"], precision="bf16")[0]
+                                r["parity"] = {"max_abs_diff_of_log_probs_vs_fp32_path_same_noise": float((a16 - a32).abs().max()),
+                                               "max_abs_log_prob": float(a32.abs().max()),
+                                               "test_bound_vs_the_bf16_oracle": "1e-2 of max|logit| (tests/test_gpu_parity_fullsize.py::test_config1_*)"}
+                        except Exception as exc:
+                            r["parity"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:120])}
                     if r.get("roofline"):
                         tr = profile_traffic(("pconv_bf16", "pconv_gemm"), "_" + name.replace("[", "").replace("]", ""))
                         if tr:

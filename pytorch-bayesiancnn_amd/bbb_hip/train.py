@@ -156,7 +156,7 @@ def allreduce_gradients(params, group=None, bucket_bytes=64 << 20):
 
 
 def elbo(log_outputs, target, kl, beta, train_size):
-    """metrics.ELBO.forward (metrics.py:19-24): nll_loss(mean) * train_size + beta * kl."""
+    """metrics.ELBO.forward (metrics.py:7-14): nll_loss(mean) * train_size + beta * kl."""
     return F.nll_loss(log_outputs, target, reduction="mean") * train_size + beta * kl
 
 

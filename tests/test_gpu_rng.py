@@ -97,3 +97,44 @@ def test_graphed_step_keeps_the_host_offset_in_step(env):
     with torch.no_grad():
         want = fwd(env, E=4)                       # eager step under the same seed = first replay
     assert torch.equal(a, want)
+
+
+def test_device_noise_distribution_at_1e8_samples():
+    """The noise contract's output as a DISTRIBUTION (review r05: one moment test was all that guarded it): 1e8 device normals
+    (Philox4x32-7 -> 23-bit uniforms -> Box-Muller with the hardware log / sin / cos; ten (call, stream) pairs of 1e7 elements) --
+    mean, variance, skewness, excess kurtosis within 5 standard errors of N(0, 1)'s; tail counts beyond 2, 3 and 4 sigma within 5
+    binomial standard deviations; Kolmogorov-Smirnov distance of every 1e7-sample block against the normal CDF below the
+    alpha = 0.001 critical value 1.95 / sqrt(n); no value beyond the contract's bound sqrt(-2 ln 2^-23) = 5.65."""
+    import math
+    from bbb_hip import ops
+    n_blk, blocks = 10_000_000, 10
+    n = n_blk * blocks
+    s1 = s2 = s3 = s4 = 0.0
+    tails = {2.0: 0, 3.0: 0, 4.0: 0}
+    worst_ks, worst_abs = 0.0, 0.0
+    grid = (torch.arange(n_blk, device="cuda", dtype=torch.float64) + 0.5) / n_blk
+    for blk in range(blocks):
+        z = ops.eps_dump(n_blk, 987654321 + blk, 1000 * blk + 7, blk % 3, torch.device("cuda"))
+        zd = z.double()
+        s1 += float(zd.sum()); s2 += float((zd * zd).sum()); s3 += float((zd ** 3).sum()); s4 += float((zd ** 4).sum())
+        a = z.abs()
+        worst_abs = max(worst_abs, float(a.max()))
+        for t in tails:
+            tails[t] += int((a > t).sum())
+        zs, _ = torch.sort(zd)
+        cdf = 0.5 * (1.0 + torch.erf(zs / math.sqrt(2.0)))
+        worst_ks = max(worst_ks, float((cdf - grid).abs().max()) + 0.5 / n_blk)
+        del z, zd, a, zs, cdf
+    mean = s1 / n
+    var = s2 / n - mean * mean
+    skew = (s3 / n - 3 * mean * s2 / n + 2 * mean ** 3) / var ** 1.5
+    kurt = (s4 / n - 4 * mean * s3 / n + 6 * mean * mean * s2 / n - 3 * mean ** 4) / (var * var) - 3.0
+    print(f"[noise 1e8] mean {mean:.2e} var-1 {var - 1:.2e} skew {skew:.2e} excess kurtosis {kurt:.2e} KS {worst_ks:.2e} max|z| {worst_abs:.3f} "
+          f"tails {tails}")
+    assert abs(mean) <= 5 / math.sqrt(n) and abs(var - 1) <= 5 * math.sqrt(2 / n)
+    assert abs(skew) <= 5 * math.sqrt(6 / n) and abs(kurt) <= 5 * math.sqrt(24 / n)
+    for t, cnt in tails.items():
+        pr = math.erfc(t / math.sqrt(2.0))
+        assert abs(cnt - n * pr) <= 5 * math.sqrt(n * pr * (1 - pr)), (t, cnt, n * pr)
+    assert worst_ks <= 1.95 / math.sqrt(n_blk)
+    assert worst_abs <= 5.66
