@@ -1453,7 +1453,6 @@ def main():
                         r["steps_per_launch"] = spl
                         r1, _, _ = run_config(c, nst, 5, depth, dev, want_roofline=False, steps_per_launch=1, preheat_s=0.1, single_lane=False)
                         r["one_step_per_launch"] = {"ms_per_step": r1["ms_per_step"], "value": r1["value"]}
-                    del n2, x2
                     if c["precision"] == "bf16":
                         # what the bf16 storage path's numbers are held to (review r05): the project's own bf16 oracle states the
                         # rounding points (tests: 1e-2 of max|logit|, a self-consistency bound -- the reference has no bf16); the
@@ -1470,6 +1469,7 @@ def main():
                                                "test_bound_vs_the_bf16_oracle": "1e-2 of max|logit| (tests/test_gpu_parity_fullsize.py::test_config1_*)"}
                         except Exception as exc:
                             r["parity"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:120])}
+                    del n2, x2
                     if r.get("roofline"):
                         tr = profile_traffic(("pconv_bf16", "pconv_gemm"), "_" + name.replace("[", "").replace("]", ""))
                         if tr:
