@@ -1062,8 +1062,9 @@ def training_step(dev, steps):
                         "what": "executed FLOPs of forward + wgrad + dgrad (in-bounds taps; 3 x forward - the first layer's dgrad) over the "
                                 "whole step's wall time"},
            "launch_by_launch_ms_per_step": round(1e3 * res["launch_by_launch"], 4), "path": path,
-           "note": "BayesianAlexNet bs=512 num_ens=10, fp32, train.train_step as called (it captures itself as one hipGraph after 3 "
-                   "identical calls; graph=False = launch_by_launch); round 1 (reference-layout autograd path): 8.3 ms"}
+           "note": "BayesianAlexNet bs=512 num_ens=10, fp32, train.train_step as called: steps of >= 2048 (image x draw) rows stay launch by "
+                   "launch (GPU-bound; weight gradients on a second stream beside the input gradients, round 6: 3.02 -> 2.83 ms), smaller "
+                   "ones capture themselves as one hipGraph after 3 identical calls; round 1 (reference-layout autograd path): 8.3 ms"}
     del net, x, y, opt
     # the reference's own defaults (config_bayesian.py:1-18: layer_type 'lrt', batch_size 256, train_ens 1): eager and as one hipGraph
     try:

@@ -179,6 +179,13 @@ class _MCForward(torch.autograd.Function):
         B = x_shape[0]
         gws = [None] * len(mus)
         g = g_logits.contiguous() if g_logits is not None else None
+        # a layer's weight / bias gradients and its input gradient are independent: the former run on a side stream beside the latter
+        # (both are launches that leave the chip partly idle on their own); joined before the parameter pass's backward.  Tensors
+        # the side stream reads stay referenced in `keep` until the join (the allocator must not hand them out again before).
+        # (eager launches only: inside a captured step the forks cost more than the overlap gains -- 4.8 against 3.05 ms per step)
+        side = _side_stream(g.device) if (g is not None and overlap_wgrad[0] and not torch.cuda.is_current_stream_capturing()) else None
+        main = torch.cuda.current_stream(g.device) if side is not None else None
+        keep = []
         for li in range(len(tape) - 1, -1, -1):
             rec = tape[li]
             y, w5, x_in, act = rec["y"], rec["w"], rec["x"], rec["act"]
@@ -193,23 +200,46 @@ class _MCForward(torch.autograd.Function):
                 g_pre = ops.pool_act_backward_chwn(g, y, 0, 1, act, pad_planes=pad)
             else:
                 g_pre = g
-            gws[2 * li + 1] = ops.plane_sums(g_pre)                       # bias gradient [E, Cout]
-            Cin = x_in.shape[1]
-            if Cin % 4 == 0 or not rec["first"]:                         # (6-channel inputs etc.: padded to 8 inside)
-                gw = ops.conv2d_chwn_weight_grad(g_pre, x_in, tuple(w5.shape), stride, padding, dilation)
+            def weight_side(g_pre=g_pre, x_in=x_in, w5=w5, rec=rec, li=li, stride=stride, padding=padding, dilation=dilation):
+                gws[2 * li + 1] = ops.plane_sums(g_pre)                   # bias gradient [E, Cout]
+                Cin = x_in.shape[1]
+                if Cin % 4 == 0 or not rec["first"]:                     # (6-channel inputs etc.: padded to 8 inside)
+                    gw = ops.conv2d_chwn_weight_grad(g_pre, x_in, tuple(w5.shape), stride, padding, dilation)
+                else:
+                    # 3-channel first layer: its input is shared by all draws, so the draws stack into the GEMM's row dimension
+                    gw = ops.conv2d_chwn_weight_grad_shared_input(g_pre, ctx.x_nchw, tuple(w5.shape), stride, padding, dilation)
+                gws[2 * li] = gw.reshape(ws_shape(rec))
+
+            if side is not None and not rec["first"]:
+                keep.append(g_pre)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    weight_side()
             else:
-                # 3-channel first layer: its input is shared by all draws, so the draws stack into the GEMM's row dimension
-                gw = ops.conv2d_chwn_weight_grad_shared_input(g_pre, ctx.x_nchw, tuple(w5.shape), stride, padding, dilation)
-            gws[2 * li] = gw.reshape(ws_shape(rec))
+                weight_side()
             if not rec["first"]:
                 g = ops.conv2d_chwn_input_grad(g_pre, w5, (x_in.shape[2], x_in.shape[3]), padding, dilation)
             else:
                 g = None
+        if side is not None:
+            main.wait_stream(side)
+        del keep
         gmu, grho = ops.reparam_kl_backward(mus, rhos, gws, g_kl, pm, ps, ids, seed, call0, E)
         out = [None, None]
         for a, b in zip(gmu, grho):
             out += [a, b]
         return tuple(out)
+
+
+overlap_wgrad = [True]
+_side_streams = {}
+
+
+def _side_stream(device):
+    key = torch.device(device).index
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+    return _side_streams[key]
 
 
 def _check_versions(versions):
