@@ -334,6 +334,10 @@ class _MCForwardLRT(torch.autograd.Function):
         ctx.cfg["spent"] = True
         grads = [None] * (4 * len(tape))
         g = g_logits.contiguous()
+        # (as in _MCForward: the weight-side work of a layer on a second stream beside its input gradients, eager launches only)
+        side = _side_stream(g.device) if (overlap_wgrad[0] and not torch.cuda.is_current_stream_capturing()) else None
+        main = torch.cuda.current_stream(g.device) if side is not None else None
+        keep = []
         for li in range(len(tape) - 1, -1, -1):
             rec = tape[li]
             y, am, av, x_in, act = rec["y"], rec["am"], rec["av"], rec["x"], rec["act"]
@@ -346,24 +350,36 @@ class _MCForwardLRT(torch.autograd.Function):
             g_mu, g_var = ops.lrt_pool_act_backward_chwn(g, y, am, av, k, s, act, pad_planes=pad)
             if am.shape[0] == 1 and g_mu.shape[0] > 1:      # first layer: one pair of moments feeds every draw
                 g_mu, g_var = ops.sum_over_draws(g_mu, keepdim=True), ops.sum_over_draws(g_var, keepdim=True)
-            grads[4 * li + 2] = ops.plane_sums(g_mu, over_draws=True)
-            grads[4 * li + 3] = ops.plane_sums(g_var, over_draws=True)
-            wshape = (1,) + tuple(w_mu.shape)
-            if x_in.shape[1] % 4 == 0 or not rec["first"]:
-                gw_mu = ops.conv2d_chwn_weight_grad(g_mu, x_in, wshape, stride, padding, dilation)
-                gw_var = ops.conv2d_chwn_weight_grad(g_var, ops.square(x_in), wshape, stride, padding, dilation)
-                gw_mu, gw_var = ops.sum_over_draws(gw_mu), ops.sum_over_draws(gw_var)
+            def weight_side(g_mu=g_mu, g_var=g_var, x_in=x_in, w_mu=w_mu, rec=rec, li=li, stride=stride, padding=padding, dilation=dilation):
+                grads[4 * li + 2] = ops.plane_sums(g_mu, over_draws=True)
+                grads[4 * li + 3] = ops.plane_sums(g_var, over_draws=True)
+                wshape = (1,) + tuple(w_mu.shape)
+                if x_in.shape[1] % 4 == 0 or not rec["first"]:
+                    gw_mu = ops.conv2d_chwn_weight_grad(g_mu, x_in, wshape, stride, padding, dilation)
+                    gw_var = ops.conv2d_chwn_weight_grad(g_var, ops.square(x_in), wshape, stride, padding, dilation)
+                    gw_mu, gw_var = ops.sum_over_draws(gw_mu), ops.sum_over_draws(gw_var)
+                else:
+                    xn = ctx.x_nchw
+                    gw_mu = ops.conv2d_chwn_weight_grad_shared_input(g_mu, xn, wshape, stride, padding, dilation)[0]
+                    gw_var = ops.conv2d_chwn_weight_grad_shared_input(g_var, ops.square(xn), wshape, stride, padding, dilation)[0]
+                m = rec["layer"]
+                grads[4 * li] = gw_mu.reshape(m.W_mu.shape)
+                grads[4 * li + 1] = gw_var.reshape(m.W_mu.shape)
+
+            if side is not None and not rec["first"]:
+                keep += [g_mu, g_var]
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    weight_side()
             else:
-                xn = ctx.x_nchw
-                gw_mu = ops.conv2d_chwn_weight_grad_shared_input(g_mu, xn, wshape, stride, padding, dilation)[0]
-                gw_var = ops.conv2d_chwn_weight_grad_shared_input(g_var, ops.square(xn), wshape, stride, padding, dilation)[0]
-            m = rec["layer"]
-            grads[4 * li] = gw_mu.reshape(m.W_mu.shape)
-            grads[4 * li + 1] = gw_var.reshape(m.W_mu.shape)
+                weight_side()
             if not rec["first"]:
                 hw = (x_in.shape[2], x_in.shape[3])
                 g = ops.lrt_input_grad_combine(ops.conv2d_chwn_input_grad(g_mu, w_mu.unsqueeze(0), hw, padding, dilation), x_in,
                                                ops.conv2d_chwn_input_grad(g_var, w_var.unsqueeze(0), hw, padding, dilation))
+        if side is not None:
+            main.wait_stream(side)
+        del keep
         return (None, None, *grads)
 
 
