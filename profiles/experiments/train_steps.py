@@ -19,3 +19,12 @@ for _ in range(10):
     train.train_step(net, opt, x, y, E, 0.1, 50000.0, graph=False)
 torch.cuda.synchronize()
 print(lt, B, E, "ms per step %.3f" % ((time.perf_counter() - t0) * 100))
+if os.environ.get("TRAIN_STEPS_LONG", "1") == "1":      # a longer, warmer measurement (the first ten steps above are what the trace script cuts)
+    for _ in range(30):
+        train.train_step(net, opt, x, y, E, 0.1, 50000.0, graph=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(40):
+        train.train_step(net, opt, x, y, E, 0.1, 50000.0, graph=False)
+    torch.cuda.synchronize()
+    print(lt, B, E, "warm ms per step %.3f" % ((time.perf_counter() - t0) * 25))

@@ -1828,21 +1828,27 @@ def lrt_pool_act_backward_chwn(g_out, y, act_mu, act_var, k, s, act, pad_planes=
     return outs[0], outs[1]
 
 
-def conv2d_chwn_input_grad(g_pre, w, x_hw, padding, dilation):
+def flip_transpose_w(w):
+    """[E, Cout, Cin, kh, kw] -> [E, Cin, Cout, kh, kw] with the taps spatially flipped: the weight operand of the input gradient."""
+    w = w.contiguous()
+    E, Cout, Cin, kh, kw = w.shape
+    w_t = torch.empty((E, Cin, Cout, kh, kw), dtype=torch.float32, device=w.device)
+    with on_device(w.device):
+        check(_lib.lib().bbb_flip_transpose_w(w.data_ptr(), w_t.data_ptr(), E, Cout, Cin, kh * kw, cur_stream(w.device)),
+              "bbb_flip_transpose_w")
+    return w_t
+
+
+def conv2d_chwn_input_grad(g_pre, w, x_hw, padding, dilation, w_flipped=None):
     """d loss / d x of a STRIDE-1 y = conv(x, w) in the batch-innermost layout, on the forward kernel itself: the convolution
     of g_pre [E, Cout, Ho, Wo, B] with the spatially flipped, channel-transposed weights, padding d*(k-1) - p.
-    w [E, Cout, Cin, kh, kw] -> [E, Cin, H, W, B]."""
+    w [E, Cout, Cin, kh, kw] -> [E, Cin, H, W, B].  w_flipped: flip_transpose_w(w) computed ahead (off the gradient chain)."""
     (ph, pw), (dh, dw) = _pair(padding), _pair(dilation)
     kh, kw = w.shape[3], w.shape[4]
     qh, qw = dh * (kh - 1) - ph, dw * (kw - 1) - pw
     if qh < 0 or qw < 0:
         raise _lib.BBBHipError("conv2d_chwn_input_grad: padding larger than the kernel reach")
-    w = w.contiguous()
-    E, Cout, Cin = w.shape[0], w.shape[1], w.shape[2]
-    w_t = torch.empty((E, Cin, Cout, kh, kw), dtype=torch.float32, device=w.device)   # flipped taps, channels transposed
-    with on_device(w.device):
-        check(_lib.lib().bbb_flip_transpose_w(w.data_ptr(), w_t.data_ptr(), E, Cout, Cin, kh * kw, cur_stream(w.device)),
-              "bbb_flip_transpose_w")
+    w_t = w_flipped if w_flipped is not None else flip_transpose_w(w)
     gx = conv2d_chwn_forward(g_pre, w_t, None, 1, (qh, qw), (dh, dw))
     if gx.shape[2] != x_hw[0] or gx.shape[3] != x_hw[1]:
         raise _lib.BBBHipError("conv2d_chwn_input_grad: geometry mismatch (stride-1 layers only)")
