@@ -9,8 +9,8 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 { for ARGS in "bbb 512 10" "lrt 256 1"; do
     rm -rf /tmp/kt && mkdir -p /tmp/kt
-    rocprofv3 --kernel-trace -d /tmp/kt -o kt -- python $R/profiles/experiments/train_steps.py $ARGS > /tmp/kt/log.txt 2>&1
-    echo "# rocprofv3 --kernel-trace -- python profiles/experiments/train_steps.py $ARGS   ($TAG; 5 warm-up + 10 steps, eager; totals over the last 10 steps)"
+    TRAIN_STEPS_LONG=0 rocprofv3 --kernel-trace -d /tmp/kt -o kt -- python $R/profiles/experiments/train_steps.py $ARGS > /tmp/kt/log.txt 2>&1
+    echo "# rocprofv3 --kernel-trace -- python profiles/experiments/train_steps.py $ARGS   ($TAG; 5 warm-up + 10 steps, eager; totals over the 15 steps -- the weight-side launches run on two side streams beside the gradient chain, so durations add up to more than the wall time)"
     tail -2 /tmp/kt/log.txt
     python $R/profiles/summarize_rocpd.py $(find /tmp/kt -name '*.db' | head -1) --last-steps 10 --by-grid 2>&1 | head -70
     echo
