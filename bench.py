@@ -1426,7 +1426,7 @@ def main():
                 except Exception as exc:
                     second["fusion_ab_fp32"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:160])}
             try:
-                second["training_step"] = training_step(dev, max(5, args.steps // 5))
+                second["training_step"] = training_step(dev, max(12, args.steps // 5))
                 ts = second["training_step"]
                 if out["roofline"] is not None and "roofline" in ts:
                     out["roofline"]["training_step_ms"] = ts["ms_per_step"]
