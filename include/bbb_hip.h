@@ -446,6 +446,10 @@ int bbb_mc_tail(const float* logits, int draws, int batch, int classes, int mean
 /* bbb_mc_tail for logits stored batch-innermost, [draws][C][B] (output of the batched ensemble path); lse_out is [B][C]. */
 int bbb_mc_tail_cb(const float* logits, int draws, int batch, int classes, int mean_over,
                    float* lse_out, void* stream);
+/* Backward of bbb_mc_tail_cb (training extension, ABI 12; loss.backward() of main_bayesian.py:57 through log_softmax + logmeanexp):
+ * g_logits [draws][classes][batch] from g_lse [batch][classes] and the forward's lse [batch][classes]. */
+int bbb_mc_tail_cb_bwd(const float* logits, const float* lse, const float* g_lse, float* g_logits, int draws, int batch, int classes,
+                       int mean_over, void* stream);
 
 /* The same for a rank's WORK UNITS (bbb_conv_desc_t: unit u = unit_off + e is draw u / slices, batch slice u % slices):
  * logits [units][C][batch_slice] -> lse_out [slices * batch_slice][C]; image b of slice s gets the log-sum-exp over the local

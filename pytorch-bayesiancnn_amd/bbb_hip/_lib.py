@@ -80,6 +80,7 @@ _SIGNATURES = {
     "bbb_nchw_to_chwn_bf16_slices": (c_int, [c_void_p, c_void_p, c_int, c_i64, c_int, c_void_p]),
     "bbb_mc_tail": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "bbb_mc_tail_cb": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "bbb_mc_tail_cb_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "bbb_mc_tail_units": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "bbb_mc_tail_units_step": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                        c_u32, c_void_p]),

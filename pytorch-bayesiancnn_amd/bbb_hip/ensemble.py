@@ -997,8 +997,11 @@ def _local_lse(net, x, draws, seed, call0, mean_over, fuse_act=True, timers=None
             # training on the batch-innermost kernels: one autograd node for the whole batched forward
             logits_cb, kl1 = fast_train.mc_logits_autograd(net, x, draws, seed, call0, alias=param_alias)
             stats["path"] = "chwn-autograd"
-            lse = torch.logsumexp(F.log_softmax(logits_cb.permute(0, 2, 1), dim=2), dim=0) \
-                - (math.log(mean_over) if mean_over > 0 else 0.0)
+            if logits_cb.shape[0] <= 512 and hip_loss_tail[0]:
+                lse = ops.mc_tail_cb_autograd(logits_cb, mean_over)       # log_softmax + logmeanexp, forward and backward one launch each
+            else:
+                lse = torch.logsumexp(F.log_softmax(logits_cb.permute(0, 2, 1), dim=2), dim=0) \
+                    - (math.log(mean_over) if mean_over > 0 else 0.0)
             return lse, kl1
     logits, kl1 = mc_logits(net, x, draws, seed, call0, fuse_act=fuse_act, timers=timers, layout="nchw")
     if torch.is_grad_enabled() and logits.requires_grad:
@@ -1007,6 +1010,9 @@ def _local_lse(net, x, draws, seed, call0, mean_over, fuse_act=True, timers=None
     else:
         lse = _run(timers, "mc_tail", 0, lambda: ops.mc_tail(logits, mean_over=mean_over))
     return lse, kl1
+
+
+hip_loss_tail = [True]      # training: the loss tail's log_softmax + logmeanexp on the HIP kernels (False: torch ops, as until round 5)
 
 
 def group_share(num_ens, steps, rank, world):

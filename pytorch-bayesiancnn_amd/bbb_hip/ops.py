@@ -1239,6 +1239,38 @@ def mc_tail_cb(logits, mean_over=0, step_end=None):
     return mc_tail_units(logits, 1, 0, mean_over, step_end)
 
 
+class _McTailCB(torch.autograd.Function):
+    """lse = mc_tail_cb(logits [E, C, B]) with its backward in ONE launch (bbb_mc_tail_cb_bwd): the training step's loss tail
+    (log_softmax + logmeanexp, main_bayesian.py:49-53) was ~15 ATen launches forward and backward."""
+
+    @staticmethod
+    def forward(ctx, logits, mean_over):
+        logits = logits.contiguous()
+        lse = mc_tail_cb(logits, mean_over=mean_over)
+        ctx.save_for_backward(logits, lse)
+        ctx.mean_over = int(mean_over)
+        return lse
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, lse = ctx.saved_tensors
+        g = g.contiguous()
+        E, C, B = logits.shape
+        out = torch.empty_like(logits)
+        with on_device(logits.device):
+            check(_lib.lib().bbb_mc_tail_cb_bwd(logits.data_ptr(), lse.data_ptr(), g.data_ptr(), out.data_ptr(), E, B, C, ctx.mean_over,
+                                                cur_stream(logits.device)), "bbb_mc_tail_cb_bwd")
+        return out, None
+
+
+def mc_tail_cb_autograd(logits, mean_over=0):
+    """Differentiable mc_tail_cb: logits [E, C, B] (requires grad) -> lse [B, C]."""
+    require_device(logits)
+    if logits.shape[0] > 512:
+        raise _lib.BBBHipError("too many draws for one tail launch")
+    return _McTailCB.apply(logits, int(mean_over))
+
+
 def mc_tail_units(logits, slices, unit_off, mean_over=0, step_end=None):
     """mc_tail_cb for a rank's work units: logits [U, C, Bs] (unit u = unit_off + e is draw u // slices, batch slice
     u % slices) -> [slices * Bs, C]; -inf rows for slices the rank holds no unit of.

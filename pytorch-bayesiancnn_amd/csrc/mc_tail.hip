@@ -365,6 +365,52 @@ extern "C" int bbb_mc_tail_units(const float* logits, int units, int slices, int
                                   nullptr, 0u, stream);
 }
 
+namespace {
+// Backward of the tail (training extension; main_bayesian.py:49-53 under autograd): lse[b][c] = logsumexp_e ls[e][b][c] - log(mean_over),
+// ls[e][b][:] = log_softmax(logits[e][:][b]).  With g = d loss / d lse:
+//   H[e][b][c] = g[b][c] * exp(ls[e][b][c] - (lse[b][c] + log(mean_over)))          (softmax over the draws)
+//   d loss / d logits[e][k][b] = H[e][b][k] - exp(ls[e][b][k]) * sum_c H[e][b][c]
+// One thread per (draw, image); three passes over the classes (logits are [E][C][B]: consecutive lanes = consecutive images).
+__global__ __launch_bounds__(256) void mc_tail_cb_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ lse,
+                                                             const float* __restrict__ g, float* __restrict__ g_logits, int E, int C, int B,
+                                                             float add) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)E * B) return;
+    const int e = (int)(i / B), b = (int)(i - (int64_t)e * B);
+    const float* p = logits + (int64_t)e * C * B + b;
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, p[(int64_t)c * B]);
+    float se = 0.0f;
+    for (int c = 0; c < C; ++c) se += expf(p[(int64_t)c * B] - mx);
+    const float lz = mx + logf(se);
+    float sum_h = 0.0f;
+    for (int c = 0; c < C; ++c) {
+        const float ls = p[(int64_t)c * B] - lz;
+        sum_h += g[(int64_t)b * C + c] * expf(ls - (lse[(int64_t)b * C + c] + add));
+    }
+    float* o = g_logits + (int64_t)e * C * B + b;
+    for (int c = 0; c < C; ++c) {
+        const float ls = p[(int64_t)c * B] - lz;
+        const float h = g[(int64_t)b * C + c] * expf(ls - (lse[(int64_t)b * C + c] + add));
+        o[(int64_t)c * B] = h - expf(ls) * sum_h;
+    }
+}
+}  // namespace
+
+extern "C" int bbb_mc_tail_cb_bwd(const float* logits, const float* lse, const float* g_lse, float* g_logits, int draws, int batch,
+                                  int classes, int mean_over, void* stream) {
+    if (logits == nullptr || lse == nullptr || g_lse == nullptr || g_logits == nullptr || draws <= 0 || batch <= 0 || classes <= 0 ||
+        mean_over < 0)
+        return BBB_EINVAL;
+    if ((((uintptr_t)logits | (uintptr_t)lse | (uintptr_t)g_lse | (uintptr_t)g_logits) & 3u) != 0) return BBB_EALIGN;
+    const int64_t n = (int64_t)draws * batch;
+    const int64_t blocks = (n + 255) / 256;
+    if (blocks > 0x7fffffffLL) return BBB_ESHAPE;
+    hipLaunchKernelGGL(mc_tail_cb_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, logits, lse, g_lse, g_logits, draws,
+                       classes, batch, mean_over > 0 ? logf((float)mean_over) : 0.0f);
+    return (int)hipGetLastError();
+}
+
 extern "C" int bbb_mc_tail_cb(const float* logits, int draws, int batch, int classes, int mean_over, float* lse_out,
                               void* stream) {
     if (draws > 512) return BBB_EINVAL;
