@@ -593,10 +593,8 @@ def run_config(cfg, steps, warmup, pipeline, dev, group=None, world=1, want_roof
             step()
         flush()
         elapsed, (lo, kl) = timed_block(steps)
-        lo, kl = lo.clone(), kl.clone()
-        torch.cuda.synchronize(dev)
-        assert torch.isfinite(lo).all() and torch.isfinite(kl).all()
-        if multi:
+        lo, kl = lo.clone(), kl.clone()                  # (checked for finiteness AFTER the statistics blocks below: a host round trip here
+        if multi:                                        #  idles the part, and the block behind it measured 15 % low on every box)
             t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=group)
             elapsed = t.item()
@@ -618,7 +616,9 @@ def run_config(cfg, steps, warmup, pipeline, dev, group=None, world=1, want_roof
             out["ms_per_step"] = round(1e3 * cfg["B"] * E / med, 4)
             out["stats"] = {"blocks": len(vals), "steps_per_block": steps, "median": round(med, 1),
                             "p10": round(pctl(vals, 0.1), 1), "p90": round(pctl(vals, 0.9), 1), "unit": "samples/s",
-                            "value_is": "median of the blocks"}
+                            "value_is": "median of the blocks", "block_values": [round(v, 1) for v in vals]}
+        torch.cuda.synchronize(dev)
+        assert torch.isfinite(lo).all() and torch.isfinite(kl).all()
         del gstep, step, flush
         if not multi and single_lane and (pipeline > 1 or G > 1):
             g1 = ensemble.GraphedMC(net, x, E, precision=prec)
