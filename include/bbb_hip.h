@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define BBB_ABI_VERSION 12
+#define BBB_ABI_VERSION 13
 #define BBB_MAX_SEGMENTS 16
 
 #define BBB_EINVAL (-1)   /* bad argument (null pointer, non-positive size, too many segments) */
@@ -497,9 +497,20 @@ int bbb_transpose2d(const float* in, float* out, int64_t rows, int64_t cols, voi
 int bbb_transpose_batched(const float* in, float* out, int rows, int cols, int nb1, int nb2, int64_t in_b1, int64_t in_b2,
                           int64_t in_row, int64_t out_b1, int64_t out_b2, int64_t out_col, void* stream);
 
+/* The same with three batch dimensions nb[3] (product <= 65535; strides in_b[3] / out_b[3]) and a summed one:
+ * out[i1*out_b[0] + i2*out_b[1] + i3*out_b[2] + c*out_col + r] = sum_{s < nsum, ascending} in[i1*in_b[0] + i2*in_b[1] + i3*in_b[2]
+ * + s*in_sum + r*in_row + c].  Training extension: the batch chunks of a role-swapped weight gradient summed in a fixed order
+ * while the taps move innermost; an output gradient written straight into the chunked weight-operand layout. */
+int bbb_transpose_sum_batched(const float* in, float* out, int rows, int cols, const int32_t* nb, const int64_t* in_b,
+                              const int64_t* out_b, int64_t in_row, int64_t out_col, int nsum, int64_t in_sum, void* stream);
+
 /* Training extension: out [draws][cin][cout][kh*kw] = w [draws][cout][cin][kh*kw] with the taps reversed (spatial flip +
  * channel transpose: the weights of the stride-1 input-gradient convolution). */
 int bbb_flip_transpose_w(const float* w, float* out, int64_t draws, int cout, int cin, int khkw, void* stream);
+/* The same over two sources: out's draws [0, draws_each) from w0, [draws_each, 2*draws_each) from w1 (the mean and variance
+ * weights of a local-reparameterisation layer as one operand: both input gradients in one launch of the forward kernel). */
+int bbb_flip_transpose_w_pair(const float* w0, const float* w1, float* out, int64_t draws_each, int cout, int cin, int khkw,
+                              void* stream);
 
 /* Training extension: im2col of an NCHW batch x [batch][cin][h][w] (geometry from d; draws / strides / act ignored) into
  * out [ho*wo][batch][Jp], Jp = cin*kh*kw rounded up to 4 (pad columns zero): the K-major operand of the first layer's

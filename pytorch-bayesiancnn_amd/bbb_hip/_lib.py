@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede CDLL: shares torch's HIP runtime)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BBB_HIP_LIB") or os.path.join(_HERE, "libbbb_hip.so")   # env override: experiments only
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 MAX_SEGMENTS = 16
 SIGMA_SQUARED = 1
 KL_TEXTBOOK = 2
@@ -91,8 +91,11 @@ _SIGNATURES = {
     "bbb_uncertainty": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "bbb_transpose2d": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_void_p]),
     "bbb_flip_transpose_w": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_void_p]),
+    "bbb_flip_transpose_w_pair": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_void_p]),
     "bbb_im2col_pbj": (c_int, [c_void_p, c_void_p, ctypes.POINTER(ConvDesc), c_void_p]),
     "bbb_transpose_batched": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_void_p]),
+    "bbb_transpose_sum_batched": (c_int, [c_void_p, c_void_p, c_int, c_int, ctypes.POINTER(c_i32), ctypes.POINTER(c_i64),
+                                          ctypes.POINTER(c_i64), c_i64, c_i64, c_int, c_i64, c_void_p]),
     "bbb_conv2d_chwn_splitk_scratch": (c_i64, [ctypes.POINTER(ConvDesc), c_int, ctypes.POINTER(c_i32)]),
     "bbb_conv2d_chwn_splitk_fwd": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_i64,
                                            c_void_p]),

@@ -232,6 +232,7 @@ class _MCForward(torch.autograd.Function):
         return tuple(out)
 
 
+pair_lrt_backward = [True]      # an LRT layer's (mean, variance) gradient pairs as the two draws of one launch (see _MCForwardLRT._backward)
 overlap_wgrad = [True]
 _side_streams = {}
 
@@ -367,14 +368,31 @@ class _MCForwardLRT(torch.autograd.Function):
             # one pass: pooling / activation backward AND the split into d/d act_mu, d/d act_var (was ~10 ATen kernels per layer)
             k, s = rec["pool"] if rec["pool"] is not None else (0, 1)
             pad = rec["first"] and x_in.shape[1] % 4 != 0                # feeds conv2d_chwn_weight_grad_shared_input
-            g_mu, g_var = ops.lrt_pool_act_backward_chwn(g, y, am, av, k, s, act, pad_planes=pad)
+            # below the first layer the pair (d/d act_mu, d/d act_var) stays ONE buffer: its two weight gradients (with x, x^2) and,
+            # for a single draw, its two input gradients (with W_mu, W_var) run as the draws of one launch each
+            g_pair = None
+            if pair_lrt_backward[0] and not rec["first"]:
+                g_pair = ops.lrt_pool_act_backward_chwn(g, y, am, av, k, s, act, stacked=True)        # [2, E, Cout, Ho, Wo, B]
+                g_mu, g_var = g_pair[0], g_pair[1]
+            else:
+                g_mu, g_var = ops.lrt_pool_act_backward_chwn(g, y, am, av, k, s, act, pad_planes=pad)
             if am.shape[0] == 1 and g_mu.shape[0] > 1:      # first layer: one pair of moments feeds every draw
                 g_mu, g_var = ops.sum_over_draws(g_mu, keepdim=True), ops.sum_over_draws(g_var, keepdim=True)
-            def weight_side(g_mu=g_mu, g_var=g_var, x_in=x_in, w_mu=w_mu, rec=rec, li=li, stride=stride, padding=padding, dilation=dilation):
-                grads[4 * li + 2] = ops.plane_sums(g_mu, over_draws=True)
-                grads[4 * li + 3] = ops.plane_sums(g_var, over_draws=True)
+            def weight_side(g_mu=g_mu, g_var=g_var, x_in=x_in, w_mu=w_mu, rec=rec, li=li, stride=stride, padding=padding, dilation=dilation,
+                            g_pair=g_pair):
                 wshape = (1,) + tuple(w_mu.shape)
-                if x_in.shape[1] % 4 == 0 or not rec["first"]:
+                Ed = g_mu.shape[0]
+                if g_pair is not None and Ed == 1:
+                    gb = ops.plane_sums(g_pair.reshape((2,) + tuple(g_mu.shape[1:])))               # [2, Cout]
+                    grads[4 * li + 2], grads[4 * li + 3] = gb[0], gb[1]
+                else:
+                    grads[4 * li + 2] = ops.plane_sums(g_mu, over_draws=True)
+                    grads[4 * li + 3] = ops.plane_sums(g_var, over_draws=True)
+                if g_pair is not None and x_in.shape[0] == Ed:
+                    gw = ops.conv2d_chwn_weight_grad(g_pair.reshape((2 * Ed,) + tuple(g_mu.shape[1:])), x_in,
+                                                     (2 * Ed,) + tuple(w_mu.shape), stride, padding, dilation, x_squares=True)
+                    gw_mu, gw_var = ops.sum_over_draws(gw[:Ed]), ops.sum_over_draws(gw[Ed:])
+                elif x_in.shape[1] % 4 == 0 or not rec["first"]:
                     gw_mu = ops.conv2d_chwn_weight_grad(g_mu, x_in, wshape, stride, padding, dilation)
                     gw_var = ops.conv2d_chwn_weight_grad(g_var, ops.square(x_in), wshape, stride, padding, dilation)
                     gw_mu, gw_var = ops.sum_over_draws(gw_mu), ops.sum_over_draws(gw_var)
@@ -395,8 +413,14 @@ class _MCForwardLRT(torch.autograd.Function):
                 weight_side()
             if not rec["first"]:
                 hw = (x_in.shape[2], x_in.shape[3])
-                g = ops.lrt_input_grad_combine(ops.conv2d_chwn_input_grad(g_mu, w_mu.unsqueeze(0), hw, padding, dilation), x_in,
-                                               ops.conv2d_chwn_input_grad(g_var, w_var.unsqueeze(0), hw, padding, dilation))
+                if g_pair is not None and g_mu.shape[0] == 1:
+                    w_t = ops.flip_transpose_w_pair(w_mu.unsqueeze(0), w_var.unsqueeze(0))
+                    gx = ops.conv2d_chwn_input_grad(g_pair.reshape((2,) + tuple(g_mu.shape[1:])), w_mu.unsqueeze(0), hw, padding, dilation,
+                                                    w_flipped=w_t)
+                    g = ops.lrt_input_grad_combine(gx[0:1], x_in, gx[1:2])
+                else:
+                    g = ops.lrt_input_grad_combine(ops.conv2d_chwn_input_grad(g_mu, w_mu.unsqueeze(0), hw, padding, dilation), x_in,
+                                                   ops.conv2d_chwn_input_grad(g_var, w_var.unsqueeze(0), hw, padding, dilation))
         if side is not None:
             for st_ in side.streams:
                 main.wait_stream(st_)

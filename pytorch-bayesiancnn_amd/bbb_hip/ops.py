@@ -1811,11 +1811,15 @@ def sum_over_draws(x, keepdim=False):
     return out
 
 
-def square(x):
-    """x * x (bbb_lrt_glue mode 0): the operand of the LRT variance contraction's weight gradient."""
+def square(x, out=None):
+    """x * x (bbb_lrt_glue mode 0): the operand of the LRT variance contraction's weight gradient.  out: a contiguous tensor of
+    x's element count to write into."""
     require_device(x)
     x = x.contiguous()
-    out = torch.empty_like(x)
+    if out is None:
+        out = torch.empty_like(x)
+    elif not out.is_contiguous() or out.numel() != x.numel() or out.dtype != torch.float32:
+        raise _lib.BBBHipError("square: out must be a contiguous fp32 tensor of x's size")
     with on_device(x.device):
         check(_lib.lib().bbb_lrt_glue(0, x.data_ptr(), 0, out.data_ptr(), x.numel(), 0, 0, cur_stream(x.device)), "bbb_lrt_glue")
     return out
@@ -1832,10 +1836,11 @@ def lrt_input_grad_combine(g1, x, g2):
     return out
 
 
-def lrt_pool_act_backward_chwn(g_out, y, act_mu, act_var, k, s, act, pad_planes=False):
+def lrt_pool_act_backward_chwn(g_out, y, act_mu, act_var, k, s, act, pad_planes=False, stacked=False):
     """pool_act_backward_chwn for a local-reparameterisation layer: -> (g_mu, g_var), the gradients w.r.t. act_mu and act_var
     (bbb_lrt_pool_act_bwd_chwn).  act_mu / act_var: y's shape, or one draw's worth ([1, C, H, W, B]) when every draw was sampled
-    from the same pair of moments."""
+    from the same pair of moments.  stacked (without pad_planes): the two land in ONE buffer [2, *y.shape], returned as such --
+    the weight-side and input-side contractions of the pair then run as the draws of one launch."""
     require_device(g_out, y, act_mu, act_var)
     g_out, y, act_mu, act_var = g_out.contiguous(), y.contiguous(), act_mu.contiguous(), act_var.contiguous()
     *lead, H, W, B = y.shape
@@ -1850,6 +1855,9 @@ def lrt_pool_act_backward_chwn(g_out, y, act_mu, act_var, k, s, act, pad_planes=
     if pitch != K:
         bufs = [torch.empty((planes, pitch), dtype=torch.float32, device=y.device) for _ in range(2)]
         outs = [b[:, :K].view(*lead, H, W, B) for b in bufs]
+    elif stacked:
+        both = torch.empty((2,) + tuple(y.shape), dtype=torch.float32, device=y.device)
+        bufs = outs = [both[0], both[1]]
     else:
         bufs = outs = [torch.empty_like(y), torch.empty_like(y)]
     with on_device(y.device):
@@ -1857,6 +1865,8 @@ def lrt_pool_act_backward_chwn(g_out, y, act_mu, act_var, k, s, act, pad_planes=
                                                    bufs[0].data_ptr(), bufs[1].data_ptr(), planes, mom_planes, H, W, B, int(k), int(s),
                                                    ACT_CODE[act], pitch if pitch != K else 0, cur_stream(y.device)),
               "bbb_lrt_pool_act_bwd_chwn")
+    if stacked and pitch == K:
+        return both
     return outs[0], outs[1]
 
 
@@ -1868,6 +1878,21 @@ def flip_transpose_w(w):
     with on_device(w.device):
         check(_lib.lib().bbb_flip_transpose_w(w.data_ptr(), w_t.data_ptr(), E, Cout, Cin, kh * kw, cur_stream(w.device)),
               "bbb_flip_transpose_w")
+    return w_t
+
+
+def flip_transpose_w_pair(w0, w1):
+    """flip_transpose_w of two weight sets of one shape as ONE operand: [E, Cout, Cin, kh, kw] x 2 -> [2E, Cin, Cout, kh, kw], w0's
+    draws first (bbb_flip_transpose_w_pair: an LRT layer's mean and variance weights for both input gradients in one launch)."""
+    require_device(w0, w1)
+    w0, w1 = w0.contiguous(), w1.contiguous()
+    if w0.shape != w1.shape or w0.dim() != 5:
+        raise _lib.BBBHipError("flip_transpose_w_pair: two [E, Cout, Cin, kh, kw] tensors of one shape")
+    E, Cout, Cin, kh, kw = w0.shape
+    w_t = torch.empty((2 * E, Cin, Cout, kh, kw), dtype=torch.float32, device=w0.device)
+    with on_device(w0.device):
+        check(_lib.lib().bbb_flip_transpose_w_pair(w0.data_ptr(), w1.data_ptr(), w_t.data_ptr(), E, Cout, Cin, kh * kw,
+                                                   cur_stream(w0.device)), "bbb_flip_transpose_w_pair")
     return w_t
 
 
@@ -1897,29 +1922,55 @@ def _transpose_batched(src, out, rows, cols, nb1, nb2, ib1, ib2, ir, ob1, ob2, o
     return True
 
 
-def chwn_to_bhwc(x):
-    """[E, C, H, W, B] -> [E, B, H, W, C] (the batch becomes the contraction channels, C the innermost axis)."""
+def _transpose_sum_batched(src, out, rows, cols, nb, ib, ob, ir, oc, nsum=1, in_sum=0):
+    """bbb_transpose_sum_batched: three batch dimensions `nb` with strides `ib` / `ob`, `nsum` slices `in_sum` apart summed in
+    ascending order.  False (nothing launched) when the batch does not fit one grid."""
+    if nb[0] * nb[1] * nb[2] > 65535 or (rows + 31) // 32 > 65535:
+        return False
+    with on_device(src.device):
+        check(_lib.lib().bbb_transpose_sum_batched(src.data_ptr(), out.data_ptr(), rows, cols, (ctypes.c_int32 * 3)(*nb),
+                                                   (ctypes.c_int64 * 3)(*ib), (ctypes.c_int64 * 3)(*ob), ir, oc, nsum, in_sum,
+                                                   cur_stream(src.device)), "bbb_transpose_sum_batched")
+    return True
+
+
+def chwn_to_bhwc(x, out=None):
+    """[E, C, H, W, B] -> [E, B, H, W, C] (the batch becomes the contraction channels, C the innermost axis).  out: a contiguous
+    [E, B, H, W, C] tensor to write into."""
     E, C, H, W, B = x.shape
     x = x.contiguous()
-    out = torch.empty((E, B, H, W, C), dtype=x.dtype, device=x.device)
+    if out is None:
+        out = torch.empty((E, B, H, W, C), dtype=x.dtype, device=x.device)
+    elif tuple(out.shape) != (E, B, H, W, C) or not out.is_contiguous():
+        raise _lib.BBBHipError("chwn_to_bhwc: out must be a contiguous [E, B, H, W, C] tensor")
     HW = H * W
     if not _transpose_batched(x, out, C, B, E, HW, C * HW * B, B, HW * B, B * HW * C, C, HW * C):
-        out = x.permute(0, 4, 2, 3, 1).contiguous()
+        out.copy_(x.permute(0, 4, 2, 3, 1))
     return out
 
 
-def chwn_grad_as_weights(g):
-    """[E, Cout, Ho, Wo, B] -> [E, Cout, B, Ho, Wo] (the output gradient in the layout of a weight operand)."""
+def chwn_grad_as_weights(g, chunks=1):
+    """[E, Cout, Ho, Wo, B] -> [E, Cout, B, Ho, Wo] (the output gradient in the layout of a weight operand); with `chunks` = S
+    the batch splits into S slices that become extra draws: [E*S, Cout, B/S, Ho, Wo], slice s of draw e at index e*S + s."""
     E, Co, Ho, Wo, B = g.shape
     g = g.contiguous()
-    out = torch.empty((E, Co, B, Ho, Wo), dtype=g.dtype, device=g.device)
     P_ = Ho * Wo
+    S = int(chunks)
+    if S > 1:
+        Bs = B // S
+        out = torch.empty((E * S, Co, Bs, Ho, Wo), dtype=g.dtype, device=g.device)
+        if _transpose_sum_batched(g, out, P_, Bs, (E, S, Co), (Co * P_ * B, Bs, P_ * B), (S * Co * Bs * P_, Co * Bs * P_, Bs * P_),
+                                  B, P_):
+            return out
+        return (chwn_grad_as_weights(g).reshape(E, Co, S, Bs, Ho, Wo).permute(0, 2, 1, 3, 4, 5)
+                .reshape(E * S, Co, Bs, Ho, Wo))
+    out = torch.empty((E, Co, B, Ho, Wo), dtype=g.dtype, device=g.device)
     if not _transpose_batched(g, out, P_, B, E * Co, 1, P_ * B, 0, B, B * P_, 0, P_):
         out = g.permute(0, 1, 4, 2, 3).contiguous()
     return out
 
 
-def conv2d_chwn_weight_grad(g_pre, x, w_shape, stride, padding, dilation):
+def conv2d_chwn_weight_grad(g_pre, x, w_shape, stride, padding, dilation, x_squares=False):
     """d loss / d w in the batch-innermost layout, again on the forward kernel with the roles swapped: the batch becomes the
     contraction channels, the layer's input channels the innermost ("image") axis, the output pixels the kernel taps:
         gw[e][n][tap][ci] = sum_{b, opix} g_pre'[e][n][b][opix] * x'[e][b][ipix(tap, opix)][ci]
@@ -1927,7 +1978,10 @@ def conv2d_chwn_weight_grad(g_pre, x, w_shape, stride, padding, dilation):
     are skipped as in the forward.  The innermost axis moves as 16-byte vectors: an input with Cin % 4 != 0 is padded with zero
     planes first.  x may be shared by all draws ([1, ...]).  A launch that would occupy fewer than 512 workgroups (one draw of a small model) splits the batch into
     S chunks that run as extra draws and are summed in a fixed order.  g_pre [E, Cout, Ho, Wo, B], x [E|1, Cin, H, W, B] ->
-    [E, Cout, Cin, kh, kw]."""
+    [E, Cout, Cin, kh, kw].
+    x_squares (the two weight gradients of a local-reparameterisation layer as one launch): g_pre holds 2E' draws -- the gradients
+    w.r.t. the E' mean activations, then the E' variance activations -- and x [E', ...] pairs with the first half, its squares with
+    the second; -> [2E', Cout, Cin, kh, kw]."""
     (sh, sw), (ph, pw), (dh, dw) = _pair(stride), _pair(padding), _pair(dilation)
     Ew, Cout, Cin, kh, kw = w_shape
     if Cin % 4 != 0:
@@ -1936,28 +1990,36 @@ def conv2d_chwn_weight_grad(g_pre, x, w_shape, stride, padding, dilation):
         Cp = (Cin + 3) & ~3
         xp = x.new_zeros((x.shape[0], Cp) + tuple(x.shape[2:]))
         xp[:, :Cin] = x
-        return conv2d_chwn_weight_grad(g_pre, xp, (Ew, Cout, Cp, kh, kw), stride, padding, dilation)[:, :, :Cin].contiguous()
+        return conv2d_chwn_weight_grad(g_pre, xp, (Ew, Cout, Cp, kh, kw), stride, padding, dilation,
+                                       x_squares=x_squares)[:, :, :Cin].contiguous()
     E, B = g_pre.shape[0], g_pre.shape[4]
-    xr = chwn_to_bhwc(x)                                                # [E|1, B, H, W, Cin]
-    gr = chwn_grad_as_weights(g_pre)                                    # [E, Cout, B, Ho, Wo]
+    if x_squares:
+        Ex = x.shape[0]
+        if E != 2 * Ex:
+            raise _lib.BBBHipError("conv2d_chwn_weight_grad(x_squares): g_pre must hold two draws per draw of x")
+        xr = torch.empty((2 * Ex, B, x.shape[2], x.shape[3], Cin), dtype=torch.float32, device=x.device)
+        chwn_to_bhwc(x, out=xr[:Ex])
+        square(xr[:Ex], out=xr[Ex:])                                    # (x^2 transposed = the transposed x, squared)
+    else:
+        xr = chwn_to_bhwc(x)                                            # [E|1, B, H, W, Cin]
     wgs = E * kh * kw * -(-Cout // 64) * -(-Cin // 64)
     S = 1
     while wgs * S < 512 and B % (2 * S) == 0 and B // (2 * S) >= 8:
         S *= 2
+    gr = chwn_grad_as_weights(g_pre, S)                                 # [E*S, Cout, B/S, Ho, Wo]
     if S > 1:
         if xr.shape[0] == 1 and E > 1:
             xr = xr.expand(E, *xr.shape[1:])
         xr = xr.reshape(xr.shape[0] * S, B // S, *xr.shape[2:])
-        gr = gr.reshape(E, Cout, S, B // S, *gr.shape[3:]).permute(0, 2, 1, 3, 4, 5).reshape(E * S, Cout, B // S, *gr.shape[3:])
     y = conv2d_chwn_forward(xr, gr, None, (dh, dw), (ph, pw), (sh, sw))  # [E*S, Cout, kh', kw', Cin], kh' >= kh
-    if S > 1:
-        y = y.reshape(E, S, *y.shape[1:]).sum(1)
-    if y.shape[2] == kh and y.shape[3] == kw:                           # [E, Cout, kh*kw, Cin] -> [E, Cout, Cin, kh*kw]
-        y = y.contiguous()
+    if y.shape[2] == kh and y.shape[3] == kw:                           # sum_s [E, S, Cout, kh*kw, Cin] -> [E, Cout, Cin, kh*kw]
         gw = torch.empty((E, Cout, Cin, kh, kw), dtype=torch.float32, device=y.device)
         T = kh * kw
-        if _transpose_batched(y, gw, T, Cin, E * Cout, 1, T * Cin, 0, Cin, Cin * T, 0, T):
+        if _transpose_sum_batched(y, gw, T, Cin, (E, Cout, 1), (S * Cout * T * Cin, T * Cin, 0), (Cout * Cin * T, Cin * T, 0), Cin, T,
+                                  S, Cout * T * Cin):
             return gw
+    if S > 1:
+        y = y.reshape(E, S, *y.shape[1:]).sum(1)
     return y[:, :, :kh, :kw, :].permute(0, 1, 4, 2, 3).contiguous()
 
 

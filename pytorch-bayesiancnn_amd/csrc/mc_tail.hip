@@ -223,8 +223,9 @@ __global__ __launch_bounds__(256) void im2col_pbj_kernel(const float* __restrict
 
 // Weights of the input-gradient convolution (training extension): out[e][ci][n][r][q] = w[e][n][ci][kh-1-r][kw-1-q] -- the
 // spatial flip and the channel transpose of conv2d_chwn_input_grad in one pass (coalesced writes; reads hit L2).
-__global__ __launch_bounds__(256) void flip_transpose_w_kernel(const float* __restrict__ w, float* __restrict__ out, int64_t total,
-                                                               int Cout, int Cin, int khkw) {
+// (w1 != nullptr: draws e >= e1 read w1's draw e - e1 -- the mean and variance weights of an LRT layer as one two-draw operand)
+__global__ __launch_bounds__(256) void flip_transpose_w_kernel(const float* __restrict__ w, const float* __restrict__ w1, int64_t e1,
+                                                               float* __restrict__ out, int64_t total, int Cout, int Cin, int khkw) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int t = (int)(i % khkw);
@@ -232,8 +233,10 @@ __global__ __launch_bounds__(256) void flip_transpose_w_kernel(const float* __re
     const int n = (int)(r % Cout);
     r /= Cout;
     const int ci = (int)(r % Cin);
-    const int64_t e = r / Cin;
-    out[i] = w[((e * Cout + n) * Cin + ci) * khkw + (khkw - 1 - t)];
+    int64_t e = r / Cin;
+    const float* src = w;
+    if (w1 != nullptr && e >= e1) src = w1, e -= e1;
+    out[i] = src[((e * Cout + n) * Cin + ci) * khkw + (khkw - 1 - t)];
 }
 
 // Batched strided transpose (training extension: the operand permutations of the role-swapped weight-gradient launch):
@@ -258,6 +261,41 @@ __global__ __launch_bounds__(256) void transpose_batched_kernel(const float* __r
     for (int i = 0; i < 4; ++i) {
         const int c = c0 + ty + i * 8, r = r0 + tx;
         if (r < R && c < Cc) dst[(int64_t)c * oc + r] = tile[tx][ty + i * 8];
+    }
+}
+
+// The same tile transpose with three batch dimensions and a summed one:
+//   out[i1*ob1 + i2*ob2 + i3*ob3 + c*oc + r] = sum_{s < ns, ascending} in[i1*ib1 + i2*ib2 + i3*ib3 + s*is + r*ir + c]
+// (the S batch chunks of a role-swapped weight gradient summed in a fixed order while the taps move innermost; ns = 1 and a
+// split batch index as i2 writes an output gradient straight into the chunked weight-operand layout).
+struct TransposeExArgs {
+    int32_t R, C, nb2, nb3, ns;
+    int64_t ib1, ib2, ib3, is, ir, ob1, ob2, ob3, oc;
+};
+__global__ __launch_bounds__(256) void transpose_sum_batched_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                                    const TransposeExArgs a) {
+    __shared__ float tile[32][33];
+    const int i3 = blockIdx.z % a.nb3, i12 = blockIdx.z / a.nb3;
+    const int i2 = i12 % a.nb2, i1 = i12 / a.nb2;
+    const float* src = in + i1 * a.ib1 + i2 * a.ib2 + i3 * a.ib3;
+    float* dst = out + i1 * a.ob1 + i2 * a.ob2 + i3 * a.ob3;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + i * 8, c = c0 + tx;
+        if (r < a.R && c < a.C) {
+            const float* q = src + (int64_t)r * a.ir + c;
+            float acc = q[0];
+            for (int s = 1; s < a.ns; ++s) acc += q[(int64_t)s * a.is];
+            tile[ty + i * 8][tx] = acc;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + i * 8, r = r0 + tx;
+        if (r < a.R && c < a.C) dst[(int64_t)c * a.oc + r] = tile[tx][ty + i * 8];
     }
 }
 
@@ -499,6 +537,24 @@ extern "C" int bbb_transpose_batched(const float* in, float* out, int rows, int 
     return (int)hipGetLastError();
 }
 
+extern "C" int bbb_transpose_sum_batched(const float* in, float* out, int rows, int cols, const int32_t* nb, const int64_t* in_b,
+                                         const int64_t* out_b, int64_t in_row, int64_t out_col, int nsum, int64_t in_sum,
+                                         void* stream) {
+    if (in == nullptr || out == nullptr || nb == nullptr || in_b == nullptr || out_b == nullptr || rows <= 0 || cols <= 0 ||
+        nb[0] <= 0 || nb[1] <= 0 || nb[2] <= 0 || nsum <= 0)
+        return BBB_EINVAL;
+    if ((((uintptr_t)in | (uintptr_t)out) & 3u) != 0) return BBB_EALIGN;
+    const int64_t n = (int64_t)nb[0] * nb[1] * nb[2], gy = (rows + 31) / 32;
+    if (n > 65535 || gy > 65535) return BBB_ESHAPE;
+    TransposeExArgs a;
+    a.R = rows, a.C = cols, a.nb2 = nb[1], a.nb3 = nb[2], a.ns = nsum;
+    a.ib1 = in_b[0], a.ib2 = in_b[1], a.ib3 = in_b[2], a.is = in_sum, a.ir = in_row;
+    a.ob1 = out_b[0], a.ob2 = out_b[1], a.ob3 = out_b[2], a.oc = out_col;
+    hipLaunchKernelGGL(transpose_sum_batched_kernel, dim3((cols + 31) / 32, (unsigned)gy, (unsigned)n), dim3(256), 0, (hipStream_t)stream,
+                       in, out, a);
+    return (int)hipGetLastError();
+}
+
 extern "C" int bbb_im2col_pbj(const float* x, float* out, const bbb_conv_desc_t* d, void* stream) {
     if (x == nullptr || out == nullptr || d == nullptr || d->batch <= 0 || d->cin <= 0 || d->h <= 0 || d->w <= 0 || d->kh <= 0 ||
         d->kw <= 0 || d->stride_h <= 0 || d->stride_w <= 0 || d->pad_h < 0 || d->pad_w < 0 || d->dil_h <= 0 || d->dil_w <= 0)
@@ -522,6 +578,19 @@ extern "C" int bbb_flip_transpose_w(const float* w, float* out, int64_t draws, i
     const int64_t total = draws * cout * cin * khkw;
     const int64_t blocks = (total + 255) / 256;
     if (blocks > 0x7fffffffLL) return BBB_ESHAPE;
-    hipLaunchKernelGGL(flip_transpose_w_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, out, total, cout, cin, khkw);
+    hipLaunchKernelGGL(flip_transpose_w_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, (const float*)nullptr,
+                       (int64_t)0, out, total, cout, cin, khkw);
+    return (int)hipGetLastError();
+}
+
+extern "C" int bbb_flip_transpose_w_pair(const float* w0, const float* w1, float* out, int64_t draws_each, int cout, int cin, int khkw,
+                                         void* stream) {
+    if (w0 == nullptr || w1 == nullptr || out == nullptr || draws_each <= 0 || cout <= 0 || cin <= 0 || khkw <= 0) return BBB_EINVAL;
+    if ((((uintptr_t)w0 | (uintptr_t)w1 | (uintptr_t)out) & 3u) != 0) return BBB_EALIGN;
+    const int64_t total = 2 * draws_each * cout * cin * khkw;
+    const int64_t blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffffLL) return BBB_ESHAPE;
+    hipLaunchKernelGGL(flip_transpose_w_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w0, w1, draws_each, out, total,
+                       cout, cin, khkw);
     return (int)hipGetLastError();
 }

@@ -102,6 +102,40 @@ def test_chwn_wgrad_dgrad_vs_torch_float64(env, Cin, Cout, kk, pad, H):
         np.testing.assert_allclose(gx[e].cpu().numpy(), xt.grad.permute(1, 2, 3, 0).float().cpu().numpy(), rtol=2e-4, atol=2e-4)
 
 
+@pytest.mark.parametrize("E,shared", [(1, False), (3, False), (3, True)])
+def test_chwn_wgrad_batch_chunks_vs_torch_float64(env, E, shared):
+    """A launch of few workgroups splits the batch into S chunks that run as extra draws: the output gradient lands in the
+    chunked weight-operand layout in one pass and the chunk sums fold into the final tap transpose (bbb_transpose_sum_batched)."""
+    ops = env["ops"]
+    g = torch.Generator(device="cuda").manual_seed(E)
+    Cin, Cout, kk, pad, H, B = 16, 24, 3, 1, 5, 64
+    x = torch.randn(1 if shared else E, Cin, H, H, B, device="cuda", generator=g)
+    gy = torch.randn(E, Cout, H, H, B, device="cuda", generator=g)
+    S = 4
+    gr = ops.chwn_grad_as_weights(gy, S)
+    want = gy.permute(0, 1, 4, 2, 3).reshape(E, Cout, S, B // S, H, H).permute(0, 2, 1, 3, 4, 5).reshape(E * S, Cout, B // S, H, H)
+    assert torch.equal(gr, want)
+    gw = ops.conv2d_chwn_weight_grad(gy, x, (E, Cout, Cin, kk, kk), 1, pad, 1)
+    for e in range(E):
+        xt = x[0 if shared else e].permute(3, 0, 1, 2).double()
+        wt = torch.zeros(Cout, Cin, kk, kk, device="cuda", dtype=torch.float64, requires_grad=True)
+        F.conv2d(xt, wt, None, 1, pad).backward(gy[e].permute(3, 0, 1, 2).double())
+        np.testing.assert_allclose(gw[e].cpu().numpy(), wt.grad.float().cpu().numpy(), rtol=2e-4, atol=3e-4)
+
+
+def test_transpose_sum_batched_entry(env):
+    ops = env["ops"]
+    g = torch.Generator(device="cuda").manual_seed(3)
+    a = torch.randn(2, 5, 3, 37, 41, device="cuda", generator=g)          # [i1][s][i2][r][c]
+    out = torch.empty(2, 3, 41, 37, device="cuda")
+    assert ops._transpose_sum_batched(a, out, 37, 41, (2, 3, 1), (5 * 3 * 37 * 41, 37 * 41, 0), (3 * 41 * 37, 41 * 37, 0), 41, 37,
+                                      5, 3 * 37 * 41)
+    want = a[:, 0]
+    for s_ in range(1, 5):
+        want = want + a[:, s_]                                            # ascending order, one rounding per addition
+    assert torch.equal(out, want.transpose(2, 3).contiguous())
+
+
 @pytest.mark.parametrize("net_type,cin,B,lt", [("alexnet", 3, 16, "bbb"), ("3conv3fc", 3, 8, "bbb"), ("alexnet", 3, 64, "bbb"),
                                               ("alexnet", 3, 16, "lrt"), ("3conv3fc", 3, 8, "lrt"),
                                               ("lenet", 1, 8, "bbb"), ("lenet", 1, 16, "lrt")])
@@ -136,6 +170,43 @@ def test_fast_autograd_matches_reference_layout_autograd(env, net_type, cin, B, 
         scale = float(gb[n].abs().max()) + 1e-12
         err = float((ga[n] - gb[n]).abs().max()) / scale
         assert err <= 2e-3, (n, err)
+
+
+@pytest.mark.parametrize("net_type,cin,B,E", [("alexnet", 3, 64, 1), ("alexnet", 3, 16, 3), ("lenet", 1, 32, 1), ("3conv3fc", 3, 8, 1)])
+def test_lrt_paired_backward_equals_the_two_launch_form(env, net_type, cin, B, E):
+    """An LRT layer's two weight gradients (g_mu with x, g_var with x^2) and, for one draw, its two input gradients (with W_mu,
+    W_var) run as the two draws of one launch each (fast_train.pair_lrt_backward): the same products as the two-launch form,
+    the batch chunks of the weight gradient summed in a different grouping."""
+    ens, ft = env["ens"], env["ft"]
+    torch.manual_seed(4)
+    net = env["zoo"].getModel(net_type, cin, 10, P.CONFIG_PRIORS, "lrt", "softplus").cuda()
+    env["rng"].assign_stream_ids(net)
+    x = torch.rand(B, cin, 32, 32, device="cuda")
+    y = torch.randint(0, 10, (B,), device="cuda")
+    grads = {}
+    for paired in (True, False):
+        ft.pair_lrt_backward[0] = paired
+        try:
+            net.zero_grad(set_to_none=True)
+            env["rng"].manual_seed(6, call=3)
+            lo, kl = ens.mc_forward(net, x, E, kl_mode="mean")
+            assert ens.stats["path"] == "chwn-autograd"
+            (F.nll_loss(lo, y) * 100.0 + 1e-6 * kl).backward()
+            grads[paired] = {n: p.grad.detach().clone() for n, p in net.named_parameters()}
+        finally:
+            ft.pair_lrt_backward[0] = True
+    for n in grads[True]:
+        scale = float(grads[False][n].abs().max()) + 1e-12
+        err = float((grads[True][n] - grads[False][n]).abs().max()) / scale
+        assert err <= 2e-5, (n, err)
+
+
+def test_flip_transpose_w_pair_entry(env):
+    ops = env["ops"]
+    g = torch.Generator(device="cuda").manual_seed(8)
+    w0 = torch.randn(2, 5, 7, 3, 3, device="cuda", generator=g)
+    w1 = torch.randn(2, 5, 7, 3, 3, device="cuda", generator=g)
+    assert torch.equal(ops.flip_transpose_w_pair(w0, w1), torch.cat([ops.flip_transpose_w(w0), ops.flip_transpose_w(w1)]))
 
 
 def test_lenet_is_eligible_and_odd_batches_fall_back(env):

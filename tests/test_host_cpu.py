@@ -52,7 +52,7 @@ def test_library_exports_every_declared_symbol(built):
     h = _lib.lib()                      # CDLL + argtypes for every symbol; raises if one is missing
     for name in decl:
         assert hasattr(h, name)
-    assert h.bbb_abi_version() == 12
+    assert h.bbb_abi_version() == 13
     assert b"gfx950" in h.bbb_build_info()
 
 
