@@ -64,6 +64,8 @@ typedef struct bbb_segment {
 
 #define BBB_SIGMA_SQUARED 1u   /* flags: write sigma^2 (the LRT variance operand) instead of sigma */
 #define BBB_KL_TEXTBOOK   2u   /* flags: KL(q||p) instead of the reference's swapped-argument form */
+#define BBB_GW_MEAN_ONLY  4u   /* bbb_reparam_kl_bwd flags: the `w` gradients reach mu only (no eps term into rho): an LRT layer's
+                                * d loss / d W_mu folded into the KL backward instead of a separate accumulation per tensor */
 
 /*
  * Fused reparameterisation + KL over up to BBB_MAX_SEGMENTS tensors and `draws` Monte-Carlo draws in

@@ -17,6 +17,7 @@ ABI_VERSION = 13
 MAX_SEGMENTS = 16
 SIGMA_SQUARED = 1
 KL_TEXTBOOK = 2
+GW_MEAN_ONLY = 4
 
 c_void_p, c_int, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 c_u64, c_u32, c_i64, c_i32 = ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int64, ctypes.c_int32

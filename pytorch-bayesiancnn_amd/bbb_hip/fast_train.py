@@ -446,10 +446,11 @@ def mc_logits_autograd(net, x, draws, seed, call0, alias=None):
             m, r, _ = l._param_lists()
             mus += [A(t) for t in m]
             rhos += [A(t) for t in r]
-        kl, s2 = ops.kl_only(mus, rhos, layers[0].prior_mu, layers[0].prior_sigma, want_sigma=True, sigma_squared=True)
+        kl, s2, mu = ops.kl_only(mus, rhos, layers[0].prior_mu, layers[0].prior_sigma, want_sigma=True, sigma_squared=True,
+                                 mu_through=True)
         flat = []
         for li, l in enumerate(layers):
-            flat += [A(l.W_mu), s2[2 * li], A(l.bias_mu), s2[2 * li + 1]]
+            flat += [mu[2 * li], s2[2 * li], mu[2 * li + 1], s2[2 * li + 1]]
         cfg = dict(net=net, draws=int(draws), seed=seed, call0=call0)
         logits = _MCForwardLRT.apply(cfg, x, *flat)
         logits.bbb_cfg = cfg

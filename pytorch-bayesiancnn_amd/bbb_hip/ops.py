@@ -145,9 +145,10 @@ def reparam_kl_forward(mus, rhos, prior_mu, prior_sigma, stream_ids, seed, call0
 
 
 def reparam_kl_backward(mus, rhos, gws, gkl, prior_mu, prior_sigma, stream_ids, seed, call0, draws, eps=None,
-                        textbook_kl=False, gsigmas=None, sigma_squared=False):
+                        textbook_kl=False, gsigmas=None, sigma_squared=False, gws_mean_only=False):
     """grad_mu[i], grad_rho[i] for every tensor (see bbb_reparam_kl_bwd).  gsigmas: gradients w.r.t. the forward's sigma
-    (sigma_squared: sigma^2) outputs, entries may be None."""
+    (sigma_squared: sigma^2) outputs, entries may be None.  gws_mean_only: gws are gradients w.r.t. the means themselves
+    (BBB_GW_MEAN_ONLY: added into grad_mu, nothing into grad_rho)."""
     require_device(*mus, *rhos)
     dev = mus[0].device
     mus = [m.contiguous() for m in mus]
@@ -166,6 +167,7 @@ def reparam_kl_backward(mus, rhos, gws, gkl, prior_mu, prior_sigma, stream_ids, 
     if gkl is not None:
         gkl = gkl.to(device=dev, dtype=torch.float32).contiguous()
     flags = (_lib.KL_TEXTBOOK if textbook_kl else 0) | (_lib.SIGMA_SQUARED if (sigma_squared and gsigmas is not None) else 0)
+    flags |= _lib.GW_MEAN_ONLY if gws_mean_only else 0
     with on_device(dev):
         rc = _lib.lib().bbb_reparam_kl_bwd(segs, len(mus), draws, float(prior_mu), float(prior_sigma), seed,
                                            call0 & 0xFFFFFFFF, flags, ptr(gkl), pm, pr, rng.call_dev_ptr(dev), cur_stream(dev))
@@ -1482,23 +1484,31 @@ class _KLOnly(torch.autograd.Function):
                                         textbook_kl=cfg.get("textbook_kl", False))
         ctx.cfg = cfg
         ctx.save_for_backward(*params)
-        if sig is None:
-            return (kl,)
-        return (kl, *sig)
+        ctx.n_sig = 0 if sig is None else len(sig)
+        out = (kl,) if sig is None else (kl, *sig)
+        if cfg.get("mu_through", False):
+            # the means again, as outputs of THIS node: what consumes them (the LRT forward node) hands its gradients back here,
+            # where the backward kernel adds them to d KL / d mu -- instead of one accumulation launch per tensor in the engine
+            out = out + tuple(m.view_as(m) for m in mus)
+        return out
 
     @staticmethod
-    def backward(ctx, gkl, *gsig):
+    def backward(ctx, gkl, *gout):
         params = ctx.saved_tensors
         cfg = ctx.cfg
         mus, rhos = list(params[0::2]), list(params[1::2])
+        gsig, gthru = gout[:ctx.n_sig], gout[ctx.n_sig:]
         # d sigma / d rho = sigmoid(rho), d sigma^2 / d rho = 2 sigma sigmoid(rho): folded into the backward kernel (the LRT
         # training step spent ~70 ATen launches per step on these twelve small tensors)
         gs = None
         if gsig and any(g is not None for g in gsig):
             gs = [gsig[i] if i < len(gsig) else None for i in range(len(mus))]
-        gmu, grho = reparam_kl_backward(mus, rhos, [None] * len(mus), gkl, cfg["prior_mu"], cfg["prior_sigma"],
+        gws = [None] * len(mus)
+        if gthru and any(g is not None for g in gthru):
+            gws = [gthru[i] if i < len(gthru) else None for i in range(len(mus))]
+        gmu, grho = reparam_kl_backward(mus, rhos, gws, gkl, cfg["prior_mu"], cfg["prior_sigma"],
                                         cfg["stream_ids"], 0, 0, 1, textbook_kl=cfg.get("textbook_kl", False), gsigmas=gs,
-                                        sigma_squared=cfg.get("sigma_squared", False))
+                                        sigma_squared=cfg.get("sigma_squared", False), gws_mean_only=True)
         out = [None]
         for a, b in zip(gmu, grho):
             out += [a, b]
@@ -1714,17 +1724,23 @@ def sample_weights(mus, rhos, prior_mu, prior_sigma, stream_ids, seed, call0, dr
     return out[0], list(out[1:])
 
 
-def kl_only(mus, rhos, prior_mu, prior_sigma, want_sigma=False, sigma_squared=False, textbook_kl=False):
+def kl_only(mus, rhos, prior_mu, prior_sigma, want_sigma=False, sigma_squared=False, textbook_kl=False, mu_through=False):
+    """-> (kl, [sigma ...]) -- with mu_through (and want_sigma) -> (kl, [sigma ...], [mu ...]): the means as outputs of the same
+    autograd node, so that gradients w.r.t. them are added to d KL / d mu inside its one backward launch."""
     if _no_grad_needed(list(mus) + list(rhos)):
         _, sig, kl = reparam_kl_forward([m.detach() for m in mus], [r.detach() for r in rhos], prior_mu, prior_sigma, [0] * len(mus), 0, 0, 1,
                                         sample=False, want_sigma=want_sigma, sigma_squared=sigma_squared, textbook_kl=textbook_kl)
-        return kl, (list(sig) if sig is not None else [])
+        sig = list(sig) if sig is not None else []
+        return (kl, sig, list(mus)) if mu_through else (kl, sig)
     cfg = dict(prior_mu=prior_mu, prior_sigma=prior_sigma, stream_ids=[0] * len(mus), want_sigma=want_sigma,
-               sigma_squared=sigma_squared, textbook_kl=textbook_kl)
+               sigma_squared=sigma_squared, textbook_kl=textbook_kl, mu_through=mu_through)
     flat = []
     for m, r in zip(mus, rhos):
         flat += [m, r]
     out = _KLOnly.apply(cfg, *flat)
+    if mu_through:
+        n_sig = len(out) - 1 - len(mus)
+        return out[0], list(out[1:1 + n_sig]), list(out[1 + n_sig:])
     return out[0], list(out[1:])
 
 

@@ -494,6 +494,7 @@ __global__ __launch_bounds__(kThreads) void reparam_kl_bwd_kernel(const ReparamA
     const bool textbook = (a.flags & BBB_KL_TEXTBOOK) != 0;
     const float gkl = a.gkl ? *a.gkl : 0.0f;
     const bool sq = (a.flags & BBB_SIGMA_SQUARED) != 0;
+    const bool mean_only = (a.flags & BBB_GW_MEAN_ONLY) != 0;   // gw is a gradient w.r.t. mu itself: nothing of it reaches rho
     const float* __restrict__ gsig = sg.sigma;                  // backward: gradient w.r.t. the sigma (or sigma^2) output, or NULL
     const bool aligned = ((((uintptr_t)sg.mu | (uintptr_t)sg.rho | (uintptr_t)sg.w | (uintptr_t)sg.eps |
                             (uintptr_t)gmu_out | (uintptr_t)grho_out) & 15u) == 0) && ((sg.draw_stride & 3) == 0);
@@ -521,7 +522,10 @@ __global__ __launch_bounds__(kThreads) void reparam_kl_bwd_kernel(const ReparamA
             for (int e = 0; e < a.draws; ++e) {
                 float z[4], gw[4];
                 const int64_t o = (int64_t)e * sg.draw_stride + i0;
-                if (sg.eps != nullptr) {
+                if (mean_only) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) z[j] = 0.0f;
+                } else if (sg.eps != nullptr) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) z[j] = j < cnt ? sg.eps[o + j] : 0.0f;
                 } else {

@@ -226,6 +226,7 @@ def test_bbb_outputs_follow_lrt_moments(env):
     torch.manual_seed(0)
     pri = dict(P.DEFAULT_PRIORS)
     layer = env["layers"].BBB_Conv2d(3, 8, 3, padding=1, priors=pri).cuda()
+    env["rng"].assign_stream_ids(layer)       # (the noise streams of a stand-alone layer otherwise depend on how many layers the process built before)
     x = torch.rand(2, 3, 6, 6, device="cuda")
     E = 4000
     env["rng"].manual_seed(9)
@@ -241,7 +242,8 @@ def test_bbb_outputs_follow_lrt_moments(env):
     z = np.abs(mean - am) / np.sqrt(av / E)
     assert z.max() < 5.0 and np.mean(z) < 1.2            # |mean - act_mu| within sampling error
     ratio = var / av
-    assert 0.85 < ratio.min() and ratio.max() < 1.15 and abs(ratio.mean() - 1) < 0.01
+    # (every output sums the SAME E weight draws: the ratios are correlated, their mean has up to sqrt(2 / E) = 0.022 of spread)
+    assert 0.85 < ratio.min() and ratio.max() < 1.15 and abs(ratio.mean() - 1) < 0.04
 
 
 def test_train_step_runs_and_learns(env):
