@@ -239,6 +239,15 @@ __global__ __launch_bounds__(256) void flip_transpose_w_kernel(const float* __re
     out[i] = src[((e * Cout + n) * Cin + ci) * khkw + (khkw - 1 - t)];
 }
 
+static int launch_flip_transpose(const float* w0, const float* w1, int64_t e1, float* out, int64_t draws, int cout, int cin, int khkw,
+                                 hipStream_t stream) {
+    const int64_t total = draws * cout * cin * khkw;
+    const int64_t blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffffLL) return BBB_ESHAPE;
+    hipLaunchKernelGGL(flip_transpose_w_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, w0, w1, e1, out, total, cout, cin, khkw);
+    return (int)hipGetLastError();
+}
+
 // Batched strided transpose (training extension: the operand permutations of the role-swapped weight-gradient launch):
 //   out[i1*ob1 + i2*ob2 + c*oc + r] = in[i1*ib1 + i2*ib2 + r*ir + c],  r < R, c < C, (i1, i2) < (nb1, nb2)
 // i.e. every batch entry is an [R][C] matrix with contiguous columns that lands as a [C][R] matrix with contiguous rows.
@@ -297,6 +306,47 @@ __global__ __launch_bounds__(256) void transpose_sum_batched_kernel(const float*
         const int c = c0 + ty + i * 8, r = r0 + tx;
         if (r < a.R && c < a.C) dst[(int64_t)c * a.oc + r] = tile[tx][ty + i * 8];
     }
+}
+
+// Few rows (R <= 32: the pixels of a small output map, the taps of a kernel) landing contiguously (oc == R): a 32 x 32 tile would be
+// mostly empty and its 4R-byte output runs uncoalesced (measured 0.5 TB/s on the weight-gradient operands of the metric shape).
+// One block moves blockDim.x columns of one batch entry: coalesced row reads -> LDS [column][R | 1] -> ONE linear, fully coalesced
+// write of the blockDim.x * R contiguous outputs.
+__global__ __launch_bounds__(256) void transpose_few_rows_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                                 const TransposeExArgs a) {
+    __shared__ float tile[256 * 33];
+    const int i3 = blockIdx.z % a.nb3, i12 = blockIdx.z / a.nb3;
+    const int i2 = i12 % a.nb2, i1 = i12 / a.nb2;
+    const float* src = in + i1 * a.ib1 + i2 * a.ib2 + i3 * a.ib3;
+    float* dst = out + i1 * a.ob1 + i2 * a.ob2 + i3 * a.ob3;
+    const int R = a.R, Rp = R | 1, nt = blockDim.x, tid = threadIdx.x;
+    const int c0 = blockIdx.x * nt, c = c0 + tid;
+    if (c < a.C) {
+        for (int r = 0; r < R; ++r) {
+            const float* q = src + (int64_t)r * a.ir + c;
+            float acc = q[0];
+            for (int s = 1; s < a.ns; ++s) acc += q[(int64_t)s * a.is];
+            tile[tid * Rp + r] = acc;
+        }
+    }
+    __syncthreads();
+    const int ncol = min(nt, a.C - c0), total = ncol * R;
+    float* d = dst + (int64_t)c0 * R;
+    for (int i = tid; i < total; i += nt) {
+        const int cc = i / R, r = i - cc * R;
+        d[i] = tile[cc * Rp + r];
+    }
+}
+
+static int launch_transpose_ex(const float* in, float* out, const TransposeExArgs& a, int64_t n, hipStream_t stream) {
+    // (large operands only: on the small ones of a one-draw step the tiles' parallelism wins, above all with a summed dimension)
+    if (a.R <= 32 && a.oc == a.R && a.ns == 1 && n * a.R * a.C >= (1 << 20)) {
+        const int nt = a.C <= 64 ? 64 : (a.C <= 128 ? 128 : 256);
+        hipLaunchKernelGGL(transpose_few_rows_kernel, dim3((a.C + nt - 1) / nt, 1, (unsigned)n), dim3(nt), 0, stream, in, out, a);
+    } else {
+        hipLaunchKernelGGL(transpose_sum_batched_kernel, dim3((a.C + 31) / 32, (a.R + 31) / 32, (unsigned)n), dim3(256), 0, stream, in, out, a);
+    }
+    return (int)hipGetLastError();
 }
 
 // y[e] = act(act_mu + sqrt(act_var) * eps[e]) for E draws of ONE pair of LRT moments (batch-innermost layout).  Used when the
@@ -532,6 +582,13 @@ extern "C" int bbb_transpose_batched(const float* in, float* out, int rows, int 
     if ((((uintptr_t)in | (uintptr_t)out) & 3u) != 0) return BBB_EALIGN;
     const int64_t nb = (int64_t)nb1 * nb2, gy = (rows + 31) / 32;
     if (nb > 65535 || gy > 65535) return BBB_ESHAPE;
+    if (rows <= 32 && out_col == rows && nb * rows * cols >= (1 << 20)) {
+        TransposeExArgs a;
+        a.R = rows, a.C = cols, a.nb2 = nb2, a.nb3 = 1, a.ns = 1;
+        a.ib1 = in_b1, a.ib2 = in_b2, a.ib3 = 0, a.is = 0, a.ir = in_row;
+        a.ob1 = out_b1, a.ob2 = out_b2, a.ob3 = 0, a.oc = out_col;
+        return launch_transpose_ex(in, out, a, nb, (hipStream_t)stream);
+    }
     hipLaunchKernelGGL(transpose_batched_kernel, dim3((cols + 31) / 32, (unsigned)gy, (unsigned)nb), dim3(256), 0, (hipStream_t)stream, in, out,
                        rows, cols, nb2, in_b1, in_b2, in_row, out_b1, out_b2, out_col);
     return (int)hipGetLastError();
@@ -550,9 +607,7 @@ extern "C" int bbb_transpose_sum_batched(const float* in, float* out, int rows, 
     a.R = rows, a.C = cols, a.nb2 = nb[1], a.nb3 = nb[2], a.ns = nsum;
     a.ib1 = in_b[0], a.ib2 = in_b[1], a.ib3 = in_b[2], a.is = in_sum, a.ir = in_row;
     a.ob1 = out_b[0], a.ob2 = out_b[1], a.ob3 = out_b[2], a.oc = out_col;
-    hipLaunchKernelGGL(transpose_sum_batched_kernel, dim3((cols + 31) / 32, (unsigned)gy, (unsigned)n), dim3(256), 0, (hipStream_t)stream,
-                       in, out, a);
-    return (int)hipGetLastError();
+    return launch_transpose_ex(in, out, a, n, (hipStream_t)stream);
 }
 
 extern "C" int bbb_im2col_pbj(const float* x, float* out, const bbb_conv_desc_t* d, void* stream) {
@@ -575,22 +630,12 @@ extern "C" int bbb_im2col_pbj(const float* x, float* out, const bbb_conv_desc_t*
 extern "C" int bbb_flip_transpose_w(const float* w, float* out, int64_t draws, int cout, int cin, int khkw, void* stream) {
     if (w == nullptr || out == nullptr || draws <= 0 || cout <= 0 || cin <= 0 || khkw <= 0) return BBB_EINVAL;
     if ((((uintptr_t)w | (uintptr_t)out) & 3u) != 0) return BBB_EALIGN;
-    const int64_t total = draws * cout * cin * khkw;
-    const int64_t blocks = (total + 255) / 256;
-    if (blocks > 0x7fffffffLL) return BBB_ESHAPE;
-    hipLaunchKernelGGL(flip_transpose_w_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, (const float*)nullptr,
-                       (int64_t)0, out, total, cout, cin, khkw);
-    return (int)hipGetLastError();
+    return launch_flip_transpose(w, nullptr, 0, out, draws, cout, cin, khkw, (hipStream_t)stream);
 }
 
 extern "C" int bbb_flip_transpose_w_pair(const float* w0, const float* w1, float* out, int64_t draws_each, int cout, int cin, int khkw,
                                          void* stream) {
     if (w0 == nullptr || w1 == nullptr || out == nullptr || draws_each <= 0 || cout <= 0 || cin <= 0 || khkw <= 0) return BBB_EINVAL;
     if ((((uintptr_t)w0 | (uintptr_t)w1 | (uintptr_t)out) & 3u) != 0) return BBB_EALIGN;
-    const int64_t total = 2 * draws_each * cout * cin * khkw;
-    const int64_t blocks = (total + 255) / 256;
-    if (blocks > 0x7fffffffLL) return BBB_ESHAPE;
-    hipLaunchKernelGGL(flip_transpose_w_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w0, w1, draws_each, out, total,
-                       cout, cin, khkw);
-    return (int)hipGetLastError();
+    return launch_flip_transpose(w0, w1, draws_each, out, 2 * draws_each, cout, cin, khkw, (hipStream_t)stream);
 }

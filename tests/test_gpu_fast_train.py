@@ -123,6 +123,23 @@ def test_chwn_wgrad_batch_chunks_vs_torch_float64(env, E, shared):
         np.testing.assert_allclose(gw[e].cpu().numpy(), wt.grad.float().cpu().numpy(), rtol=2e-4, atol=3e-4)
 
 
+@pytest.mark.parametrize("R,C", [(1, 10), (4, 512), (9, 64), (16, 100), (25, 300), (32, 257), (33, 70), (4, 18001), (9, 8000), (16, 4400),
+                                 (32, 2300)])
+def test_transposes_with_few_rows(env, R, C):
+    """Large operands (>= 2^20 elements) of <= 32 rows landing contiguously, nothing summed, take the few-rows kernel (column reads
+    -> LDS -> one linear write), anything else the 32 x 32 tiles: both entries, with batch strides and a summed dimension."""
+    ops = env["ops"]
+    g = torch.Generator(device="cuda").manual_seed(R * 1000 + C)
+    a = torch.randn(3, 2, 5, R, C, device="cuda", generator=g)             # [i1][s][i2][r][c]
+    out = torch.full((3, 5, C, R), float("nan"), device="cuda")
+    assert ops._transpose_sum_batched(a, out, R, C, (3, 5, 1), (2 * 5 * R * C, R * C, 0), (5 * C * R, C * R, 0), C, R, 2, 5 * R * C)
+    assert torch.equal(out, (a[:, 0] + a[:, 1]).transpose(2, 3).contiguous())
+    b = a[:, 0].contiguous()                                               # [3][5][R][C]
+    out2 = torch.full((3, 5, C, R), float("nan"), device="cuda")
+    assert ops._transpose_batched(b, out2, R, C, 3, 5, 5 * R * C, R * C, C, 5 * C * R, C * R, R)
+    assert torch.equal(out2, b.transpose(2, 3).contiguous())
+
+
 def test_transpose_sum_batched_entry(env):
     ops = env["ops"]
     g = torch.Generator(device="cuda").manual_seed(3)
@@ -201,12 +218,18 @@ def test_lrt_paired_backward_equals_the_two_launch_form(env, net_type, cin, B, E
         assert err <= 2e-5, (n, err)
 
 
-def test_flip_transpose_w_pair_entry(env):
+@pytest.mark.parametrize("E,Cout,Cin,k", [(2, 5, 7, 3), (3, 10, 128, 1), (2, 192, 64, 5), (1, 33, 50, 3), (1, 8, 4, 11), (2, 16, 16, (2, 3))])
+def test_flip_transpose_w_entries(env, E, Cout, Cin, k):
+    """[E, Cout, Cin, kh, kw] -> [E, Cin, Cout, kh, kw] with the taps reversed: the LDS-tiled kernel (up to 32 taps), the
+    one-thread-per-output kernel (11 x 11), and the two-source form."""
     ops = env["ops"]
-    g = torch.Generator(device="cuda").manual_seed(8)
-    w0 = torch.randn(2, 5, 7, 3, 3, device="cuda", generator=g)
-    w1 = torch.randn(2, 5, 7, 3, 3, device="cuda", generator=g)
-    assert torch.equal(ops.flip_transpose_w_pair(w0, w1), torch.cat([ops.flip_transpose_w(w0), ops.flip_transpose_w(w1)]))
+    kh, kw = (k, k) if isinstance(k, int) else k
+    g = torch.Generator(device="cuda").manual_seed(8 + Cout)
+    w0 = torch.randn(E, Cout, Cin, kh, kw, device="cuda", generator=g)
+    w1 = torch.randn(E, Cout, Cin, kh, kw, device="cuda", generator=g)
+    want0, want1 = (w.flip(3, 4).transpose(1, 2).contiguous() for w in (w0, w1))
+    assert torch.equal(ops.flip_transpose_w(w0), want0)
+    assert torch.equal(ops.flip_transpose_w_pair(w0, w1), torch.cat([want0, want1]))
 
 
 def test_lenet_is_eligible_and_odd_batches_fall_back(env):
