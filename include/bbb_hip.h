@@ -453,6 +453,19 @@ int bbb_mc_tail_cb(const float* logits, int draws, int batch, int classes, int m
 int bbb_mc_tail_cb_bwd(const float* logits, const float* lse, const float* g_lse, float* g_logits, int draws, int batch, int classes,
                        int mean_over, void* stream);
 
+/* Training extension: the ELBO of one Monte-Carlo step on the device (metrics.py:7-14: nll_loss(log_outputs, target, mean) *
+ * train_size + beta * kl; main_bayesian.py:55-56).  lse [batch][classes] = bbb_mc_tail_cb's output, target [batch] int64 (entries
+ * outside [0, classes) contribute nothing), kl / loss_out device scalars; beta_dev != NULL: the KL weight is read from the device
+ * (a captured step's run-time value) instead of `beta`.  One block, fixed summation order. */
+int bbb_elbo_cb_fwd(const float* lse, const int64_t* target, const float* kl, float beta, const float* beta_dev, float train_size,
+                    int batch, int classes, float* loss_out, void* stream);
+/* Its backward in one launch: g_logits [draws][classes][batch] = d loss / d logits through log_softmax + logmeanexp (as
+ * bbb_mc_tail_cb_bwd with g_lse = -(train_size / batch) * g_loss at the target class), g_kl (device scalar, may be NULL) =
+ * beta * g_loss. */
+int bbb_elbo_cb_bwd(const float* logits, const float* lse, const int64_t* target, const float* g_loss, float beta,
+                    const float* beta_dev, float train_size, float* g_logits, float* g_kl, int draws, int batch, int classes,
+                    int mean_over, void* stream);
+
 /* The same for a rank's WORK UNITS (bbb_conv_desc_t: unit u = unit_off + e is draw u / slices, batch slice u % slices):
  * logits [units][C][batch_slice] -> lse_out [slices * batch_slice][C]; image b of slice s gets the log-sum-exp over the local
  * units of that slice, -inf where the rank holds none (the ranks' blocks are then combined by one more log-sum-exp). */

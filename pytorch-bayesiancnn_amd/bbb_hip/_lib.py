@@ -93,6 +93,9 @@ _SIGNATURES = {
     "bbb_transpose2d": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_void_p]),
     "bbb_flip_transpose_w": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_void_p]),
     "bbb_flip_transpose_w_pair": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_void_p]),
+    "bbb_elbo_cb_fwd": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_float, c_void_p, ctypes.c_float, c_int, c_int, c_void_p, c_void_p]),
+    "bbb_elbo_cb_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_float, c_void_p, ctypes.c_float, c_void_p, c_void_p,
+                                c_int, c_int, c_int, c_int, c_void_p]),
     "bbb_im2col_pbj": (c_int, [c_void_p, c_void_p, ctypes.POINTER(ConvDesc), c_void_p]),
     "bbb_transpose_batched": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_void_p]),
     "bbb_transpose_sum_batched": (c_int, [c_void_p, c_void_p, c_int, c_int, ctypes.POINTER(c_i32), ctypes.POINTER(c_i64),

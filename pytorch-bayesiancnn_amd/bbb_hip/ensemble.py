@@ -932,7 +932,7 @@ def mc_logits(net, x, draws, seed, call0, fuse_act=True, timers=None, eps=None, 
 
 
 def _local_lse(net, x, draws, seed, call0, mean_over, fuse_act=True, timers=None, streams=1, precision="fp32", units=None, b_offset=0,
-               step_end=None, groups=1, param_alias=None, share=None):
+               step_end=None, groups=1, param_alias=None, share=None, elbo=None):
     """(log-sum-exp over the local draws of the per-draw log_softmax [B, C], kl of one forward), staying in the
     batch-innermost layout end to end when the fast path applies.  units = (S, lo, hi): the local work is the unit range
     lo..hi-1 instead of `draws` whole draws (call0 = call index of draw 0); rows of slices without a local unit are -inf.
@@ -943,7 +943,10 @@ def _local_lse(net, x, draws, seed, call0, mean_over, fuse_act=True, timers=None
     -> [G * B, C], block g = step g's result.
     share = (D, off): one rank's part of a group of steps (see _mc_logits_chwn; `draws` = its slabs, call0 = its first call)
     -> [n * B, C] for the n = ceil((draws + off) / D) steps it touches: block k = log-sum-exp over ITS draws of that step, no
-    mean (group_share / GraphedMC steps > 1 with a process group combine the ranks' blocks)."""
+    mean (group_share / GraphedMC steps > 1 with a process group combine the ranks' blocks).
+    elbo = [target, beta, train_size, None] (a training step, train.train_step): on the batch-innermost autograd path the loss
+    nll_loss(lse, target) * train_size + beta * kl is formed by the tail's own launches (ops.elbo_cb_autograd) and left in elbo[3];
+    elbo[3] still None on return: the caller forms it."""
     _check_precision(precision, net, x, fuse_act)
     if share is not None:
         D, off = int(share[0]), int(share[1])
@@ -997,6 +1000,9 @@ def _local_lse(net, x, draws, seed, call0, mean_over, fuse_act=True, timers=None
             # training on the batch-innermost kernels: one autograd node for the whole batched forward
             logits_cb, kl1 = fast_train.mc_logits_autograd(net, x, draws, seed, call0, alias=param_alias)
             stats["path"] = "chwn-autograd"
+            if elbo is not None and hip_loss_tail[0] and ops.elbo_cb_ok(logits_cb, kl1, elbo[0], elbo[1]):
+                elbo[3], lse = ops.elbo_cb_autograd(logits_cb, kl1, elbo[0], elbo[1], elbo[2], mean_over)
+                return lse, kl1
             if logits_cb.shape[0] <= 512 and hip_loss_tail[0]:
                 lse = ops.mc_tail_cb_autograd(logits_cb, mean_over)       # log_softmax + logmeanexp, forward and backward one launch each
             else:

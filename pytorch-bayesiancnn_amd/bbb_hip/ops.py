@@ -1265,6 +1265,62 @@ class _McTailCB(torch.autograd.Function):
         return out, None
 
 
+class _ElboCB(torch.autograd.Function):
+    """(loss, lse) = the whole loss tail of a training step: log_softmax + logmeanexp (bbb_mc_tail_cb), then nll_loss(mean) *
+    train_size + beta * kl in one block (bbb_elbo_cb_fwd); backward in ONE launch (bbb_elbo_cb_bwd: d loss / d logits and
+    d loss / d kl).  main_bayesian.py:49-56 / metrics.py:7-14 upstream -- ~25 ATen launches forward and backward otherwise."""
+
+    @staticmethod
+    def forward(ctx, logits, kl, target, beta, train_size, mean_over):
+        logits = logits.contiguous()
+        E, C, B = logits.shape
+        lse = mc_tail_cb(logits, mean_over=mean_over)
+        klc = kl.detach().reshape(()).contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=logits.device)
+        beta_t = beta if torch.is_tensor(beta) else None
+        with on_device(logits.device):
+            check(_lib.lib().bbb_elbo_cb_fwd(lse.data_ptr(), target.data_ptr(), klc.data_ptr(), 0.0 if beta_t is not None else float(beta),
+                                             ptr(beta_t), float(train_size), B, C, loss.data_ptr(), cur_stream(logits.device)),
+                  "bbb_elbo_cb_fwd")
+        ctx.save_for_backward(logits, lse, target)
+        ctx.beta, ctx.beta_t, ctx.train_size, ctx.mean_over = (None if beta_t is not None else float(beta)), beta_t, float(train_size), int(mean_over)
+        ctx.kl_shape = tuple(kl.shape)
+        ctx.mark_non_differentiable(lse)
+        return loss, lse
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_lse):
+        logits, lse, target = ctx.saved_tensors
+        E, C, B = logits.shape
+        g_loss = g_loss.to(dtype=torch.float32).reshape(()).contiguous()
+        out = torch.empty_like(logits)
+        g_kl = torch.empty(ctx.kl_shape, dtype=torch.float32, device=logits.device)
+        with on_device(logits.device):
+            check(_lib.lib().bbb_elbo_cb_bwd(logits.data_ptr(), lse.data_ptr(), target.data_ptr(), g_loss.data_ptr(),
+                                             0.0 if ctx.beta_t is not None else ctx.beta, ptr(ctx.beta_t), ctx.train_size, out.data_ptr(),
+                                             g_kl.data_ptr(), E, B, C, ctx.mean_over, cur_stream(logits.device)), "bbb_elbo_cb_bwd")
+        return out, g_kl, None, None, None, None
+
+
+def elbo_cb_ok(logits, kl, target, beta):
+    """The fused loss tail takes: logits [E <= 512, C, B] fp32 on the device, a one-element fp32 kl there too, int64 targets [B] there too,
+    beta a Python number or a one-element fp32 device tensor."""
+    return (torch.is_tensor(logits) and logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 3 and logits.shape[0] <= 512
+            and torch.is_tensor(kl) and kl.device == logits.device and kl.dtype == torch.float32 and kl.numel() == 1
+            and torch.is_tensor(target) and target.device == logits.device and target.dtype == torch.int64
+            and target.dim() == 1 and target.shape[0] == logits.shape[2] and target.is_contiguous()
+            and (not torch.is_tensor(beta) or (beta.device == logits.device and beta.dtype == torch.float32 and beta.numel() == 1
+                                               and not beta.requires_grad)))
+
+
+def elbo_cb_autograd(logits, kl, target, beta, train_size, mean_over=0):
+    """Differentiable (loss, lse [B, C]) of one Monte-Carlo training step from its logits [E, C, B] and the KL of one forward."""
+    require_device(logits)
+    if not elbo_cb_ok(logits, kl, target, beta):
+        raise _lib.BBBHipError("elbo_cb_autograd: see elbo_cb_ok for the accepted operands")
+    return _ElboCB.apply(logits, kl, target, beta, float(train_size), int(mean_over))
+
+
 def mc_tail_cb_autograd(logits, mean_over=0):
     """Differentiable mc_tail_cb: logits [E, C, B] (requires grad) -> lse [B, C]."""
     require_device(logits)

@@ -10,7 +10,7 @@ import weakref
 import torch
 import torch.nn.functional as F
 
-from . import _lib, ensemble, ops
+from . import _lib, ensemble, ops, rng
 from ._lib import AdamSegment, check, cur_stream
 
 
@@ -160,6 +160,20 @@ def elbo(log_outputs, target, kl, beta, train_size):
     return F.nll_loss(log_outputs, target, reduction="mean") * train_size + beta * kl
 
 
+def forward_loss(net, x, target, num_ens, beta, train_size, seed_call=None, param_alias=None):
+    """The forward half of a training iteration (main_bayesian.py:43-56): num_ens stochastic forwards batched over the draws,
+    kl of one forward (= the reference's kl / num_ens), logmeanexp, ELBO -> (loss, log_outputs, kl).  On the batch-innermost
+    autograd path the loss tail is two HIP launches forward and one backward (ops.elbo_cb_autograd); elsewhere torch ops.
+    seed_call: (seed, call0) reserved by the caller (a captured step); default: num_ens fresh call indices."""
+    if seed_call is None:
+        rng.assign_stream_ids(net)
+        seed_call = rng.next_calls(int(num_ens))
+    req = [target, beta, float(train_size), None]
+    log_outputs, kl = ensemble._local_lse(net, x, int(num_ens), seed_call[0], seed_call[1], int(num_ens), param_alias=param_alias, elbo=req)
+    loss = req[3] if req[3] is not None else elbo(log_outputs, target, kl, beta, train_size)
+    return loss, log_outputs, kl
+
+
 auto_graph = {"enabled": True, "after": 3,       # train_step captures itself once this many identical calls in a row were seen,
               "max_rows": 2048}                  # for steps of fewer than this many (image x draw) rows: larger steps are GPU-bound, and launch by
                                                  # launch their weight gradients overlap the input gradients on a second stream, which a
@@ -262,8 +276,7 @@ def train_step(net, optimizer, x, target, num_ens, beta, train_size, dp_group=No
                 st["streak"] = -(1 << 60)            # capture refused (stale gradient accumulators): launch by launch from here on
             return g.warm_loss.clone(), g.warm_log_outputs.clone(), g.warm_kl.clone()
     optimizer.zero_grad()
-    log_outputs, kl = ensemble.mc_forward(net, x, num_ens, kl_mode="mean")
-    loss = elbo(log_outputs, target, kl, beta, train_size)
+    loss, log_outputs, kl = forward_loss(net, x, target, num_ens, beta, train_size)
     loss.backward()
     if dp_group is not None:
         allreduce_gradients([p for g in optimizer.param_groups for p in g["params"]], dp_group)
@@ -346,8 +359,8 @@ class GraphedTrainStep:
         alias = None
         if ensemble.fast_autograd and fast_train.train_path_ok(self.net, self.x):
             alias = {id(p): p.detach().requires_grad_(True) for p in params}
-        log_outputs, kl = ensemble._local_lse(self.net, self.x, self.num_ens, self.seed, self.call0, self.num_ens, param_alias=alias)
-        loss = elbo(log_outputs, self.target, kl, self.beta, self.train_size)      # kl of one forward = kl / num_ens of the sum
+        loss, log_outputs, kl = forward_loss(self.net, self.x, self.target, self.num_ens, self.beta, self.train_size,   # kl of one forward
+                                             seed_call=(self.seed, self.call0), param_alias=alias)           # = kl / num_ens of the sum
         leaves = params if alias is None else [alias[id(p)] for p in params]
         grads = torch.autograd.grad(loss, leaves, allow_unused=True)
         for p, g in zip(params, grads):

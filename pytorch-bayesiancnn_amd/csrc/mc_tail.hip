@@ -459,10 +459,20 @@ namespace {
 //   H[e][b][c] = g[b][c] * exp(ls[e][b][c] - (lse[b][c] + log(mean_over)))          (softmax over the draws)
 //   d loss / d logits[e][k][b] = H[e][b][k] - exp(ls[e][b][k]) * sum_c H[e][b][c]
 // One thread per (draw, image); three passes over the classes (logits are [E][C][B]: consecutive lanes = consecutive images).
+// ELBO = true (bbb_elbo_cb_bwd): g[b][c] is not read but IS the gradient of nll_loss(mean) * train_size w.r.t. lse:
+// -(train_size / B) * g_loss at c == target[b], 0 elsewhere (gscale = train_size / B); thread 0 also writes d loss / d kl = beta * g_loss.
+template <bool ELBO>
 __global__ __launch_bounds__(256) void mc_tail_cb_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ lse,
                                                              const float* __restrict__ g, float* __restrict__ g_logits, int E, int C, int B,
-                                                             float add) {
+                                                             float add, const int64_t* __restrict__ target, const float* __restrict__ g_loss,
+                                                             float gscale, float beta, const float* __restrict__ beta_dev,
+                                                             float* __restrict__ g_kl) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float gl = 0.0f;
+    if (ELBO) {
+        gl = *g_loss;
+        if (i == 0 && g_kl != nullptr) *g_kl = (beta_dev ? *beta_dev : beta) * gl;
+    }
     if (i >= (int64_t)E * B) return;
     const int e = (int)(i / B), b = (int)(i - (int64_t)e * B);
     const float* p = logits + (int64_t)e * C * B + b;
@@ -471,17 +481,51 @@ __global__ __launch_bounds__(256) void mc_tail_cb_bwd_kernel(const float* __rest
     float se = 0.0f;
     for (int c = 0; c < C; ++c) se += expf(p[(int64_t)c * B] - mx);
     const float lz = mx + logf(se);
+    float* o = g_logits + (int64_t)e * C * B + b;
+    if (ELBO) {
+        const int64_t t = target[b];
+        float h = 0.0f, sum_h = 0.0f;
+        if (t >= 0 && t < C) {
+            const float ls = p[t * B] - lz;
+            h = -gscale * gl * expf(ls - (lse[(int64_t)b * C + t] + add));
+            sum_h = h;
+        }
+        for (int c = 0; c < C; ++c) {
+            const float ls = p[(int64_t)c * B] - lz;
+            o[(int64_t)c * B] = (c == t ? h : 0.0f) - expf(ls) * sum_h;
+        }
+        return;
+    }
     float sum_h = 0.0f;
     for (int c = 0; c < C; ++c) {
         const float ls = p[(int64_t)c * B] - lz;
         sum_h += g[(int64_t)b * C + c] * expf(ls - (lse[(int64_t)b * C + c] + add));
     }
-    float* o = g_logits + (int64_t)e * C * B + b;
     for (int c = 0; c < C; ++c) {
         const float ls = p[(int64_t)c * B] - lz;
         const float h = g[(int64_t)b * C + c] * expf(ls - (lse[(int64_t)b * C + c] + add));
         o[(int64_t)c * B] = h - expf(ls) * sum_h;
     }
+}
+
+// loss = nll_loss(lse, target, mean) * train_size + beta * kl (metrics.py:7-14 upstream) in one block: per-thread partial sums over the
+// images in a fixed stride, then a fixed tree -- the same value on every run.  Targets outside [0, C) contribute nothing.
+__global__ __launch_bounds__(256) void elbo_cb_kernel(const float* __restrict__ lse, const int64_t* __restrict__ target,
+                                                      const float* __restrict__ kl, float beta, const float* __restrict__ beta_dev,
+                                                      float train_size, int B, int C, float* __restrict__ loss) {
+    __shared__ float part[256];
+    float acc = 0.0f;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        const int64_t t = target[b];
+        if (t >= 0 && t < C) acc += lse[(int64_t)b * C + t];
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss = (-part[0] / (float)B) * train_size + (beta_dev ? *beta_dev : beta) * (*kl);
 }
 }  // namespace
 
@@ -494,8 +538,37 @@ extern "C" int bbb_mc_tail_cb_bwd(const float* logits, const float* lse, const f
     const int64_t n = (int64_t)draws * batch;
     const int64_t blocks = (n + 255) / 256;
     if (blocks > 0x7fffffffLL) return BBB_ESHAPE;
-    hipLaunchKernelGGL(mc_tail_cb_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, logits, lse, g_lse, g_logits, draws,
-                       classes, batch, mean_over > 0 ? logf((float)mean_over) : 0.0f);
+    hipLaunchKernelGGL(mc_tail_cb_bwd_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, logits, lse, g_lse, g_logits,
+                       draws, classes, batch, mean_over > 0 ? logf((float)mean_over) : 0.0f, (const int64_t*)nullptr, (const float*)nullptr,
+                       0.0f, 0.0f, (const float*)nullptr, (float*)nullptr);
+    return (int)hipGetLastError();
+}
+
+extern "C" int bbb_elbo_cb_fwd(const float* lse, const int64_t* target, const float* kl, float beta, const float* beta_dev,
+                               float train_size, int batch, int classes, float* loss_out, void* stream) {
+    if (lse == nullptr || target == nullptr || kl == nullptr || loss_out == nullptr || batch <= 0 || classes <= 0) return BBB_EINVAL;
+    if ((((uintptr_t)lse | (uintptr_t)kl | (uintptr_t)beta_dev | (uintptr_t)loss_out) & 3u) != 0 || ((uintptr_t)target & 7u) != 0)
+        return BBB_EALIGN;
+    hipLaunchKernelGGL(elbo_cb_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, lse, target, kl, beta, beta_dev, train_size, batch,
+                       classes, loss_out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int bbb_elbo_cb_bwd(const float* logits, const float* lse, const int64_t* target, const float* g_loss, float beta,
+                               const float* beta_dev, float train_size, float* g_logits, float* g_kl, int draws, int batch, int classes,
+                               int mean_over, void* stream) {
+    if (logits == nullptr || lse == nullptr || target == nullptr || g_loss == nullptr || g_logits == nullptr || draws <= 0 ||
+        batch <= 0 || classes <= 0 || mean_over < 0)
+        return BBB_EINVAL;
+    if ((((uintptr_t)logits | (uintptr_t)lse | (uintptr_t)g_loss | (uintptr_t)beta_dev | (uintptr_t)g_logits | (uintptr_t)g_kl) & 3u) != 0 ||
+        ((uintptr_t)target & 7u) != 0)
+        return BBB_EALIGN;
+    const int64_t n = (int64_t)draws * batch;
+    const int64_t blocks = (n + 255) / 256;
+    if (blocks > 0x7fffffffLL) return BBB_ESHAPE;
+    hipLaunchKernelGGL(mc_tail_cb_bwd_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, logits, lse,
+                       (const float*)nullptr, g_logits, draws, classes, batch, mean_over > 0 ? logf((float)mean_over) : 0.0f, target, g_loss,
+                       train_size / (float)batch, beta, beta_dev, g_kl);
     return (int)hipGetLastError();
 }
 

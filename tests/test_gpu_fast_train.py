@@ -367,6 +367,31 @@ def test_training_glue_kernels_vs_torch():
     assert torch.equal(ops.square(off), off * off)
 
 
+@pytest.mark.parametrize("E,C,B,dev_beta", [(1, 10, 256, False), (10, 10, 512, True), (3, 100, 36, False)])
+def test_fused_elbo_tail_matches_torch(E, C, B, dev_beta):
+    """ops.elbo_cb_autograd = F.nll_loss(logmeanexp(log_softmax(logits)), target) * train_size + beta * kl (metrics.py:7-14,
+    main_bayesian.py:49-56 upstream), values and both gradients; beta as a Python number or a device scalar (a captured step)."""
+    from bbb_hip import ops
+    g = torch.Generator(device="cuda").manual_seed(E * 100 + C)
+    logits = (torch.randn(E, C, B, device="cuda", generator=g) * 3).requires_grad_(True)
+    kl = (torch.rand((), device="cuda", generator=g) * 1e4).requires_grad_(True)
+    target = torch.randint(0, C, (B,), device="cuda", generator=g)
+    beta, n = 0.037, 50000.0
+    bt = torch.full((), beta, device="cuda") if dev_beta else beta
+    loss, lse = ops.elbo_cb_autograd(logits, kl, target, bt, n, E)
+    assert not lse.requires_grad
+    loss.backward()
+    l2 = logits.detach().double().requires_grad_(True)
+    k2 = kl.detach().double().requires_grad_(True)
+    lse2 = torch.logsumexp(F.log_softmax(l2.permute(0, 2, 1), dim=2), dim=0) - np.log(E)
+    want = F.nll_loss(lse2, target) * n + beta * k2
+    want.backward()
+    np.testing.assert_allclose(lse.cpu().numpy(), lse2.detach().float().cpu().numpy(), rtol=2e-5, atol=2e-5)
+    assert abs(loss.item() - want.item()) <= 2e-6 * abs(want.item())
+    np.testing.assert_allclose(logits.grad.cpu().numpy(), l2.grad.float().cpu().numpy(), rtol=2e-4, atol=2e-6 * n / B)
+    assert abs(kl.grad.item() - beta) <= 1e-7
+
+
 def test_hip_loss_tail_matches_the_torch_tail():
     """ops.mc_tail_cb_autograd (log_softmax + logmeanexp over the draws, forward and backward one HIP launch each) against the torch
     ops it replaced in the training step: values to 2e-6, gradients to 1e-5 of their largest magnitude, for 10 / 100 classes, one and
