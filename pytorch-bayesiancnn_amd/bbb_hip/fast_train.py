@@ -186,6 +186,16 @@ class _MCForward(torch.autograd.Function):
         side = _side_stream(g.device) if (g is not None and overlap_wgrad[0] and not torch.cuda.is_current_stream_capturing()) else None
         main = torch.cuda.current_stream(g.device) if side is not None else None
         keep = []
+        # the first layer's im2col depends on the batch alone: on a side stream NOW, beside the small last layers' launches, instead of
+        # in the tail of the chain where nothing else is left to run beside it
+        xk_first = [None]
+        r0 = tape[0]
+        if side is not None and g is not None and r0["x"].shape[1] % 4 != 0:
+            side.wait_stream(main)
+            xk_stream = side.current
+            with torch.cuda.stream(xk_stream):
+                xk_first[0] = ops.im2col_pbj(ctx.x_nchw, tuple(r0["w"].shape), *r0["geom"])
+            keep.append(xk_first[0])
         for li in range(len(tape) - 1, -1, -1):
             rec = tape[li]
             y, w5, x_in, act = rec["y"], rec["w"], rec["x"], rec["act"]
@@ -207,7 +217,7 @@ class _MCForward(torch.autograd.Function):
                     gw = ops.conv2d_chwn_weight_grad(g_pre, x_in, tuple(w5.shape), stride, padding, dilation)
                 else:
                     # 3-channel first layer: its input is shared by all draws, so the draws stack into the GEMM's row dimension
-                    gw = ops.conv2d_chwn_weight_grad_shared_input(g_pre, ctx.x_nchw, tuple(w5.shape), stride, padding, dilation)
+                    gw = ops.conv2d_chwn_weight_grad_shared_input(g_pre, ctx.x_nchw, tuple(w5.shape), stride, padding, dilation, xk=xk_first[0])
                 gws[2 * li] = gw.reshape(ws_shape(rec))
 
             if side is not None and not rec["first"]:
@@ -216,6 +226,8 @@ class _MCForward(torch.autograd.Function):
                 with torch.cuda.stream(side.current):
                     weight_side()
             else:
+                if rec["first"] and xk_first[0] is not None:
+                    main.wait_stream(xk_stream)
                 weight_side()
             if not rec["first"]:
                 g = ops.conv2d_chwn_input_grad(g_pre, w5, (x_in.shape[2], x_in.shape[3]), padding, dilation)
@@ -397,9 +409,9 @@ class _MCForwardLRT(torch.autograd.Function):
                     gw_var = ops.conv2d_chwn_weight_grad(g_var, ops.square(x_in), wshape, stride, padding, dilation)
                     gw_mu, gw_var = ops.sum_over_draws(gw_mu), ops.sum_over_draws(gw_var)
                 else:
-                    xn = ctx.x_nchw
-                    gw_mu = ops.conv2d_chwn_weight_grad_shared_input(g_mu, xn, wshape, stride, padding, dilation)[0]
-                    gw_var = ops.conv2d_chwn_weight_grad_shared_input(g_var, ops.square(xn), wshape, stride, padding, dilation)[0]
+                    xk = ops.im2col_pbj(ctx.x_nchw, wshape, stride, padding, dilation)      # (its square = the im2col of x^2)
+                    gw_mu = ops.conv2d_chwn_weight_grad_shared_input(g_mu, None, wshape, stride, padding, dilation, xk=xk)[0]
+                    gw_var = ops.conv2d_chwn_weight_grad_shared_input(g_var, None, wshape, stride, padding, dilation, xk=ops.square(xk))[0]
                 m = rec["layer"]
                 grads[4 * li] = gw_mu.reshape(m.W_mu.shape)
                 grads[4 * li + 1] = gw_var.reshape(m.W_mu.shape)

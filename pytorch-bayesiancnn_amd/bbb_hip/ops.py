@@ -8,6 +8,7 @@ anywhere.  Activations, pooling and the loss tail use torch autograd (element-wi
 """
 import contextlib
 import ctypes
+import os
 import itertools
 import sys
 import threading
@@ -2095,29 +2096,40 @@ def conv2d_chwn_weight_grad(g_pre, x, w_shape, stride, padding, dilation, x_squa
     return y[:, :, :kh, :kw, :].permute(0, 1, 4, 2, 3).contiguous()
 
 
-def conv2d_chwn_weight_grad_shared_input(g_pre, x_nchw, w_shape, stride, padding, dilation):
+def im2col_pbj(x_nchw, w_shape, stride, padding, dilation):
+    """The im2col of a shared first-layer input for conv2d_chwn_weight_grad_shared_input (bbb_im2col_pbj): x [B, Cin, H, W] ->
+    [Ho * Wo, B, Jp] with j = (ci, r, q), Jp = Cin * kh * kw rounded up to 4 (zero columns).  It depends on the batch alone: a
+    training step may build it off the gradient chain; its elementwise square is the im2col of x^2 (the LRT variance side)."""
+    _, Cout, Cin, kh, kw = w_shape
+    x_nchw = x_nchw.contiguous()
+    dd, ho, wo = _desc(x_nchw.unsqueeze(0), _Shape((1, Cout, Cin, kh, kw)), stride, padding, dilation, 1, False, False, None)
+    Jp = (Cin * kh * kw + 3) // 4 * 4
+    xk = torch.empty((ho * wo, x_nchw.shape[0], Jp), dtype=torch.float32, device=x_nchw.device)
+    with on_device(x_nchw.device):
+        check(_lib.lib().bbb_im2col_pbj(x_nchw.data_ptr(), xk.data_ptr(), ctypes.byref(dd), cur_stream(x_nchw.device)), "bbb_im2col_pbj")
+    return xk
+
+
+def conv2d_chwn_weight_grad_shared_input(g_pre, x_nchw, w_shape, stride, padding, dilation, xk=None):
     """Weight gradient of a layer whose INPUT is the same for every draw (a model's first layer; 3-channel images do not fit
     the role-swapped launch, whose innermost axis would be Cin).  The draws stack into the row dimension instead:
         GW[(e, n)][j] = sum_k G[(e, n)][k] * Xcol[k][j],   k = (output pixel, image), j = (ci, r, q)
     -- g_pre's own memory IS the [E*Cout, K] matrix G, Xcol is the im2col of the shared input (built once: F.unfold + one
     permute), and the product runs on the forward kernel as a 1x1 "convolution" with K as the contraction channels and j as
     the innermost axis, K split into S slices that run as the launch's draws (w_row_pitch lets a slice of G's rows be read in
-    place) and are summed in a fixed order.  g_pre [E, Cout, Ho, Wo, B], x_nchw [B, Cin, H, W] -> [E, Cout, Cin, kh, kw]."""
+    place) and are summed in a fixed order.  g_pre [E, Cout, Ho, Wo, B], x_nchw [B, Cin, H, W] -> [E, Cout, Cin, kh, kw].
+    xk: im2col_pbj(x_nchw, ...) built ahead (x_nchw is then only checked for its batch size and may be None)."""
     E, Cout, Ho, Wo, B = g_pre.shape
     _, _, Cin, kh, kw = w_shape
-    x_nchw = x_nchw.contiguous()
-    dd, ho, wo = _desc(x_nchw.unsqueeze(0), torch.empty((1, Cout, Cin, kh, kw), device="meta"), stride, padding, dilation, 1, False,
-                       False, None)
-    if (ho, wo) != (Ho, Wo) or x_nchw.shape[0] != B:
-        raise _lib.BBBHipError("conv2d_chwn_weight_grad_shared_input: geometry mismatch")
     J, P_ = Cin * kh * kw, Ho * Wo
     Jp = (J + 3) // 4 * 4
     K = P_ * B
-    xk = torch.empty((P_, B, Jp), dtype=torch.float32, device=g_pre.device)
-    with on_device(g_pre.device):
-        check(_lib.lib().bbb_im2col_pbj(x_nchw.data_ptr(), xk.data_ptr(), ctypes.byref(dd), cur_stream(g_pre.device)), "bbb_im2col_pbj")
+    if xk is None:
+        xk = im2col_pbj(x_nchw, w_shape, stride, padding, dilation)
+    if tuple(xk.shape) != (P_, B, Jp) or not xk.is_contiguous():
+        raise _lib.BBBHipError("conv2d_chwn_weight_grad_shared_input: geometry mismatch")
     M = E * Cout
-    wgs = -(-M // 64) * -(-Jp // 64)
+    wgs = -(-M // 64) * -(-Jp // 128)            # slices sized for the launcher's 128-wide tiles (>= 768 of them; 64-wide: 2.50 -> 2.48 ms per 512 x 10 step)
     S = 1
     while wgs * S < 768 and K % (2 * S) == 0 and (K // (2 * S)) % 4 == 0 and K // (2 * S) >= 256:
         S *= 2

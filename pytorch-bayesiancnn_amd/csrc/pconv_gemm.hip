@@ -266,6 +266,9 @@ int launch(PConvArgs& a, int draws, hipStream_t st) {
     }
     const int64_t nb128 = pixels * ((a.B + 127) / 128) * a.G;
     int bm = (LRT || nb128 < 768) ? 64 : 128;        // (round 3 re-measured 600 / 300: conv4 +10 %, conv5 +25 % slower with 128)
+    // an image axis that 128-wide tiles would pad by >= 25 % and 64-wide ones by less (192 = the input channels of conv3's
+    // role-swapped weight gradient: 256 against 192): 64.  Same sums per element either way.
+    if (bm == 128 && (a.B + 127) / 128 * 128 * 4 >= a.B * 5 && (a.B + 63) / 64 * 64 < (a.B + 127) / 128 * 128) bm = 64;
     const int64_t items64 = pixels * ((a.B + 63) / 64) * a.G;
     const bool cross = a.ksplit > 1 && a.part != nullptr && items64 <= split_max_items(LRT);
     if (cross) bm = 64;
