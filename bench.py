@@ -1063,7 +1063,7 @@ def training_step(dev, steps):
                                 "whole step's wall time"},
            "launch_by_launch_ms_per_step": round(1e3 * res["launch_by_launch"], 4), "path": path,
            "note": "BayesianAlexNet bs=512 num_ens=10, fp32, train.train_step as called: steps of >= 2048 (image x draw) rows stay launch by "
-                   "launch (GPU-bound; weight gradients on two side streams beside the input gradients, HIP loss tail incl. the ELBO: round 6 3.02 -> 2.52 ms), smaller "
+                   "launch (GPU-bound; weight gradients on two side streams beside the input gradients, HIP loss tail incl. the ELBO: round 6 3.02 -> 2.47 ms), smaller "
                    "ones capture themselves as one hipGraph after 3 identical calls; round 1 (reference-layout autograd path): 8.3 ms"}
     del net, x, y, opt
     # the reference's own defaults (config_bayesian.py:1-18: layer_type 'lrt', batch_size 256, train_ens 1): eager and as one hipGraph
