@@ -182,6 +182,11 @@ typedef struct bbb_conv_desc {
                              conv1) -> y [draws][cout][hp][wp][B]; the maximum is taken over the fp32 contraction results, then
                              bias, activation and the bf16 rounding once per pooled pixel (non-decreasing: the same values as
                              bbb_maxpool_chwn_bf16 of the unfused launch). */
+    int32_t w_tap_major;  /* fp32 batch-innermost entries (bbb_conv2d_chwn_fwd, _splitk_fwd, the LRT forms; ABI 13): 1 = w rows are
+                             [kh][kw][cin] instead of [cin][kh][kw] AND the contraction runs tap-major (in-bounds taps outermost, cin
+                             innermost) -- the same products, summed in another order.  Training extension: the role-swapped weight
+                             gradient reads the output gradient [cout][ho][wo][batch] in place as such a weight operand (no
+                             transposed copy).  Elsewhere it must be 0. */
 } bbb_conv_desc_t;
 
 /*

@@ -38,7 +38,7 @@ class ConvDesc(ctypes.Structure):
                 ("dil_h", c_i32), ("dil_w", c_i32), ("draws", c_i32), ("x_draw_stride", c_i64),
                 ("w_draw_stride", c_i64), ("b_draw_stride", c_i64), ("act", c_i32),
                 ("unit_div", c_i32), ("unit_off", c_i32), ("x_unit_mod", c_i32), ("w_row_pitch", c_i32), ("b_offset", c_i32),
-                ("x_unit_div", c_i32), ("x_unit_off", c_i32), ("pool", c_i32)]
+                ("x_unit_div", c_i32), ("x_unit_off", c_i32), ("pool", c_i32), ("w_tap_major", c_i32)]
 
 
 _SIGNATURES = {

@@ -509,7 +509,7 @@ def _pool_fusion_rule(x_shape, w_shape, stride, padding, dilation, draws, pool_m
 
 
 def conv2d_chwn_forward(x, w, bias, stride=1, padding=0, dilation=1, act=None, out=None, units=None, n_units=None,
-                        x_per_slice=False, x_div=1, bf16x3=None, x_s3=False, out_s3=False, x_off=0, pool=False):
+                        x_per_slice=False, x_div=1, bf16x3=None, x_s3=False, out_s3=False, x_off=0, pool=False, w_tap_major=False):
     """Batch-innermost conv for the ensemble path.  x: [E|1, Cin, H, W, B] (B % 4 == 0); w: [E|1, Cout, Cin, kh, kw];
     bias [E|1, Cout] or None -> y [E, Cout, Ho, Wo, B].  Padding taps are skipped, not multiplied.
     Work units (ensemble sharding): units = (S, off), n_units = U output slabs; w / bias hold the weight sets of the draws
@@ -522,11 +522,19 @@ def conv2d_chwn_forward(x, w, bias, stride=1, padding=0, dilation=1, act=None, o
     tensor [E|1, 3, C, H, W, B] holding the hi / mid / lo pieces of the same fp32 values (s3_from_f32 / s3_to_f32).
     pool = True (fp32 kernel, layers without a split contraction, even Ho and Wo): the launch also applies MaxPool2d(2, 2) to the
     activated output -> y [E, Cout, Ho/2, Wo/2, B], bit for bit maxpool_chwn(conv2d_chwn_forward(...), 2, 2) (pool_fusion_ok says
-    when that pays)."""
+    when that pays).
+    w_tap_major = True (fp32 kernel only): w is given as [E|1, Cout, kh, kw, Cin] and the contraction runs tap-major
+    (bbb_conv_desc_t::w_tap_major) -- the same products in another summation order."""
     require_device(w, bias)
     require_device(x, dtype=torch.bfloat16 if x_s3 else torch.float32)
     x, w = x.contiguous(), w.contiguous()
     bias = None if bias is None else bias.contiguous()
+    w_mem = w
+    if w_tap_major:
+        if x_s3 or out_s3 or bf16x3:
+            raise _lib.BBBHipError("w_tap_major: fp32 kernel only")
+        bf16x3 = False
+        w = _Shape((w.shape[0], w.shape[1], w.shape[4], w.shape[2], w.shape[3]))
     if x_s3:
         if x.dim() != 6 or x.shape[1] != 3 or x.shape[5] % 8:
             raise _lib.BBBHipError("an S3 input is a bf16 tensor [E|1, 3, C, H, W, B] with B % 8 == 0")
@@ -552,6 +560,8 @@ def conv2d_chwn_forward(x, w, bias, stride=1, padding=0, dilation=1, act=None, o
         d, ho, wo = _desc_chwn(x5, w, stride, padding, dilation, E, x5.shape[0] == 1 and E > 1, w.shape[0] == 1 and E > 1, act)
     if x_s3:
         d.x_draw_stride *= 3                                   # bf16 elements per S3 slab
+    if w_tap_major:
+        d.w_tap_major = 1
     B = x5.shape[4]
     if pool:
         if x_s3 or out_s3 or bf16x3 or ho % 2 or wo % 2:
@@ -571,7 +581,7 @@ def conv2d_chwn_forward(x, w, bias, stride=1, padding=0, dilation=1, act=None, o
     with on_device(x.device):
         if x_s3 or out_s3 or (not pool and (bf16x3 if bf16x3 is not None else current_config().gemm_mode == "bf16x3")
                               and E * ho * wo * -(-w.shape[1] // 64) * -(-B // 128) >= current_config().bf16x3_min_workgroups):
-            check(_lib.lib().bbb_conv2d_chwn_bf16x3_fwd(ctypes.byref(d), x.data_ptr(), w.data_ptr(), ptr(bias), y.data_ptr(),
+            check(_lib.lib().bbb_conv2d_chwn_bf16x3_fwd(ctypes.byref(d), x.data_ptr(), w_mem.data_ptr(), ptr(bias), y.data_ptr(),
                                                         (1 if x_s3 else 0) | (2 if out_s3 else 0), cur_stream(x.device)),
                   "bbb_conv2d_chwn_bf16x3_fwd")
             return y
@@ -579,11 +589,11 @@ def conv2d_chwn_forward(x, w, bias, stride=1, padding=0, dilation=1, act=None, o
         if ks > 1 and pool:
             raise _lib.BBBHipError("pool=True: this layer's contraction is split (conv + maxpool_chwn instead)")
         if ks > 1:
-            check(_lib.lib().bbb_conv2d_chwn_splitk_fwd(ctypes.byref(d), x.data_ptr(), w.data_ptr(), ptr(bias), y.data_ptr(), ks,
+            check(_lib.lib().bbb_conv2d_chwn_splitk_fwd(ctypes.byref(d), x.data_ptr(), w_mem.data_ptr(), ptr(bias), y.data_ptr(), ks,
                                                         ptr(scr), 0 if scr is None else scr.numel(), cur_stream(x.device)),
                   "bbb_conv2d_chwn_splitk_fwd")
         else:
-            check(_lib.lib().bbb_conv2d_chwn_fwd(ctypes.byref(d), x.data_ptr(), w.data_ptr(), ptr(bias), y.data_ptr(),
+            check(_lib.lib().bbb_conv2d_chwn_fwd(ctypes.byref(d), x.data_ptr(), w_mem.data_ptr(), ptr(bias), y.data_ptr(),
                                                  cur_stream(x.device)), "bbb_conv2d_chwn_fwd")
     return y
 
@@ -2043,6 +2053,12 @@ def chwn_grad_as_weights(g, chunks=1):
     return out
 
 
+# conv2d_chwn_weight_grad may read a large launch's output gradient in place as a tap-major weight operand (no transposed copy, 250 MB
+# per 512 x 10 step).  Measured slower, so off: 2.54 against 2.47 ms per step (profiles/experiments/ab_wgrad_inplace.py) -- with the
+# images innermost in k, consecutive rows of the role-swapped input are a whole image apart instead of adjacent.
+wgrad_in_place = [False]
+
+
 def conv2d_chwn_weight_grad(g_pre, x, w_shape, stride, padding, dilation, x_squares=False):
     """d loss / d w in the batch-innermost layout, again on the forward kernel with the roles swapped: the batch becomes the
     contraction channels, the layer's input channels the innermost ("image") axis, the output pixels the kernel taps:
@@ -2079,12 +2095,17 @@ def conv2d_chwn_weight_grad(g_pre, x, w_shape, stride, padding, dilation, x_squa
     S = 1
     while wgs * S < 512 and B % (2 * S) == 0 and B // (2 * S) >= 8:
         S *= 2
-    gr = chwn_grad_as_weights(g_pre, S)                                 # [E*S, Cout, B/S, Ho, Wo]
-    if S > 1:
-        if xr.shape[0] == 1 and E > 1:
-            xr = xr.expand(E, *xr.shape[1:])
-        xr = xr.reshape(xr.shape[0] * S, B // S, *xr.shape[2:])
-    y = conv2d_chwn_forward(xr, gr, None, (dh, dw), (ph, pw), (sh, sw))  # [E*S, Cout, kh', kw', Cin], kh' >= kh
+    if S == 1 and wgrad_in_place[0] and current_config().gemm_mode != "bf16x3":
+        # the output gradient [E, Cout, Ho, Wo, B] IS a tap-major weight operand (taps = output pixels, channels = images): read in
+        # place, the contraction running (pixel, image) instead of (image, pixel) -- no transposed copy (250 MB per 512 x 10 step)
+        y = conv2d_chwn_forward(xr, g_pre.contiguous(), None, (dh, dw), (ph, pw), (sh, sw), w_tap_major=True)
+    else:
+        gr = chwn_grad_as_weights(g_pre, S)                             # [E*S, Cout, B/S, Ho, Wo]
+        if S > 1:
+            if xr.shape[0] == 1 and E > 1:
+                xr = xr.expand(E, *xr.shape[1:])
+            xr = xr.reshape(xr.shape[0] * S, B // S, *xr.shape[2:])
+        y = conv2d_chwn_forward(xr, gr, None, (dh, dw), (ph, pw), (sh, sw))  # [E*S, Cout, kh', kw', Cin], kh' >= kh
     if y.shape[2] == kh and y.shape[3] == kw:                           # sum_s [E, S, Cout, kh*kw, Cin] -> [E, Cout, Cin, kh*kw]
         gw = torch.empty((E, Cout, Cin, kh, kw), dtype=torch.float32, device=y.device)
         T = kh * kw

@@ -299,7 +299,7 @@ int check_desc(const bbb_conv_desc_t* d, ConvArgs& a) {
         d->stride_h <= 0 || d->stride_w <= 0 || d->pad_h < 0 || d->pad_w < 0 || d->dil_h <= 0 || d->dil_w <= 0 ||
         d->draws <= 0 || d->act < 0 || d->act > 2)
         return BBB_EINVAL;
-    if (d->unit_div > 1 || d->x_unit_mod != 0 || d->b_offset != 0 || d->w_row_pitch != 0 || d->x_unit_div > 1 || d->x_unit_off != 0 || d->pool != 0) return BBB_EINVAL;   // batch-innermost entries only
+    if (d->unit_div > 1 || d->x_unit_mod != 0 || d->b_offset != 0 || d->w_row_pitch != 0 || d->x_unit_div > 1 || d->x_unit_off != 0 || d->pool != 0 || d->w_tap_major != 0) return BBB_EINVAL;   // batch-innermost entries only
     const int ho = (d->h + 2 * d->pad_h - d->dil_h * (d->kh - 1) - 1) / d->stride_h + 1;
     const int wo = (d->w + 2 * d->pad_w - d->dil_w * (d->kw - 1) - 1) / d->stride_w + 1;
     if (ho <= 0 || wo <= 0) return BBB_ESHAPE;

@@ -1554,7 +1554,7 @@ extern "C" int bbb_conv2d_chwn_bf16_fwd(const bbb_conv_desc_t* d, const void* x,
     a.x_inv = x_inv;
     a.wtap = tap_major ? 1 : 0;
     if (d->unit_div < 0 || d->unit_off < 0 || d->x_unit_mod < 0 || (d->unit_div > 1 && d->unit_off >= d->unit_div) ||
-        (d->x_unit_mod > 0 && d->x_unit_mod != d->unit_div) || d->w_row_pitch != 0)
+        (d->x_unit_mod > 0 && d->x_unit_mod != d->unit_div) || d->w_row_pitch != 0 || d->w_tap_major != 0)
         return BBB_EINVAL;
     // pooling in the launch (bbb_conv_desc_t::pool): first layers with a short contraction only (pconv_bf16_smallk_pool_kernel);
     // 1 = MaxPool2d(2, 2), (k << 8) | s otherwise; admitted: 2 / 2 and 3 / 2 (at most one window closes per conv column)

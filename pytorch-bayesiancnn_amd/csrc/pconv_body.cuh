@@ -109,6 +109,7 @@ __device__ __forceinline__ void pconv_item(const PConvArgs& p, const int64_t ite
     // in-bounds tap ranges of the current conv pixel (POOL: re-set per window pixel; all wave-uniform)
     int ihb, iwb, r_lo, q_lo, nq, nrq, Keff, ntiles;
     float inv_nrq, inv_nq;
+    const float inv_cin = 1.0f / (float)p.Cin;
     auto set_pixel = [&](int oh, int ow) {
         if constexpr (POOL) {            // re-set inside a loop: keep the pixel's state in scalar registers
             oh = __builtin_amdgcn_readfirstlane(oh);
@@ -171,14 +172,21 @@ __device__ __forceinline__ void pconv_item(const PConvArgs& p, const int64_t ite
         const int k = chunk * KCH + tid;
         uint32_t wo = kWInv, xo = kXInv;
         if (k < Keff) {
-            int ci = (int)((float)k * inv_nrq);
-            int rq = k - ci * nrq;
-            if (rq < 0) { --ci; rq += nrq; } else if (rq >= nrq) { ++ci; rq -= nrq; }
+            int ci, rq;
+            if (p.wtap) {                     // tap-major contraction (bbb_conv_desc_t::w_tap_major): k = (in-bounds tap, ci)
+                rq = (int)((float)k * inv_cin);
+                ci = k - rq * p.Cin;
+                if (ci < 0) { --rq; ci += p.Cin; } else if (ci >= p.Cin) { ++rq; ci -= p.Cin; }
+            } else {
+                ci = (int)((float)k * inv_nrq);
+                rq = k - ci * nrq;
+                if (rq < 0) { --ci; rq += nrq; } else if (rq >= nrq) { ++ci; rq -= nrq; }
+            }
             int rr = (int)((float)rq * inv_nq);
             int qq = rq - rr * nq;
             if (qq < 0) { --rr; qq += nq; } else if (qq >= nq) { ++rr; qq -= nq; }
             const int r = r_lo + rr, q = q_lo + qq;
-            wo = (uint32_t)(ci * p.khkw + r * p.kw + q) * 4u;                                    // byte offset in a row
+            wo = (p.wtap ? (uint32_t)((r * p.kw + q) * p.Cin + ci) : (uint32_t)(ci * p.khkw + r * p.kw + q)) * 4u;   // byte offset in a row
             xo = (uint32_t)((ci * p.H + ihb + r * p.dh) * p.W + iwb + q * p.dw) * (uint32_t)p.B * 4u;   // row byte offset
         }
         kt_w[chunk & 1][tid] = (int32_t)wo;

@@ -642,7 +642,7 @@ int c8x3_launch(const bbb_conv_desc_t* d, const void* x, const float* w, const f
         return BBB_EINVAL;
     if (d->batch <= 0 || d->cin <= 0 || d->h <= 0 || d->w <= 0 || d->cout <= 0 || d->kh <= 0 || d->kw <= 0 || d->stride_h <= 0 ||
         d->stride_w <= 0 || d->pad_h < 0 || d->pad_w < 0 || d->dil_h <= 0 || d->dil_w <= 0 || d->draws <= 0 || d->act < 0 || d->act > 2 ||
-        d->pool != 0 || d->w_row_pitch != 0)
+        d->pool != 0 || d->w_row_pitch != 0 || d->w_tap_major != 0)
         return BBB_EINVAL;
     const bool of32 = (flags & BBB_C8X3_OUT_F32) != 0;
     const bool poolp = (flags & BBB_C8X3_POOL) != 0;

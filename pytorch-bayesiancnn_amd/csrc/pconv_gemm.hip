@@ -219,6 +219,8 @@ int fill(const bbb_conv_desc_t* d, PConvArgs& a) {
     a.x_div = d->x_unit_div; a.x_off = d->x_unit_off;
     if (d->pool != 0 && d->pool != 1) return BBB_EINVAL;
     a.pool = d->pool;
+    if (d->w_tap_major != 0 && d->w_tap_major != 1) return BBB_EINVAL;
+    a.wtap = d->w_tap_major;
     if (a.pool) {
         if ((ho & 1) || (wo & 1)) return BBB_EINVAL;
         a.y_ds = (int64_t)d->cout * (ho / 2) * (wo / 2) * d->batch;
@@ -410,7 +412,7 @@ extern "C" int bbb_conv2d_chwn_bf16x3_fwd(const bbb_conv_desc_t* d, const void* 
     PConvArgs a = {};
     const int rc = fill(d, a);
     if (rc != 0) return rc;
-    if (x == nullptr || w == nullptr || y == nullptr || (flags & ~3u) != 0 || a.pool) return BBB_EINVAL;
+    if (x == nullptr || w == nullptr || y == nullptr || (flags & ~3u) != 0 || a.pool || a.wtap) return BBB_EINVAL;
     if ((((uintptr_t)x | (uintptr_t)y) & 15u) != 0 || (((uintptr_t)w | (uintptr_t)bias) & 3u) != 0) return BBB_EALIGN;
     const bool xs3 = (flags & BBB_S3_IN) != 0, ys3 = (flags & BBB_S3_OUT) != 0;
     if ((xs3 || ys3) && d->batch % 8 != 0) return BBB_ESHAPE;           // S3 rows move as 16-byte vectors of 8 bf16

@@ -102,6 +102,49 @@ def test_chwn_wgrad_dgrad_vs_torch_float64(env, Cin, Cout, kk, pad, H):
         np.testing.assert_allclose(gx[e].cpu().numpy(), xt.grad.permute(1, 2, 3, 0).float().cpu().numpy(), rtol=2e-4, atol=2e-4)
 
 
+@pytest.mark.parametrize("E,Cin,Cout,kk,pad,H,B,act", [(2, 8, 12, 3, 1, 6, 8, None), (3, 64, 70, 5, 2, 4, 4, "softplus"), (1, 16, 10, 1, 0, 1, 16, None),
+                                                         (2, 20, 33, 3, 0, 7, 12, "relu")])
+def test_tap_major_weight_operand(env, E, Cin, Cout, kk, pad, H, B, act):
+    """bbb_conv_desc_t::w_tap_major: weights given as [E, Cout, kh, kw, Cin], contraction (tap, channel) instead of (channel, tap):
+    the same products, so the plain launch's result up to fp32 summation order -- plain and split-contraction launches."""
+    ops = env["ops"]
+    g = torch.Generator(device="cuda").manual_seed(Cin + Cout)
+    x = torch.randn(E, Cin, H, H, B, device="cuda", generator=g)
+    w = torch.randn(E, Cout, Cin, kk, kk, device="cuda", generator=g) * 0.2
+    b = torch.randn(E, Cout, device="cuda", generator=g)
+    w_tm = w.permute(0, 1, 3, 4, 2).contiguous()
+    for split in (False, True):
+        with ops.use_config(split_k=split):
+            want = ops.conv2d_chwn_forward(x, w, b, 1, pad, 1, act=act)
+            got = ops.conv2d_chwn_forward(x, w_tm, b, 1, pad, 1, act=act, w_tap_major=True)
+        np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=2e-5)
+    with pytest.raises(Exception):
+        ops.conv2d_chwn_forward(x, w_tm, b, 1, pad, 1, w_tap_major=True, bf16x3=True)
+
+
+@pytest.mark.parametrize("E,shared", [(2, False), (3, True)])
+def test_chwn_wgrad_reads_the_output_gradient_in_place(env, E, shared):
+    """A launch that is not cut into batch chunks CAN read g_pre [E, Cout, Ho, Wo, B] in place as a tap-major weight operand
+    (ops.wgrad_in_place, an option): same gradient as the transposed-copy form up to summation order, and as torch's in float64."""
+    ops = env["ops"]
+    g = torch.Generator(device="cuda").manual_seed(40 + E)
+    Cin, Cout, kk, pad, H, B = 64, 192, 5, 2, 4, 4                       # (B = 4: no chunks)
+    x = torch.randn(1 if shared else E, Cin, H, H, B, device="cuda", generator=g)
+    gy = torch.randn(E, Cout, H, H, B, device="cuda", generator=g)
+    old = ops.conv2d_chwn_weight_grad(gy, x, (E, Cout, Cin, kk, kk), 1, pad, 1)
+    ops.wgrad_in_place[0] = True                                          # (off by default: measured slower on the metric shape)
+    try:
+        got = ops.conv2d_chwn_weight_grad(gy, x, (E, Cout, Cin, kk, kk), 1, pad, 1)
+    finally:
+        ops.wgrad_in_place[0] = False
+    np.testing.assert_allclose(got.cpu().numpy(), old.cpu().numpy(), rtol=2e-5, atol=2e-5)
+    for e in range(E):
+        xt = x[0 if shared else e].permute(3, 0, 1, 2).double()
+        wt = torch.zeros(Cout, Cin, kk, kk, device="cuda", dtype=torch.float64, requires_grad=True)
+        F.conv2d(xt, wt, None, 1, pad).backward(gy[e].permute(3, 0, 1, 2).double())
+        np.testing.assert_allclose(got[e].cpu().numpy(), wt.grad.float().cpu().numpy(), rtol=2e-4, atol=2e-4)
+
+
 @pytest.mark.parametrize("E,shared", [(1, False), (3, False), (3, True)])
 def test_chwn_wgrad_batch_chunks_vs_torch_float64(env, E, shared):
     """A launch of few workgroups splits the batch into S chunks that run as extra draws: the output gradient lands in the
