@@ -317,10 +317,16 @@ class LaunchConfig:
     pool_fuse_weight_budget   bytes of weight tiles concurrently live per XCD that a fused launch may have (see pool_fusion_ok)
     c8x3        split-bf16 mode: layers with Cin % 16 == 0 take the MFMA-ready-operand kernel (csrc/pconv_c8x3.hip), whatever the
                 launch size (a property of the layer: partitions of a step keep its bits)
-    c8x3_s2d    ... and a strided first layer on few channels (s2d_layer_ok: AlexNet conv1) joins them in space-to-depth form"""
+    c8x3_s2d    ... and a strided first layer on few channels (s2d_layer_ok: AlexNet conv1) joins them in space-to-depth form
+    dropin_precision   "fp32" | "bf16": what a whole-model `net(x)` through the drop-in layers computes in.  "bf16" = the bf16 storage
+                path of ensemble.mc_forward(precision="bf16") (sampled weights and activations in bf16, fp32 accumulation, fp32 logits)
+                behind the unmodified `for j in range(num_ens): net(x)` loop -- inference only, BBB models the batch-innermost path
+                covers; anything else (autograd enabled, LRT layers, hooks, a layer called on its own) raises instead of silently
+                computing in fp32"""
     FIELDS = ("gemm_mode", "bf16x3_min_workgroups", "s3_min_images", "split_k", "pool_fusion", "pool_fuse_min_items",
               "pool_fuse_imbalance", "launches_overlap", "pool_fuse_min_items_overlapped", "pool_fuse_weight_budget",
-              "bf16_pool_fuse_min_rows", "bf16_pool_fuse_min_rows_overlapped", "bf16_c8", "bf16_c8_min_items", "c8x3", "c8x3_s2d")
+              "bf16_pool_fuse_min_rows", "bf16_pool_fuse_min_rows_overlapped", "bf16_c8", "bf16_c8_min_items", "c8x3", "c8x3_s2d",
+              "dropin_precision")
     __slots__ = FIELDS
 
     def __init__(self, **kw):
@@ -340,6 +346,7 @@ class LaunchConfig:
         self.bf16_c8 = True                            # (bf16_c8_input_ok) channel-interleaved activations between a pooled first layer and a
         self.bf16_c8_min_items = 0                     # layer that has the strip form over them, for launches of at least this many strip
                                                        # workgroups (0: always -- measured faster from one step per launch on); False: never
+        self.dropin_precision = "fp32"
         self.c8x3 = True                               # split-bf16 mode: layers (behind the first) with Cin % 32 == 0 run on the
                                                        # MFMA-ready-operand kernel (conv2d_c8x3_forward: channel-interleaved split
                                                        # activations + tap-major weights from the parameter pass); False: round 4's

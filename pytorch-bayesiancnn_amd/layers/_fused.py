@@ -24,7 +24,8 @@ def enter(wrapper):
     from ._base import BayesianLayer
     if isinstance(wrapper, BayesianLayer):
         return None
-    layers = [m for m in wrapper.modules() if isinstance(m, BayesianLayer)]
+    from bbb_hip import ensemble
+    layers = ensemble.bayesian_layers(wrapper)           # (cached on the module: walking the tree costs ~10 us per forward)
     if not layers:
         return None
     sc = _Scope()
@@ -78,7 +79,7 @@ speculation = {"enabled": True, "max_draws": 32,
                "graph_after": 2, "graphs": 4}
 
 
-def _logit_graph(wrapper, st, x, K, seed, pver):
+def _logit_graph(wrapper, st, x, K, seed, pver, precision="fp32"):
     """The cached GraphedLogits for this (model, input shape, K, seed, parameter storage, kernel modes), building it on the
     `graph_after`-th sighting; None = run eagerly (not seen often enough yet, capture not possible, or the path does not apply)."""
     from bbb_hip import ensemble, ops
@@ -98,7 +99,7 @@ def _logit_graph(wrapper, st, x, K, seed, pver):
         # an optimisation of a forward the eager path serves anyway: whatever goes wrong while warming up / capturing (allocator,
         # a capture the runtime refuses) must not surface from the user's net(x) -- this key simply stays eager
         try:
-            g = ensemble.GraphedLogits(wrapper, x, K)
+            g = ensemble.GraphedLogits(wrapper, x, K, precision=precision)
             ent[1] = g if g.graph is not None else False
         except Exception as exc:                       # noqa: BLE001
             ent[1] = False
@@ -288,6 +289,12 @@ def fast_forward(wrapper, x):
     if _hooks_present(wrapper, mods):
         return None
     grad = torch.is_grad_enabled() and ensemble.any_requires_grad(wrapper)
+    from bbb_hip import ops
+    prec = ops.current_config().dropin_precision
+    if prec != "fp32":
+        if grad:
+            return None                               # (ModuleWrapper.forward raises: bf16 is inference only)
+        ensemble._check_precision(prec, wrapper, x, True)     # raises unless the bf16 inference path covers this model and input
     if grad:
         # training / the reference's validate loop (which does not disable autograd): the same kernels behind ONE autograd node
         from bbb_hip import fast_train
@@ -304,7 +311,8 @@ def fast_forward(wrapper, x):
     # parameter versions AND storage addresses (module.to() / .data assignments replace storage without a version bump), plus the
     # identity of the cached structure (a replaced layer or Parameter object rebuilds it)
     pver = (id(st),) + tuple((p._version, p.data_ptr()) for p in st["params"])
-    same_x = sp.xref is not None and sp.xref() is x and sp.xver == x._version and sp.pver == pver and sp.grad == grad
+    mode = (grad, prec)                               # (cached draws belong to one autograd mode and one precision)
+    same_x = sp.xref is not None and sp.xref() is x and sp.xver == x._version and sp.pver == pver and sp.grad == mode
     can_spec = speculation["enabled"] and rng._graph_counter["tensor"] is None and not torch.cuda.is_current_stream_capturing()
     seed, call = rng.get_state()
     if same_x and grad and sp.logits is not None and getattr(sp.logits, "bbb_cfg", {}).get("spent"):
@@ -337,12 +345,12 @@ def fast_forward(wrapper, x):
         from bbb_hip import fast_train
         logits, kl = fast_train.mc_logits_autograd(wrapper, x, K, seed, call)
     else:
-        g = _logit_graph(wrapper, st, x, K, seed, pver) if K > 1 else None
+        g = _logit_graph(wrapper, st, x, K, seed, pver, prec) if K > 1 else None
         if g is not None:
             logits, kl = g.run(x, call)               # one graph launch; the buffers are the graph's: keep our own copy
             logits, kl = logits.clone(), kl.clone()
         else:
-            out = ensemble._mc_logits_chwn(wrapper, x, K, seed, call)
+            out = ensemble._mc_logits_chwn(wrapper, x, K, seed, call, precision=prec)
             if out is None:
                 rng.rewind((seed, call))              # nothing was launched: give the call index back
                 return None
@@ -350,7 +358,7 @@ def fast_forward(wrapper, x):
     for l in layers:
         l.__dict__["_kl"] = None
     import weakref
-    sp.xref, sp.xver, sp.pver, sp.grad = weakref.ref(x), x._version, pver, grad
+    sp.xref, sp.xver, sp.pver, sp.grad = weakref.ref(x), x._version, pver, mode
     if K > 1:
         sp.seed, sp.next_call, sp.logits, sp.kl, sp.idx = seed, (call + 1) & 0xFFFFFFFF, logits, kl, 1
         sp.batches += 1

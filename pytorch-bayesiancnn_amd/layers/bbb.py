@@ -16,6 +16,8 @@ class _BBBLayer(BayesianLayer):
             w, b = self._presampled
             self.__dict__["_presampled"] = None
             return w, b
+        from .misc import _refuse_low_precision
+        _refuse_low_precision("a Bayesian layer called on its own")
         if self.training or sample:
             seed, call = rng.layer_call()
             eps = None

@@ -16,6 +16,8 @@ class _LRTLayer(BayesianLayer):
             out = self._presampled
             self.__dict__["_presampled"] = None
             return out
+        from .misc import _refuse_low_precision
+        _refuse_low_precision("a Bayesian layer called on its own")
         kl, sig2 = ops.kl_only(mus, rhos, self.prior_mu, self.prior_sigma, want_sigma=True, sigma_squared=True)
         self._take_kl(kl)
         return sig2[0], (sig2[1] if self.use_bias else None)

@@ -23,6 +23,15 @@ class reference_layout:
         return False
 
 
+def _refuse_low_precision(why):
+    """ops.LaunchConfig.dropin_precision = "bf16" asks for the bf16 inference path: a forward that cannot take it must not quietly
+    compute in fp32."""
+    from bbb_hip import _lib, ops, rng
+    if ops.current_config().dropin_precision != "fp32" and not rng._scope:
+        raise _lib.BBBHipError("dropin_precision=%r: %s -- bf16 covers whole-model inference forwards of BBB models under "
+                               "torch.no_grad() only" % (ops.current_config().dropin_precision, why))
+
+
 class ModuleWrapper(nn.Module):
     """nn.Module with recursive flags and the universal (x) -> (x, kl) forward."""
 
@@ -39,6 +48,8 @@ class ModuleWrapper(nn.Module):
             out = _fused.fast_forward(self, x)      # inference on the batch-innermost kernels (what mc_forward runs), E = 1
             if out is not None:
                 return out
+        _refuse_low_precision("this forward runs layer by layer (autograd enabled, hooks, replayed noise, a layout the batched path "
+                              "does not cover, or reference_layout())")
         scope = None
         try:
             scope = _fused.enter(self)      # one noise call index (and, when possible, ONE fused reparam+KL

@@ -428,3 +428,61 @@ def test_bf16_refuses_what_it_does_not_cover(env):
         env["ens"].mc_forward(net, torch.rand(12, 1, 32, 32, device="cuda"), 2, precision="bf16")     # B % 8 != 0
     with pytest.raises(BBBHipError):
         env["ens"].mc_forward(net, torch.rand(8, 1, 32, 32, device="cuda"), 2, precision="bf16")      # autograd on
+
+
+@pytest.mark.parametrize("net_type,cin,B", [("3conv3fc", 3, 64), ("alexnet", 3, 32), ("lenet", 1, 16)])
+def test_dropin_loop_in_bf16(env, net_type, cin, B):
+    """ops.LaunchConfig.dropin_precision = "bf16": the unmodified `for j in range(num_ens): net(x)` loop (main_bayesian.py:73-80)
+    runs the bf16 storage path -- call j returns draw j of the batched bf16 launch under the same noise calls, KL as in fp32."""
+    ops, ens, rng = env["ops"], env["ens"], env["rng"]
+    torch.manual_seed(3)
+    net = env["zoo"].getModel(net_type, cin, 10, P.CONFIG_PRIORS, "bbb", "softplus").cuda()
+    rng.assign_stream_ids(net)
+    x = torch.rand(B, cin, 32, 32, device="cuda")
+    E = 5
+    with torch.no_grad():
+        rng.manual_seed(11, call=4)
+        want, kl_want = ens._mc_logits_chwn(net, x, E, 11, 4, precision="bf16")          # [E, C, B]
+        rng.manual_seed(11, call=4)
+        with ops.use_config(dropin_precision="bf16"):
+            outs = [net(x) for _ in range(E)]
+        rng.manual_seed(11, call=4)
+        fp32 = [net(x)[0] for _ in range(E)]
+    for j, (o, kl) in enumerate(outs):
+        assert o.dtype == torch.float32 and o.shape == (B, 10)
+        assert torch.equal(o, want[j].t()), j
+        assert torch.equal(kl.reshape(()), kl_want.reshape(()))
+        # bf16 storage of weights and activations: close to, and different from, the fp32 forward of the same draw
+        d = float((o - fp32[j]).abs().max())
+        assert 0.0 < d <= 3e-2 * float(fp32[j].abs().max()) + 1e-3, (j, d)
+    rng.use_device_generator()
+
+
+def test_dropin_bf16_refuses_what_it_does_not_cover(env):
+    from bbb_hip._lib import BBBHipError
+    ops = env["ops"]
+    torch.manual_seed(4)
+    net = env["zoo"].getModel("3conv3fc", 3, 10, P.CONFIG_PRIORS, "bbb", "softplus").cuda()
+    lrt = env["zoo"].getModel("3conv3fc", 3, 10, P.CONFIG_PRIORS, "lrt", "softplus").cuda()
+    x = torch.rand(16, 3, 32, 32, device="cuda")
+    with ops.use_config(dropin_precision="bf16"):
+        with pytest.raises(BBBHipError):
+            net(x)                                                   # autograd enabled: bf16 is inference only
+        with torch.no_grad():
+            with pytest.raises(BBBHipError):
+                lrt(x)                                               # LRT layers
+            with pytest.raises(BBBHipError):
+                net(x[:12])                                          # B % 8 != 0
+            with pytest.raises(BBBHipError):
+                net.conv1(x)                                         # a layer on its own
+            h = net.conv2.register_forward_hook(lambda m, i, o: None)
+            try:
+                with pytest.raises(BBBHipError):
+                    net(x)                                           # hooks: the layer-by-layer path, fp32 only
+            finally:
+                h.remove()
+            out, kl = net(x)                                         # and what it does cover still runs
+            assert out.shape == (16, 10) and torch.isfinite(out).all()
+    with torch.no_grad():
+        out32, _ = net(x)                                            # back in fp32 outside the context
+    assert out32.dtype == torch.float32
