@@ -520,9 +520,11 @@ int bbb_transpose_batched(const float* in, float* out, int rows, int cols, int n
 /* The same with three batch dimensions nb[3] (product <= 65535; strides in_b[3] / out_b[3]) and a summed one:
  * out[i1*out_b[0] + i2*out_b[1] + i3*out_b[2] + c*out_col + r] = sum_{s < nsum, ascending} in[i1*in_b[0] + i2*in_b[1] + i3*in_b[2]
  * + s*in_sum + r*in_row + c].  Training extension: the batch chunks of a role-swapped weight gradient summed in a fixed order
- * while the taps move innermost; an output gradient written straight into the chunked weight-operand layout. */
+ * while the taps move innermost; an output gradient written straight into the chunked weight-operand layout.  square_off != 0: every
+ * output's square is written too, square_off elements behind it (x and x^2 of an LRT layer's weight gradients in one pass). */
 int bbb_transpose_sum_batched(const float* in, float* out, int rows, int cols, const int32_t* nb, const int64_t* in_b,
-                              const int64_t* out_b, int64_t in_row, int64_t out_col, int nsum, int64_t in_sum, void* stream);
+                              const int64_t* out_b, int64_t in_row, int64_t out_col, int nsum, int64_t in_sum, int64_t square_off,
+                              void* stream);
 
 /* Training extension: out [draws][cin][cout][kh*kw] = w [draws][cout][cin][kh*kw] with the taps reversed (spatial flip +
  * channel transpose: the weights of the stride-1 input-gradient convolution). */

@@ -99,7 +99,7 @@ _SIGNATURES = {
     "bbb_im2col_pbj": (c_int, [c_void_p, c_void_p, ctypes.POINTER(ConvDesc), c_void_p]),
     "bbb_transpose_batched": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_void_p]),
     "bbb_transpose_sum_batched": (c_int, [c_void_p, c_void_p, c_int, c_int, ctypes.POINTER(c_i32), ctypes.POINTER(c_i64),
-                                          ctypes.POINTER(c_i64), c_i64, c_i64, c_int, c_i64, c_void_p]),
+                                          ctypes.POINTER(c_i64), c_i64, c_i64, c_int, c_i64, c_i64, c_void_p]),
     "bbb_conv2d_chwn_splitk_scratch": (c_i64, [ctypes.POINTER(ConvDesc), c_int, ctypes.POINTER(c_i32)]),
     "bbb_conv2d_chwn_splitk_fwd": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_i64,
                                            c_void_p]),

@@ -2012,15 +2012,16 @@ def _transpose_batched(src, out, rows, cols, nb1, nb2, ib1, ib2, ir, ob1, ob2, o
     return True
 
 
-def _transpose_sum_batched(src, out, rows, cols, nb, ib, ob, ir, oc, nsum=1, in_sum=0):
+def _transpose_sum_batched(src, out, rows, cols, nb, ib, ob, ir, oc, nsum=1, in_sum=0, square_off=0):
     """bbb_transpose_sum_batched: three batch dimensions `nb` with strides `ib` / `ob`, `nsum` slices `in_sum` apart summed in
-    ascending order.  False (nothing launched) when the batch does not fit one grid."""
+    ascending order; square_off != 0: the squares land square_off elements behind the outputs.  False (nothing launched) when the
+    batch does not fit one grid."""
     if nb[0] * nb[1] * nb[2] > 65535 or (rows + 31) // 32 > 65535:
         return False
     with on_device(src.device):
         check(_lib.lib().bbb_transpose_sum_batched(src.data_ptr(), out.data_ptr(), rows, cols, (ctypes.c_int32 * 3)(*nb),
                                                    (ctypes.c_int64 * 3)(*ib), (ctypes.c_int64 * 3)(*ob), ir, oc, nsum, in_sum,
-                                                   cur_stream(src.device)), "bbb_transpose_sum_batched")
+                                                   int(square_off), cur_stream(src.device)), "bbb_transpose_sum_batched")
     return True
 
 
@@ -2094,8 +2095,14 @@ def conv2d_chwn_weight_grad(g_pre, x, w_shape, stride, padding, dilation, x_squa
         if E != 2 * Ex:
             raise _lib.BBBHipError("conv2d_chwn_weight_grad(x_squares): g_pre must hold two draws per draw of x")
         xr = torch.empty((2 * Ex, B, x.shape[2], x.shape[3], Cin), dtype=torch.float32, device=x.device)
-        chwn_to_bhwc(x, out=xr[:Ex])
-        square(xr[:Ex], out=xr[Ex:])                                    # (x^2 transposed = the transposed x, squared)
+        H_, W_ = x.shape[2], x.shape[3]
+        HW_ = H_ * W_
+        xc = x.contiguous()
+        # the transposed x and, behind it, its squares (x^2 transposed = the transposed x, squared) in ONE pass
+        if not _transpose_sum_batched(xc, xr, Cin, B, (Ex, HW_, 1), (Cin * HW_ * B, B, 0), (B * HW_ * Cin, Cin, 0), HW_ * B, HW_ * Cin,
+                                      square_off=Ex * B * HW_ * Cin):
+            chwn_to_bhwc(xc, out=xr[:Ex])
+            square(xr[:Ex], out=xr[Ex:])
     else:
         xr = chwn_to_bhwc(x)                                            # [E|1, B, H, W, Cin]
     wgs = E * kh * kw * -(-Cout // 64) * -(-Cin // 64)

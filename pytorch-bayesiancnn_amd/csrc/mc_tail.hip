@@ -280,6 +280,7 @@ __global__ __launch_bounds__(256) void transpose_batched_kernel(const float* __r
 struct TransposeExArgs {
     int32_t R, C, nb2, nb3, ns;
     int64_t ib1, ib2, ib3, is, ir, ob1, ob2, ob3, oc;
+    int64_t sq;          // != 0: the squares of the outputs are written too, `sq` elements behind them (x and x^2 of an LRT weight gradient)
 };
 __global__ __launch_bounds__(256) void transpose_sum_batched_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                                     const TransposeExArgs a) {
@@ -304,7 +305,11 @@ __global__ __launch_bounds__(256) void transpose_sum_batched_kernel(const float*
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = c0 + ty + i * 8, r = r0 + tx;
-        if (r < a.R && c < a.C) dst[(int64_t)c * a.oc + r] = tile[tx][ty + i * 8];
+        if (r < a.R && c < a.C) {
+            const float v = tile[tx][ty + i * 8];
+            dst[(int64_t)c * a.oc + r] = v;
+            if (a.sq != 0) dst[a.sq + (int64_t)c * a.oc + r] = v * v;
+        }
     }
 }
 
@@ -340,7 +345,7 @@ __global__ __launch_bounds__(256) void transpose_few_rows_kernel(const float* __
 
 static int launch_transpose_ex(const float* in, float* out, const TransposeExArgs& a, int64_t n, hipStream_t stream) {
     // (large operands only: on the small ones of a one-draw step the tiles' parallelism wins, above all with a summed dimension)
-    if (a.R <= 32 && a.oc == a.R && a.ns == 1 && n * a.R * a.C >= (1 << 20)) {
+    if (a.R <= 32 && a.oc == a.R && a.ns == 1 && a.sq == 0 && n * a.R * a.C >= (1 << 20)) {
         const int nt = a.C <= 64 ? 64 : (a.C <= 128 ? 128 : 256);
         hipLaunchKernelGGL(transpose_few_rows_kernel, dim3((a.C + nt - 1) / nt, 1, (unsigned)n), dim3(nt), 0, stream, in, out, a);
     } else {
@@ -659,7 +664,7 @@ extern "C" int bbb_transpose_batched(const float* in, float* out, int rows, int 
         TransposeExArgs a;
         a.R = rows, a.C = cols, a.nb2 = nb2, a.nb3 = 1, a.ns = 1;
         a.ib1 = in_b1, a.ib2 = in_b2, a.ib3 = 0, a.is = 0, a.ir = in_row;
-        a.ob1 = out_b1, a.ob2 = out_b2, a.ob3 = 0, a.oc = out_col;
+        a.ob1 = out_b1, a.ob2 = out_b2, a.ob3 = 0, a.oc = out_col, a.sq = 0;
         return launch_transpose_ex(in, out, a, nb, (hipStream_t)stream);
     }
     hipLaunchKernelGGL(transpose_batched_kernel, dim3((cols + 31) / 32, (unsigned)gy, (unsigned)nb), dim3(256), 0, (hipStream_t)stream, in, out,
@@ -669,9 +674,9 @@ extern "C" int bbb_transpose_batched(const float* in, float* out, int rows, int 
 
 extern "C" int bbb_transpose_sum_batched(const float* in, float* out, int rows, int cols, const int32_t* nb, const int64_t* in_b,
                                          const int64_t* out_b, int64_t in_row, int64_t out_col, int nsum, int64_t in_sum,
-                                         void* stream) {
+                                         int64_t square_off, void* stream) {
     if (in == nullptr || out == nullptr || nb == nullptr || in_b == nullptr || out_b == nullptr || rows <= 0 || cols <= 0 ||
-        nb[0] <= 0 || nb[1] <= 0 || nb[2] <= 0 || nsum <= 0)
+        nb[0] <= 0 || nb[1] <= 0 || nb[2] <= 0 || nsum <= 0 || square_off < 0)
         return BBB_EINVAL;
     if ((((uintptr_t)in | (uintptr_t)out) & 3u) != 0) return BBB_EALIGN;
     const int64_t n = (int64_t)nb[0] * nb[1] * nb[2], gy = (rows + 31) / 32;
@@ -679,7 +684,7 @@ extern "C" int bbb_transpose_sum_batched(const float* in, float* out, int rows, 
     TransposeExArgs a;
     a.R = rows, a.C = cols, a.nb2 = nb[1], a.nb3 = nb[2], a.ns = nsum;
     a.ib1 = in_b[0], a.ib2 = in_b[1], a.ib3 = in_b[2], a.is = in_sum, a.ir = in_row;
-    a.ob1 = out_b[0], a.ob2 = out_b[1], a.ob3 = out_b[2], a.oc = out_col;
+    a.ob1 = out_b[0], a.ob2 = out_b[1], a.ob3 = out_b[2], a.oc = out_col, a.sq = square_off;
     return launch_transpose_ex(in, out, a, n, (hipStream_t)stream);
 }
 

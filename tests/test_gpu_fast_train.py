@@ -194,6 +194,11 @@ def test_transpose_sum_batched_entry(env):
     for s_ in range(1, 5):
         want = want + a[:, s_]                                            # ascending order, one rounding per addition
     assert torch.equal(out, want.transpose(2, 3).contiguous())
+    # square_off: the squares of the outputs land behind them (one pass for x and x^2 of an LRT layer's weight gradients)
+    out2 = torch.empty(2, 2, 3, 41, 37, device="cuda")
+    assert ops._transpose_sum_batched(a, out2, 37, 41, (2, 3, 1), (5 * 3 * 37 * 41, 37 * 41, 0), (3 * 41 * 37, 41 * 37, 0), 41, 37,
+                                      5, 3 * 37 * 41, square_off=2 * 3 * 41 * 37)
+    assert torch.equal(out2[0], out) and torch.equal(out2[1], out * out)
 
 
 @pytest.mark.parametrize("net_type,cin,B,lt", [("alexnet", 3, 16, "bbb"), ("3conv3fc", 3, 8, "bbb"), ("alexnet", 3, 64, "bbb"),
