@@ -533,6 +533,16 @@ int bbb_flip_transpose_w(const float* w, float* out, int64_t draws, int cout, in
  * weights of a local-reparameterisation layer as one operand: both input gradients in one launch of the forward kernel). */
 int bbb_flip_transpose_w_pair(const float* w0, const float* w1, float* out, int64_t draws_each, int cout, int cin, int khkw,
                               void* stream);
+/* ... and for up to 16 weight sets in ONE launch (every layer's input-gradient weights of a training step): segment i flips
+ * `draws` sets [cout][cin][khkw] from w0 -- or, with w1 != NULL, draws / 2 from w0 then draws / 2 from w1 -- into out. */
+typedef struct {
+    const float* w0;
+    const float* w1;      /* NULL, or the second source (draws must then be even) */
+    float* out;           /* [draws][cin][cout][khkw] */
+    int64_t draws;
+    int32_t cout, cin, khkw, reserved;
+} bbb_flip_seg_t;
+int bbb_flip_transpose_w_multi(const bbb_flip_seg_t* segs, int n_segs, void* stream);
 
 /* Training extension: im2col of an NCHW batch x [batch][cin][h][w] (geometry from d; draws / strides / act ignored) into
  * out [ho*wo][batch][Jp], Jp = cin*kh*kw rounded up to 4 (pad columns zero): the K-major operand of the first layer's

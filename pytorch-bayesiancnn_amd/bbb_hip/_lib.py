@@ -32,6 +32,11 @@ class AdamSegment(ctypes.Structure):
     _fields_ = [("param", c_void_p), ("grad", c_void_p), ("exp_avg", c_void_p), ("exp_avg_sq", c_void_p), ("n", c_i64)]
 
 
+class FlipSeg(ctypes.Structure):
+    _fields_ = [("w0", c_void_p), ("w1", c_void_p), ("out", c_void_p), ("draws", c_i64), ("cout", c_i32), ("cin", c_i32),
+                ("khkw", c_i32), ("reserved", c_i32)]
+
+
 class ConvDesc(ctypes.Structure):
     _fields_ = [("batch", c_i32), ("cin", c_i32), ("h", c_i32), ("w", c_i32), ("cout", c_i32), ("kh", c_i32),
                 ("kw", c_i32), ("stride_h", c_i32), ("stride_w", c_i32), ("pad_h", c_i32), ("pad_w", c_i32),
@@ -92,6 +97,7 @@ _SIGNATURES = {
     "bbb_uncertainty": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "bbb_transpose2d": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_void_p]),
     "bbb_flip_transpose_w": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_void_p]),
+    "bbb_flip_transpose_w_multi": (c_int, [ctypes.POINTER(FlipSeg), c_int, c_void_p]),
     "bbb_flip_transpose_w_pair": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_void_p]),
     "bbb_elbo_cb_fwd": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_float, c_void_p, ctypes.c_float, c_int, c_int, c_void_p, c_void_p]),
     "bbb_elbo_cb_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_float, c_void_p, ctypes.c_float, c_void_p, c_void_p,

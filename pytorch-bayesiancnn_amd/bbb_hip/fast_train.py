@@ -196,6 +196,14 @@ class _MCForward(torch.autograd.Function):
             with torch.cuda.stream(xk_stream):
                 xk_first[0] = ops.im2col_pbj(ctx.x_nchw, tuple(r0["w"].shape), *r0["geom"])
             keep.append(xk_first[0])
+        # every layer's input-gradient weights (flipped, channel-transposed: they depend on the sampled weights alone) in ONE launch up
+        # front instead of one launch per layer on the chain -- for launch-bound steps (no side streams: captured, small).  A
+        # many-draw step keeps them on the chain: up front, even on the side stream, they cost it 40 us (2.45 -> 2.49 ms at 512 x 10,
+        # profiles/experiments/ab_flips_up_front.py)
+        w_flipped = {}
+        if flips_up_front[0] and side is None and g is not None and len(tape) > 1:
+            outs = ops.flip_transpose_w_multi([tape[li]["w"] for li in range(1, len(tape))])
+            w_flipped = {li: o for li, o in zip(range(1, len(tape)), outs)}
         for li in range(len(tape) - 1, -1, -1):
             rec = tape[li]
             y, w5, x_in, act = rec["y"], rec["w"], rec["x"], rec["act"]
@@ -230,7 +238,7 @@ class _MCForward(torch.autograd.Function):
                     main.wait_stream(xk_stream)
                 weight_side()
             if not rec["first"]:
-                g = ops.conv2d_chwn_input_grad(g_pre, w5, (x_in.shape[2], x_in.shape[3]), padding, dilation)
+                g = ops.conv2d_chwn_input_grad(g_pre, w5, (x_in.shape[2], x_in.shape[3]), padding, dilation, w_flipped=w_flipped.get(li))
             else:
                 g = None
         if side is not None:
@@ -244,6 +252,7 @@ class _MCForward(torch.autograd.Function):
         return tuple(out)
 
 
+flips_up_front = [True]         # every layer's flipped input-gradient weights in one launch at the start of the backward
 pair_lrt_backward = [True]      # an LRT layer's (mean, variance) gradient pairs as the two draws of one launch (see _MCForwardLRT._backward)
 overlap_wgrad = [True]
 _side_streams = {}
@@ -371,6 +380,12 @@ class _MCForwardLRT(torch.autograd.Function):
         side = _side_stream(g.device) if (overlap_wgrad[0] and not torch.cuda.is_current_stream_capturing()) else None
         main = torch.cuda.current_stream(g.device) if side is not None else None
         keep = []
+        # (as in _MCForward: the flipped input-gradient weights of every layer -- mean and variance sets -- in one launch up front)
+        w_flipped = {}
+        if flips_up_front[0] and len(tape) > 1:
+            pairs = [(tape[li]["w_mu"].unsqueeze(0), tape[li]["w_var"].unsqueeze(0)) for li in range(1, len(tape))]
+            outs = ops.flip_transpose_w_multi(pairs)                     # [2, Cin, Cout, kh, kw] each: the mean set, then the variance set
+            w_flipped = {li: o for li, o in zip(range(1, len(tape)), outs)}
         for li in range(len(tape) - 1, -1, -1):
             rec = tape[li]
             y, am, av, x_in, act = rec["y"], rec["am"], rec["av"], rec["x"], rec["act"]
@@ -425,14 +440,18 @@ class _MCForwardLRT(torch.autograd.Function):
                 weight_side()
             if not rec["first"]:
                 hw = (x_in.shape[2], x_in.shape[3])
+                w_t = w_flipped.get(li)
                 if g_pair is not None and g_mu.shape[0] == 1:
-                    w_t = ops.flip_transpose_w_pair(w_mu.unsqueeze(0), w_var.unsqueeze(0))
+                    if w_t is None:
+                        w_t = ops.flip_transpose_w_pair(w_mu.unsqueeze(0), w_var.unsqueeze(0))
                     gx = ops.conv2d_chwn_input_grad(g_pair.reshape((2,) + tuple(g_mu.shape[1:])), w_mu.unsqueeze(0), hw, padding, dilation,
                                                     w_flipped=w_t)
                     g = ops.lrt_input_grad_combine(gx[0:1], x_in, gx[1:2])
                 else:
-                    g = ops.lrt_input_grad_combine(ops.conv2d_chwn_input_grad(g_mu, w_mu.unsqueeze(0), hw, padding, dilation), x_in,
-                                                   ops.conv2d_chwn_input_grad(g_var, w_var.unsqueeze(0), hw, padding, dilation))
+                    t_mu, t_var = (w_t[0:1], w_t[1:2]) if w_t is not None else (None, None)
+                    g = ops.lrt_input_grad_combine(ops.conv2d_chwn_input_grad(g_mu, w_mu.unsqueeze(0), hw, padding, dilation, w_flipped=t_mu),
+                                                   x_in,
+                                                   ops.conv2d_chwn_input_grad(g_var, w_var.unsqueeze(0), hw, padding, dilation, w_flipped=t_var))
         if side is not None:
             for st_ in side.streams:
                 main.wait_stream(st_)

@@ -1986,6 +1986,36 @@ def flip_transpose_w_pair(w0, w1):
     return w_t
 
 
+def flip_transpose_w_multi(sets):
+    """flip_transpose_w / flip_transpose_w_pair for several layers in ONE launch (bbb_flip_transpose_w_multi): `sets` = a list of
+    w [E, Cout, Cin, kh, kw] or (w0, w1) pairs of one shape -> the list of [E | 2E, Cin, Cout, kh, kw] results."""
+    if not sets:
+        return []
+    if len(sets) > 16:
+        return flip_transpose_w_multi(sets[:16]) + flip_transpose_w_multi(sets[16:])
+    segs = (_lib.FlipSeg * len(sets))()
+    outs, hold = [], []
+    for i, s_ in enumerate(sets):
+        w0, w1 = s_ if isinstance(s_, (tuple, list)) else (s_, None)
+        require_device(w0) if w1 is None else require_device(w0, w1)
+        w0 = w0.contiguous()
+        E, Cout, Cin, kh, kw = w0.shape
+        if w1 is not None:
+            w1 = w1.contiguous()
+            if w1.shape != w0.shape:
+                raise _lib.BBBHipError("flip_transpose_w_multi: the two sources of a pair must have one shape")
+        n = E if w1 is None else 2 * E
+        o = torch.empty((n, Cin, Cout, kh, kw), dtype=torch.float32, device=w0.device)
+        segs[i].w0, segs[i].w1, segs[i].out = w0.data_ptr(), (0 if w1 is None else w1.data_ptr()), o.data_ptr()
+        segs[i].draws, segs[i].cout, segs[i].cin, segs[i].khkw = n, Cout, Cin, kh * kw
+        outs.append(o)
+        hold += [w0, w1]
+    dev = outs[0].device
+    with on_device(dev):
+        check(_lib.lib().bbb_flip_transpose_w_multi(segs, len(sets), cur_stream(dev)), "bbb_flip_transpose_w_multi")
+    return outs
+
+
 def conv2d_chwn_input_grad(g_pre, w, x_hw, padding, dilation, w_flipped=None):
     """d loss / d x of a STRIDE-1 y = conv(x, w) in the batch-innermost layout, on the forward kernel itself: the convolution
     of g_pre [E, Cout, Ho, Wo, B] with the spatially flipped, channel-transposed weights, padding d*(k-1) - p.

@@ -239,6 +239,36 @@ __global__ __launch_bounds__(256) void flip_transpose_w_kernel(const float* __re
     out[i] = src[((e * Cout + n) * Cin + ci) * khkw + (khkw - 1 - t)];
 }
 
+// Several weight sets in ONE launch (every layer's input-gradient weights of a training step, up front): block -> segment by a
+// prefix table, then the one-thread-per-output gather above.
+constexpr int kMaxFlipSegs = 16;
+struct FlipMultiArgs {
+    const float* w0[kMaxFlipSegs];
+    const float* w1[kMaxFlipSegs];
+    float* out[kMaxFlipSegs];
+    int64_t total[kMaxFlipSegs];
+    int64_t e1[kMaxFlipSegs];
+    int32_t cout[kMaxFlipSegs], cin[kMaxFlipSegs], khkw[kMaxFlipSegs];
+    uint32_t block_begin[kMaxFlipSegs + 1];
+    int32_t n;
+};
+__global__ __launch_bounds__(256) void flip_transpose_w_multi_kernel(const FlipMultiArgs a) {
+    int sgi = 0;
+    while (sgi + 1 < a.n && blockIdx.x >= a.block_begin[sgi + 1]) ++sgi;
+    const int64_t i = (int64_t)(blockIdx.x - a.block_begin[sgi]) * blockDim.x + threadIdx.x;
+    if (i >= a.total[sgi]) return;
+    const int Cout = a.cout[sgi], Cin = a.cin[sgi], khkw = a.khkw[sgi];
+    const int t = (int)(i % khkw);
+    int64_t r = i / khkw;
+    const int n = (int)(r % Cout);
+    r /= Cout;
+    const int ci = (int)(r % Cin);
+    int64_t e = r / Cin;
+    const float* src = a.w0[sgi];
+    if (a.w1[sgi] != nullptr && e >= a.e1[sgi]) src = a.w1[sgi], e -= a.e1[sgi];
+    a.out[sgi][i] = src[((e * Cout + n) * Cin + ci) * khkw + (khkw - 1 - t)];
+}
+
 static int launch_flip_transpose(const float* w0, const float* w1, int64_t e1, float* out, int64_t draws, int cout, int cin, int khkw,
                                  hipStream_t stream) {
     const int64_t total = draws * cout * cin * khkw;
@@ -709,6 +739,30 @@ extern "C" int bbb_flip_transpose_w(const float* w, float* out, int64_t draws, i
     if (w == nullptr || out == nullptr || draws <= 0 || cout <= 0 || cin <= 0 || khkw <= 0) return BBB_EINVAL;
     if ((((uintptr_t)w | (uintptr_t)out) & 3u) != 0) return BBB_EALIGN;
     return launch_flip_transpose(w, nullptr, 0, out, draws, cout, cin, khkw, (hipStream_t)stream);
+}
+
+extern "C" int bbb_flip_transpose_w_multi(const bbb_flip_seg_t* segs, int n_segs, void* stream) {
+    if (segs == nullptr || n_segs <= 0 || n_segs > kMaxFlipSegs) return BBB_EINVAL;
+    FlipMultiArgs a;
+    a.n = n_segs;
+    uint64_t blocks = 0;
+    for (int i = 0; i < n_segs; ++i) {
+        const bbb_flip_seg_t& g = segs[i];
+        if (g.w0 == nullptr || g.out == nullptr || g.draws <= 0 || g.cout <= 0 || g.cin <= 0 || g.khkw <= 0 ||
+            (g.w1 != nullptr && (g.draws & 1)))
+            return BBB_EINVAL;
+        if ((((uintptr_t)g.w0 | (uintptr_t)g.w1 | (uintptr_t)g.out) & 3u) != 0) return BBB_EALIGN;
+        a.w0[i] = g.w0; a.w1[i] = g.w1; a.out[i] = g.out;
+        a.e1[i] = g.w1 != nullptr ? g.draws / 2 : g.draws;
+        a.cout[i] = g.cout; a.cin[i] = g.cin; a.khkw[i] = g.khkw;
+        a.total[i] = g.draws * g.cout * g.cin * g.khkw;
+        a.block_begin[i] = (uint32_t)blocks;
+        blocks += (uint64_t)((a.total[i] + 255) / 256);
+        if (blocks > 0x7fffffffULL) return BBB_ESHAPE;
+    }
+    a.block_begin[n_segs] = (uint32_t)blocks;
+    hipLaunchKernelGGL(flip_transpose_w_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
 }
 
 extern "C" int bbb_flip_transpose_w_pair(const float* w0, const float* w1, float* out, int64_t draws_each, int cout, int cin, int khkw,

@@ -465,3 +465,19 @@ def test_hip_loss_tail_matches_the_torch_tail():
             g64, = torch.autograd.grad(loss_of(torch_tail(lg.double())), lg, retain_graph=True)
             scale = float(g64.abs().max())
             assert float((ga - g64).abs().max()) <= 1e-5 * scale and float((gb - g64).abs().max()) <= 1e-5 * scale
+
+
+def test_flip_transpose_w_multi_entry(env):
+    """Several layers' input-gradient weights (single sets and mean / variance pairs) flipped in one launch."""
+    ops = env["ops"]
+    g = torch.Generator(device="cuda").manual_seed(77)
+    a = torch.randn(3, 12, 8, 3, 3, device="cuda", generator=g)
+    b0, b1 = (torch.randn(1, 10, 128, 1, 1, device="cuda", generator=g) for _ in range(2))
+    c = torch.randn(2, 5, 7, 5, 5, device="cuda", generator=g)
+    outs = ops.flip_transpose_w_multi([a, (b0, b1), c])
+    assert torch.equal(outs[0], ops.flip_transpose_w(a))
+    assert torch.equal(outs[1], ops.flip_transpose_w_pair(b0, b1))
+    assert torch.equal(outs[2], ops.flip_transpose_w(c))
+    many = [torch.randn(1, 4, 4, 1, 1, device="cuda", generator=g) for _ in range(19)]          # more than one launch's 16 segments
+    for o, w in zip(ops.flip_transpose_w_multi(many), many):
+        assert torch.equal(o, ops.flip_transpose_w(w))
