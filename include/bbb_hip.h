@@ -378,10 +378,13 @@ int bbb_pool_act_bwd_chwn(const float* g_out, const float* y, float* g_pre, int6
  * -- the gradient w.r.t. act_var, since sqrt(act_var) * eps = v - act_mu.  act_mu / act_var: [moment_planes][h][w][B] with
  * moment_planes == planes, or a divisor of it when consecutive groups of moment_planes planes (the draws of a first layer whose
  * input and weights every draw shares) were sampled from ONE pair of moments.  g_mu and g_var share out_plane_pitch.
+ * g_out2 / x_out (both or neither; ABI 13): the incoming gradient is g_out + 2 * x_out * g_out2 -- the two input gradients of the
+ * LRT layer above (through its mean and its variance weights) and this layer's output x_out [x_planes][hp][wp][B] (x_planes divides
+ * planes), combined on the fly with bbb_lrt_glue mode 1's arithmetic instead of by a launch of its own.
  */
 int bbb_lrt_pool_act_bwd_chwn(const float* g_out, const float* y, const float* act_mu, const float* act_var, float* g_mu,
                               float* g_var, int64_t planes, int64_t moment_planes, int h, int w, int batch, int k, int s, int act,
-                              int64_t out_plane_pitch, void* stream);
+                              int64_t out_plane_pitch, const float* g_out2, const float* x_out, int64_t x_planes, void* stream);
 
 /*
  * E noise draws from ONE pair of LRT moments, batch-innermost: y[e] = act(act_mu + sqrt(act_var) * eps[e]) with eps exactly

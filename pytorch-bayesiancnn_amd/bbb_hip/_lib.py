@@ -79,7 +79,7 @@ _SIGNATURES = {
     "bbb_maxpool_chwn": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "bbb_pool_act_bwd_chwn": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_i64, c_void_p]),
     "bbb_lrt_pool_act_bwd_chwn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_int, c_int, c_int,
-                                          c_int, c_int, c_int, c_i64, c_void_p]),
+                                          c_int, c_int, c_int, c_i64, c_void_p, c_void_p, c_i64, c_void_p]),
     "bbb_conv2d_chwn_bf16_fwd": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_u32, c_void_p]),
     "bbb_maxpool_chwn_bf16": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "bbb_nchw_to_chwn_bf16": (c_int, [c_void_p, c_void_p, c_int, c_i64, c_void_p]),

@@ -252,6 +252,7 @@ class _MCForward(torch.autograd.Function):
         return tuple(out)
 
 
+fold_lrt_combine = [True]       # an LRT layer's g1 + 2 x g2 is formed inside the pooling / activation backward of the layer below
 flips_up_front = [True]         # every layer's flipped input-gradient weights in one launch at the start of the backward
 pair_lrt_backward = [True]      # an LRT layer's (mean, variance) gradient pairs as the two draws of one launch (see _MCForwardLRT._backward)
 overlap_wgrad = [True]
@@ -391,7 +392,13 @@ class _MCForwardLRT(torch.autograd.Function):
             y, am, av, x_in, act = rec["y"], rec["am"], rec["av"], rec["x"], rec["act"]
             w_mu, w_var = rec["w_mu"], rec["w_var"]
             stride, padding, dilation = rec["geom"]
-            g = g.reshape(rec["out_shape"])
+            # the incoming gradient: a tensor (the logits' gradient), or the layer above's two input gradients + this layer's output,
+            # combined (g1 + 2 x g2) inside the pass below instead of by a launch of its own
+            comb = None
+            if isinstance(g, tuple):
+                g, comb = g[0].reshape(rec["out_shape"]), (g[1].reshape((-1,) + tuple(rec["out_shape"][1:])), g[2].reshape(rec["out_shape"]))
+            else:
+                g = g.reshape(rec["out_shape"])
             # one pass: pooling / activation backward AND the split into d/d act_mu, d/d act_var (was ~10 ATen kernels per layer)
             k, s = rec["pool"] if rec["pool"] is not None else (0, 1)
             pad = rec["first"] and x_in.shape[1] % 4 != 0                # feeds conv2d_chwn_weight_grad_shared_input
@@ -399,10 +406,10 @@ class _MCForwardLRT(torch.autograd.Function):
             # for a single draw, its two input gradients (with W_mu, W_var) run as the draws of one launch each
             g_pair = None
             if pair_lrt_backward[0] and not rec["first"]:
-                g_pair = ops.lrt_pool_act_backward_chwn(g, y, am, av, k, s, act, stacked=True)        # [2, E, Cout, Ho, Wo, B]
+                g_pair = ops.lrt_pool_act_backward_chwn(g, y, am, av, k, s, act, stacked=True, combine=comb)        # [2, E, Cout, Ho, Wo, B]
                 g_mu, g_var = g_pair[0], g_pair[1]
             else:
-                g_mu, g_var = ops.lrt_pool_act_backward_chwn(g, y, am, av, k, s, act, pad_planes=pad)
+                g_mu, g_var = ops.lrt_pool_act_backward_chwn(g, y, am, av, k, s, act, pad_planes=pad, combine=comb)
             if am.shape[0] == 1 and g_mu.shape[0] > 1:      # first layer: one pair of moments feeds every draw
                 g_mu, g_var = ops.sum_over_draws(g_mu, keepdim=True), ops.sum_over_draws(g_var, keepdim=True)
             def weight_side(g_mu=g_mu, g_var=g_var, x_in=x_in, w_mu=w_mu, rec=rec, li=li, stride=stride, padding=padding, dilation=dilation,
@@ -446,12 +453,13 @@ class _MCForwardLRT(torch.autograd.Function):
                         w_t = ops.flip_transpose_w_pair(w_mu.unsqueeze(0), w_var.unsqueeze(0))
                     gx = ops.conv2d_chwn_input_grad(g_pair.reshape((2,) + tuple(g_mu.shape[1:])), w_mu.unsqueeze(0), hw, padding, dilation,
                                                     w_flipped=w_t)
-                    g = ops.lrt_input_grad_combine(gx[0:1], x_in, gx[1:2])
+                    g1, g2 = gx[0:1], gx[1:2]
                 else:
                     t_mu, t_var = (w_t[0:1], w_t[1:2]) if w_t is not None else (None, None)
-                    g = ops.lrt_input_grad_combine(ops.conv2d_chwn_input_grad(g_mu, w_mu.unsqueeze(0), hw, padding, dilation, w_flipped=t_mu),
-                                                   x_in,
-                                                   ops.conv2d_chwn_input_grad(g_var, w_var.unsqueeze(0), hw, padding, dilation, w_flipped=t_var))
+                    g1 = ops.conv2d_chwn_input_grad(g_mu, w_mu.unsqueeze(0), hw, padding, dilation, w_flipped=t_mu)
+                    g2 = ops.conv2d_chwn_input_grad(g_var, w_var.unsqueeze(0), hw, padding, dilation, w_flipped=t_var)
+                # (g1 + 2 x g2 is formed by the layer below's pooling / activation pass)
+                g = (g1, x_in, g2) if fold_lrt_combine[0] else ops.lrt_input_grad_combine(g1, x_in, g2)
         if side is not None:
             for st_ in side.streams:
                 main.wait_stream(st_)

@@ -1926,13 +1926,22 @@ def lrt_input_grad_combine(g1, x, g2):
     return out
 
 
-def lrt_pool_act_backward_chwn(g_out, y, act_mu, act_var, k, s, act, pad_planes=False, stacked=False):
+def lrt_pool_act_backward_chwn(g_out, y, act_mu, act_var, k, s, act, pad_planes=False, stacked=False, combine=None):
     """pool_act_backward_chwn for a local-reparameterisation layer: -> (g_mu, g_var), the gradients w.r.t. act_mu and act_var
     (bbb_lrt_pool_act_bwd_chwn).  act_mu / act_var: y's shape, or one draw's worth ([1, C, H, W, B]) when every draw was sampled
     from the same pair of moments.  stacked (without pad_planes): the two land in ONE buffer [2, *y.shape], returned as such --
-    the weight-side and input-side contractions of the pair then run as the draws of one launch."""
+    the weight-side and input-side contractions of the pair then run as the draws of one launch.
+    combine = (x_out, g_out2): the incoming gradient is g_out + 2 * x_out * g_out2 (lrt_input_grad_combine of the layer above,
+    formed on the fly: g_out / g_out2 = its two input gradients, x_out = this layer's output, [E|1, ...] of g_out's trailing shape)."""
     require_device(g_out, y, act_mu, act_var)
     g_out, y, act_mu, act_var = g_out.contiguous(), y.contiguous(), act_mu.contiguous(), act_var.contiguous()
+    g2p, xcp, x_planes = 0, 0, 0
+    if combine is not None:
+        xc, g2 = combine[0].contiguous(), combine[1].contiguous()
+        require_device(xc, g2)
+        if g2.numel() != g_out.numel() or g_out.numel() % xc.numel() != 0:
+            raise _lib.BBBHipError("lrt_pool_act_backward_chwn: combine = (x_out, g_out2) of g_out's shape (x_out may hold one draw)")
+        g2p, xcp = g2.data_ptr(), xc.data_ptr()
     *lead, H, W, B = y.shape
     planes = 1
     for v in lead:
@@ -1953,7 +1962,9 @@ def lrt_pool_act_backward_chwn(g_out, y, act_mu, act_var, k, s, act, pad_planes=
     with on_device(y.device):
         check(_lib.lib().bbb_lrt_pool_act_bwd_chwn(g_out.data_ptr(), y.data_ptr(), act_mu.data_ptr(), act_var.data_ptr(),
                                                    bufs[0].data_ptr(), bufs[1].data_ptr(), planes, mom_planes, H, W, B, int(k), int(s),
-                                                   ACT_CODE[act], pitch if pitch != K else 0, cur_stream(y.device)),
+                                                   ACT_CODE[act], pitch if pitch != K else 0, g2p, xcp,
+                                                   (planes * xc.numel() // g_out.numel()) if combine is not None else 0,
+                                                   cur_stream(y.device)),
               "bbb_lrt_pool_act_bwd_chwn")
     if stacked and pitch == K:
         return both

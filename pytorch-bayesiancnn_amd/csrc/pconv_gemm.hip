@@ -119,9 +119,22 @@ __global__ __launch_bounds__(256) void pool_act_bwd_chwn_kernel(const float* __r
                                                                 float* __restrict__ g_pre, int64_t total4, int H, int W, int Hp,
                                                                 int Wp, int B4, int k, int s, int act, int64_t out_pitch4,
                                                                 const float* __restrict__ am, const float* __restrict__ av,
-                                                                float* __restrict__ g_var, int64_t mom_planes) {
+                                                                float* __restrict__ g_var, int64_t mom_planes,
+                                                                const float* __restrict__ g2, const float* __restrict__ xc,
+                                                                int64_t xc_total4) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total4) return;
+    // g2 != NULL (an LRT layer below another one): the incoming gradient is g_out + 2 * xc * g2 -- the two input gradients of the
+    // layer above combined on the fly (bbb_lrt_glue mode 1's fmaf, bit for bit) instead of by a launch of its own
+    auto incoming = [&](int64_t idx) {
+        f32x4 gv = reinterpret_cast<const f32x4*>(g_out)[idx];
+        if (g2 != nullptr) {
+            const f32x4 b4v = reinterpret_cast<const f32x4*>(g2)[idx], x4v = reinterpret_cast<const f32x4*>(xc)[idx % xc_total4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) gv[u] = fmaf(2.0f * x4v[u], b4v[u], gv[u]);
+        }
+        return gv;
+    };
     const int b4 = (int)(i % B4);
     int64_t t = i / B4;
     const int w = (int)(t % W);
@@ -132,9 +145,9 @@ __global__ __launch_bounds__(256) void pool_act_bwd_chwn_kernel(const float* __r
     const f32x4 me = yp[((int64_t)h * W + w) * B4];
     f32x4 g = f32x4{0.f, 0.f, 0.f, 0.f};
     if (k == 0) {
-        g = reinterpret_cast<const f32x4*>(g_out)[i];
+        g = incoming(i);
     } else {
-        const f32x4* gp = reinterpret_cast<const f32x4*>(g_out) + pl * Hp * Wp * B4 + b4;
+        const int64_t gbase = pl * Hp * Wp * B4 + b4;
         // windows (ph, pw) with ph*s <= h < ph*s + k
         const int ph_lo = h - k + 1 > 0 ? (h - k + 1 + s - 1) / s : 0, ph_hi = h / s < Hp - 1 ? h / s : Hp - 1;
         const int pw_lo = w - k + 1 > 0 ? (w - k + 1 + s - 1) / s : 0, pw_hi = w / s < Wp - 1 ? w / s : Wp - 1;
@@ -151,7 +164,7 @@ __global__ __launch_bounds__(256) void pool_act_bwd_chwn_kernel(const float* __r
 #pragma unroll
                         for (int u = 0; u < 4; ++u) first[u] = first[u] && (idx < my ? v[u] < me[u] : v[u] <= me[u]);
                     }
-                const f32x4 go = gp[((int64_t)ph * Wp + pw) * B4];
+                const f32x4 go = incoming(gbase + ((int64_t)ph * Wp + pw) * B4);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) g[u] += first[u] ? go[u] : 0.0f;
             }
@@ -618,7 +631,8 @@ extern "C" int bbb_maxpool_chwn(const float* x, float* y, int64_t planes, int h,
 
 namespace {
 int pool_act_bwd_launch(const float* g_out, const float* y, float* g_pre, int64_t planes, int h, int w, int batch, int k, int s, int act,
-                        int64_t out_plane_pitch, const float* am, const float* av, float* g_var, int64_t mom_planes, void* stream) {
+                        int64_t out_plane_pitch, const float* am, const float* av, float* g_var, int64_t mom_planes, void* stream,
+                        const float* g2 = nullptr, const float* xc = nullptr, int64_t xc_planes = 0) {
     if (g_out == nullptr || y == nullptr || g_pre == nullptr || planes <= 0 || h <= 0 || w <= 0 || batch <= 0 || k < 0 ||
         (k > 0 && s <= 0) || act < 0 || act > 2)
         return BBB_EINVAL;
@@ -629,8 +643,14 @@ int pool_act_bwd_launch(const float* g_out, const float* y, float* g_pre, int64_
     const int64_t total4 = planes * h * w * (batch / 4);
     const int64_t blocks = (total4 + 255) / 256;
     if (blocks > 0x7fffffffLL) return BBB_ESHAPE;
+    if ((g2 == nullptr) != (xc == nullptr)) return BBB_EINVAL;
+    if (g2 != nullptr) {
+        if (xc_planes <= 0 || planes % xc_planes != 0) return BBB_EINVAL;
+        if ((((uintptr_t)g2 | (uintptr_t)xc) & 15u) != 0) return BBB_EALIGN;
+    }
     hipLaunchKernelGGL(pool_act_bwd_chwn_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g_out, y, g_pre, total4, h, w,
-                       hp, wp, batch / 4, k, s, act, out_plane_pitch / 4, am, av, g_var, mom_planes);
+                       hp, wp, batch / 4, k, s, act, out_plane_pitch / 4, am, av, g_var, mom_planes, g2, xc,
+                       g2 != nullptr ? xc_planes * hp * wp * (batch / 4) : (int64_t)1);
     return (int)hipGetLastError();
 }
 }  // namespace
@@ -642,10 +662,11 @@ extern "C" int bbb_pool_act_bwd_chwn(const float* g_out, const float* y, float* 
 
 extern "C" int bbb_lrt_pool_act_bwd_chwn(const float* g_out, const float* y, const float* act_mu, const float* act_var, float* g_mu,
                                          float* g_var, int64_t planes, int64_t moment_planes, int h, int w, int batch, int k, int s,
-                                         int act, int64_t out_plane_pitch, void* stream) {
+                                         int act, int64_t out_plane_pitch, const float* g_out2, const float* x_out, int64_t x_planes,
+                                         void* stream) {
     if (act_mu == nullptr || act_var == nullptr || g_var == nullptr) return BBB_EINVAL;
     if (moment_planes <= 0 || planes % moment_planes != 0) return BBB_EINVAL;
     if ((((uintptr_t)act_mu | (uintptr_t)act_var | (uintptr_t)g_var) & 15u) != 0) return BBB_EALIGN;
     return pool_act_bwd_launch(g_out, y, g_mu, planes, h, w, batch, k, s, act, out_plane_pitch, act_mu, act_var, g_var, moment_planes,
-                               stream);
+                               stream, g_out2, x_out, x_planes);
 }

@@ -481,3 +481,29 @@ def test_flip_transpose_w_multi_entry(env):
     many = [torch.randn(1, 4, 4, 1, 1, device="cuda", generator=g) for _ in range(19)]          # more than one launch's 16 segments
     for o, w in zip(ops.flip_transpose_w_multi(many), many):
         assert torch.equal(o, ops.flip_transpose_w(w))
+
+
+@pytest.mark.parametrize("net_type,cin,B,E", [("alexnet", 3, 32, 1), ("3conv3fc", 3, 8, 2), ("lenet", 1, 16, 3)])
+def test_lrt_combine_folded_into_the_layer_below(env, net_type, cin, B, E):
+    """g1 + 2 x g2 (the two input gradients of an LRT layer) formed inside the pooling / activation backward of the layer below
+    (bbb_lrt_pool_act_bwd_chwn g_out2 / x_out) = the separate bbb_lrt_glue launch, bit for bit: same fmaf per element."""
+    ens, ft = env["ens"], env["ft"]
+    torch.manual_seed(9)
+    net = env["zoo"].getModel(net_type, cin, 10, P.CONFIG_PRIORS, "lrt", "relu" if net_type == "lenet" else "softplus").cuda()
+    env["rng"].assign_stream_ids(net)
+    x = torch.rand(B, cin, 32, 32, device="cuda")
+    y = torch.randint(0, 10, (B,), device="cuda")
+    grads = {}
+    for fold in (True, False):
+        ft.fold_lrt_combine[0] = fold
+        try:
+            net.zero_grad(set_to_none=True)
+            env["rng"].manual_seed(8, call=1)
+            lo, kl = ens.mc_forward(net, x, E, kl_mode="mean")
+            assert ens.stats["path"] == "chwn-autograd"
+            (F.nll_loss(lo, y) * 100.0 + 1e-6 * kl).backward()
+            grads[fold] = {n: p.grad.detach().clone() for n, p in net.named_parameters()}
+        finally:
+            ft.fold_lrt_combine[0] = True
+    for n in grads[True]:
+        assert torch.equal(grads[True][n], grads[False][n]), n
